@@ -1,0 +1,155 @@
+/*
+ * ogmm_hip.h -- C ABI of libogmm_hip.so: the MI355X (gfx950) kernels of the overlap-guided GMM
+ * registration hot path of gfmei/ogmm, GMMReg.forward(src, tgt, is_test=False).
+ *
+ * The reference has no FFI of its own: its only boundary is the Python nn.Module surface
+ * (models/gmmreg.py:33,50).  The entry points below are what a binding for that path would call --
+ * one per tensor-op cluster of the reference -- and each cites the reference code it replaces
+ * (paths relative to the reference root).  The Python host in ogmm_amd/ binds them with ctypes
+ * (INTEGRATION.md shows the stub); nothing here depends on PyTorch.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; float = IEEE binary32; indices int32
+ *   - point-major layouts: a cloud is xyz[N][3]; a feature map is feats[rows][ld] with the
+ *     channel index contiguous (the reference is channel-major [B,C,N]; the host transposes the
+ *     3-channel inputs once, every later tensor is produced point-major)
+ *   - "C" clouds = 2B for a batch of B pairs (src clouds first, then tgt clouds)
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued, nothing synchronises
+ *   - return value 0 = enqueued; non-zero = rejected (bad argument / launch failure), message in
+ *     ogmm_last_error().  No entry point retains a pointer after it returns.
+ */
+#ifndef OGMM_HIP_H
+#define OGMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OGMM_ABI_VERSION 1
+
+int ogmm_abi_version(void);
+/* thread-local, valid until the next failing call on this thread */
+const char* ogmm_last_error(void);
+
+/* ---- K1: kNN graph.  lib/utils.py:12-44 (square_distance + knn); callers models/dgcnn.py:135,
+ * lib/utils.py:52 <- models/attn.py:69.
+ * dist(i,j) = max(1e-12, (-2 * fma(z_i,z_j, fma(y_i,y_j, x_i*x_j)) + |p_i|^2) + |p_j|^2)  -- the exact
+ * fp32 rounding sequence of the reference on CPU, so index sets reproduce bit-for-bit; the k
+ * smallest in ascending order, ties towards the lower index.  1 <= k <= 32, k <= N. */
+int ogmm_knn(const float* xyz /*[C][N][3]*/, int C, int N, int k, int32_t* idx /*[C][N][k]*/, void* stream);
+
+/* ---- K5: farthest point sampling.  lib/utils.py:170-198 (farthest_point_sample).
+ * start != NULL: is_center=False with the torch.randint draw (:190) as an explicit input [C].
+ * start == NULL: is_center=True (:183-188): running-min seeded with distances to the centroid.
+ * `n_sets` independent samplings of the same clouds run in one launch (start is [n_sets][C],
+ * ids is [n_sets][C][npoint]). */
+int ogmm_fps(const float* xyz /*[C][N][3]*/, int C, int N, int npoint, int n_sets,
+             const int32_t* start, int32_t* ids, void* stream);
+
+/* ---- K6: row gather.  lib/utils.py:111-127 (index_points) as used by get_anchor_corrs :260-261.
+ * out[c][s][:] = feats[(cloud_map ? cloud_map[c] : c) * N + ids[c'][s]][:], c' the same mapped cloud.
+ * cloud_map lets the cross-attention read the OTHER cloud's anchors (models/gmmreg.py:71-72). */
+int ogmm_gather_rows(const float* feats, int64_t ld, int C, int N, int D, const int32_t* ids /*[C][S]*/, int S,
+                     const int32_t* cloud_map, float* out /*[C][S][D]*/, void* stream);
+
+/* ---- the 1x1-convolution engine (K3 layers 2-4, K4, K8, K10, K11, K12, K13 similarity, K9 products):
+ * every nn.Conv1d/Conv2d(kernel_size=1) of models/dgcnn.py:19-35,121-125, models/attn.py:21,34-57,91-92
+ * and the einsum/matmul contractions of models/attn.py:79,82 and models/gmmreg.py:75.
+ *   C[z][m][n] = act( alpha * sum_k A[z][m][k] * B[z][n][k] * scale[.] + shift[.] ) + Res[z][m][n]
+ * A may be given as two column pieces [A | A2] (torch.cat on channels: models/attn.py:111,
+ * models/gmmreg.py:82-83) against one B of row length K1+K2.  scale/shift (NULL = 1/0) index the
+ * column n (folded eval-mode BatchNorm + conv bias) or the row m when row_affine != 0.
+ * pool_k > 0 (EdgeConv, models/dgcnn.py:139-148): rows are edges in groups of pool_k per point;
+ * besides C (stored only if store_c) pool_out[m / pool_k][n] = max over the group (inputs >= 0
+ * after ReLU required: act must be OGMM_ACT_RELU).
+ * Exact fp32: v_mfma_f32_32x32x2_f32 accumulation.  K1, K2, lda, lda2, ldb multiples of 4;
+ * all base pointers 16-byte aligned. */
+enum { OGMM_ACT_NONE = 0, OGMM_ACT_RELU = 1, OGMM_ACT_LEAKY02 = 2, OGMM_ACT_SIGMOID = 3 };
+
+typedef struct ogmm_gemm {
+    const float* A;  int64_t lda;  int32_t K1;
+    const float* A2; int64_t lda2; int32_t K2;
+    const float* B;  int64_t ldb;
+    float* C;        int64_t ldc;
+    const float* Res; int64_t ldr;
+    int32_t M, N;
+    int32_t batch_outer, batch_inner;            /* z = zo * batch_inner + zi; both >= 1 */
+    int64_t sA_o, sA_i, sA2_o, sA2_i, sB_o, sB_i, sC_o, sC_i, sR_o, sR_i;   /* element strides */
+    const float* scale; const float* shift; int32_t row_affine;
+    float alpha;
+    int32_t act;
+    int32_t pool_k; float* pool_out; int64_t ldp; int32_t store_c;
+} ogmm_gemm;
+
+int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
+
+/* ---- K2+K3 layer 1: neighbour gather + cat(x_j - x_i, x_i) + conv 6->64 + BN + ReLU + max over k.
+ * lib/utils.py:56-64, models/dgcnn.py:137-139.  h1 [C*N*k][64] (the un-pooled tensor feeds conv2),
+ * pooled written to pool_out[point][0..63] with row stride ldp. */
+int ogmm_edgeconv_first(const float* xyz, const int32_t* idx, int C, int N, int k,
+                        const float* W /*[64][6]*/, const float* scale, const float* shift,
+                        float* h1, float* pool_out, int64_t ldp, void* stream);
+
+/* ---- K7 front half: PositionEncoding up to its two 64-channel hidden maps.  models/attn.py:65-73:
+ * centroid, g=|p-c|^2 -> conv_dis.0 (1->64)+BN+LeakyReLU -> hid_dis; 5-NN offsets, cosine with the
+ * global offset -> conv_ang1 (1->64)+BN+LeakyReLU -> max over k_pos -> hid_ang.  The two 64->D/2
+ * convolutions that follow go through ogmm_gemm_nt. idx rows have stride idx_ld (first k_pos used). */
+int ogmm_pos_hidden(const float* xyz, const int32_t* idx, int idx_ld, int k_pos, int C, int N,
+                    const float* w_dis /*[64]*/, const float* s_dis, const float* t_dis,
+                    const float* w_ang /*[64]*/, const float* s_ang, const float* t_ang,
+                    float* hid_dis /*[C*N][64]*/, float* hid_ang /*[C*N][64]*/, void* stream);
+
+/* ---- K9 middle: in-place softmax over the last axis (keys).  models/attn.py:80. cols <= 1024. */
+int ogmm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream);
+
+/* ---- K10 middle: InstanceNorm1d(affine=False, eps) + ReLU in place over the N points of each
+ * (cloud, channel).  models/attn.py:24-25.  x [C][N][ld], D channels. */
+int ogmm_instnorm_relu(float* x, int64_t ld, int C, int N, int D, float eps, void* stream);
+
+/* ---- K13 pieces.  models/gmmreg.py:74: F.normalize over channels (eps 1e-12), rows of length D. */
+int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream);
+/* Cout = 1 convolutions (proj.net.3, overlap.net.6): y[m] = act(dot(x[m][:], w) + b). */
+int ogmm_rowdot(const float* x, int64_t ldx, int64_t rows, int D, const float* w, const float* b /*device [1]*/,
+                int act, float* y, int64_t ldy, void* stream);
+/* models/gmmreg.py:79-80 given S = src_fn^T tgt_fn [B][N][N]:
+ *   wo_src[b][m] = sum_n softmax_n(S[b][m][:])[n] * o_src[b][n]     (sic: reference indexes o_src by n)
+ *   wo_tgt[b][n] = sum_m softmax_m(S[b][:][n])[m] * o_tgt[b][m]
+ * outputs are written with element stride `ldo` (they are channels 512/513 of the conv2 input). */
+int ogmm_overlap_cross(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in,
+                       float* wo_src, float* wo_tgt, int64_t ldo, void* stream);
+
+/* ---- K15: overlap-weighted Sinkhorn k-means, the whole E/M loop on chip.  lib/utils.py:269-288
+ * (wkeans_plus) with :69-108 (sinkhorn, log domain), :130-140 (gmm_params).  Centres start at
+ * xyz[ids0]; p = o / max(sum o, 1e-4); per outer iteration: cost = cdist(xyz, mu)/tau, `sk_iters`
+ * Sinkhorn sweeps (the reference's batch-mean early exit, :99-102, never fires on this path and is
+ * not implemented), gamma = exp(K), nan->0, rows / max(rowsum, 1e-3), pi = mean, mu = gamma^T xyz /
+ * (N pi + 1e-5). */
+int ogmm_gmm_em(const float* xyz, const float* o /*[C][N]*/, const int32_t* ids0 /*[C][J]*/, int C, int N, int J,
+                int iters, int sk_iters, float epsilon, float tau,
+                float* gamma /*[C][N][J]*/, float* pi /*[C][J]*/, float* mu /*[C][J][3]*/, void* stream);
+
+/* ---- K16: mu_feat = gamma^T feats / (N pi + 1e-5).  lib/utils.py:289 / :130-140. */
+int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,
+                       float* mu_feat /*[C][J][D]*/, void* stream);
+
+/* ---- K17+K18: cluster matching and the weighted rigid solve.  models/dgcnn.py:96-115 (GMMSVD, is_sk=False),
+ * lib/utils.py:222-226, lib/se3.py:256-289.  One wavefront per pair; 3x3 SVD by Jacobi in registers (fp64). */
+int ogmm_match_kabsch(const float* mu_s /*[B][J][3]*/, const float* mu_t, const float* f_s /*[B][J][D]*/, const float* f_t,
+                      int B, int J, int D, float temperature, float* R /*[B][3][3]*/, float* t /*[B][3]*/,
+                      float* scores /*[B][J][J] or NULL*/, void* stream);
+/* lib/se3.py:256-289 alone: src, corr [B][3][J], w [B][J]. */
+int ogmm_kabsch(const float* src, const float* corr, const float* w, int B, int J, float* R, float* t, void* stream);
+
+/* ---- K19: CluLoss.  lib/loss.py:109-118 + :16-57 + lib/utils.py:244-254: anchors = feature of the
+ * point nearest to each cluster centre; positives = mu_feat; InfoNCE with 2J-1 logits, label 0.
+ * row_loss_sum[c] = sum over the cloud's 2J rows of the cross-entropy (the host divides by C*2J / applies
+ * the 0.5 of models/gmmreg.py:110); near[c][j] = chosen point index. */
+int ogmm_clu_infonce(const float* xyz, const float* mu, const float* feats, int64_t ld, const float* mu_feat,
+                     int C, int N, int J, int D, float tau, float* row_loss_sum /*[C]*/, int32_t* near /*[C][J]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGMM_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libogmm_hip.so (include/ogmm_hip.h).  No fallback: if the library is missing or a
+symbol does not resolve, importing the ops fails loudly -- the product path has no CPU route."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
+
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
+
+
+class GemmDesc(Structure):
+    """Mirror of `struct ogmm_gemm`."""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("K1", c_int32),
+        ("A2", c_void_p), ("lda2", c_int64), ("K2", c_int32),
+        ("B", c_void_p), ("ldb", c_int64),
+        ("C", c_void_p), ("ldc", c_int64),
+        ("Res", c_void_p), ("ldr", c_int64),
+        ("M", c_int32), ("N", c_int32),
+        ("batch_outer", c_int32), ("batch_inner", c_int32),
+        ("sA_o", c_int64), ("sA_i", c_int64), ("sA2_o", c_int64), ("sA2_i", c_int64),
+        ("sB_o", c_int64), ("sB_i", c_int64), ("sC_o", c_int64), ("sC_i", c_int64),
+        ("sR_o", c_int64), ("sR_i", c_int64),
+        ("scale", c_void_p), ("shift", c_void_p), ("row_affine", c_int32),
+        ("alpha", c_float),
+        ("act", c_int32),
+        ("pool_k", c_int32), ("pool_out", c_void_p), ("ldp", c_int64), ("store_c", c_int32),
+    ]
+
+
+# name -> argtypes (restype is int for all but the two noted); the list doubles as the export check in tests
+PROTOTYPES = {
+    "ogmm_abi_version": [],
+    "ogmm_last_error": [],
+    "ogmm_knn": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ogmm_fps": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ogmm_gather_rows": [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "ogmm_gemm_nt": [POINTER(GemmDesc), c_void_p],
+    "ogmm_edgeconv_first": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
+    "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],
+    "ogmm_instnorm_relu": [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p],
+    "ogmm_l2norm_rows": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
+    "ogmm_rowdot": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
+    "ogmm_overlap_cross": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_gmm_em": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogmm_gmm_feat_mean": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ogmm_match_kabsch": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogmm_kabsch": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "ogmm_clu_infonce": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+}
+
+_lib = None
+
+
+class OgmmError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the in-tree shared library once and checks ABI version and symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise OgmmError("libogmm_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C ogmm_amd/csrc`); there is no CPU fallback for the product path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError here = missing export
+        fn.argtypes = argtypes
+        fn.restype = c_char_p if name == "ogmm_last_error" else c_int
+    if lib.ogmm_abi_version() != ABI_VERSION:
+        raise OgmmError("libogmm_hip.so ABI %d != binding ABI %d" % (lib.ogmm_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise OgmmError("%s failed: %s" % (name, lib.ogmm_last_error().decode(errors="replace")))

@@ -1,0 +1,237 @@
+// The 1x1-convolution engine: exact-fp32 NT GEMM on v_mfma_f32_32x32x2_f32 with fused epilogues.
+//
+//   C[z][m][n] = act(alpha * sum_k [A|A2][z][m][k] * B[z][n][k] * scale + shift) + Res
+//
+// Replaces every nn.Conv1d/Conv2d(kernel_size=1) (+ eval BatchNorm + activation) of
+// models/dgcnn.py:19-35,121-152 and models/attn.py:17-27,34-57,91-99, the attention products of
+// models/attn.py:79,82 and the N x N similarity of models/gmmreg.py:75.
+//
+// Tiling (gfx950, wave64): a workgroup of WM x WN waves owns a (MT*32*WM) x (NT*32*WN) tile; each wave
+// keeps MT x NT 32x32 accumulators (16 VGPRs each).  K is walked in tiles of 32 floats staged through
+// LDS as row-major [rows][36] (4 floats of padding make the ds_read_b128 fragment loads conflict-free);
+// the next tile's global loads are issued before the MFMAs of the current one.  The k order inside a
+// tile is permuted (lane half h takes k = 8g+4h+s at MFMA step s) so that one ds_read_b128 feeds four
+// MFMAs; A and B use the same permutation, so the sum is over the same set of products.
+//
+// Workgroup -> tile map is XCD-aware: all N-tiles of one M-tile run on the same XCD (block b is
+// dispatched to XCD b % 8), so the A panel is fetched into one L2 only.
+#include "ogmm_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case OGMM_ACT_RELU: return fmaxf(v, 0.0f);
+        case OGMM_ACT_LEAKY02: return v > 0.0f ? v : 0.2f * v;
+        case OGMM_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+template <int MT, int NT, int WM, int WN, bool POOL>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const ogmm_gemm g, const int rows_per_tile,
+                                                               const int m_tiles, const int n_tiles) {
+    constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
+    constexpr int A_F4 = BM * 8 / T, B_F4 = BN * 8 / T;
+    static_assert((BM * 8) % T == 0 && (BN * 8) % T == 0, "tile / thread mismatch");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    float* As = smem;
+    float* Bs = smem + BM * LDS_LD;
+
+    // XCD-aware tile assignment
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile_m = (local / n_tiles) * 8 + xcd;
+    const int tile_n = local % n_tiles;
+    if (tile_m >= m_tiles) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
+    const float* __restrict__ A = g.A + zo * g.sA_o + zi * g.sA_i;
+    const float* __restrict__ A2 = g.A2 ? g.A2 + zo * g.sA2_o + zi * g.sA2_i : nullptr;
+    const float* __restrict__ Bm = g.B + zo * g.sB_o + zi * g.sB_i;
+
+    const int m0 = tile_m * rows_per_tile, n0 = tile_n * BN;
+    const int m_end = min(g.M, m0 + rows_per_tile);
+    const int nk1 = (g.K1 + BK - 1) / BK, nk2 = (g.K2 + BK - 1) / BK, nk = nk1 + nk2;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&](int t) {
+        const bool second = t >= nk1;
+        const float* Ap = second ? A2 : A;
+        const int64_t ld = second ? g.lda2 : g.lda;
+        const int kbase = second ? (t - nk1) * BK : t * BK;
+        const int Kp = second ? g.K2 : g.K1;
+        const int kB = second ? g.K1 + kbase : kbase;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int f = tid + i * T, row = f >> 3, kq = (f & 7) * 4;
+            const int gm = m0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gm < m_end && kbase + kq < Kp) v = *reinterpret_cast<const f32x4*>(Ap + (int64_t)gm * ld + kbase + kq);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int f = tid + i * T, row = f >> 3, kq = (f & 7) * 4;
+            const int gn = n0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gn < g.N && kbase + kq < Kp) v = *reinterpret_cast<const f32x4*>(Bm + (int64_t)gn * g.ldb + kB + kq);
+            rb[i] = v;
+        }
+    };
+
+    load_tile(0);
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int f = tid + i * T;
+            *reinterpret_cast<f32x4*>(&As[(f >> 3) * LDS_LD + (f & 7) * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int f = tid + i * T;
+            *reinterpret_cast<f32x4*>(&Bs[(f >> 3) * LDS_LD + (f & 7) * 4]) = rb[i];
+        }
+        __syncthreads();
+        if (t + 1 < nk) load_tile(t + 1);
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 32 + lr) * LDS_LD + kg * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 32 + lr) * LDS_LD + kg * 8 + lh * 4]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---------------- epilogue
+    float* __restrict__ Cm = g.C ? g.C + zo * g.sC_o + zi * g.sC_i : nullptr;
+    const float* __restrict__ Rm = g.Res ? g.Res + zo * g.sR_o + zi * g.sR_i : nullptr;
+    const bool store_c = Cm != nullptr && (!POOL || g.store_c);
+    int* pool_s = reinterpret_cast<int*>(smem);
+    const int groups = POOL ? (m_end - m0) / g.pool_k : 0;
+    if (POOL) {
+        __syncthreads();
+        for (int i = tid; i < groups * BN; i += T) pool_s[i] = 0;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int cl = (wn * NT + j) * 32 + lr;      // column inside the tile
+        const int col = n0 + cl;
+        const bool col_ok = col < g.N;
+        float cs = 1.0f, ct = 0.0f;
+        if (!g.row_affine && col_ok) {
+            if (g.scale) cs = g.scale[col];
+            if (g.shift) ct = g.shift[col];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int cur_group = -1;
+            float cur_max = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // row inside the tile
+                const int row = m0 + rl;
+                if (row < m_end && col_ok) {
+                    float s = cs, sh = ct;
+                    if (g.row_affine) {
+                        s = g.scale ? g.scale[row] : 1.0f;
+                        sh = g.shift ? g.shift[row] : 0.0f;
+                    }
+                    float v = apply_act(fmaf(acc[i][j][r] * g.alpha, s, sh), g.act);
+                    if (Rm) v += Rm[(int64_t)row * g.ldr + col];
+                    if (store_c) Cm[(int64_t)row * g.ldc + col] = v;
+                    if (POOL) {
+                        const int grp = rl / g.pool_k;
+                        if (grp != cur_group) {
+                            if (cur_group >= 0) atomicMax(&pool_s[cur_group * BN + cl], __float_as_int(cur_max));
+                            cur_group = grp;
+                            cur_max = v;
+                        } else {
+                            cur_max = fmaxf(cur_max, v);
+                        }
+                    }
+                }
+            }
+            if (POOL && cur_group >= 0) atomicMax(&pool_s[cur_group * BN + cl], __float_as_int(cur_max));
+        }
+    }
+    if (POOL) {
+        __syncthreads();
+        float* __restrict__ Pm = g.pool_out + zo * 0;   // pooled output is not batched
+        const int64_t p0 = (int64_t)(m0 / g.pool_k);
+        for (int i = tid; i < groups * BN; i += T) {
+            const int p = i / BN, c = i % BN;
+            if (n0 + c < g.N) Pm[(p0 + p) * g.ldp + n0 + c] = __int_as_float(pool_s[i]);
+        }
+    }
+}
+
+template <int MT, int NT, int WM, int WN, bool POOL>
+int launch(const ogmm_gemm& g, hipStream_t stream) {
+    constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
+    const int rows_per_tile = POOL ? (BM / g.pool_k) * g.pool_k : BM;
+    const int m_tiles = (g.M + rows_per_tile - 1) / rows_per_tile;
+    const int n_tiles = (g.N + BN - 1) / BN;
+    const int m_tiles8 = (m_tiles + 7) / 8 * 8;
+    dim3 grid((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)(g.batch_outer * g.batch_inner));
+    hipLaunchKernelGGL((gemm_nt_kernel<MT, NT, WM, WN, POOL>), grid, dim3(T), 0, stream, g, rows_per_tile, m_tiles, n_tiles);
+    return ogmm::check_launch("ogmm_gemm_nt");
+}
+
+}  // namespace
+
+extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
+    OGMM_REQUIRE(d != nullptr, "ogmm_gemm_nt: null descriptor");
+    const ogmm_gemm& g = *d;
+    OGMM_REQUIRE(g.A && g.B && g.M > 0 && g.N > 0 && g.K1 > 0, "ogmm_gemm_nt: A, B, M, N, K1 required");
+    OGMM_REQUIRE(g.K2 >= 0 && (g.K2 == 0 || g.A2), "ogmm_gemm_nt: K2 > 0 needs A2");
+    OGMM_REQUIRE(g.K1 % 4 == 0 && g.K2 % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && (g.K2 == 0 || g.lda2 % 4 == 0),
+                 "ogmm_gemm_nt: K1, K2, lda, lda2, ldb must be multiples of 4 (got %d %d %lld %lld %lld)", g.K1, g.K2,
+                 (long long)g.lda, (long long)g.lda2, (long long)g.ldb);
+    OGMM_REQUIRE(g.K2 == 0 || g.K1 % BK == 0, "ogmm_gemm_nt: with two A pieces K1 must be a multiple of %d", BK);
+    OGMM_REQUIRE(ogmm::aligned16(g.A) && ogmm::aligned16(g.B) && (!g.A2 || ogmm::aligned16(g.A2)),
+                 "ogmm_gemm_nt: operand pointers must be 16-byte aligned");
+    OGMM_REQUIRE(g.sA_o % 4 == 0 && g.sA_i % 4 == 0 && g.sB_o % 4 == 0 && g.sB_i % 4 == 0 && g.sA2_o % 4 == 0 && g.sA2_i % 4 == 0,
+                 "ogmm_gemm_nt: batch strides of A/B must be multiples of 4");
+    OGMM_REQUIRE(g.batch_outer >= 1 && g.batch_inner >= 1, "ogmm_gemm_nt: batch counts must be >= 1");
+    OGMM_REQUIRE(g.C || g.pool_k > 0, "ogmm_gemm_nt: no output");
+    OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
+    hipStream_t s = ogmm::as_stream(stream);
+    if (g.pool_k > 0) {
+        OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
+                         g.batch_outer * g.batch_inner == 1,
+                     "ogmm_gemm_nt: pooling needs pool_out, ReLU, 4 <= pool_k <= 160, M %% pool_k == 0, no batching");
+        return g.N <= 64 ? launch<5, 1, 1, 2, true>(g, s) : launch<5, 1, 1, 4, true>(g, s);
+    }
+    return g.N <= 64 ? launch<2, 1, 2, 2, false>(g, s) : launch<2, 2, 2, 2, false>(g, s);
+}

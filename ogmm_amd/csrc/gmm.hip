@@ -1,0 +1,531 @@
+// K15 overlap-weighted Sinkhorn k-means ("GMM E/M"), K16 cluster feature means, K17 cluster matching,
+// K18 weighted Kabsch with an in-register 3x3 SVD, K19 CluLoss (nearest-point anchors + InfoNCE).
+//
+// The reference runs ~3000 tiny launches and 200 host syncs per forward here (lib/utils.py:269-291 calling
+// :69-108 ten times, each with ten sweeps and an .item() per sweep) plus a device->host->device SVD
+// (lib/se3.py:276).  Here the whole E/M loop of one cloud runs inside one workgroup with the state in
+// LDS/registers, and the rigid solve runs one pair per wavefront without leaving the GPU.
+#include "ogmm_common.h"
+
+namespace {
+
+using namespace ogmm;
+
+// ================================================================================================
+// K15.  One workgroup (EM_T threads) per cloud.  Nothing of size N x J is stored: cost and kernel
+// entries are recomputed from xyz (LDS), mu (LDS), u (LDS), v (LDS) whenever needed.
+//   u-step: rows -> threads (row n = tid + i*EM_T), reduction over j is thread-local;
+//   v-step and M-step: columns -> waves (j = wave + i*n_waves), lanes stride over rows, wave reduce.
+// log-sum-exp is evaluated online (running max + rescaled sum) so each entry costs one exp.
+// ================================================================================================
+constexpr int EM_T = 1024;
+
+struct LSE { float m, s; };
+__device__ __forceinline__ void lse_push(LSE& a, float x) {
+    if (x > a.m) { a.s = a.s * expf(a.m - x) + 1.0f; a.m = x; }
+    else a.s += expf(x - a.m);
+}
+__device__ __forceinline__ LSE lse_merge(LSE a, LSE b) {
+    const float m = fmaxf(a.m, b.m);
+    if (m == -__builtin_inff()) return LSE{m, 0.0f};
+    return LSE{m, a.s * expf(a.m - m) + b.s * expf(b.m - m)};
+}
+
+// torch.cdist (matmul form, lib/utils.py:280): sqrt(clamp(chain([-2x, |x|^2, 1] . [mu, 1, |mu|^2]), 0))
+__device__ __forceinline__ float cdist_mm(float x, float y, float z, float xn, float mx, float my, float mz, float mn) {
+    float acc = mul_rn(-2.0f * x, mx);
+    acc = __fmaf_rn(-2.0f * y, my, acc);
+    acc = __fmaf_rn(-2.0f * z, mz, acc);
+    acc = add_rn(acc, xn);
+    acc = add_rn(acc, mn);
+    return sqrtf(fmaxf(acc, 0.0f));
+}
+
+__global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ xyz, const float* __restrict__ o,
+                                                      const int32_t* __restrict__ ids0, int N, int J, int iters, int sk_iters,
+                                                      float inv_eps, float eps, float inv_tau, float* __restrict__ gamma,
+                                                      float* __restrict__ pi_out, float* __restrict__ mu_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* pts = reinterpret_cast<float4*>(lds);        // [N]  x, y, z, |p|^2
+    const int Npad = (N + 3) / 4 * 4;                     // keeps mu 16-byte aligned
+    float* u = lds + 4 * (size_t)N;                       // [N]
+    float* logp = u + Npad;                               // [N]
+    float* rclip = logp + Npad;                           // [N]  max(rowsum, 1e-3)
+    float4* mu = reinterpret_cast<float4*>(rclip + Npad); // [J]  mx, my, mz, |mu|^2
+    float* v = reinterpret_cast<float*>(mu + J);          // [J]
+    float* red = v + J;                                   // [16]
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = EM_T / 64;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
+    const float* __restrict__ oc = o + (int64_t)c * N;
+
+    // p = o / max(sum o, 1e-4)   (lib/utils.py:275-276)
+    float part = 0.0f;
+    for (int n = tid; n < N; n += EM_T) {
+        const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
+        pts[n] = make_float4(x, y, z, sqnorm3(x, y, z));
+        part += oc[n];
+    }
+    part = wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    float osum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) osum += red[w];
+    osum = fmaxf(osum, 1e-4f);
+    for (int n = tid; n < N; n += EM_T) logp[n] = logf(oc[n] / osum + 1e-8f);
+    for (int j = tid; j < J; j += EM_T) {
+        const float4 p = pts[ids0[(int64_t)c * J + j]];
+        mu[j] = p;
+    }
+    const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
+    __syncthreads();
+
+    for (int it = 0; it < iters; ++it) {
+        for (int n = tid; n < N; n += EM_T) u[n] = 0.0f;
+        for (int j = tid; j < J; j += EM_T) v[j] = 0.0f;
+        __syncthreads();
+        for (int sk = 0; sk < sk_iters; ++sk) {
+            // u^{l+1}: rows on threads
+            for (int n = tid; n < N; n += EM_T) {
+                const float4 p = pts[n];
+                const float un = u[n];
+                LSE a = {-__builtin_inff(), 0.0f};
+                for (int j = 0; j < J; ++j) {
+                    const float4 m = mu[j];
+                    const float cst = cdist_mm(p.x, p.y, p.z, p.w, m.x, m.y, m.z, m.w) * inv_tau;
+                    lse_push(a, ((-cst + un) + v[j]) * inv_eps);
+                }
+                u[n] = eps * (logp[n] - (a.m + logf(a.s))) + un;
+            }
+            __syncthreads();
+            // v^{l+1}: columns on waves
+            for (int j = wave; j < J; j += NW) {
+                const float4 m = mu[j];
+                const float vj = v[j];
+                LSE a = {-__builtin_inff(), 0.0f};
+                for (int n = lane; n < N; n += 64) {
+                    const float4 p = pts[n];
+                    const float cst = cdist_mm(p.x, p.y, p.z, p.w, m.x, m.y, m.z, m.w) * inv_tau;
+                    lse_push(a, ((-cst + u[n]) + vj) * inv_eps);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    LSE b = {__shfl_xor(a.m, off, 64), __shfl_xor(a.s, off, 64)};
+                    a = lse_merge(a, b);
+                }
+                if (lane == 0) v[j] = eps * (logq - (a.m + logf(a.s))) + vj;
+            }
+            __syncthreads();
+        }
+        // gamma = exp(K); nan -> 0 (inf -> FLT_MAX); row scale 1 / max(rowsum, 1e-3)   (lib/utils.py:281-287)
+        const bool last = it + 1 == iters;
+        for (int n = tid; n < N; n += EM_T) {
+            const float4 p = pts[n];
+            const float un = u[n];
+            float rs = 0.0f;
+            for (int j = 0; j < J; ++j) {
+                const float4 m = mu[j];
+                const float cst = cdist_mm(p.x, p.y, p.z, p.w, m.x, m.y, m.z, m.w) * inv_tau;
+                float g = expf(((-cst + un) + v[j]) * inv_eps);
+                g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+                rs += g;
+            }
+            const float rc = fmaxf(rs, 1e-3f);
+            rclip[n] = rc;
+            if (last) {
+                float* __restrict__ grow = gamma + ((int64_t)c * N + n) * J;
+                for (int j = 0; j < J; ++j) {
+                    const float4 m = mu[j];
+                    const float cst = cdist_mm(p.x, p.y, p.z, p.w, m.x, m.y, m.z, m.w) * inv_tau;
+                    float g = expf(((-cst + un) + v[j]) * inv_eps);
+                    g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+                    grow[j] = g / rc;
+                }
+            }
+        }
+        __syncthreads();
+        // pi = mean_n gamma; mu = gamma^T xyz / (N pi + 1e-5)   (lib/utils.py:130-140), fp64 column sums
+        for (int j = wave; j < J; j += NW) {
+            const float4 m = mu[j];
+            const float vj = v[j];
+            double sg = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+            for (int n = lane; n < N; n += 64) {
+                const float4 p = pts[n];
+                const float cst = cdist_mm(p.x, p.y, p.z, p.w, m.x, m.y, m.z, m.w) * inv_tau;
+                float g = expf(((-cst + u[n]) + vj) * inv_eps);
+                g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+                g = g / rclip[n];
+                sg += g;
+                sx += (double)g * p.x; sy += (double)g * p.y; sz += (double)g * p.z;
+            }
+            sg = wave_sum_d(sg); sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
+            if (lane == 0) {
+                const float pj = (float)sg / (float)N;
+                const float npi = pj * (float)N + 1e-5f;
+                const float nx = (float)sx / npi, ny = (float)sy / npi, nz = (float)sz / npi;
+                mu[j] = make_float4(nx, ny, nz, sqnorm3(nx, ny, nz));
+                if (last) {
+                    pi_out[(int64_t)c * J + j] = pj;
+                    float* mo = mu_out + ((int64_t)c * J + j) * 3;
+                    mo[0] = nx; mo[1] = ny; mo[2] = nz;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================
+// K16.  mu_feat[c][j][d] = sum_n gamma[c][n][j] * feats[c][n][d] / (N pi[c][j] + 1e-5)
+// block = (cloud, 64-channel slab, 16-cluster slab): 64 channels x 4 row lanes, 16 accumulators each.
+// ================================================================================================
+__global__ __launch_bounds__(256) void gmm_feat_mean_kernel(const float* __restrict__ gamma, const float* __restrict__ pi,
+                                                            const float* __restrict__ feats, int64_t ld, int N, int J, int D,
+                                                            float* __restrict__ mu_feat) {
+    __shared__ float gs[64][17];
+    __shared__ float red[4][16][64];
+    const int c = blockIdx.z, ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + ch, j0 = blockIdx.y * 16;
+    const float* __restrict__ F = feats + (int64_t)c * N * ld;
+    const float* __restrict__ G = gamma + (int64_t)c * N * J;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            const int r = i >> 4, j = i & 15;
+            gs[r][j] = (n0 + r < N && j0 + j < J) ? G[(int64_t)(n0 + r) * J + j0 + j] : 0.0f;
+        }
+        __syncthreads();
+        for (int r = rl; r < 64; r += 4) {
+            if (n0 + r >= N) break;
+            const float f = d < D ? F[(int64_t)(n0 + r) * ld + d] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(gs[r][j], f, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[rl][j][ch] = acc[j];
+    __syncthreads();
+    if (rl == 0 && d < D) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j0 + j >= J) break;
+            const float s = (red[0][j][ch] + red[1][j][ch]) + (red[2][j][ch] + red[3][j][ch]);
+            const float npi = pi[(int64_t)c * J + j0 + j] * (float)N + 1e-5f;
+            mu_feat[((int64_t)c * J + j0 + j) * D + d] = s / npi;
+        }
+    }
+}
+
+// ================================================================================================
+// K18.  Weighted Kabsch (lib/se3.py:256-289) for one pair, executed by one lane in fp64.
+//   cov = sum_n w_n (s_n - cs)(c_n - cc)^T (+1e-5 I);  cov = U S V^T;  R = V diag(1,1,det) U^T
+// With (v1,v2) the two leading right singular vectors and u_i = cov v_i / sigma_i, the proper rotation is
+//   R = v1 u1^T + v2 u2^T + (v1 x v2)(u1 x u2)^T
+// which equals the reference's V U^T with V[:,2] negated when det(V U^T) <= 0, independent of the sign
+// ambiguities of the SVD.  (v1,v2) come from a cyclic Jacobi eigen-decomposition of cov^T cov.
+// ================================================================================================
+__device__ void jacobi_eig3(double A[3][3], double V[3][3]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            if (fabs(A[p][q]) < 1e-300) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+            for (int k = 0; k < 3; ++k) {   // A <- A J
+                const double akp = A[k][p], akq = A[k][q];
+                A[k][p] = cs * akp - sn * akq;
+                A[k][q] = sn * akp + cs * akq;
+            }
+            for (int k = 0; k < 3; ++k) {   // A <- J^T A
+                const double apk = A[p][k], aqk = A[q][k];
+                A[p][k] = cs * apk - sn * aqk;
+                A[q][k] = sn * apk + cs * aqk;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = cs * vkp - sn * vkq;
+                V[k][q] = sn * vkp + cs * vkq;
+            }
+        }
+    }
+}
+
+__device__ void rotation_from_cov(const double cov[3][3], double R[3][3]) {
+    double AtA[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) s += cov[k][i] * cov[k][j];
+        AtA[i][j] = s;
+    }
+    jacobi_eig3(AtA, V);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b)
+        if (AtA[ord[b]][ord[b]] > AtA[ord[a]][ord[a]]) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    double v[2][3], uu[2][3];
+    for (int i = 0; i < 2; ++i) for (int k = 0; k < 3; ++k) v[i][k] = V[k][ord[i]];
+    for (int i = 0; i < 2; ++i) {
+        for (int k = 0; k < 3; ++k) uu[i][k] = cov[k][0] * v[i][0] + cov[k][1] * v[i][1] + cov[k][2] * v[i][2];
+        if (i == 1) {   // Gram-Schmidt against u1
+            const double d = uu[1][0] * uu[0][0] + uu[1][1] * uu[0][1] + uu[1][2] * uu[0][2];
+            for (int k = 0; k < 3; ++k) uu[1][k] -= d * uu[0][k];
+        }
+        const double nrm = sqrt(uu[i][0] * uu[i][0] + uu[i][1] * uu[i][1] + uu[i][2] * uu[i][2]);
+        const double inv = nrm > 0 ? 1.0 / nrm : 0.0;
+        for (int k = 0; k < 3; ++k) uu[i][k] *= inv;
+    }
+    const double v3[3] = {v[0][1] * v[1][2] - v[0][2] * v[1][1], v[0][2] * v[1][0] - v[0][0] * v[1][2], v[0][0] * v[1][1] - v[0][1] * v[1][0]};
+    const double u3[3] = {uu[0][1] * uu[1][2] - uu[0][2] * uu[1][1], uu[0][2] * uu[1][0] - uu[0][0] * uu[1][2],
+                          uu[0][0] * uu[1][1] - uu[0][1] * uu[1][0]};
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) R[a][b] = v[0][a] * uu[0][b] + v[1][a] * uu[1][b] + v3[a] * u3[b];
+}
+
+// src/corr given as callable accessors (a = axis, n = cluster)
+template <class FS, class FC, class FW>
+__device__ void kabsch_solve(int J, FS src, FC corr, FW wgt, float* __restrict__ R_out, float* __restrict__ t_out) {
+    double ws = 0.0, cs[3] = {0, 0, 0}, cc[3] = {0, 0, 0};
+    for (int n = 0; n < J; ++n) {
+        const double w = wgt(n);
+        ws += w;
+        for (int a = 0; a < 3; ++a) { cs[a] += w * src(a, n); cc[a] += w * corr(a, n); }
+    }
+    for (int a = 0; a < 3; ++a) { cs[a] /= ws; cc[a] /= ws; }
+    double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int n = 0; n < J; ++n) {
+        const double w = wgt(n);
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] += (src(a, n) - cs[a]) * w * (corr(b, n) - cc[b]);
+    }
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        if (cov[a][b] != cov[a][b]) cov[a][b] = 0.0;      // nan_to_num(nan=0)
+        if (a == b) cov[a][b] += 1e-5;
+    }
+    double R[3][3];
+    rotation_from_cov(cov, R);
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) R_out[a * 3 + b] = (float)R[a][b];
+        t_out[a] = (float)(-(R[a][0] * cs[0] + R[a][1] * cs[1] + R[a][2] * cs[2]) + cc[a]);
+    }
+}
+
+__global__ void kabsch_kernel(const float* __restrict__ src, const float* __restrict__ corr, const float* __restrict__ w, int B, int J,
+                              float* __restrict__ R, float* __restrict__ t) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* s = src + (int64_t)b * 3 * J;
+    const float* cr = corr + (int64_t)b * 3 * J;
+    const float* ww = w + (int64_t)b * J;
+    kabsch_solve(J, [&](int a, int n) { return (double)s[a * J + n]; }, [&](int a, int n) { return (double)cr[a * J + n]; },
+                 [&](int n) { return (double)ww[n]; }, R + (int64_t)b * 9, t + (int64_t)b * 3);
+}
+
+// ================================================================================================
+// K17+K18.  One workgroup of 256 threads per pair: cosine similarity J x J (each wave reduces one entry
+// at a time over D with coalesced 16-byte lane loads), softmax(sim / T) over target clusters, soft
+// correspondences, then the rigid solve on lane 0.   models/dgcnn.py:96-115.
+// ================================================================================================
+__global__ __launch_bounds__(256) void match_kabsch_kernel(const float* __restrict__ mu_s, const float* __restrict__ mu_t,
+                                                           const float* __restrict__ f_s, const float* __restrict__ f_t, int J, int D,
+                                                           float inv_temp, float* __restrict__ R, float* __restrict__ t,
+                                                           float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sim = lds;                 // [J][J]
+    float* ns = sim + J * J;          // [J] norms of f_s rows
+    float* nt = ns + J;               // [J]
+    float* corr = nt + J;             // [3][J]
+    float* wsum = corr + 3 * J;       // [J]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ Fs = f_s + (int64_t)b * J * D;
+    const float* __restrict__ Ft = f_t + (int64_t)b * J * D;
+    for (int r = wave; r < 2 * J; r += 4) {
+        const float* __restrict__ p = r < J ? Fs + (int64_t)r * D : Ft + (int64_t)(r - J) * D;
+        float ss = 0.0f;
+        for (int d = lane; d < D; d += 64) ss = fmaf(p[d], p[d], ss);
+        ss = wave_sum(ss);
+        if (lane == 0) (r < J ? ns[r] : nt[r - J]) = fmaxf(sqrtf(ss), 1e-12f);
+    }
+    __syncthreads();
+    for (int e = wave; e < J * J; e += 4) {
+        const int n = e / J, m = e % J;
+        const float* __restrict__ p = Fs + (int64_t)n * D;
+        const float* __restrict__ q = Ft + (int64_t)m * D;
+        const float in = ns[n], im = nt[m];
+        float acc = 0.0f;
+        for (int d = lane; d < D; d += 64) acc = fmaf(p[d] / in, q[d] / im, acc);
+        acc = wave_sum(acc);
+        if (lane == 0) sim[e] = acc;
+    }
+    __syncthreads();
+    for (int n = wave; n < J; n += 4) {     // softmax over m, one wave per source cluster
+        float mx = -__builtin_inff();
+        for (int m = lane; m < J; m += 64) mx = fmaxf(mx, sim[n * J + m] * inv_temp);
+        mx = wave_max(mx);
+        float se = 0.0f;
+        for (int m = lane; m < J; m += 64) se += expf(sim[n * J + m] * inv_temp - mx);
+        se = wave_sum(se);
+        float cx = 0.0f, cy = 0.0f, cz = 0.0f, ws = 0.0f;
+        for (int m = lane; m < J; m += 64) {
+            const float sc = expf(sim[n * J + m] * inv_temp - mx) / se;
+            if (scores) scores[((int64_t)b * J + n) * J + m] = sc;
+            const float* __restrict__ mt = mu_t + ((int64_t)b * J + m) * 3;
+            cx = fmaf(mt[0], sc, cx); cy = fmaf(mt[1], sc, cy); cz = fmaf(mt[2], sc, cz);
+            ws += sc;
+        }
+        cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz); ws = wave_sum(ws);
+        if (lane == 0) { corr[n] = cx; corr[J + n] = cy; corr[2 * J + n] = cz; wsum[n] = ws; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float* __restrict__ ms = mu_s + (int64_t)b * J * 3;
+        kabsch_solve(J, [&](int a, int n) { return (double)ms[n * 3 + a]; }, [&](int a, int n) { return (double)corr[a * J + n]; },
+                     [&](int n) { return (double)wsum[n]; }, R + (int64_t)b * 9, t + (int64_t)b * 3);
+    }
+}
+
+// ================================================================================================
+// K19.  (a) nearest point to each cluster centre (lib/utils.py:244-254, cdist in matmul form + top-1);
+//       (b) InfoNCE rows (lib/loss.py:22-57): block = (cluster m, cloud); wave w computes one family of
+//           J cosine scores  w=0: x_m.x_n  1: x_m.y_n  2: y_m.x_n  3: y_m.y_n   (x = anchors, y = positives).
+// ================================================================================================
+__global__ __launch_bounds__(256) void nearest_point_kernel(const float* __restrict__ xyz, const float* __restrict__ mu, int N, int J,
+                                                            int32_t* __restrict__ near) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int j = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
+    const float* __restrict__ m = mu + ((int64_t)c * J + j) * 3;
+    const float mx = m[0], my = m[1], mz = m[2], mn = sqnorm3(mx, my, mz);
+    float best = __builtin_inff();
+    int bidx = 0x7fffffff;
+    for (int n = tid; n < N; n += 256) {
+        const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
+        // cdist(mu, xyz): the roles of x1/x2 are swapped relative to cdist_mm: chain([-2mu,|mu|^2,1].[x,1,|x|^2])
+        float acc = mul_rn(-2.0f * mx, x);
+        acc = __fmaf_rn(-2.0f * my, y, acc);
+        acc = __fmaf_rn(-2.0f * mz, z, acc);
+        acc = add_rn(acc, mn);
+        acc = add_rn(acc, sqnorm3(x, y, z));
+        const float d = sqrtf(fmaxf(acc, 0.0f));
+        if (d < best) { best = d; bidx = n; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov < best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] < best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+        near[(int64_t)c * J + j] = bidx;
+    }
+}
+
+__global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restrict__ feats, int64_t ld, const float* __restrict__ mu_feat,
+                                                           const int32_t* __restrict__ near, int N, int J, int D, float inv_tau,
+                                                           float* __restrict__ row_loss) {
+    extern __shared__ __attribute__((aligned(16))) float sc[];   // [4][J]
+    const int m = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ F = feats + (int64_t)c * N * ld;
+    const float* __restrict__ Y = mu_feat + (int64_t)c * J * D;
+    const int32_t* __restrict__ nr = near + (int64_t)c * J;
+    const bool a_is_x = wave < 2, b_is_x = (wave & 1) == 0;
+    const float* __restrict__ pa = a_is_x ? F + (int64_t)nr[m] * ld : Y + (int64_t)m * D;
+    float na = 0.0f;
+    for (int d = lane; d < D; d += 64) na = fmaf(pa[d], pa[d], na);
+    na = fmaxf(sqrtf(wave_sum(na)), 1e-12f);
+    for (int n = 0; n < J; ++n) {
+        const float* __restrict__ pb = b_is_x ? F + (int64_t)nr[n] * ld : Y + (int64_t)n * D;
+        float nb = 0.0f, dot = 0.0f;
+        for (int d = lane; d < D; d += 64) { nb = fmaf(pb[d], pb[d], nb); }
+        nb = fmaxf(sqrtf(wave_sum(nb)), 1e-12f);
+        for (int d = lane; d < D; d += 64) dot = fmaf(pa[d] / na, pb[d] / nb, dot);
+        dot = wave_sum(dot);
+        if (lane == 0) sc[wave * J + n] = dot * inv_tau;
+    }
+    __syncthreads();
+    // x-row m: logits [xy[m][m] | xx[m][n!=m] | xy[m][n!=m]];  y-row m: [yx[m][m] | yx[m][n!=m] | yy[m][n!=m]]
+    if (wave < 2) {
+        const float* s_own = wave == 0 ? sc + 0 * J : sc + 2 * J;     // negatives, first family (xx | yx)
+        const float* s_oth = wave == 0 ? sc + 1 * J : sc + 3 * J;     // second family (xy | yy)
+        const float pos = wave == 0 ? sc[1 * J + m] : sc[2 * J + m];
+        float mx = pos;
+        for (int n = lane; n < J; n += 64)
+            if (n != m) mx = fmaxf(mx, fmaxf(s_own[n], s_oth[n]));
+        mx = wave_max(mx);
+        float se = 0.0f;
+        for (int n = lane; n < J; n += 64)
+            if (n != m) se += expf(s_own[n] - mx) + expf(s_oth[n] - mx);
+        se = wave_sum(se) + expf(pos - mx);
+        if (lane == 0) row_loss[((int64_t)c * 2 + wave) * J + m] = (mx + logf(se)) - pos;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- entry points
+extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
+                           float epsilon, float tau, float* gamma, float* pi, float* mu, void* stream) {
+    OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu, "ogmm_gmm_em: null pointer");
+    OGMM_REQUIRE(C > 0 && N > 0 && J > 0 && J <= N && iters > 0 && sk_iters >= 0 && epsilon > 0 && tau > 0, "ogmm_gmm_em: bad sizes C=%d N=%d J=%d", C, N, J);
+    const int Npad = (N + 3) / 4 * 4;   // keeps the float4 mu array 16-byte aligned behind 7 per-point floats
+    const size_t lds = ((size_t)4 * N + 3 * (size_t)Npad + 4 * (size_t)J + J + 16) * sizeof(float);
+    OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_gmm_em: N=%d, J=%d needs %zu B of LDS (> 160 KiB)", N, J, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const float inv_eps = (float)(1.0 / (double)epsilon);   // torch divides by a python scalar as multiply-by-reciprocal
+    const float inv_tau = (float)(1.0 / (double)tau);
+    hipLaunchKernelGGL(gmm_em_kernel, dim3(C), dim3(EM_T), lds, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters, sk_iters, inv_eps,
+                       epsilon, inv_tau, gamma, pi, mu);
+    return ogmm::check_launch("ogmm_gmm_em");
+}
+
+extern "C" int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,
+                                  float* mu_feat, void* stream) {
+    OGMM_REQUIRE(gamma && pi && feats && mu_feat && C > 0 && N > 0 && J > 0 && D > 0 && ld >= D, "ogmm_gmm_feat_mean: null pointer or bad sizes");
+    hipLaunchKernelGGL(gmm_feat_mean_kernel, dim3((D + 63) / 64, (J + 15) / 16, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats,
+                       ld, N, J, D, mu_feat);
+    return ogmm::check_launch("ogmm_gmm_feat_mean");
+}
+
+extern "C" int ogmm_match_kabsch(const float* mu_s, const float* mu_t, const float* f_s, const float* f_t, int B, int J, int D,
+                                 float temperature, float* R, float* t, float* scores, void* stream) {
+    OGMM_REQUIRE(mu_s && mu_t && f_s && f_t && R && t && B > 0 && J > 0 && D > 0 && temperature > 0, "ogmm_match_kabsch: null pointer or bad sizes");
+    const size_t lds = ((size_t)J * J + 6 * (size_t)J) * sizeof(float);
+    OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_match_kabsch: J=%d too large for LDS", J);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kabsch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(match_kabsch_kernel, dim3(B), dim3(256), lds, ogmm::as_stream(stream), mu_s, mu_t, f_s, f_t, J, D,
+                       (float)(1.0 / (double)temperature), R, t, scores);
+    return ogmm::check_launch("ogmm_match_kabsch");
+}
+
+extern "C" int ogmm_kabsch(const float* src, const float* corr, const float* w, int B, int J, float* R, float* t, void* stream) {
+    OGMM_REQUIRE(src && corr && w && R && t && B > 0 && J > 0, "ogmm_kabsch: null pointer or bad sizes");
+    hipLaunchKernelGGL(kabsch_kernel, dim3((B + 63) / 64), dim3(64), 0, ogmm::as_stream(stream), src, corr, w, B, J, R, t);
+    return ogmm::check_launch("ogmm_kabsch");
+}
+
+extern "C" int ogmm_clu_infonce(const float* xyz, const float* mu, const float* feats, int64_t ld, const float* mu_feat, int C, int N,
+                                int J, int D, float tau, float* row_loss, int32_t* near, void* stream) {
+    OGMM_REQUIRE(xyz && mu && feats && mu_feat && row_loss && near && C > 0 && N > 0 && J > 1 && D > 0 && tau > 0,
+                 "ogmm_clu_infonce: null pointer or bad sizes (J must be >= 2)");
+    hipStream_t s = ogmm::as_stream(stream);
+    hipLaunchKernelGGL(nearest_point_kernel, dim3(J, C), dim3(256), 0, s, xyz, mu, N, J, near);
+    hipLaunchKernelGGL(infonce_rows_kernel, dim3(J, C), dim3(256), 4 * (size_t)J * sizeof(float), s, feats, ld, mu_feat, near, N, J, D,
+                       (float)(1.0 / (double)tau), row_loss);
+    return ogmm::check_launch("ogmm_clu_infonce");
+}

@@ -1,0 +1,193 @@
+// K1 kNN graph, K5 farthest-point sampling, K6 row gather.
+//
+// Both selection kernels reproduce the reference's fp32 distance VALUES bit-for-bit (see the oracle
+// header for the probed rounding sequences), because 1-ulp differences flip neighbour sets / FPS chains
+// and every later feature depends on them (SURVEY.md section 7 "hard parts").
+#include "ogmm_common.h"
+
+namespace {
+
+using namespace ogmm;
+
+// ------------------------------------------------------------------------------------------------
+// kNN: one thread per query point, the whole cloud (x,y,z,|p|^2) resident in LDS, candidates are
+// visited in index order and kept in a sorted register list (strict '<' => ties keep the lower index).
+// HBM traffic is the compulsory 12 B/point in + 4k B/point out; the N x N distance matrix of
+// lib/utils.py:28-33 is never materialised.
+// ------------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, int N, int k, int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float4 pts[];   // [N]
+    const int c = blockIdx.y;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const float x = cloud[3 * j], y = cloud[3 * j + 1], z = cloud[3 * j + 2];
+        pts[j] = make_float4(x, y, z, sqnorm3(x, y, z));
+    }
+    __syncthreads();
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const float4 pq = pts[q];
+    float dk[KMAX];
+    int ik[KMAX];
+#pragma unroll
+    for (int p = 0; p < KMAX; ++p) { dk[p] = __builtin_inff(); ik[p] = 0; }
+    for (int j = 0; j < N; ++j) {
+        const float4 pj = pts[j];
+        // torch.matmul with K=3: fma(z,z', fma(y,y', x*x'));  then -2*., + |q|^2, + |p_j|^2, clamp(1e-12)
+        const float dot = __fmaf_rn(pq.z, pj.z, __fmaf_rn(pq.y, pj.y, mul_rn(pq.x, pj.x)));
+        const float d = fmaxf(add_rn(add_rn(mul_rn(-2.0f, dot), pq.w), pj.w), 1e-12f);
+        if (d < dk[KMAX - 1]) {
+#pragma unroll
+            for (int p = KMAX - 1; p > 0; --p) {
+                if (d < dk[p - 1]) { dk[p] = dk[p - 1]; ik[p] = ik[p - 1]; }
+                else if (d < dk[p]) { dk[p] = d; ik[p] = j; }
+            }
+            if (d < dk[0]) { dk[0] = d; ik[0] = j; }
+        }
+    }
+    int32_t* out = idx + ((int64_t)c * N + q) * k;
+#pragma unroll
+    for (int p = 0; p < KMAX; ++p)
+        if (p < k) out[p] = ik[p];
+}
+
+// ------------------------------------------------------------------------------------------------
+// FPS: one workgroup per (sampling, cloud); points and the running-min array live in registers
+// (PPT points per thread, interleaved so loads coalesce), a copy of the cloud in LDS serves the
+// centroid fetch; per pick: PPT distance updates, a wave argmax by shuffles, one LDS hop across waves.
+// ------------------------------------------------------------------------------------------------
+struct Best { float v; int i; };
+__device__ __forceinline__ Best better(Best a, Best b) {   // torch.max: first maximal index
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_kernel(const float* __restrict__ xyz, int C, int N, int npoint,
+                                                  const int32_t* __restrict__ start, int32_t* __restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // xyz copy [3N] + reduction scratch
+    float* cloud_s = lds;
+    __shared__ Best wave_best[4];
+    __shared__ double csum[4][3];
+    const int c = blockIdx.x, set = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
+    for (int j = tid; j < 3 * N; j += 256) cloud_s[j] = cloud[j];
+    __syncthreads();
+    float px[PPT], py[PPT], pz[PPT], run[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * 256;
+        const bool ok = p < N;
+        px[i] = ok ? cloud_s[3 * p] : 0.f;
+        py[i] = ok ? cloud_s[3 * p + 1] : 0.f;
+        pz[i] = ok ? cloud_s[3 * p + 2] : 0.f;
+        run[i] = 1e10f;
+    }
+    auto block_argmax = [&]() -> int {
+        Best b = {-1.0f, 0x7fffffff};
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = tid + i * 256;
+            if (p < N) b = better(b, Best{run[i], p});
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Best other = {__shfl_xor(b.v, o, 64), __shfl_xor(b.i, o, 64)};
+            b = better(b, other);
+        }
+        __syncthreads();            // previous readers of wave_best are done
+        if (lane == 0) wave_best[wave] = b;
+        __syncthreads();
+        Best r = wave_best[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) r = better(r, wave_best[w]);
+        return r.i;
+    };
+    auto update = [&](float cx, float cy, float cz) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float d = sqdist3_direct(px[i], py[i], pz[i], cx, cy, cz);
+            if (d < run[i]) run[i] = d;
+        }
+    };
+
+    int far;
+    if (start == nullptr) {
+        // is_center=True: centroid = mean over the N points (fp64 accumulation, rounded once)
+        double sx = 0, sy = 0, sz = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            if (tid + i * 256 < N) { sx += px[i]; sy += py[i]; sz += pz[i]; }
+        sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
+        if (lane == 0) { csum[wave][0] = sx; csum[wave][1] = sy; csum[wave][2] = sz; }
+        __syncthreads();
+        const float fn = (float)N;
+        const float cx = (float)(csum[0][0] + csum[1][0] + csum[2][0] + csum[3][0]) / fn;
+        const float cy = (float)(csum[0][1] + csum[1][1] + csum[2][1] + csum[3][1]) / fn;
+        const float cz = (float)(csum[0][2] + csum[1][2] + csum[2][2] + csum[3][2]) / fn;
+        update(cx, cy, cz);
+        far = block_argmax();
+    } else {
+        far = start[(int64_t)set * C + c];
+    }
+    int32_t* out = ids + ((int64_t)set * C + c) * npoint;
+    for (int s = 0; s < npoint; ++s) {
+        if (tid == 0) out[s] = far;
+        update(cloud_s[3 * far], cloud_s[3 * far + 1], cloud_s[3 * far + 2]);
+        if (s + 1 < npoint) far = block_argmax();
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ feats, int64_t ld, int N, int D,
+                                                          const int32_t* __restrict__ ids, int S,
+                                                          const int32_t* __restrict__ cloud_map, float* __restrict__ out) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    const int sc = cloud_map ? cloud_map[c] : c;
+    const int row = ids[(int64_t)sc * S + s];
+    const float* __restrict__ src = feats + ((int64_t)sc * N + row) * ld;
+    float* __restrict__ dst = out + ((int64_t)c * S + s) * D;
+    for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4)
+        *reinterpret_cast<float4*>(dst + d) = *reinterpret_cast<const float4*>(src + d);
+}
+
+}  // namespace
+
+extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, void* stream) {
+    OGMM_REQUIRE(xyz && idx && C > 0 && N > 0, "ogmm_knn: null pointer or empty input");
+    OGMM_REQUIRE(k >= 1 && k <= 32 && k <= N, "ogmm_knn: need 1 <= k <= min(32, N), got k=%d N=%d", k, N);
+    OGMM_REQUIRE((size_t)N * 16 <= 160 * 1024, "ogmm_knn: N=%d does not fit the LDS-resident cloud (max 10240)", N);
+    dim3 grid((N + 255) / 256, C);
+    const size_t lds = (size_t)N * sizeof(float4);
+    hipStream_t s = ogmm::as_stream(stream);
+    if (k <= 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(256), lds, s, xyz, N, k, idx);
+    else if (k <= 20) hipLaunchKernelGGL(knn_kernel<20>, grid, dim3(256), lds, s, xyz, N, k, idx);
+    else hipLaunchKernelGGL(knn_kernel<32>, grid, dim3(256), lds, s, xyz, N, k, idx);
+    return ogmm::check_launch("ogmm_knn");
+}
+
+extern "C" int ogmm_fps(const float* xyz, int C, int N, int npoint, int n_sets, const int32_t* start, int32_t* ids, void* stream) {
+    OGMM_REQUIRE(xyz && ids && C > 0 && N > 0 && npoint > 0 && n_sets > 0, "ogmm_fps: null pointer or empty input");
+    OGMM_REQUIRE(npoint <= N, "ogmm_fps: npoint=%d > N=%d", npoint, N);
+    OGMM_REQUIRE(N <= 4096, "ogmm_fps: N=%d > 4096 points per cloud not supported", N);
+    OGMM_REQUIRE(start != nullptr || n_sets == 1, "ogmm_fps: centre start supports one sampling per call");
+    dim3 grid(C, n_sets);
+    const size_t lds = (size_t)N * 3 * sizeof(float);
+    hipStream_t s = ogmm::as_stream(stream);
+    const int ppt = (N + 255) / 256;
+    if (ppt <= 1) hipLaunchKernelGGL(fps_kernel<1>, grid, dim3(256), lds, s, xyz, C, N, npoint, start, ids);
+    else if (ppt <= 2) hipLaunchKernelGGL(fps_kernel<2>, grid, dim3(256), lds, s, xyz, C, N, npoint, start, ids);
+    else if (ppt <= 4) hipLaunchKernelGGL(fps_kernel<4>, grid, dim3(256), lds, s, xyz, C, N, npoint, start, ids);
+    else if (ppt <= 8) hipLaunchKernelGGL(fps_kernel<8>, grid, dim3(256), lds, s, xyz, C, N, npoint, start, ids);
+    else hipLaunchKernelGGL(fps_kernel<16>, grid, dim3(256), lds, s, xyz, C, N, npoint, start, ids);
+    return ogmm::check_launch("ogmm_fps");
+}
+
+extern "C" int ogmm_gather_rows(const float* feats, int64_t ld, int C, int N, int D, const int32_t* ids, int S,
+                                const int32_t* cloud_map, float* out, void* stream) {
+    OGMM_REQUIRE(feats && ids && out && C > 0 && N > 0 && S > 0, "ogmm_gather_rows: null pointer or empty input");
+    OGMM_REQUIRE(D > 0 && D % 4 == 0 && ld % 4 == 0 && ogmm::aligned16(feats) && ogmm::aligned16(out),
+                 "ogmm_gather_rows: D and ld must be multiples of 4 and pointers 16-byte aligned");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(S, C), dim3(128), 0, ogmm::as_stream(stream), feats, ld, N, D, ids, S, cloud_map, out);
+    return ogmm::check_launch("ogmm_gather_rows");
+}

@@ -1,0 +1,220 @@
+// HBM-bound row/column kernels around the GEMM engine:
+//   softmax over attention keys (models/attn.py:80), InstanceNorm1d+ReLU (models/attn.py:24-25),
+//   channel L2-normalisation (models/gmmreg.py:74), Cout=1 convolutions (models/dgcnn.py:27,34),
+//   and the row/column softmax-weighted sums of the overlap block (models/gmmreg.py:79-80).
+// One wavefront per row with 16-byte lane loads where rows are contiguous; column reductions put 64
+// consecutive channels on 64 consecutive lanes so every global access is a full 256-byte line.
+#include "ogmm_common.h"
+
+namespace {
+
+using namespace ogmm;
+
+// ---------------------------------------------------------------- softmax over the last axis, in place
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int64_t rows, int cols, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* __restrict__ p = x + row * ld;
+    float v[16];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < cols ? p[c] : -__builtin_inff();
+        m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < cols ? expf(v[i] - m) : 0.0f;
+        s += v[i];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + i * 64;
+        if (c < cols) p[c] = v[i] / s;
+    }
+}
+
+// ---------------------------------------------------------------- InstanceNorm1d(affine=False) + ReLU, in place
+// block = (cloud, 64-channel slab): 64 channels x 4 row lanes; statistics accumulate in fp64 like
+// PyTorch's CPU batch-norm statistics (acc_type<float> = double); biased variance; the slab
+// (N x 256 B) stays L2-resident for the second and third sweep.
+__global__ __launch_bounds__(256) void instnorm_relu_kernel(float* __restrict__ x, int64_t ld, int N, int D, float eps) {
+    __shared__ double red[4][64];
+    __shared__ float s_alpha[64], s_beta[64];
+    const int c = blockIdx.y, ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + ch;
+    const bool ok = col < D;
+    float* __restrict__ base = x + (int64_t)c * N * ld + col;
+    double acc = 0.0;
+    if (ok) for (int n = rl; n < N; n += 4) acc += base[(int64_t)n * ld];
+    red[rl][ch] = acc;
+    __syncthreads();
+    const double mean = (red[0][ch] + red[1][ch] + red[2][ch] + red[3][ch]) / N;
+    __syncthreads();
+    acc = 0.0;
+    if (ok) for (int n = rl; n < N; n += 4) { const double d = base[(int64_t)n * ld] - mean; acc += d * d; }
+    red[rl][ch] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        const double var = (red[0][ch] + red[1][ch] + red[2][ch] + red[3][ch]) / N;
+        const double inv = 1.0 / sqrt(var + (double)eps);
+        s_alpha[ch] = (float)inv;
+        s_beta[ch] = (float)(-mean * inv);
+    }
+    __syncthreads();
+    const float a = s_alpha[ch], b = s_beta[ch];
+    if (ok) for (int n = rl; n < N; n += 4) {
+        float* q = base + (int64_t)n * ld;
+        *q = fmaxf(fmaf(*q, a, b), 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------- F.normalize(dim=channels), one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int D,
+                                                          float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* __restrict__ p = x + row * ldx;
+    float ss = 0.0f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + d);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    float* __restrict__ q = out + row * ldo;
+    for (int d = lane * 4; d < D; d += 256) {
+        float4 v = *reinterpret_cast<const float4*>(p + d);
+        v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
+        *reinterpret_cast<float4*>(q + d) = v;
+    }
+}
+
+// ---------------------------------------------------------------- Cout = 1 convolution, one wave per row
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int D,
+                                                     const float* __restrict__ w, const float* __restrict__ b, int act,
+                                                     float* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* __restrict__ p = x + row * ldx;
+    float acc = 0.0f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + d);
+        const float4 ww = *reinterpret_cast<const float4*>(w + d);
+        acc = fmaf(v.w, ww.w, fmaf(v.z, ww.z, fmaf(v.y, ww.y, fmaf(v.x, ww.x, acc))));
+    }
+    acc = wave_sum(acc) + (b ? b[0] : 0.0f);
+    if (act == OGMM_ACT_SIGMOID) acc = 1.0f / (1.0f + expf(-acc));
+    else if (act == OGMM_ACT_RELU) acc = fmaxf(acc, 0.0f);
+    else if (act == OGMM_ACT_LEAKY02) acc = acc > 0.0f ? acc : 0.2f * acc;
+    if (lane == 0) y[row * ldy] = acc;
+}
+
+// ---------------------------------------------------------------- overlap block, row direction (one wave per row m)
+//   wo_src[b][m] = sum_n softmax_n(S[b][m][:])[n] * o_src[b][n]
+__global__ __launch_bounds__(256) void overlap_rows_kernel(const float* __restrict__ S, int N, const float* __restrict__ o_src,
+                                                           int64_t ldo_in, float* __restrict__ wo_src, int64_t ldo) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= N) return;
+    const float* __restrict__ row = S + ((int64_t)b * N + m) * N;
+    const float* __restrict__ o = o_src + (int64_t)b * N * ldo_in;
+    float mx = -__builtin_inff();
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, row[n]);
+    mx = wave_max(mx);
+    float se = 0.0f, so = 0.0f;
+    for (int n = lane; n < N; n += 64) {
+        const float e = expf(row[n] - mx);
+        se += e;
+        so = fmaf(e, o[(int64_t)n * ldo_in], so);
+    }
+    se = wave_sum(se);
+    so = wave_sum(so);
+    if (lane == 0) wo_src[((int64_t)b * N + m) * ldo] = so / se;
+}
+
+// ---------------------------------------------------------------- overlap block, column direction
+//   wo_tgt[b][n] = sum_m softmax_m(S[b][:][n])[m] * o_tgt[b][m]; block = 64 columns x 4 row lanes, online softmax
+__global__ __launch_bounds__(256) void overlap_cols_kernel(const float* __restrict__ S, int N, const float* __restrict__ o_tgt,
+                                                           int64_t ldo_in, float* __restrict__ wo_tgt, int64_t ldo) {
+    __shared__ float sm[4][64], ss[4][64], st[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cl;
+    const float* __restrict__ Sb = S + (int64_t)b * N * N;
+    const float* __restrict__ o = o_tgt + (int64_t)b * N * ldo_in;
+    float mx = -__builtin_inff(), se = 0.0f, so = 0.0f;
+    if (n < N) {
+        for (int m = rl; m < N; m += 4) {
+            const float v = Sb[(int64_t)m * N + n];
+            const float om = o[(int64_t)m * ldo_in];
+            if (v > mx) {
+                const float r = expf(mx - v);   // exp(-inf) = 0 on the first element
+                se = se * r + 1.0f;
+                so = so * r + om;
+                mx = v;
+            } else {
+                const float e = expf(v - mx);
+                se += e;
+                so = fmaf(e, om, so);
+            }
+        }
+    }
+    sm[rl][cl] = mx; ss[rl][cl] = se; st[rl][cl] = so;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        float M = fmaxf(fmaxf(sm[0][cl], sm[1][cl]), fmaxf(sm[2][cl], sm[3][cl]));
+        float E = 0.0f, T = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = expf(sm[i][cl] - M);
+            E = fmaf(ss[i][cl], r, E);
+            T = fmaf(st[i][cl], r, T);
+        }
+        wo_tgt[((int64_t)b * N + n) * ldo] = T / E;
+    }
+}
+
+}  // namespace
+
+extern "C" int ogmm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream) {
+    OGMM_REQUIRE(x && rows > 0 && cols > 0 && cols <= 1024 && ld >= cols, "ogmm_softmax_rows: need 0 < cols <= 1024 <= ld (cols=%d)", cols);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ogmm::as_stream(stream), x, rows, cols, ld);
+    return ogmm::check_launch("ogmm_softmax_rows");
+}
+
+extern "C" int ogmm_instnorm_relu(float* x, int64_t ld, int C, int N, int D, float eps, void* stream) {
+    OGMM_REQUIRE(x && C > 0 && N > 0 && D > 0 && ld >= D, "ogmm_instnorm_relu: bad sizes C=%d N=%d D=%d", C, N, D);
+    hipLaunchKernelGGL(instnorm_relu_kernel, dim3((D + 63) / 64, C), dim3(256), 0, ogmm::as_stream(stream), x, ld, N, D, eps);
+    return ogmm::check_launch("ogmm_instnorm_relu");
+}
+
+extern "C" int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream) {
+    OGMM_REQUIRE(x && out && rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ogmm::aligned16(x) && ogmm::aligned16(out),
+                 "ogmm_l2norm_rows: D, ldx, ldo must be multiples of 4 and pointers 16-byte aligned");
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ogmm::as_stream(stream), x, ldx, rows, D, out, ldo);
+    return ogmm::check_launch("ogmm_l2norm_rows");
+}
+
+extern "C" int ogmm_rowdot(const float* x, int64_t ldx, int64_t rows, int D, const float* w, const float* b, int act, float* y,
+                           int64_t ldy, void* stream) {
+    OGMM_REQUIRE(x && w && y && rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ogmm::aligned16(x) && ogmm::aligned16(w),
+                 "ogmm_rowdot: D, ldx must be multiples of 4 and pointers 16-byte aligned");
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ogmm::as_stream(stream), x, ldx, rows, D, w, b, act, y, ldy);
+    return ogmm::check_launch("ogmm_rowdot");
+}
+
+extern "C" int ogmm_overlap_cross(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in, float* wo_src,
+                                  float* wo_tgt, int64_t ldo, void* stream) {
+    OGMM_REQUIRE(S && o_src && o_tgt && wo_src && wo_tgt && B > 0 && N > 0 && ldo_in >= 1 && ldo >= 1, "ogmm_overlap_cross: null pointer or empty input");
+    hipStream_t s = ogmm::as_stream(stream);
+    hipLaunchKernelGGL(overlap_rows_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, S, N, o_src, ldo_in, wo_src, ldo);
+    hipLaunchKernelGGL(overlap_cols_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, S, N, o_tgt, ldo_in, wo_tgt, ldo);
+    return ogmm::check_launch("ogmm_overlap_cross");
+}

@@ -1,0 +1,316 @@
+"""Drop-in `GMMReg` for gfmei/ogmm's models/gmmreg.py:32-119, running on the HIP kernels of libogmm_hip.so.
+
+Same constructor (`GMMReg(emb_dims, n_clusters, config)`, config needs gnn_k / num_heads / km_clusters /
+overlap_radius), same call (`model(src, tgt, is_test=False)` with src, tgt float32 [B,3,N]), same 5-tuple
+`(rot [B,3,3], trans [B,3], src_o [B,N], tgt_o [B,N], loss [])`, same 153 state_dict keys so the reference's
+`optim_model.pt` / `model_XXXX.pt` load with `load_state_dict`.
+
+What runs where: this file is host orchestration only (the reference's forward is Python too).  Every tensor
+operation of the forward is a kernel of libogmm_hip.so reached through ogmm_amd/ops.py; PyTorch provides
+device buffers and the stream.  There is no CPU fallback: CPU tensors raise.
+
+Scope of this round: eval-mode forward (`model.eval()`, `is_test=False`).  Training-mode BatchNorm statistics /
+autograd and the open3d ICP refinement of `is_test=True` (models/gmmreg.py:115-117) raise NotImplementedError.
+
+Layout: clouds are stacked as C = 2B (src clouds, then tgt clouds: in eval mode the shared-weight src/tgt calls of
+the reference are independent, models/gmmreg.py:52-53) and feature maps are point-major [C*N, channels].
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import OgmmError
+from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+BN_EPS = 1e-5
+
+
+# ------------------------------------------------------------------------------------------ parameters
+def state_spec(D=512):
+    """(key, shape) for the reference's 153 state_dict entries, in its registration order."""
+    spec = []
+
+    def conv(name, cout, cin, nd, bias):
+        spec.append((name + ".weight", (cout, cin) + (1,) * nd))
+        if bias:
+            spec.append((name + ".bias", (cout,)))
+
+    def bn(name, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            spec.append((name + "." + leaf, (c,)))
+        spec.append((name + ".num_batches_tracked", ()))
+
+    for i, (co, ci) in enumerate(((64, 6), (64, 64), (128, 64), (256, 128), (D, 512)), 1):   # models/dgcnn.py:121-125
+        conv("emd.conv%d" % i, co, ci, 2, False)
+    for i, c in enumerate((64, 64, 128, 256, D), 1):                                            # models/dgcnn.py:126-130
+        bn("emd.bn%d" % i, c)
+    conv("proj.net.0", D // 2, D, 1, True); bn("proj.net.1", D // 2); conv("proj.net.3", 1, D // 2, 1, True)   # gmmreg.py:36
+    for name, cin, hid, cout in (("overlap", D, D // 2, 1), ("conv1", D, 2 * D, D), ("conv2", D + 2, 2 * D, D)):  # gmmreg.py:37-39
+        conv(name + ".net.0", hid, cin, 1, True); bn(name + ".net.1", hid)
+        conv(name + ".net.3", hid, hid, 1, True); bn(name + ".net.4", hid)
+        conv(name + ".net.6", cout, hid, 1, True)
+    conv("pos.conv_dis.0", 64, 1, 1, False); bn("pos.conv_dis.1", 64)                          # models/attn.py:34-57
+    conv("pos.conv_dis.3", D // 2, 64, 1, False); bn("pos.conv_dis.4", D // 2)
+    conv("pos.conv_ang1.0", 64, 1, 2, False); bn("pos.conv_ang1.1", 64)
+    conv("pos.conv_ang2.0", D // 2, 64, 1, False); bn("pos.conv_ang2.1", D // 2)
+    conv("pos.conv.0", D, D, 1, False); bn("pos.conv.1", D)                                     # defined, never applied
+    for name in ("sattn1", "cattn", "sattn2"):                                                  # models/attn.py:85-107
+        conv(name + ".attn.merge", D, D, 1, True)
+        for i in range(3):
+            conv(name + ".attn.proj.%d" % i, D, D, 1, True)
+        conv(name + ".mlp.0", 2 * D, 2 * D, 1, True)
+        conv(name + ".mlp.3", D, 2 * D, 1, True)
+    return spec
+
+
+class _Node(nn.Module):
+    """Name-only container so that parameter paths reproduce the reference's state_dict keys."""
+
+
+def _build_tree(root, spec):
+    for key, shape in spec:
+        *path, leaf = key.split(".")
+        node = root
+        for part in path:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        if leaf in ("running_mean", "running_var"):
+            node.register_buffer(leaf, torch.zeros(shape) if leaf == "running_mean" else torch.ones(shape))
+        elif leaf == "num_batches_tracked":
+            node.register_buffer(leaf, torch.zeros((), dtype=torch.long))
+        else:
+            node.register_parameter(leaf, nn.Parameter(torch.empty(shape)))
+
+
+def _default_init(module, spec):
+    """PyTorch's own defaults for Conv (kaiming-uniform a=sqrt(5) <=> U(+-1/sqrt(fan_in))) and BatchNorm (1, 0),
+    plus the zero bias of models/attn.py:107."""
+    sd = dict(module.named_parameters())
+    shapes = dict(spec)
+    with torch.no_grad():
+        for key, p in sd.items():
+            base, leaf = key.rsplit(".", 1)
+            is_bn = (base + ".running_var") in shapes
+            if is_bn:
+                p.fill_(1.0 if leaf == "weight" else 0.0)
+            else:
+                w_shape = shapes[base + ".weight"]
+                bound = 1.0 / math.sqrt(max(1, int(torch.tensor(w_shape[1:]).prod())))
+                p.uniform_(-bound, bound)
+        for name in ("sattn1", "cattn", "sattn2"):
+            sd[name + ".mlp.3.bias"].zero_()
+
+
+# ------------------------------------------------------------------------------------------ weight packing
+def _fold_bn(sd, bn, conv_bias=None):
+    """eval BatchNorm (+ preceding conv bias) as y = acc * scale + shift, computed in fp64 and rounded once."""
+    w, b = sd[bn + ".weight"].double(), sd[bn + ".bias"].double()
+    mean, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
+    s = w / torch.sqrt(var + BN_EPS)
+    t = b - mean * s
+    if conv_bias is not None:
+        t = t + conv_bias.double() * s
+    return s.float().contiguous(), t.float().contiguous()
+
+
+def _w2d(sd, key, pad_to=None):
+    w = sd[key + ".weight"]
+    w = w.reshape(w.shape[0], w.shape[1]).float()
+    if pad_to is not None and w.shape[1] < pad_to:
+        w = torch.cat([w, w.new_zeros(w.shape[0], pad_to - w.shape[1])], dim=1)
+    return w.contiguous()
+
+
+def pack_weights(sd, D, H):
+    """state_dict (tensors already on the target device) -> dict of kernel-ready layers.  Done once per load:
+    BN folded to scale/shift, conv2.net.0 zero-padded from 514 to 516 input channels (16-byte rows), attention
+    projections re-ordered head-major (reference channel c = d*H + h, models/attn.py:96 -> c' = h*dh + d) with the
+    merge convolution's input columns permuted to match."""
+    L = {}
+    dh = D // H
+
+    def conv_bn(key, bn, has_bias, pad_to=None):
+        s, t = _fold_bn(sd, bn, sd[key + ".bias"] if has_bias else None)
+        return {"W": _w2d(sd, key, pad_to), "scale": s, "shift": t}
+
+    def conv_bias(key):
+        return {"W": _w2d(sd, key), "shift": sd[key + ".bias"].float().contiguous()}
+
+    for i in range(1, 6):
+        L["emd%d" % i] = conv_bn("emd.conv%d" % i, "emd.bn%d" % i, False)
+    s, t = _fold_bn(sd, "pos.conv_dis.1")
+    sa, ta = _fold_bn(sd, "pos.conv_ang1.1")
+    L["pos"] = {"w_dis": sd["pos.conv_dis.0.weight"].reshape(-1).float().contiguous(), "s_dis": s, "t_dis": t,
+                "w_ang": sd["pos.conv_ang1.0.weight"].reshape(-1).float().contiguous(), "s_ang": sa, "t_ang": ta}
+    L["pos_dis2"] = conv_bn("pos.conv_dis.3", "pos.conv_dis.4", False)
+    L["pos_ang2"] = conv_bn("pos.conv_ang2.0", "pos.conv_ang2.1", False)
+    cprime = torch.arange(D, device=sd["emd.conv1.weight"].device)
+    old_of_new = (cprime % dh) * H + (cprime // dh)
+    for name in ("sattn1", "cattn", "sattn2"):
+        T = {}
+        for i, tag in enumerate(("q", "k", "v")):
+            w = _w2d(sd, "%s.attn.proj.%d" % (name, i))
+            b = sd["%s.attn.proj.%d.bias" % (name, i)].float()
+            T[tag] = {"W": w[old_of_new].contiguous(), "shift": b[old_of_new].contiguous()}
+        wm = _w2d(sd, name + ".attn.merge")
+        T["merge"] = {"W": wm[:, old_of_new].contiguous(), "shift": sd[name + ".attn.merge.bias"].float().contiguous()}
+        T["mlp0"] = conv_bias(name + ".mlp.0")
+        T["mlp3"] = conv_bias(name + ".mlp.3")
+        L[name] = T
+    for name in ("conv1", "conv2", "overlap"):
+        cin = sd[name + ".net.0.weight"].shape[1]
+        S = {"0": conv_bn(name + ".net.0", name + ".net.1", True, pad_to=(cin + 3) // 4 * 4),
+             "3": conv_bn(name + ".net.3", name + ".net.4", True)}
+        if sd[name + ".net.6.weight"].shape[0] == 1:
+            S["6"] = {"w": sd[name + ".net.6.weight"].reshape(-1).float().contiguous(), "b": sd[name + ".net.6.bias"].float().contiguous()}
+        else:
+            S["6"] = conv_bias(name + ".net.6")
+        L[name] = S
+    L["proj"] = {"0": conv_bn("proj.net.0", "proj.net.1", True),
+                 "3": {"w": sd["proj.net.3.weight"].reshape(-1).float().contiguous(), "b": sd["proj.net.3.bias"].float().contiguous()}}
+    return L
+
+
+# ------------------------------------------------------------------------------------------ the module
+class GMMReg(nn.Module):
+    def __init__(self, emb_dims, n_clusters, config):
+        super().__init__()
+        if emb_dims % config.num_heads != 0 or (emb_dims // config.num_heads) % 4 != 0 or emb_dims % 64 != 0:
+            raise ValueError("emb_dims must be a multiple of 64 and of 4*num_heads")
+        self.emb_dims, self.n_clusters, self.config = emb_dims, n_clusters, config
+        spec = state_spec(emb_dims)
+        _build_tree(self, spec)
+        _default_init(self, spec)
+        self._packed = None
+        self._packed_key = None
+        self.last_intermediates = None
+
+    # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved
+    def _layers(self):
+        sd = self.state_dict()
+        key = tuple((t.data_ptr(), t._version) for t in sd.values())
+        if self._packed is None or key != self._packed_key:
+            self._packed = pack_weights(sd, self.emb_dims, self.config.num_heads)
+            self._packed_key = key
+        return self._packed
+
+    def _transformer(self, L, x, anchors, C, N, res):
+        """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D], anchors [C, M, D]."""
+        D, H = self.emb_dims, self.config.num_heads
+        dh, M = D // H, anchors.shape[1]
+        dev = x.device
+        q = ops.conv1x1(x, L["q"])
+        kk = ops.conv1x1(anchors.view(C * M, D), L["k"])
+        vT = torch.empty((C, D, M), dtype=torch.float32, device=dev)            # V^T per cloud: rows = head-major channels
+        ops.gemm_nt(L["v"]["W"], D, D, anchors, D, D, M, C=vT, ldc=M, shift=L["v"]["shift"], row_affine=True,
+                    batch=(C, 1), sB=(M * D, 0), sC=(D * M, 0))
+        S = torch.empty((C, H, N, M), dtype=torch.float32, device=dev)
+        ops.gemm_nt(q, D, dh, kk, D, N, M, C=S, ldc=M, alpha=1.0 / dh ** .5, batch=(C, H),
+                    sA=(N * D, dh), sB=(M * D, dh), sC=(H * N * M, N * M))
+        ops.softmax_rows_(S.view(C * H * N, M))
+        o = torch.empty((C * N, D), dtype=torch.float32, device=dev)
+        ops.gemm_nt(S, M, M, vT, M, N, dh, C=o, ldc=D, batch=(C, H), sA=(H * N * M, N * M), sB=(D * M, dh * M), sC=(N * D, dh))
+        msg = ops.conv1x1(o, L["merge"])
+        z = ops.conv1x1(x, L["mlp0"], x2=msg)
+        ops.instnorm_relu_(z, C, N, BN_EPS)
+        return ops.conv1x1(z, L["mlp3"], res=res)
+
+    @staticmethod
+    def _stack3(S, x, x2=None):
+        """models/dgcnn.py:19-28 (`CONV`, used='proj') with a Cout > 1 last layer."""
+        h = ops.conv1x1(x, S["0"], ACT_RELU, x2=x2)
+        h = ops.conv1x1(h, S["3"], ACT_RELU)
+        return ops.conv1x1(h, S["6"])
+
+    def forward(self, src, tgt, is_test=False, fps_starts=None, capture=False):
+        """models/gmmreg.py:50-119.  `fps_starts` (int64/int32 [6,B], optional) pins the six `torch.randint` draws of
+        lib/utils.py:190; when None they are drawn from torch's global CPU generator in the reference's call order,
+        so the same `torch.manual_seed` gives the same anchors as the reference."""
+        if not (isinstance(src, torch.Tensor) and src.is_cuda and tgt.is_cuda):
+            raise OgmmError("GMMReg.forward needs CUDA/ROCm tensors: the MI355X path has no CPU fallback")
+        if self.training:
+            raise NotImplementedError("training-mode forward/backward is not built yet (eval-mode inference only); call .eval()")
+        if is_test:
+            raise NotImplementedError("is_test=True needs the open3d ICP refinement (models/gmmreg.py:115-117): out of scope")
+        if src.dim() != 3 or src.shape[1] != 3 or src.shape != tgt.shape or src.dtype != torch.float32 or tgt.dtype != torch.float32:
+            raise OgmmError("src and tgt must be float32 [B,3,N] of equal shape (models/gmmreg.py:79-80 needs N_src == N_tgt)")
+        cfg = self.config
+        B, _, N = src.shape
+        C, D, H, k, M, J = 2 * B, self.emb_dims, cfg.num_heads, cfg.gnn_k, cfg.km_clusters, self.n_clusters
+        if M % 4 != 0 or M > N or J > N or k > N:
+            raise OgmmError("km_clusters must be a multiple of 4 and km_clusters, n_clusters, gnn_k <= N")
+        dev = src.device
+        if self.emd.conv1.weight.device != dev:
+            raise OgmmError("GMMReg parameters live on %s but the inputs on %s: call model.to(device) first" % (self.emd.conv1.weight.device, dev))
+        L = self._layers()
+        cap = {} if capture else None
+
+        if fps_starts is None:
+            fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
+        fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()   # [stage][src clouds | tgt clouds]
+
+        xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()         # [C,N,3]
+        idx = ops.knn(xyz, k)
+        ids_a = ops.fps(xyz, M, fps_starts)                                       # [3,C,M]: all three random-start samplings at once
+        ids_j = ops.fps(xyz, J, None)                                             # centre-start sampling for the GMM init
+        swap = torch.cat([torch.arange(B, C), torch.arange(0, B)]).to(device=dev, dtype=torch.int32)
+
+        # ---- DGCNN (models/dgcnn.py:133-154)
+        R = C * N
+        xcat = torch.empty((R, 512), dtype=torch.float32, device=dev)
+        h = ops.edgeconv_first(xyz, idx, L["emd1"], xcat[:, 0:64])
+        h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128])
+        h = ops.edgeconv_layer(h, L["emd3"], k, xcat[:, 128:256])
+        ops.edgeconv_layer(h, L["emd4"], k, xcat[:, 256:512], store=False)
+        del h
+        emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU)
+
+        # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)
+        idx5 = idx if k >= 5 else ops.knn(xyz, 5)
+        hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])
+        x0 = torch.empty((R, D), dtype=torch.float32, device=dev)
+        ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2])
+        ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:])
+
+        # ---- self-attention 1 + conv1 (gmmreg.py:54-57, 62-63)
+        a0 = ops.gather_rows(emb, D, C, N, D, ids_a[0])
+        t1 = self._transformer(L["sattn1"], x0, a0, C, N, res=x0)
+        ft = self._stack3(L["conv1"], t1)
+        # ---- cross-attention: keys/values are the OTHER cloud's anchors (gmmreg.py:67-72)
+        a1 = ops.gather_rows(ft, D, C, N, D, ids_a[1], cloud_map=swap)
+        f = self._transformer(L["cattn"], ft, a1, C, N, res=ft)
+
+        # ---- overlap scores (gmmreg.py:74-89)
+        fn = ops.l2norm_rows(f)
+        S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+        ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
+        ph = ops.conv1x1(f, L["proj"]["0"], ACT_RELU)
+        extra = torch.zeros((R, 4), dtype=torch.float32, device=dev)             # conv2 input channels 512 (wo), 513 (o), zero pad
+        ops.rowdot(ph, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=4)
+        ops.overlap_cross(S, extra[:B * N, 1], extra[B * N:, 1], 4, extra[:B * N, 0], extra[B * N:, 0], 4)
+        del S
+        fo = self._stack3(L["conv2"], f, x2=extra)
+        g = ops.conv1x1(fo, L["overlap"]["0"], ACT_RELU)
+        g = ops.conv1x1(g, L["overlap"]["3"], ACT_RELU)
+        o = torch.empty((C, N), dtype=torch.float32, device=dev)
+        ops.rowdot(g, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1)
+
+        # ---- self-attention 2 (gmmreg.py:92-97)
+        a2 = ops.gather_rows(f, D, C, N, D, ids_a[2])
+        f2 = self._transformer(L["sattn2"], f, a2, C, N, res=f)
+
+        # ---- GMM E/M, cluster matching, rigid solve, clustering loss (gmmreg.py:100-114)
+        gamma, pi, mu = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0)
+        muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)
+        rot, trans = ops.match_kabsch(mu[:B].contiguous(), mu[B:].contiguous(), muf[:B].contiguous(), muf[B:].contiguous(), 0.05)
+        row_loss, near = ops.clu_infonce(xyz, mu, f2, muf, C, N, 0.1)
+        loss = row_loss.mean()          # 0.5 * (mean over src rows + mean over tgt rows), gmmreg.py:110
+
+        if capture:
+            cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0], o_logit=extra[:, 1],
+                       o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss)
+            self.last_intermediates = cap
+        return rot, trans, o[:B], o[B:], loss

@@ -1,0 +1,249 @@
+"""Thin torch-tensor wrappers over the C ABI (include/ogmm_hip.h).  PyTorch is plumbing here: it owns the
+device memory and the stream; every function enqueues HIP kernels of libogmm_hip.so on torch's current
+stream and returns without synchronising.  All tensors must be CUDA (ROCm) tensors -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, GemmDesc  # noqa: F401
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.OgmmError("%s must be a CUDA/ROCm tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise _lib.OgmmError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _f32(t, name):
+    return _chk(t, torch.float32, name)
+
+
+def _i32(t, name):
+    return _chk(t, torch.int32, name)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ---------------------------------------------------------------------------------------------- selection
+def knn(xyz, k):
+    """xyz [C,N,3] -> idx [C,N,k] int32   (lib/utils.py:37-44)."""
+    xyz = _f32(xyz, "xyz")
+    assert xyz.is_contiguous() and xyz.dim() == 3 and xyz.shape[2] == 3
+    C, N, _ = xyz.shape
+    idx = torch.empty((C, N, k), dtype=torch.int32, device=xyz.device)
+    _lib.call("ogmm_knn", _p(xyz), C, N, k, _p(idx), _stream())
+    return idx
+
+
+def fps(xyz, npoint, start=None):
+    """xyz [C,N,3]; start None (centre start) -> ids [C,npoint]; start [S,C] int32 -> ids [S,C,npoint]
+    (lib/utils.py:170-198)."""
+    xyz = _f32(xyz, "xyz")
+    assert xyz.is_contiguous()
+    C, N, _ = xyz.shape
+    if start is None:
+        ids = torch.empty((C, npoint), dtype=torch.int32, device=xyz.device)
+        _lib.call("ogmm_fps", _p(xyz), C, N, npoint, 1, None, _p(ids), _stream())
+        return ids
+    start = _i32(start, "start")
+    assert start.is_contiguous() and start.dim() == 2 and start.shape[1] == C
+    S = start.shape[0]
+    ids = torch.empty((S, C, npoint), dtype=torch.int32, device=xyz.device)
+    _lib.call("ogmm_fps", _p(xyz), C, N, npoint, S, _p(start), _p(ids), _stream())
+    return ids
+
+
+def gather_rows(feats, ld, C, N, D, ids, cloud_map=None):
+    """feats rows [(C*N), ld] -> [C,S,D] with out[c,s] = feats[map(c)*N + ids[map(c),s]]   (lib/utils.py:111-127)."""
+    feats, ids = _f32(feats, "feats"), _i32(ids, "ids")
+    assert ids.is_contiguous() and ids.shape[0] == C
+    S = ids.shape[1]
+    out = torch.empty((C, S, D), dtype=torch.float32, device=feats.device)
+    if cloud_map is not None:
+        cloud_map = _i32(cloud_map, "cloud_map")
+    _lib.call("ogmm_gather_rows", _p(feats), ld, C, N, D, _p(ids), S, _p(cloud_map), _p(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- GEMM engine
+def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
+            alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
+            pool_k=0, pool_out=None, ldp=0, store_c=True):
+    """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`."""
+    d = GemmDesc()
+    d.A, d.lda, d.K1 = A.data_ptr(), lda, K1
+    d.A2, d.lda2, d.K2 = (A2.data_ptr() if A2 is not None else None), lda2, K2
+    d.B, d.ldb = B.data_ptr(), ldb
+    d.C, d.ldc = (C.data_ptr() if C is not None else None), ldc
+    d.Res, d.ldr = (res.data_ptr() if res is not None else None), ldr
+    d.M, d.N = M, N
+    d.batch_outer, d.batch_inner = batch
+    d.sA_o, d.sA_i = sA
+    d.sA2_o, d.sA2_i = sA2
+    d.sB_o, d.sB_i = sB
+    d.sC_o, d.sC_i = sC
+    d.sR_o, d.sR_i = sR
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.shift = shift.data_ptr() if shift is not None else None
+    d.row_affine = 1 if row_affine else 0
+    d.alpha = alpha
+    d.act = act
+    d.pool_k, d.pool_out, d.ldp, d.store_c = pool_k, (pool_out.data_ptr() if pool_out is not None else None), ldp, 1 if store_c else 0
+    _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
+
+
+def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None):
+    """y[rows, Cout] = act((x | x2)[rows, K] @ W^T * scale + shift) + res for a packed layer
+    (dict with W [Cout, Kpad], scale, shift -- see gmmreg.pack_*).  x, x2, res, out may be column views
+    of wider row-major buffers (last stride 1)."""
+    x = _f32(x, "x")
+    rows, K1 = x.shape
+    assert x.stride(1) == 1
+    W = layer["W"]
+    Cout, Kp = W.shape
+    K2 = 0
+    if x2 is not None:
+        assert x2.stride(1) == 1 and x2.shape[0] == rows
+        K2 = x2.shape[1]
+    assert K1 + K2 == Kp, "conv1x1: input channels %d+%d != packed K %d" % (K1, K2, Kp)
+    if out is None:
+        out = torch.empty((rows, Cout), dtype=torch.float32, device=x.device)
+    assert out.stride(1) == 1 and out.shape == (rows, Cout)
+    if res is not None:
+        assert res.stride(1) == 1 and res.shape == (rows, Cout)
+    gemm_nt(x, x.stride(0), K1, W, Kp, rows, Cout, C=out, ldc=out.stride(0),
+            A2=x2, lda2=(x2.stride(0) if x2 is not None else 0), K2=K2,
+            scale=layer.get("scale"), shift=layer.get("shift"), act=act,
+            res=res, ldr=(res.stride(0) if res is not None else 0))
+    return out
+
+
+def edgeconv_first(xyz, idx, layer, pool_out):
+    """-> h1 [C*N*k, 64]; pooled max written into pool_out[:, :64]   (models/dgcnn.py:137-139)."""
+    C, N, k = idx.shape
+    h1 = torch.empty((C * N * k, 64), dtype=torch.float32, device=xyz.device)
+    _lib.call("ogmm_edgeconv_first", _p(_f32(xyz, "xyz")), _p(_i32(idx, "idx")), C, N, k, _p(layer["W"]), _p(layer["scale"]),
+              _p(layer["shift"]), _p(h1), _p(pool_out), pool_out.stride(0), _stream())
+    return h1
+
+
+def edgeconv_layer(h, layer, k, pool_out, store=True):
+    """conv + BN + ReLU on the per-edge tensor h [E, Cin] with max over each point's k edges fused in
+    (models/dgcnn.py:141-148).  Returns the un-pooled [E, Cout] (None when store=False)."""
+    E, Cin = h.shape
+    W = layer["W"]
+    Cout = W.shape[0]
+    out = torch.empty((E, Cout), dtype=torch.float32, device=h.device) if store else None
+    gemm_nt(h, h.stride(0), Cin, W, W.shape[1], E, Cout, C=out, ldc=Cout, scale=layer["scale"], shift=layer["shift"],
+            act=ACT_RELU, pool_k=k, pool_out=pool_out, ldp=pool_out.stride(0), store_c=store)
+    return out
+
+
+def pos_hidden(xyz, idx, k_pos, p):
+    C, N, _ = xyz.shape
+    hd = torch.empty((C * N, 64), dtype=torch.float32, device=xyz.device)
+    ha = torch.empty_like(hd)
+    _lib.call("ogmm_pos_hidden", _p(xyz), _p(_i32(idx, "idx")), idx.shape[2], k_pos, C, N, _p(p["w_dis"]), _p(p["s_dis"]), _p(p["t_dis"]),
+              _p(p["w_ang"]), _p(p["s_ang"]), _p(p["t_ang"]), _p(hd), _p(ha), _stream())
+    return hd, ha
+
+
+# ---------------------------------------------------------------------------------------------- row / column kernels
+def softmax_rows_(x2d):
+    assert x2d.stride(1) == 1
+    _lib.call("ogmm_softmax_rows", _p(_f32(x2d, "x")), x2d.shape[0], x2d.shape[1], x2d.stride(0), _stream())
+    return x2d
+
+
+def instnorm_relu_(x, C, N, eps=1e-5):
+    """x [(C*N), D] row-major (stride(0) = ld): InstanceNorm over the N rows of each cloud + ReLU, in place."""
+    assert x.stride(1) == 1 and x.shape[0] == C * N
+    _lib.call("ogmm_instnorm_relu", _p(_f32(x, "x")), x.stride(0), C, N, x.shape[1], eps, _stream())
+    return x
+
+
+def l2norm_rows(x, out=None):
+    assert x.stride(1) == 1
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.call("ogmm_l2norm_rows", _p(_f32(x, "x")), x.stride(0), x.shape[0], x.shape[1], _p(out), out.stride(0), _stream())
+    return out
+
+
+def rowdot(x, w, b, act, out, ldy=1):
+    """out[m*ldy] = act(x[m,:] . w + b)."""
+    assert x.stride(1) == 1
+    _lib.call("ogmm_rowdot", _p(_f32(x, "x")), x.stride(0), x.shape[0], x.shape[1], _p(w), _p(b), act, _p(out), ldy, _stream())
+    return out
+
+
+def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo):
+    B, N, _ = S.shape
+    _lib.call("ogmm_overlap_cross", _p(_f32(S, "S")), B, N, _p(o_src), _p(o_tgt), ldo_in, _p(wo_src), _p(wo_tgt), ldo, _stream())
+
+
+# ---------------------------------------------------------------------------------------------- GMM head
+def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0):
+    """-> gamma [C,N,J], pi [C,J], mu [C,J,3]   (lib/utils.py:269-288)."""
+    C, N, _ = xyz.shape
+    J = ids0.shape[1]
+    assert o.is_contiguous() and o.shape == (C, N) and ids0.is_contiguous()
+    gamma = torch.empty((C, N, J), dtype=torch.float32, device=xyz.device)
+    pi = torch.empty((C, J), dtype=torch.float32, device=xyz.device)
+    mu = torch.empty((C, J, 3), dtype=torch.float32, device=xyz.device)
+    _lib.call("ogmm_gmm_em", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
+              _p(gamma), _p(pi), _p(mu), _stream())
+    return gamma, pi, mu
+
+
+def gmm_feat_mean(gamma, pi, feats, C, N):
+    J, D = gamma.shape[2], feats.shape[1]
+    assert feats.stride(1) == 1 and feats.shape[0] == C * N
+    out = torch.empty((C, J, D), dtype=torch.float32, device=feats.device)
+    _lib.call("ogmm_gmm_feat_mean", _p(_f32(gamma, "gamma")), _p(_f32(pi, "pi")), _p(_f32(feats, "feats")), feats.stride(0), C, N, J, D,
+              _p(out), _stream())
+    return out
+
+
+def match_kabsch(mu_s, mu_t, f_s, f_t, temperature=0.05, want_scores=False):
+    """mu_* [B,J,3], f_* [B,J,D] (contiguous) -> R [B,3,3], t [B,3] (, scores [B,J,J])   (models/dgcnn.py:96-115)."""
+    B, J, D = f_s.shape
+    for t_ in (mu_s, mu_t, f_s, f_t):
+        assert _f32(t_, "match input").is_contiguous()
+    R = torch.empty((B, 3, 3), dtype=torch.float32, device=f_s.device)
+    t = torch.empty((B, 3), dtype=torch.float32, device=f_s.device)
+    sc = torch.empty((B, J, J), dtype=torch.float32, device=f_s.device) if want_scores else None
+    _lib.call("ogmm_match_kabsch", _p(mu_s), _p(mu_t), _p(f_s), _p(f_t), B, J, D, temperature, _p(R), _p(t), _p(sc), _stream())
+    return (R, t, sc) if want_scores else (R, t)
+
+
+def kabsch(src, corr, w):
+    """src, corr [B,3,J], w [B,1,J] or [B,J] -> R [B,3,3], t [B,3,1]   (lib/se3.py:256-289)."""
+    src, corr = _f32(src, "src").contiguous(), _f32(corr, "corr").contiguous()
+    B, _, J = src.shape
+    w = _f32(w, "w").reshape(B, J).contiguous()
+    R = torch.empty((B, 3, 3), dtype=torch.float32, device=src.device)
+    t = torch.empty((B, 3, 1), dtype=torch.float32, device=src.device)
+    _lib.call("ogmm_kabsch", _p(src), _p(corr), _p(w), B, J, _p(R), _p(t), _stream())
+    return R, t
+
+
+def clu_infonce(xyz, mu, feats, mu_feat, C, N, tau=0.1):
+    """-> (row_loss [C,2,J], near [C,J] int32)   (lib/loss.py:109-118, :22-57; lib/utils.py:244-254)."""
+    J, D = mu_feat.shape[1], mu_feat.shape[2]
+    assert feats.stride(1) == 1 and mu.is_contiguous() and mu_feat.is_contiguous()
+    row_loss = torch.empty((C, 2, J), dtype=torch.float32, device=xyz.device)
+    near = torch.empty((C, J), dtype=torch.int32, device=xyz.device)
+    _lib.call("ogmm_clu_infonce", _p(_f32(xyz, "xyz")), _p(_f32(mu, "mu")), _p(_f32(feats, "feats")), feats.stride(0), _p(mu_feat), C, N, J, D,
+              tau, _p(row_loss), _p(near), _stream())
+    return row_loss, near
