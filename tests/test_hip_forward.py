@@ -1,0 +1,109 @@
+"""GPU: GMMReg.forward on the HIP path against (a) the golden fixtures produced by the reference itself and
+(b) the CPU oracle run live on the same seeded inputs.  Target (BASELINE.json north_star): R within 1e-5 rad,
+t within 1e-5 units; discrete intermediates (kNN graph, FPS chains) identical."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names
+from oracle import ogmm_oracle as O
+from ogmm_amd import synth
+from ogmm_amd.gmmreg import GMMReg
+
+pytestmark = pytest.mark.gpu
+
+R_TOL = 1e-5      # rad
+T_TOL = 1e-5      # cloud units
+O_TOL = 5e-6      # overlap scores in (0,1)
+LOSS_TOL = 5e-5
+
+
+def build(cfg, J):
+    m = GMMReg(512, J, cfg)
+    synth.fill_state_dict(m.state_dict())
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    return m.cuda().eval(), P
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_forward_matches_reference_golden(golden, name):
+    fx = golden(name)
+    B, N, J, k, M, D, H = [int(v) for v in fx["meta"]]
+    cfg = Namespace(gnn_k=k, num_heads=H, km_clusters=M, overlap_radius=0.035, n_clusters=J)
+    model, _ = build(cfg, J)
+    src, tgt = torch.from_numpy(fx["src"]).cuda(), torch.from_numpy(fx["tgt"]).cuda()
+    with torch.no_grad():
+        R, t, so, to, loss = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]), capture=True)
+    cap = model.last_intermediates
+    idx = cap["knn_idx"].cpu().numpy()
+    assert np.array_equal(idx[:B], fx["knn_idx_src"]) and np.array_equal(idx[B:], fx["knn_idx_tgt"])
+    ids = cap["fps_anchor"].cpu().numpy()
+    for st in range(3):
+        assert np.array_equal(ids[st, :B], fx["fps%d_src" % st]) and np.array_equal(ids[st, B:], fx["fps%d_tgt" % st])
+    idj = cap["fps_J"].cpu().numpy()
+    assert np.array_equal(idj[:B], fx["fpsJ_src"]) and np.array_equal(idj[B:], fx["fpsJ_tgt"])
+    for key, g in (("emb", cap["emb"]), ("ft", cap["ft"]), ("f", cap["f"]), ("f2", cap["f2"])):
+        got = g.view(2 * B, N, D)[:, :, :8].transpose(1, 2).cpu().numpy()
+        ref = np.concatenate([fx[key + "8_src"], fx[key + "8_tgt"]], 0)
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), key
+    assert O.rotation_error_rad(R.cpu(), torch.from_numpy(fx["R"])).max().item() < R_TOL
+    assert O.translation_error(t.cpu(), torch.from_numpy(fx["t"])).max().item() < T_TOL
+    assert np.abs(so.cpu().numpy() - fx["src_o"]).max() < O_TOL and np.abs(to.cpu().numpy() - fx["tgt_o"]).max() < O_TOL
+    assert abs(loss.item() - float(fx["loss"])) < LOSS_TOL
+
+
+def test_forward_matches_oracle_live_batch():
+    """BASELINE configs[1] shape at a batch the CPU oracle finishes in seconds; also checks batch invariance
+    (pairs are independent: SURVEY.md 8e) by comparing against a B=1 run of one of the pairs."""
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    B, N = 6, 1024
+    model, P = build(cfg, 16)
+    src, tgt, _, _ = synth.make_batch(1000, B, N, "partial")
+    starts = synth.fps_starts_for(1000, B, N)
+    with torch.no_grad():
+        R, t, so, to, loss = model(src.cuda(), tgt.cuda(), fps_starts=starts)
+        Ro, to_, soo, too, losso = O.forward(P, cfg, src, tgt, starts)
+        R1, t1, so1, _, _ = model(src[3:4].cuda(), tgt[3:4].cuda(), fps_starts=starts[:, 3:4])
+    assert O.rotation_error_rad(R.cpu(), Ro).max().item() < R_TOL
+    assert O.translation_error(t.cpu(), to_).max().item() < T_TOL
+    assert (so.cpu() - soo).abs().max().item() < O_TOL and (to.cpu() - too).abs().max().item() < O_TOL
+    assert abs(loss.item() - losso.item()) < LOSS_TOL
+    assert O.rotation_error_rad(R1.cpu(), R[3:4].cpu()).max().item() < 2e-6
+    assert (so1.cpu() - so[3:4].cpu()).abs().max().item() < 2e-6
+
+
+def test_forward_draws_fps_starts_like_the_reference():
+    """With fps_starts=None the six draws come from torch's global CPU generator in the reference's order."""
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=64, overlap_radius=0.035, n_clusters=16)
+    model, _ = build(cfg, 16)
+    src, tgt, _, _ = synth.make_batch(7, 2, 256, "clean")
+    torch.manual_seed(99)
+    expect = O.draw_fps_starts(2, 256)
+    torch.manual_seed(99)
+    with torch.no_grad():
+        a = model(src.cuda(), tgt.cuda(), capture=True)
+        ids_a = model.last_intermediates["fps_anchor"].clone()
+        b = model(src.cuda(), tgt.cuda(), fps_starts=expect, capture=True)
+    assert torch.equal(ids_a, model.last_intermediates["fps_anchor"])
+    assert torch.equal(a[0], b[0])
+
+
+def test_full_size_properties_config1():
+    """BASELINE configs[1] at full size (B=64): no oracle at this size in the time budget, so size-independent
+    properties: rotations are proper, overlap in (0,1), finite loss, and sharding the batch does not change results."""
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    model, _ = build(cfg, 16)
+    B, N = 64, 1024
+    src, tgt, _, _ = synth.make_batch(0, B, N, "partial")
+    starts = synth.fps_starts_for(0, B, N)
+    with torch.no_grad():
+        R, t, so, to, loss = model(src.cuda(), tgt.cuda(), fps_starts=starts)
+        Rh, th, soh, _, _ = model(src[32:].cuda(), tgt[32:].cuda(), fps_starts=starts[:, 32:])
+    Rd = R.double().cpu()
+    assert (Rd @ Rd.transpose(1, 2) - torch.eye(3, dtype=torch.double)).abs().max().item() < 1e-5
+    assert (torch.det(Rd) - 1).abs().max().item() < 1e-5
+    assert 0 < float(so.min()) and float(so.max()) < 1 and torch.isfinite(loss)
+    assert O.rotation_error_rad(Rh.cpu(), R[32:].cpu()).max().item() < 2e-6
+    assert (soh.cpu() - so[32:].cpu()).abs().max().item() < 2e-6

@@ -1,0 +1,248 @@
+"""GPU: every C-ABI entry point against the matching oracle function on the same seeded inputs.
+Tolerances are stated per test: discrete outputs must be identical; fp32 contractions are compared with an
+fp64 evaluation of the same formula at a few ulp of the accumulated magnitude."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ogmm_oracle as O
+from ogmm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from ogmm_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def clouds(C, N, seed=0, kind="partial"):
+    src, tgt, _, _ = synth.make_batch(seed, (C + 1) // 2, N, kind)
+    return torch.cat([src, tgt], 0)[:C].transpose(1, 2).contiguous()      # [C,N,3]
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("C,N,k", [(4, 1024, 20), (3, 200, 12), (2, 2048, 5), (2, 717, 20), (1, 64, 32), (2, 33, 1)])
+def test_knn_identical_indices(ops, C, N, k):
+    xyz = clouds(C, N, seed=11)
+    ref = O.knn_indices(xyz, k)
+    got = ops.knn(dev(xyz), k).cpu().long()
+    assert torch.equal(got, ref), "mismatching rows: %d" % int((got != ref).any(-1).sum())
+
+
+def test_knn_duplicate_points_ties(ops):
+    """Exact duplicates tie at the clamped distance 1e-12; the neighbour SET must agree in distance terms."""
+    xyz = clouds(1, 256, seed=5)
+    xyz[0, 100:110] = xyz[0, 0:10]
+    d = O.sq_dist_expanded(xyz, xyz)
+    got = ops.knn(dev(xyz), 8).cpu().long()
+    ref = O.knn_indices(xyz, 8)
+    assert torch.equal(torch.gather(d, 2, got), torch.gather(d, 2, ref))      # same sorted distance values
+
+
+# ------------------------------------------------------------------------------------------------ K5 / K6
+@pytest.mark.parametrize("C,N,npoint", [(4, 1024, 128), (2, 717, 128), (3, 200, 32), (2, 2048, 64), (1, 4096, 16)])
+def test_fps_identical_chains(ops, C, N, npoint):
+    xyz = clouds(C, N, seed=21)
+    g = torch.Generator().manual_seed(1)
+    start = torch.randint(0, N, (3, C), generator=g)
+    got = ops.fps(dev(xyz), npoint, dev(start.int())).cpu().long()
+    for s in range(3):
+        assert torch.equal(got[s], O.fps(xyz, npoint, start[s])), "random-start chain %d differs" % s
+    got_c = ops.fps(dev(xyz), npoint, None).cpu().long()
+    ref_c = O.fps(xyz, npoint, None)
+    assert torch.equal(got_c, ref_c), "centre-start chain differs in %d clouds" % int((got_c != ref_c).any(-1).sum())
+
+
+def test_gather_rows_with_cloud_swap(ops):
+    C, N, D, S = 4, 50, 64, 7
+    feats = torch.randn(C * N, D)
+    ids = torch.randint(0, N, (C, S))
+    swap = torch.tensor([2, 3, 0, 1])
+    got = ops.gather_rows(dev(feats), D, C, N, D, dev(ids.int()), dev(swap.int())).cpu()
+    ref = O.gather_rows(feats.view(C, N, D), ids)[swap]
+    assert torch.equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM engine
+def _gemm_ref(A, B):
+    return (A.double() @ B.double().t())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 70, 36), (128, 128, 32), (1000, 512, 512), (129, 65, 4), (2048, 1024, 1024)])
+def test_gemm_plain(ops, M, N, K):
+    torch.manual_seed(M + N + K)
+    A, B = torch.randn(M, K), torch.randn(N, K)
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(dev(A), K, K, dev(B), K, M, N, C=out, ldc=N)
+    ref = _gemm_ref(A, B)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 4e-7 * K ** .5 * 4 + 1e-6, err          # fp32 fma-chain roundoff for |a|,|b| ~ 1
+
+
+def test_gemm_detects_transposition(ops):
+    """A = identity, asymmetric B (guide rule: symmetric inputs hide a swapped C write)."""
+    n = 96
+    A = torch.eye(n)
+    B = torch.arange(n * n, dtype=torch.float32).view(n, n) / 7.0
+    out = torch.empty(n, n, device="cuda")
+    ops.gemm_nt(dev(A), n, n, dev(B), n, n, n, C=out, ldc=n)
+    assert torch.equal(out.cpu(), B.t().contiguous())
+
+
+def test_gemm_two_pieces_epilogue_residual(ops):
+    torch.manual_seed(0)
+    M, N, K1, K2 = 333, 200, 64, 4
+    A1, A2, B = torch.randn(M, K1), torch.randn(M, K2), torch.randn(N, K1 + K2)
+    scale, shift, res = torch.rand(N) + 0.5, torch.randn(N), torch.randn(M, N)
+    for act, fn in ((ops.ACT_RELU, torch.relu), (ops.ACT_LEAKY02, lambda v: torch.nn.functional.leaky_relu(v, 0.2)),
+                    (ops.ACT_SIGMOID, torch.sigmoid), (ops.ACT_NONE, lambda v: v)):
+        out = torch.empty(M, N, device="cuda")
+        ops.gemm_nt(dev(A1), K1, K1, dev(B), K1 + K2, M, N, C=out, ldc=N, A2=dev(A2), lda2=K2, K2=K2, scale=dev(scale), shift=dev(shift),
+                    alpha=0.5, act=act, res=dev(res), ldr=N)
+        ref = fn(0.5 * _gemm_ref(torch.cat([A1, A2], 1), B) * scale.double() + shift.double()) + res.double()
+        assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def test_gemm_batched_strided_row_affine(ops):
+    torch.manual_seed(1)
+    Co, Hh, N, M, dh = 3, 4, 130, 32, 16
+    D = Hh * dh
+    q, kk = torch.randn(Co * N, D), torch.randn(Co * M, D)
+    S = torch.empty(Co, Hh, N, M, device="cuda")
+    ops.gemm_nt(dev(q), D, dh, dev(kk), D, N, M, C=S, ldc=M, alpha=0.25, batch=(Co, Hh), sA=(N * D, dh), sB=(M * D, dh), sC=(Hh * N * M, N * M))
+    ref = 0.25 * torch.einsum("cnhd,cmhd->chnm", q.view(Co, N, Hh, dh).double(), kk.view(Co, M, Hh, dh).double())
+    assert (S.cpu().double() - ref).abs().max().item() < 1e-5
+    W, bias, anchors = torch.randn(D, D), torch.randn(D), torch.randn(Co, M, D)
+    vT = torch.empty(Co, D, M, device="cuda")
+    ops.gemm_nt(dev(W), D, D, dev(anchors), D, D, M, C=vT, ldc=M, shift=dev(bias), row_affine=True, batch=(Co, 1), sB=(M * D, 0), sC=(D * M, 0))
+    ref = torch.einsum("ok,cmk->com", W.double(), anchors.double()) + bias.double()[None, :, None]
+    assert (vT.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("k,Cout", [(20, 64), (20, 128), (12, 256), (7, 64)])
+def test_gemm_edge_pooling(ops, k, Cout):
+    torch.manual_seed(k)
+    P, Cin = 37, 64
+    h = torch.randn(P * k, Cin)
+    W, s, t = torch.randn(Cout, Cin) / 8, torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
+    pool = torch.full((P, 512), -1.0, device="cuda")
+    out = ops.edgeconv_layer(dev(h), {"W": dev(W), "scale": dev(s), "shift": dev(t)}, k, pool[:, 64:64 + Cout])
+    ref = torch.relu(_gemm_ref(h, W) * s.double() + t.double())
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-5
+    assert (pool[:, 64:64 + Cout].cpu().double() - ref.view(P, k, Cout).max(1)[0]).abs().max().item() < 1e-5
+    assert bool((torch.cat([pool[:, :64], pool[:, 64 + Cout:]], 1) == -1.0).all()), "pooled write left its column slab"
+    pool2 = torch.zeros((P, Cout), device="cuda")
+    assert ops.edgeconv_layer(dev(h), {"W": dev(W), "scale": dev(s), "shift": dev(t)}, k, pool2, store=False) is None
+    assert torch.equal(pool2, pool[:, 64:64 + Cout].contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ row / column kernels
+def test_softmax_instnorm_l2norm_rowdot(ops):
+    torch.manual_seed(2)
+    x = torch.randn(1000, 128) * 3
+    got = ops.softmax_rows_(dev(x)).cpu()
+    assert (got - torch.softmax(x, -1)).abs().max().item() < 2e-7
+    C, N, D = 3, 717, 192
+    z = torch.randn(C * N, D) * 2 + 0.3
+    got = ops.instnorm_relu_(dev(z), C, N).cpu()
+    ref = torch.relu(torch.nn.functional.instance_norm(z.view(C, N, D).transpose(1, 2), eps=1e-5)).transpose(1, 2).reshape(C * N, D)
+    assert (got - ref).abs().max().item() < 2e-6
+    y = torch.randn(500, 512)
+    assert (ops.l2norm_rows(dev(y)).cpu() - torch.nn.functional.normalize(y, dim=1)).abs().max().item() < 2e-7
+    w, b = torch.randn(512) / 20, torch.randn(1)
+    out = torch.empty(500, device="cuda")
+    ops.rowdot(dev(y), dev(w), dev(b), ops.ACT_SIGMOID, out)
+    assert (out.cpu() - torch.sigmoid(y @ w + b)).abs().max().item() < 1e-6
+
+
+def test_overlap_cross(ops):
+    torch.manual_seed(3)
+    B, N = 2, 300
+    S = torch.rand(B, N, N) * 2 - 1
+    o = torch.randn(2 * B * N, 4)
+    out = torch.zeros(2 * B * N, 4, device="cuda")
+    od = dev(o)
+    ops.overlap_cross(dev(S), od[:B * N, 1], od[B * N:, 1], 4, out[:B * N, 0], out[B * N:, 0], 4)
+    o_src, o_tgt = o[:B * N, 1].view(B, 1, N), o[B * N:, 1].view(B, 1, N)
+    wo_s = torch.einsum("bmn,bdn->bdm", torch.softmax(S, -1), o_src).reshape(-1)      # models/gmmreg.py:79
+    wo_t = torch.einsum("bmn,bdm->bdn", torch.softmax(S, 1), o_tgt).reshape(-1)       # models/gmmreg.py:80
+    assert (out[:B * N, 0].cpu() - wo_s).abs().max().item() < 1e-6
+    assert (out[B * N:, 0].cpu() - wo_t).abs().max().item() < 1e-6
+    assert float(out[:, 1:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ GMM head
+@pytest.mark.parametrize("C,N,J", [(4, 1024, 16), (2, 717, 128), (2, 2048, 64), (3, 200, 8)])
+def test_gmm_em_and_feat_mean(ops, C, N, J):
+    torch.manual_seed(N + J)
+    xyz = clouds(C, N, seed=31)
+    o = torch.sigmoid(torch.randn(C, N))
+    feats = torch.randn(C, N, 64)
+    st = []
+    gamma, pi, mu, muf, ids = O.weighted_em(xyz, feats, o, J, stats=st)
+    assert set(st) == {10}
+    ids_g = ops.fps(dev(xyz), J, None)
+    assert torch.equal(ids_g.cpu().long(), ids)
+    g_gamma, g_pi, g_mu = ops.gmm_em(dev(xyz), dev(o), ids_g)
+    # fp64 run of the same algorithm = the yardstick both fp32 paths are measured against
+    gd, pid, mud, _, _ = O.weighted_em(xyz.double(), feats.double(), o.double(), J)
+    ref_err = max((pi - pid).abs().max().item(), (mu - mud).abs().max().item())
+    got_err = max((g_pi.cpu() - pid).abs().max().item(), (g_mu.cpu() - mud).abs().max().item())
+    assert got_err < max(4 * ref_err, 2e-6), (got_err, ref_err)
+    assert (g_gamma.cpu() - gd).abs().max().item() < max(4 * (gamma - gd).abs().max().item(), 2e-5)
+    g_muf = ops.gmm_feat_mean(g_gamma, g_pi, dev(feats.view(C * N, 64)), C, N)
+    mufd = O.gmm_moments(g_gamma.cpu().double(), feats.double())[1]
+    assert (g_muf.cpu() - mufd).abs().max().item() < 2e-5
+
+
+def test_kabsch_matches_lapack_and_fixes_reflections(ops):
+    torch.manual_seed(4)
+    B, J = 64, 16
+    src = torch.randn(B, 3, J)
+    Rg = torch.linalg.qr(torch.randn(B, 3, 3))[0]
+    Rg = Rg * torch.sign(torch.det(Rg))[:, None, None]
+    corr = Rg @ src + torch.randn(B, 3, 1) + 0.05 * torch.randn(B, 3, J)
+    corr[:8] = corr[:8] * torch.tensor([1.0, 1.0, -1.0])[None, :, None]         # mirrored targets: det(V U^T) < 0 branch
+    src[8:12, 2] = 0.0                                                          # coplanar sources
+    w = torch.rand(B, 1, J)
+    R, t = ops.kabsch(dev(src), dev(corr), dev(w))
+    Ro, to = O.kabsch(src.double(), corr.double(), w.double())
+    assert O.rotation_error_rad(R.cpu(), Ro).max().item() < 2e-6
+    assert (t.cpu().double() - to).abs().max().item() < 2e-6
+    assert (torch.det(R.cpu().double()) - 1).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("B,J,D", [(4, 16, 512), (2, 128, 512), (3, 8, 64)])
+def test_match_kabsch(ops, B, J, D):
+    torch.manual_seed(J)
+    mu_s, mu_t = torch.randn(B, J, 3), torch.randn(B, J, 3)
+    f_s = torch.randn(B, J, D)
+    f_t = f_s[:, torch.randperm(J)] + 0.3 * torch.randn(B, J, D)
+    R, t, sc = ops.match_kabsch(dev(mu_s), dev(mu_t), dev(f_s), dev(f_t), 0.05, want_scores=True)
+    Ro, to, sco = O.match_and_solve(mu_s.double(), mu_t.double(), f_s.double(), f_t.double())
+    assert (sc.cpu().double() - sco).abs().max().item() < 2e-5
+    assert O.rotation_error_rad(R.cpu(), Ro).max().item() < 1e-5
+    assert (t.cpu().double() - to).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("C,N,J,D", [(4, 1024, 16, 512), (2, 300, 64, 128)])
+def test_clu_infonce(ops, C, N, J, D):
+    torch.manual_seed(7)
+    xyz = clouds(C, N, seed=41)
+    feats = torch.randn(C, N, D)
+    mu = xyz[:, torch.randperm(N)[:J]] + 0.01 * torch.randn(C, J, 3)
+    muf = torch.randn(C, J, D)
+    row_loss, near = ops.clu_infonce(dev(xyz), dev(mu), dev(feats.view(C * N, D)), dev(muf), C, N, 0.1)
+    anchors, near_o = O.nearest_feats(xyz, mu, feats)
+    assert torch.equal(near.cpu().long(), near_o)
+    ref = O.info_nce(anchors.double(), muf.double(), 0.1)
+    assert abs(row_loss.mean().item() - ref.item()) < 1e-5
