@@ -36,8 +36,10 @@ const char* ogmm_last_error(void);
 /* ---- K1: kNN graph.  lib/utils.py:12-44 (square_distance + knn); callers models/dgcnn.py:135,
  * lib/utils.py:52 <- models/attn.py:69.
  * dist(i,j) = max(1e-12, (-2 * fma(z_i,z_j, fma(y_i,y_j, x_i*x_j)) + |p_i|^2) + |p_j|^2)  -- the exact
- * fp32 rounding sequence of the reference on CPU, so index sets reproduce bit-for-bit; the k
- * smallest in ascending order, ties towards the lower index.  1 <= k <= 32, k <= N. */
+ * fp32 rounding sequence of the reference on CPU, so distance rows reproduce bit-for-bit.  The kept SET is
+ * exactly the one torch.topk keeps, including when rank k is an exact tie (its CPU kernel's libstdc++
+ * heap-select / introselect is re-stated for such rows); the set is written in (distance, index) order
+ * (torch's order among equal distances is unspecified and no caller depends on it).  1 <= k <= 32, k <= N. */
 int ogmm_knn(const float* xyz /*[C][N][3]*/, int C, int N, int k, int32_t* idx /*[C][N][k]*/, void* stream);
 
 /* ---- K5: farthest point sampling.  lib/utils.py:170-198 (farthest_point_sample).

@@ -4,6 +4,7 @@
 // header for the probed rounding sequences), because 1-ulp differences flip neighbour sets / FPS chains
 // and every later feature depends on them (SURVEY.md section 7 "hard parts").
 #include "ogmm_common.h"
+#include "torch_topk_select.h"
 
 namespace {
 
@@ -11,11 +12,21 @@ using namespace ogmm;
 
 // ------------------------------------------------------------------------------------------------
 // kNN: one thread per query point, the whole cloud (x,y,z,|p|^2) resident in LDS, candidates are
-// visited in index order and kept in a sorted register list (strict '<' => ties keep the lower index).
+// visited in index order and kept in a sorted register list (strict '<' => ties keep the lower index); rows whose
+// k-th and (k+1)-th distances tie exactly are re-done with torch.topk's own (libstdc++) selection, see below.
 // HBM traffic is the compulsory 12 B/point in + 4k B/point out; the N x N distance matrix of
 // lib/utils.py:28-33 is never materialised.
 // ------------------------------------------------------------------------------------------------
-template <int KMAX>
+__device__ __forceinline__ float knn_dist(const float4 pq, const float4 pj) {
+    // torch.matmul with K=3: fma(z,z', fma(y,y', x*x'));  then -2*., + |q|^2, + |p_j|^2, clamp(1e-12)
+    const float dot = __fmaf_rn(pq.z, pj.z, __fmaf_rn(pq.y, pj.y, mul_rn(pq.x, pj.x)));
+    return fmaxf(add_rn(add_rn(mul_rn(-2.0f, dot), pq.w), pj.w), 1e-12f);
+}
+
+// KL = list length = largest supported k + 1: the extra slot holds the (k+1)-th smallest distance, which tells
+// whether rank k is an exact tie (then the row is marked by a negative first index and re-done by
+// knn_resolve_ties_kernel with torch.topk's own selection algorithm).
+template <int KL>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, int N, int k, int32_t* __restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) float4 pts[];   // [N]
     const int c = blockIdx.y;
@@ -28,28 +39,73 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= N) return;
     const float4 pq = pts[q];
-    float dk[KMAX];
-    int ik[KMAX];
+    float dk[KL];
+    int ik[KL];
 #pragma unroll
-    for (int p = 0; p < KMAX; ++p) { dk[p] = __builtin_inff(); ik[p] = 0; }
+    for (int p = 0; p < KL; ++p) { dk[p] = __builtin_inff(); ik[p] = 0; }
     for (int j = 0; j < N; ++j) {
-        const float4 pj = pts[j];
-        // torch.matmul with K=3: fma(z,z', fma(y,y', x*x'));  then -2*., + |q|^2, + |p_j|^2, clamp(1e-12)
-        const float dot = __fmaf_rn(pq.z, pj.z, __fmaf_rn(pq.y, pj.y, mul_rn(pq.x, pj.x)));
-        const float d = fmaxf(add_rn(add_rn(mul_rn(-2.0f, dot), pq.w), pj.w), 1e-12f);
-        if (d < dk[KMAX - 1]) {
+        const float d = knn_dist(pq, pts[j]);
+        if (d < dk[KL - 1]) {
 #pragma unroll
-            for (int p = KMAX - 1; p > 0; --p) {
+            for (int p = KL - 1; p > 0; --p) {
                 if (d < dk[p - 1]) { dk[p] = dk[p - 1]; ik[p] = ik[p - 1]; }
                 else if (d < dk[p]) { dk[p] = d; ik[p] = j; }
             }
             if (d < dk[0]) { dk[0] = d; ik[0] = j; }
         }
     }
+    float d_last = 0.0f, d_next = -1.0f;
+#pragma unroll
+    for (int p = 0; p < KL; ++p) {
+        if (p == k - 1) d_last = dk[p];
+        if (p == k) d_next = dk[p];
+    }
+    const bool boundary_tie = k < N && d_last == d_next;
     int32_t* out = idx + ((int64_t)c * N + q) * k;
 #pragma unroll
-    for (int p = 0; p < KMAX; ++p)
-        if (p < k) out[p] = ik[p];
+    for (int p = 0; p < KL - 1; ++p)
+        if (p < k) out[p] = (p == 0 && boundary_tie) ? ~ik[0] : ik[p];
+}
+
+// Rows marked by knn_kernel: rebuild the row's N candidates in index order and keep what torch.topk keeps
+// (torch_topk_select.h); the kept set is then written in (distance, index) order.  ~6e-5 of rows take this path.
+__global__ __launch_bounds__(256) void knn_resolve_ties_kernel(const float* __restrict__ xyz, int N, int k, int64_t total_rows,
+                                                               int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) ogmm_select::Cand cand[];   // [N]
+    __shared__ int flagged[256];
+    __shared__ int n_flagged;
+    const int tid = threadIdx.x;
+    if (tid == 0) n_flagged = 0;
+    __syncthreads();
+    const int64_t my_row = (int64_t)blockIdx.x * 256 + tid;
+    if (my_row < total_rows && idx[my_row * k] < 0) flagged[atomicAdd(&n_flagged, 1)] = tid;
+    __syncthreads();
+    const int nf = n_flagged;
+    for (int f = 0; f < nf; ++f) {
+        const int64_t row = (int64_t)blockIdx.x * 256 + flagged[f];
+        const int64_t c = row / N;
+        const int q = (int)(row % N);
+        const float* __restrict__ cloud = xyz + c * N * 3;
+        const float qx = cloud[3 * q], qy = cloud[3 * q + 1], qz = cloud[3 * q + 2];
+        const float4 pq = make_float4(qx, qy, qz, sqnorm3(qx, qy, qz));
+        for (int j = tid; j < N; j += 256) {
+            const float x = cloud[3 * j], y = cloud[3 * j + 1], z = cloud[3 * j + 2];
+            cand[j].v = knn_dist(pq, make_float4(x, y, z, sqnorm3(x, y, z)));
+            cand[j].i = j;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            ogmm_select::torch_topk_smallest_set(cand, N, k);
+            for (int a = 1; a < k; ++a) {       // order the kept set by (distance, index)
+                const ogmm_select::Cand v = cand[a];
+                int b = a;
+                while (b > 0 && (v.v < cand[b - 1].v || (v.v == cand[b - 1].v && v.i < cand[b - 1].i))) { cand[b] = cand[b - 1]; --b; }
+                cand[b] = v;
+            }
+            for (int a = 0; a < k; ++a) idx[row * k + a] = cand[a].i;
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,10 +216,14 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     dim3 grid((N + 255) / 256, C);
     const size_t lds = (size_t)N * sizeof(float4);
     hipStream_t s = ogmm::as_stream(stream);
-    if (k <= 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(256), lds, s, xyz, N, k, idx);
-    else if (k <= 20) hipLaunchKernelGGL(knn_kernel<20>, grid, dim3(256), lds, s, xyz, N, k, idx);
-    else hipLaunchKernelGGL(knn_kernel<32>, grid, dim3(256), lds, s, xyz, N, k, idx);
-    return ogmm::check_launch("ogmm_knn");
+    if (k <= 8) hipLaunchKernelGGL(knn_kernel<9>, grid, dim3(256), lds, s, xyz, N, k, idx);
+    else if (k <= 20) hipLaunchKernelGGL(knn_kernel<21>, grid, dim3(256), lds, s, xyz, N, k, idx);
+    else hipLaunchKernelGGL(knn_kernel<33>, grid, dim3(256), lds, s, xyz, N, k, idx);
+    if (int rc = ogmm::check_launch("ogmm_knn")) return rc;
+    const int64_t rows = (int64_t)C * N;
+    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)N * sizeof(ogmm_select::Cand), s, xyz,
+                       N, k, rows, idx);
+    return ogmm::check_launch("ogmm_knn(resolve ties)");
 }
 
 extern "C" int ogmm_fps(const float* xyz, int C, int N, int npoint, int n_sets, const int32_t* start, int32_t* ids, void* stream) {

@@ -269,7 +269,7 @@ class GMMReg(nn.Module):
         emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU)
 
         # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)
-        idx5 = idx if k >= 5 else ops.knn(xyz, 5)
+        idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
         hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])
         x0 = torch.empty((R, D), dtype=torch.float32, device=dev)
         ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2])

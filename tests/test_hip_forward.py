@@ -37,21 +37,34 @@ def test_forward_matches_reference_golden(golden, name):
     with torch.no_grad():
         R, t, so, to, loss = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]), capture=True)
     cap = model.last_intermediates
-    idx = cap["knn_idx"].cpu().numpy()
-    assert np.array_equal(idx[:B], fx["knn_idx_src"]) and np.array_equal(idx[B:], fx["knn_idx_tgt"])
+    # kNN graph: identical sorted distance rows and identical neighbour sets (order inside exact ties may differ)
+    idx = cap["knn_idx"].cpu().long()
+    ref_idx = torch.from_numpy(np.concatenate([fx["knn_idx_src"], fx["knn_idx_tgt"]], 0).astype(np.int64))
+    xyz = torch.cat([torch.from_numpy(fx["src"]), torch.from_numpy(fx["tgt"])], 0).transpose(1, 2).contiguous()
+    d = O.sq_dist_expanded(xyz, xyz)
+    assert torch.equal(torch.gather(d, 2, idx), torch.gather(d, 2, ref_idx))
+    set_differs = (idx.sort(-1)[0] != ref_idx.sort(-1)[0]).any(-1)
+    assert not bool(set_differs.any()), "neighbour sets differ from the reference in %d rows" % int(set_differs.sum())
     ids = cap["fps_anchor"].cpu().numpy()
     for st in range(3):
         assert np.array_equal(ids[st, :B], fx["fps%d_src" % st]) and np.array_equal(ids[st, B:], fx["fps%d_tgt" % st])
     idj = cap["fps_J"].cpu().numpy()
     assert np.array_equal(idj[:B], fx["fpsJ_src"]) and np.array_equal(idj[B:], fx["fpsJ_tgt"])
+    dk = d.topk(k + 1, dim=-1, largest=False)[0]
+    rep = {"rows_with_rank_k_tie": int((dk[:, :, k - 1] == dk[:, :, k]).sum())}
     for key, g in (("emb", cap["emb"]), ("ft", cap["ft"]), ("f", cap["f"]), ("f2", cap["f2"])):
         got = g.view(2 * B, N, D)[:, :, :8].transpose(1, 2).cpu().numpy()
         ref = np.concatenate([fx[key + "8_src"], fx[key + "8_tgt"]], 0)
-        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), key
-    assert O.rotation_error_rad(R.cpu(), torch.from_numpy(fx["R"])).max().item() < R_TOL
-    assert O.translation_error(t.cpu(), torch.from_numpy(fx["t"])).max().item() < T_TOL
-    assert np.abs(so.cpu().numpy() - fx["src_o"]).max() < O_TOL and np.abs(to.cpu().numpy() - fx["tgt_o"]).max() < O_TOL
-    assert abs(loss.item() - float(fx["loss"])) < LOSS_TOL
+        rep[key] = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+    rep["R"] = O.rotation_error_rad(R.cpu(), torch.from_numpy(fx["R"])).max().item()
+    rep["t"] = O.translation_error(t.cpu(), torch.from_numpy(fx["t"])).max().item()
+    rep["o"] = float(max(np.abs(so.cpu().numpy() - fx["src_o"]).max(), np.abs(to.cpu().numpy() - fx["tgt_o"]).max()))
+    rep["loss"] = abs(loss.item() - float(fx["loss"]))
+    print("PARITY", name, " ".join("%s=%.2e" % kv for kv in rep.items()))
+    for key in ("emb", "ft", "f", "f2"):
+        assert rep[key] < 2e-5, (key, rep)
+    assert rep["R"] < R_TOL and rep["t"] < T_TOL, rep
+    assert rep["o"] < O_TOL and rep["loss"] < LOSS_TOL, rep
 
 
 def test_forward_matches_oracle_live_batch():
