@@ -10,6 +10,11 @@ from . import _lib
 from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, GemmDesc  # noqa: F401
 
 
+# bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
+# entries are (start_event, end_event, algorithmic_flops)
+GEMM_TIMELINE = None
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -99,7 +104,14 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.alpha = alpha
     d.act = act
     d.pool_k, d.pool_out, d.ldp, d.store_c = pool_k, (pool_out.data_ptr() if pool_out is not None else None), ldp, 1 if store_c else 0
+    if GEMM_TIMELINE is None:
+        _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
+    e1.record()
+    GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * batch[0] * batch[1]))
 
 
 def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None):
