@@ -9,10 +9,14 @@ A step = one forward over one batch of 64 synthetic pairs already resident in HB
 independent, so ranks shard the global pair ids with no data-path collective (weak scaling); the only collectives are
 the barriers bracketing the timed region and a max over ranks of the elapsed time.  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel is the exact-fp32 MFMA GEMM engine (gemm_nt_kernel, ~95 % of the path's flops); its
-launches are timed live with events on the launch stream inside the timed region: achieved = sum of 2*M*N*K over the
-launches / sum of their durations, against the 157.3 TFLOP/s fp32-matrix peak of MI355X.  `path_frac` prices the whole
-forward (52.82 GFLOP/pair) against the same peak.
+roofline: the dominant kernel is the weight-GEMM engine (~90 % of the path's flops).  Default engine: fp16x3
+(gemm_nt_f16x3_kernel<2,2,2,2>: fp32 operands split into two binary16 terms, 3 v_mfma_f32_32x32x16_f16 per product block,
+fp32 accumulate -- fp32-class accuracy, parity-tested); `--precision f32` selects the exact-fp32 engine
+(gemm_nt_kernel<2,2,2,2>, v_mfma_f32_32x32x2_f32).  Its launches are timed live with events on the launch stream inside
+the timed region: achieved = sum of ALGORITHMIC flops 2*M*N*K over the launches / sum of their durations, against the
+dense MFMA peak of the issued dtype (f16: 2500 TFLOP/s; f32: 157.3 TFLOP/s).  The fp16x3 engine issues 3x the
+algorithmic flops, so its matrix-pipe utilisation is 3*frac (`issued_frac`).  `path_frac` prices the whole forward
+(52.82 GFLOP/pair) against the same peak.
 cpu_baseline: the CPU oracle (a plain-PyTorch port of the reference, bit-identical to it) timed on this host's cores on
 a bounded sample of the same workload (rank 0, N=1 only); the same sample gives the R/t error of the HIP path.
 """
@@ -31,7 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GFLOP_PER_PAIR = 52.82          # algorithmic work of one pair at N=1024, J=16 (FlopCounterMode on the reference)
-PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}   # MI355X_MICROARCH.md chip table: fp32-matrix / dense f16 MFMA
 CFG = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
 B_PER_GPU, N_POINTS, J = 64, 1024, 16
 
@@ -42,6 +46,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,6 +69,7 @@ def main():
     synth.fill_state_dict(model.state_dict())
     params_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).eval()
+    model.precision = args.precision
 
     first = rank * B_PER_GPU                                     # global pair ids of this rank's shard
     src, tgt, _, _ = synth.make_batch(first, B_PER_GPU, N_POINTS, "partial")
@@ -94,23 +100,29 @@ def main():
 
     pairs = B_PER_GPU * world * args.steps
     value = pairs / elapsed
-    gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timeline)
-    gemm_flop = sum(f for _, _, f in timeline)
+    all_gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timeline)
+    all_gemm_flop = sum(f for _, _, f, _ in timeline)
+    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v in timeline if v == args.precision]     # the <2,2,2,2> instantiation
+    gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.precision]
+    kernel = ("gemm_nt_f16x3_kernel<2,2,2,2,false> (3x v_mfma_f32_32x32x16_f16 per block)" if args.precision == "f16x3"
+              else "gemm_nt_kernel<2,2,2,2,false> (v_mfma_f32_32x32x2_f32)")
 
     result = {
         "metric": "pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "engine": args.precision,
         "config": {"workload": "BASELINE configs[1]: ModelNet40-shaped partial-overlap+noise pairs, N=1024 points, J=16 mixtures, "
                                "batch 64 per GPU, GMMReg.forward eval (D=512, k=20, M=128, H=4), closed-form weights",
                    "pairs_per_gpu_step": B_PER_GPU, "n_points": N_POINTS, "n_clusters": J, "parallelism": "pairs sharded x%d, no data-path collective" % world},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                     "kernel": "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)", "launches": len(timeline),
-                     "avg_launch_us": 1e3 * gemm_ms / max(1, len(timeline)), "gemm_share_of_step": gemm_ms / (1e3 * elapsed) if world == 1 else None,
-                     "gemm_gflop_per_pair": gemm_flop / (B_PER_GPU * args.steps) / 1e9,
-                     "path_frac": value / world * GFLOP_PER_PAIR / 1e3 / PEAK_FP32_MATRIX_TFLOPS},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": None,
+                     "kernel": kernel, "launches": len(dom), "avg_launch_us": 1e3 * gemm_ms / max(1, len(dom)),
+                     "issued_frac": (3.0 if args.precision == "f16x3" else 1.0) * achieved / peak,
+                     "kernel_share_of_step": gemm_ms / (1e3 * elapsed), "all_gemm_share_of_step": all_gemm_ms / (1e3 * elapsed),
+                     "all_gemm_gflop_per_pair": all_gemm_flop / (B_PER_GPU * args.steps) / 1e9,
+                     "path_frac": value / world * GFLOP_PER_PAIR / 1e3 / peak},
     }
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 1
+#define OGMM_ABI_VERSION 2
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -66,9 +66,19 @@ int ogmm_gather_rows(const float* feats, int64_t ld, int C, int N, int D, const 
  * pool_k > 0 (EdgeConv, models/dgcnn.py:139-148): rows are edges in groups of pool_k per point;
  * besides C (stored only if store_c) pool_out[m / pool_k][n] = max over the group (inputs >= 0
  * after ReLU required: act must be OGMM_ACT_RELU).
- * Exact fp32: v_mfma_f32_32x32x2_f32 accumulation.  K1, K2, lda, lda2, ldb multiples of 4;
- * all base pointers 16-byte aligned. */
+ * K1, K2, lda, lda2, ldb multiples of 4; all base pointers 16-byte aligned.
+ *
+ * precision = OGMM_PREC_F32: exact fp32, v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain; 157 TFLOP/s peak).
+ * precision = OGMM_PREC_F16X3: every fp32 operand x is split into two binary16 terms x = hi + lo
+ *   (hi = rn16(x), lo = rn16(x - hi): 22 significand bits) and a*b is evaluated as hi*hi + hi*lo + lo*hi on
+ *   v_mfma_f32_32x32x16_f16 with fp32 accumulation (3 of 2.5 PFLOP/s MFMAs instead of 16 fp32-rate ones).  The
+ *   dropped lo*lo term is 2^-22 relative; measured end to end it is indistinguishable from the exact-fp32 path
+ *   (DESIGN.md "precision").  A is split on the fly from fp32; B must be given pre-split as B_hi/B_lo
+ *   (binary16 [N][ldb_h], ldb_h a multiple of 8, columns beyond K zero) possibly pre-scaled by a power of two
+ *   that the caller folds into alpha.  |A| must stay below 65504: larger values are clamped and *overflow
+ *   (device int, optional) is set non-zero. */
 enum { OGMM_ACT_NONE = 0, OGMM_ACT_RELU = 1, OGMM_ACT_LEAKY02 = 2, OGMM_ACT_SIGMOID = 3 };
+enum { OGMM_PREC_F32 = 0, OGMM_PREC_F16X3 = 1 };
 
 typedef struct ogmm_gemm {
     const float* A;  int64_t lda;  int32_t K1;
@@ -83,6 +93,7 @@ typedef struct ogmm_gemm {
     float alpha;
     int32_t act;
     int32_t pool_k; float* pool_out; int64_t ldp; int32_t store_c;
+    int32_t precision; const void* B_hi; const void* B_lo; int64_t ldb_h; int32_t* overflow;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);

@@ -7,9 +7,10 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
+PREC_F32, PREC_F16X3 = 0, 1
 
 
 class GemmDesc(Structure):
@@ -29,6 +30,7 @@ class GemmDesc(Structure):
         ("alpha", c_float),
         ("act", c_int32),
         ("pool_k", c_int32), ("pool_out", c_void_p), ("ldp", c_int64), ("store_c", c_int32),
+        ("precision", c_int32), ("B_hi", c_void_p), ("B_lo", c_void_p), ("ldb_h", c_int64), ("overflow", c_void_p),
     ]
 
 

@@ -15,24 +15,14 @@
 //
 // Workgroup -> tile map is XCD-aware: all N-tiles of one M-tile run on the same XCD (block b is
 // dispatched to XCD b % 8), so the A panel is fetched into one L2 only.
-#include "ogmm_common.h"
+#include "gemm_common.h"
 
 namespace {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using namespace ogmm_gemm_detail;
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case OGMM_ACT_RELU: return fmaxf(v, 0.0f);
-        case OGMM_ACT_LEAKY02: return v > 0.0f ? v : 0.2f * v;
-        case OGMM_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-        default: return v;
-    }
-}
 
 template <int MT, int NT, int WM, int WN, bool POOL>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const ogmm_gemm g, const int rows_per_tile,
@@ -132,68 +122,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const ogmm_gemm g
         }
     }
 
-    // ---------------- epilogue
-    float* __restrict__ Cm = g.C ? g.C + zo * g.sC_o + zi * g.sC_i : nullptr;
-    const float* __restrict__ Rm = g.Res ? g.Res + zo * g.sR_o + zi * g.sR_i : nullptr;
-    const bool store_c = Cm != nullptr && (!POOL || g.store_c);
-    int* pool_s = reinterpret_cast<int*>(smem);
-    const int groups = POOL ? (m_end - m0) / g.pool_k : 0;
-    if (POOL) {
-        __syncthreads();
-        for (int i = tid; i < groups * BN; i += T) pool_s[i] = 0;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int cl = (wn * NT + j) * 32 + lr;      // column inside the tile
-        const int col = n0 + cl;
-        const bool col_ok = col < g.N;
-        float cs = 1.0f, ct = 0.0f;
-        if (!g.row_affine && col_ok) {
-            if (g.scale) cs = g.scale[col];
-            if (g.shift) ct = g.shift[col];
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            int cur_group = -1;
-            float cur_max = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // row inside the tile
-                const int row = m0 + rl;
-                if (row < m_end && col_ok) {
-                    float s = cs, sh = ct;
-                    if (g.row_affine) {
-                        s = g.scale ? g.scale[row] : 1.0f;
-                        sh = g.shift ? g.shift[row] : 0.0f;
-                    }
-                    float v = apply_act(fmaf(acc[i][j][r] * g.alpha, s, sh), g.act);
-                    if (Rm) v += Rm[(int64_t)row * g.ldr + col];
-                    if (store_c) Cm[(int64_t)row * g.ldc + col] = v;
-                    if (POOL) {
-                        const int grp = rl / g.pool_k;
-                        if (grp != cur_group) {
-                            if (cur_group >= 0) atomicMax(&pool_s[cur_group * BN + cl], __float_as_int(cur_max));
-                            cur_group = grp;
-                            cur_max = v;
-                        } else {
-                            cur_max = fmaxf(cur_max, v);
-                        }
-                    }
-                }
-            }
-            if (POOL && cur_group >= 0) atomicMax(&pool_s[cur_group * BN + cl], __float_as_int(cur_max));
-        }
-    }
-    if (POOL) {
-        __syncthreads();
-        float* __restrict__ Pm = g.pool_out + zo * 0;   // pooled output is not batched
-        const int64_t p0 = (int64_t)(m0 / g.pool_k);
-        for (int i = tid; i < groups * BN; i += T) {
-            const int p = i / BN, c = i % BN;
-            if (n0 + c < g.N) Pm[(p0 + p) * g.ldp + n0 + c] = __int_as_float(pool_s[i]);
-        }
-    }
+    gemm_epilogue<MT, NT, WM, WN, POOL>(g, acc, smem, m0, n0, m_end, zo, zi, g.alpha);
 }
 
 template <int MT, int NT, int WM, int WN, bool POOL>
@@ -210,16 +139,19 @@ int launch(const ogmm_gemm& g, hipStream_t stream) {
 
 }  // namespace
 
+namespace ogmm { int gemm_nt_f16x3(const ogmm_gemm& g, hipStream_t s); }
+
 extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(d != nullptr, "ogmm_gemm_nt: null descriptor");
     const ogmm_gemm& g = *d;
-    OGMM_REQUIRE(g.A && g.B && g.M > 0 && g.N > 0 && g.K1 > 0, "ogmm_gemm_nt: A, B, M, N, K1 required");
+    OGMM_REQUIRE(g.A && (g.B || g.precision == OGMM_PREC_F16X3) && g.M > 0 && g.N > 0 && g.K1 > 0, "ogmm_gemm_nt: A, B, M, N, K1 required");
+    OGMM_REQUIRE(g.precision == OGMM_PREC_F32 || g.precision == OGMM_PREC_F16X3, "ogmm_gemm_nt: bad precision %d", g.precision);
     OGMM_REQUIRE(g.K2 >= 0 && (g.K2 == 0 || g.A2), "ogmm_gemm_nt: K2 > 0 needs A2");
-    OGMM_REQUIRE(g.K1 % 4 == 0 && g.K2 % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && (g.K2 == 0 || g.lda2 % 4 == 0),
+    OGMM_REQUIRE(g.K1 % 4 == 0 && g.K2 % 4 == 0 && g.lda % 4 == 0 && (g.ldb % 4 == 0 || g.precision != OGMM_PREC_F32) && (g.K2 == 0 || g.lda2 % 4 == 0),
                  "ogmm_gemm_nt: K1, K2, lda, lda2, ldb must be multiples of 4 (got %d %d %lld %lld %lld)", g.K1, g.K2,
                  (long long)g.lda, (long long)g.lda2, (long long)g.ldb);
     OGMM_REQUIRE(g.K2 == 0 || g.K1 % BK == 0, "ogmm_gemm_nt: with two A pieces K1 must be a multiple of %d", BK);
-    OGMM_REQUIRE(ogmm::aligned16(g.A) && ogmm::aligned16(g.B) && (!g.A2 || ogmm::aligned16(g.A2)),
+    OGMM_REQUIRE(ogmm::aligned16(g.A) && (g.precision != OGMM_PREC_F32 || ogmm::aligned16(g.B)) && (!g.A2 || ogmm::aligned16(g.A2)),
                  "ogmm_gemm_nt: operand pointers must be 16-byte aligned");
     OGMM_REQUIRE(g.sA_o % 4 == 0 && g.sA_i % 4 == 0 && g.sB_o % 4 == 0 && g.sB_i % 4 == 0 && g.sA2_o % 4 == 0 && g.sA2_i % 4 == 0,
                  "ogmm_gemm_nt: batch strides of A/B must be multiples of 4");
@@ -227,10 +159,12 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.C || g.pool_k > 0, "ogmm_gemm_nt: no output");
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
-    if (g.pool_k > 0) {
+    if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
                      "ogmm_gemm_nt: pooling needs pool_out, ReLU, 4 <= pool_k <= 160, M %% pool_k == 0, no batching");
+    if (g.precision == OGMM_PREC_F16X3) return ogmm::gemm_nt_f16x3(g, s);
+    if (g.pool_k > 0) {
         return g.N <= 64 ? launch<5, 1, 1, 2, true>(g, s) : launch<5, 1, 1, 4, true>(g, s);
     }
     return g.N <= 64 ? launch<2, 1, 2, 2, false>(g, s) : launch<2, 2, 2, 2, false>(g, s);

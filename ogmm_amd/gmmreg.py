@@ -124,6 +124,16 @@ def _w2d(sd, key, pad_to=None):
     return w.contiguous()
 
 
+def _add_splits(L):
+    """Adds the pre-split binary16 weights (ops.split_f16) to every layer that owns a 2-D `W` with K >= 32."""
+    for v in L.values():
+        if isinstance(v, dict):
+            if "W" in v and torch.is_tensor(v["W"]) and v["W"].dim() == 2 and v["W"].shape[1] >= 32:
+                v["split"] = ops.split_f16(v["W"])
+            else:
+                _add_splits(v)
+
+
 def pack_weights(sd, D, H):
     """state_dict (tensors already on the target device) -> dict of kernel-ready layers.  Done once per load:
     BN folded to scale/shift, conv2.net.0 zero-padded from 514 to 516 input channels (16-byte rows), attention
@@ -171,6 +181,7 @@ def pack_weights(sd, D, H):
         L[name] = S
     L["proj"] = {"0": conv_bn("proj.net.0", "proj.net.1", True),
                  "3": {"w": sd["proj.net.3.weight"].reshape(-1).float().contiguous(), "b": sd["proj.net.3.bias"].float().contiguous()}}
+    _add_splits(L)
     return L
 
 
@@ -187,6 +198,10 @@ class GMMReg(nn.Module):
         self._packed = None
         self._packed_key = None
         self.last_intermediates = None
+        # "f16x3": weight GEMMs on the binary16 matrix cores with two-term operand splitting (fp32-class accuracy);
+        # "f32": everything on the exact-fp32 MFMA engine.
+        self.precision = getattr(config, "precision", "f16x3")
+        self._overflow = None
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved
     def _layers(self):
@@ -243,10 +258,16 @@ class GMMReg(nn.Module):
         if M % 4 != 0 or M > N or J > N or k > N:
             raise OgmmError("km_clusters must be a multiple of 4 and km_clusters, n_clusters, gnn_k <= N")
         dev = src.device
+        if self.precision not in ("f16x3", "f32"):
+            raise OgmmError("precision must be 'f16x3' or 'f32'")
+        if self._overflow is None or self._overflow.device != dev:
+            self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         if self.emd.conv1.weight.device != dev:
             raise OgmmError("GMMReg parameters live on %s but the inputs on %s: call model.to(device) first" % (self.emd.conv1.weight.device, dev))
         L = self._layers()
         cap = {} if capture else None
+        ops.DEFAULT_SPLIT = self.precision == "f16x3"
+        ops.DEFAULT_OVERFLOW = self._overflow
 
         if fps_starts is None:
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
@@ -314,3 +335,11 @@ class GMMReg(nn.Module):
                        o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss)
             self.last_intermediates = cap
         return rot, trans, o[:B], o[B:], loss
+
+    def fp16_overflowed(self):
+        """True if any fp16x3 GEMM since the last call clamped an activation beyond +-65504 (synchronises)."""
+        if self._overflow is None:
+            return False
+        hit = bool(self._overflow.item())
+        self._overflow.zero_()
+        return hit

@@ -7,12 +7,16 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, GemmDesc  # noqa: F401
+from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16X3, PREC_F32, GemmDesc  # noqa: F401
 
 
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_flops)
 GEMM_TIMELINE = None
+
+# engine selection for layers that carry pre-split weights (set by GMMReg.forward from model.precision)
+DEFAULT_SPLIT = True
+DEFAULT_OVERFLOW = None      # device int32[1]: set non-zero by the fp16x3 engine when |activation| > 65504 was clamped
 
 
 def _stream():
@@ -81,14 +85,38 @@ def gather_rows(feats, ld, C, N, D, ids, cloud_map=None):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM engine
+def split_f16(W, pad_to=8):
+    """fp32 [N,K] -> dict(W_hi, W_lo binary16 [N, Kpad], inv_scale): W * 2^e = hi + lo with the power of two chosen so
+    that max|W| * 2^e is in [2^11, 2^12) (keeps `lo` a normal binary16 number); inv_scale = 2^-e goes into alpha."""
+    import math
+    W = W.float()
+    amax = float(W.abs().max())
+    e = 0 if amax == 0.0 or not math.isfinite(amax) else 11 - math.floor(math.log2(amax))
+    e = max(-24, min(24, e))
+    Ws = W * (2.0 ** e)
+    K = W.shape[1]
+    Kp = (K + pad_to - 1) // pad_to * pad_to
+    if Kp != K:
+        Ws = torch.cat([Ws, Ws.new_zeros(W.shape[0], Kp - K)], dim=1)
+    hi = Ws.half()
+    lo = (Ws - hi.float()).half()
+    return {"W_hi": hi.contiguous(), "W_lo": lo.contiguous(), "inv_scale": 2.0 ** (-e)}
+
+
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
-            pool_k=0, pool_out=None, ldp=0, store_c=True):
-    """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`."""
+            pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None):
+    """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
+    split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
     d.A, d.lda, d.K1 = A.data_ptr(), lda, K1
     d.A2, d.lda2, d.K2 = (A2.data_ptr() if A2 is not None else None), lda2, K2
-    d.B, d.ldb = B.data_ptr(), ldb
+    d.B, d.ldb = (B.data_ptr() if B is not None else None), ldb
+    if split is not None:
+        d.precision = PREC_F16X3
+        d.B_hi, d.B_lo, d.ldb_h = split["W_hi"].data_ptr(), split["W_lo"].data_ptr(), split["W_hi"].shape[-1]
+        d.overflow = overflow.data_ptr() if overflow is not None else None
+        alpha = alpha * split["inv_scale"]
     d.C, d.ldc = (C.data_ptr() if C is not None else None), ldc
     d.Res, d.ldr = (res.data_ptr() if res is not None else None), ldr
     d.M, d.N = M, N
@@ -111,16 +139,20 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     e0.record()
     _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
     e1.record()
-    GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * batch[0] * batch[1]))
+    variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
+    GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * batch[0] * batch[1], variant))
 
 
-def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None):
+def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None):
     """y[rows, Cout] = act((x | x2)[rows, K] @ W^T * scale + shift) + res for a packed layer
     (dict with W [Cout, Kpad], scale, shift -- see gmmreg.pack_*).  x, x2, res, out may be column views
-    of wider row-major buffers (last stride 1)."""
+    of wider row-major buffers (last stride 1).  split=True uses the layer's pre-split weights (fp16x3 engine)
+    when the layer carries them."""
     x = _f32(x, "x")
     rows, K1 = x.shape
     assert x.stride(1) == 1
+    split = DEFAULT_SPLIT if split is None else split
+    overflow = DEFAULT_OVERFLOW if overflow is None else overflow
     W = layer["W"]
     Cout, Kp = W.shape
     K2 = 0
@@ -136,7 +168,8 @@ def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None):
     gemm_nt(x, x.stride(0), K1, W, Kp, rows, Cout, C=out, ldc=out.stride(0),
             A2=x2, lda2=(x2.stride(0) if x2 is not None else 0), K2=K2,
             scale=layer.get("scale"), shift=layer.get("shift"), act=act,
-            res=res, ldr=(res.stride(0) if res is not None else 0))
+            res=res, ldr=(res.stride(0) if res is not None else 0),
+            split=(layer.get("split") if split else None), overflow=overflow)
     return out
 
 
@@ -149,15 +182,18 @@ def edgeconv_first(xyz, idx, layer, pool_out):
     return h1
 
 
-def edgeconv_layer(h, layer, k, pool_out, store=True):
+def edgeconv_layer(h, layer, k, pool_out, store=True, split=None, overflow=None):
     """conv + BN + ReLU on the per-edge tensor h [E, Cin] with max over each point's k edges fused in
     (models/dgcnn.py:141-148).  Returns the un-pooled [E, Cout] (None when store=False)."""
     E, Cin = h.shape
+    split = DEFAULT_SPLIT if split is None else split
+    overflow = DEFAULT_OVERFLOW if overflow is None else overflow
     W = layer["W"]
     Cout = W.shape[0]
     out = torch.empty((E, Cout), dtype=torch.float32, device=h.device) if store else None
     gemm_nt(h, h.stride(0), Cin, W, W.shape[1], E, Cout, C=out, ldc=Cout, scale=layer["scale"], shift=layer["shift"],
-            act=ACT_RELU, pool_k=k, pool_out=pool_out, ldp=pool_out.stride(0), store_c=store)
+            act=ACT_RELU, pool_k=k, pool_out=pool_out, ldp=pool_out.stride(0), store_c=store,
+            split=(layer.get("split") if split else None), overflow=overflow)
     return out
 
 

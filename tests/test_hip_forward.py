@@ -20,19 +20,21 @@ O_TOL = 5e-6      # overlap scores in (0,1)
 LOSS_TOL = 5e-5
 
 
-def build(cfg, J):
+def build(cfg, J, precision="f16x3"):
     m = GMMReg(512, J, cfg)
+    m.precision = precision
     synth.fill_state_dict(m.state_dict())
     P = {k: v.clone() for k, v in m.state_dict().items()}
     return m.cuda().eval(), P
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", golden_names())
-def test_forward_matches_reference_golden(golden, name):
+def test_forward_matches_reference_golden(golden, name, precision):
     fx = golden(name)
     B, N, J, k, M, D, H = [int(v) for v in fx["meta"]]
     cfg = Namespace(gnn_k=k, num_heads=H, km_clusters=M, overlap_radius=0.035, n_clusters=J)
-    model, _ = build(cfg, J)
+    model, _ = build(cfg, J, precision)
     src, tgt = torch.from_numpy(fx["src"]).cuda(), torch.from_numpy(fx["tgt"]).cuda()
     with torch.no_grad():
         R, t, so, to, loss = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]), capture=True)
@@ -60,7 +62,8 @@ def test_forward_matches_reference_golden(golden, name):
     rep["t"] = O.translation_error(t.cpu(), torch.from_numpy(fx["t"])).max().item()
     rep["o"] = float(max(np.abs(so.cpu().numpy() - fx["src_o"]).max(), np.abs(to.cpu().numpy() - fx["tgt_o"]).max()))
     rep["loss"] = abs(loss.item() - float(fx["loss"]))
-    print("PARITY", name, " ".join("%s=%.2e" % kv for kv in rep.items()))
+    print("PARITY", precision, name, " ".join("%s=%.2e" % kv for kv in rep.items()))
+    assert not model.fp16_overflowed()
     for key in ("emb", "ft", "f", "f2"):
         assert rep[key] < 2e-5, (key, rep)
     assert rep["R"] < R_TOL and rep["t"] < T_TOL, rep

@@ -97,30 +97,60 @@ def _gemm_ref(A, B):
     return (A.double() @ B.double().t())
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 70, 36), (128, 128, 32), (1000, 512, 512), (129, 65, 4), (2048, 1024, 1024)])
-def test_gemm_plain(ops, M, N, K):
+ENGINES = ["f32", "f16x3"]
+
+
+def _split(ops, B, engine):
+    return ops.split_f16(dev(B)) if engine == "f16x3" else None
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("M,N,K", [(300, 70, 36), (128, 128, 32), (1000, 512, 512), (129, 65, 4), (2048, 1024, 1024), (257, 130, 516)])
+def test_gemm_plain(ops, M, N, K, engine):
     torch.manual_seed(M + N + K)
-    A, B = torch.randn(M, K), torch.randn(N, K)
+    A, B = torch.randn(M, K), torch.randn(N, K) * 0.05
     out = torch.empty(M, N, device="cuda")
-    ops.gemm_nt(dev(A), K, K, dev(B), K, M, N, C=out, ldc=N)
+    ops.gemm_nt(dev(A), K, K, dev(B), K, M, N, C=out, ldc=N, split=_split(ops, B, engine))
     ref = _gemm_ref(A, B)
-    # v_mfma_f32_32x32x2_f32 is a k-ordered fp32 fma chain: |err| <~ 1.5e-7 * sum_k |a_k b_k| (guide, section 3)
+    # v_mfma_f32_32x32x2_f32 is a k-ordered fp32 fma chain: |err| <~ 1.5e-7 * sum_k |a_k b_k| (guide, section 3);
+    # the fp16x3 engine adds <= 3 * 2^-22 per product on top of its own fp32 accumulation
     bound = 6e-7 * (A.double().abs() @ B.double().abs().t()) + 1e-7
     excess = ((out.cpu().double() - ref).abs() / bound).max().item()
     assert excess < 1.0, excess
 
 
-def test_gemm_detects_transposition(ops):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_gemm_detects_transposition(ops, engine):
     """A = identity, asymmetric B (guide rule: symmetric inputs hide a swapped C write)."""
     n = 96
     A = torch.eye(n)
-    B = torch.arange(n * n, dtype=torch.float32).view(n, n) / 7.0
+    B = torch.arange(n * n, dtype=torch.float32).view(n, n) / 8.0
     out = torch.empty(n, n, device="cuda")
-    ops.gemm_nt(dev(A), n, n, dev(B), n, n, n, C=out, ldc=n)
-    assert torch.equal(out.cpu(), B.t().contiguous())
+    ops.gemm_nt(dev(A), n, n, dev(B), n, n, n, C=out, ldc=n, split=_split(ops, B, engine))
+    assert torch.equal(out.cpu(), B.t().contiguous())      # exact in both engines: every entry fits 22 bits
 
 
-def test_gemm_two_pieces_epilogue_residual(ops):
+def test_gemm_f16x3_accuracy_is_fp32_class_and_flags_overflow(ops):
+    torch.manual_seed(9)
+    M, N, K = 512, 256, 1024
+    A, B = torch.randn(M, K) * 3, torch.randn(N, K) * 0.03
+    ref = _gemm_ref(A, B)
+    o32, o16 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.gemm_nt(dev(A), K, K, dev(B), K, M, N, C=o32, ldc=N)
+    ops.gemm_nt(dev(A), K, K, None, K, M, N, C=o16, ldc=N, split=ops.split_f16(dev(B)), overflow=flag)
+    e32 = (o32.cpu().double() - ref).abs().max().item()
+    e16 = (o16.cpu().double() - ref).abs().max().item()
+    print("max abs error: exact-fp32 engine %.3e, fp16x3 engine %.3e (|C| max %.2f)" % (e32, e16, ref.abs().max().item()))
+    assert e16 < 3 * e32 + 1e-6
+    assert int(flag.item()) == 0
+    A[3, 5] = 1e5
+    ops.gemm_nt(dev(A), K, K, None, K, M, N, C=o16, ldc=N, split=ops.split_f16(dev(B)), overflow=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_gemm_two_pieces_epilogue_residual(ops, engine):
     torch.manual_seed(0)
     M, N, K1, K2 = 333, 200, 64, 4
     A1, A2, B = torch.randn(M, K1), torch.randn(M, K2), torch.randn(N, K1 + K2)
@@ -129,7 +159,7 @@ def test_gemm_two_pieces_epilogue_residual(ops):
                     (ops.ACT_SIGMOID, torch.sigmoid), (ops.ACT_NONE, lambda v: v)):
         out = torch.empty(M, N, device="cuda")
         ops.gemm_nt(dev(A1), K1, K1, dev(B), K1 + K2, M, N, C=out, ldc=N, A2=dev(A2), lda2=K2, K2=K2, scale=dev(scale), shift=dev(shift),
-                    alpha=0.5, act=act, res=dev(res), ldr=N)
+                    alpha=0.5, act=act, res=dev(res), ldr=N, split=_split(ops, B, engine))
         ref = fn(0.5 * _gemm_ref(torch.cat([A1, A2], 1), B) * scale.double() + shift.double()) + res.double()
         assert (out.cpu().double() - ref).abs().max().item() < 2e-5
 
@@ -150,20 +180,22 @@ def test_gemm_batched_strided_row_affine(ops):
     assert (vT.cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("k,Cout", [(20, 64), (20, 128), (12, 256), (7, 64)])
-def test_gemm_edge_pooling(ops, k, Cout):
+def test_gemm_edge_pooling(ops, k, Cout, engine):
     torch.manual_seed(k)
     P, Cin = 37, 64
     h = torch.randn(P * k, Cin)
     W, s, t = torch.randn(Cout, Cin) / 8, torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
     pool = torch.full((P, 512), -1.0, device="cuda")
-    out = ops.edgeconv_layer(dev(h), {"W": dev(W), "scale": dev(s), "shift": dev(t)}, k, pool[:, 64:64 + Cout])
+    layer = {"W": dev(W), "scale": dev(s), "shift": dev(t), "split": _split(ops, W, engine)}
+    out = ops.edgeconv_layer(dev(h), layer, k, pool[:, 64:64 + Cout], split=engine == "f16x3")
     ref = torch.relu(_gemm_ref(h, W) * s.double() + t.double())
     assert (out.cpu().double() - ref).abs().max().item() < 1e-5
     assert (pool[:, 64:64 + Cout].cpu().double() - ref.view(P, k, Cout).max(1)[0]).abs().max().item() < 1e-5
     assert bool((torch.cat([pool[:, :64], pool[:, 64 + Cout:]], 1) == -1.0).all()), "pooled write left its column slab"
     pool2 = torch.zeros((P, Cout), device="cuda")
-    assert ops.edgeconv_layer(dev(h), {"W": dev(W), "scale": dev(s), "shift": dev(t)}, k, pool2, store=False) is None
+    assert ops.edgeconv_layer(dev(h), layer, k, pool2, store=False, split=engine == "f16x3") is None
     assert torch.equal(pool2, pool[:, 64:64 + Cout].contiguous())
 
 
