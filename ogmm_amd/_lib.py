@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
-PREC_F32, PREC_F16X3 = 0, 1
+PREC_F32, PREC_F16X3, PREC_F16X3_FRAG = 0, 1, 2
 
 
 class GemmDesc(Structure):

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const ogmm_gemm g
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     f32x4 ra[A_F4], rb[B_F4];
+    unsigned ra_ok = 0, rb_ok = 0;     // zero-selects are applied when the registers are consumed, not right after the load
     auto load_tile = [&](int t) {
         const bool second = t >= nk1;
         const float* Ap = second ? A2 : A;
@@ -70,21 +71,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const ogmm_gemm g
         const int kbase = second ? (t - nk1) * BK : t * BK;
         const int Kp = second ? g.K2 : g.K1;
         const int kB = second ? g.K1 + kbase : kbase;
+        // unconditional loads from clamped (always valid) addresses + select (no branches around loads)
+        ra_ok = 0;
+        rb_ok = 0;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int f = tid + i * T, row = f >> 3, kq = (f & 7) * 4;
             const int gm = m0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gm < m_end && kbase + kq < Kp) v = *reinterpret_cast<const f32x4*>(Ap + (int64_t)gm * ld + kbase + kq);
-            ra[i] = v;
+            const bool ok = gm < m_end && kbase + kq < Kp;
+            ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)min(gm, g.M - 1) * ld + (ok ? kbase + kq : 0));
+            ra_ok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int f = tid + i * T, row = f >> 3, kq = (f & 7) * 4;
             const int gn = n0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gn < g.N && kbase + kq < Kp) v = *reinterpret_cast<const f32x4*>(Bm + (int64_t)gn * g.ldb + kB + kq);
-            rb[i] = v;
+            const bool ok = gn < g.N && kbase + kq < Kp;
+            rb[i] = *reinterpret_cast<const f32x4*>(Bm + (int64_t)min(gn, g.N - 1) * g.ldb + (ok ? kB + kq : 0));
+            rb_ok |= (ok ? 1u : 0u) << i;
         }
     };
 
@@ -94,12 +98,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const ogmm_gemm g
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int f = tid + i * T;
-            *reinterpret_cast<f32x4*>(&As[(f >> 3) * LDS_LD + (f & 7) * 4]) = ra[i];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&As[(f >> 3) * LDS_LD + (f & 7) * 4]) = ((ra_ok >> i) & 1u) ? ra[i] : zero;
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int f = tid + i * T;
-            *reinterpret_cast<f32x4*>(&Bs[(f >> 3) * LDS_LD + (f & 7) * 4]) = rb[i];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Bs[(f >> 3) * LDS_LD + (f & 7) * 4]) = ((rb_ok >> i) & 1u) ? rb[i] : zero;
         }
         __syncthreads();
         if (t + 1 < nk) load_tile(t + 1);
@@ -139,13 +145,16 @@ int launch(const ogmm_gemm& g, hipStream_t stream) {
 
 }  // namespace
 
-namespace ogmm { int gemm_nt_f16x3(const ogmm_gemm& g, hipStream_t s); }
+namespace ogmm {
+int gemm_nt_f16x3(const ogmm_gemm& g, hipStream_t s);
+int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s);
+}
 
 extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(d != nullptr, "ogmm_gemm_nt: null descriptor");
     const ogmm_gemm& g = *d;
-    OGMM_REQUIRE(g.A && (g.B || g.precision == OGMM_PREC_F16X3) && g.M > 0 && g.N > 0 && g.K1 > 0, "ogmm_gemm_nt: A, B, M, N, K1 required");
-    OGMM_REQUIRE(g.precision == OGMM_PREC_F32 || g.precision == OGMM_PREC_F16X3, "ogmm_gemm_nt: bad precision %d", g.precision);
+    OGMM_REQUIRE(g.A && (g.B || g.precision != OGMM_PREC_F32) && g.M > 0 && g.N > 0 && g.K1 > 0, "ogmm_gemm_nt: A, B, M, N, K1 required");
+    OGMM_REQUIRE(g.precision == OGMM_PREC_F32 || g.precision == OGMM_PREC_F16X3 || g.precision == OGMM_PREC_F16X3_FRAG || (g.precision > 10 && g.precision < 30), "ogmm_gemm_nt: bad precision %d", g.precision);
     OGMM_REQUIRE(g.K2 >= 0 && (g.K2 == 0 || g.A2), "ogmm_gemm_nt: K2 > 0 needs A2");
     OGMM_REQUIRE(g.K1 % 4 == 0 && g.K2 % 4 == 0 && g.lda % 4 == 0 && (g.ldb % 4 == 0 || g.precision != OGMM_PREC_F32) && (g.K2 == 0 || g.lda2 % 4 == 0),
                  "ogmm_gemm_nt: K1, K2, lda, lda2, ldb must be multiples of 4 (got %d %d %lld %lld %lld)", g.K1, g.K2,
@@ -163,7 +172,8 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
                      "ogmm_gemm_nt: pooling needs pool_out, ReLU, 4 <= pool_k <= 160, M %% pool_k == 0, no batching");
-    if (g.precision == OGMM_PREC_F16X3) return ogmm::gemm_nt_f16x3(g, s);
+    if (g.precision == OGMM_PREC_F16X3_FRAG || g.precision > 20) return ogmm::gemm_nt_f16x3_frag(g, s);
+    if (g.precision != OGMM_PREC_F32) return ogmm::gemm_nt_f16x3(g, s);
     if (g.pool_k > 0) {
         return g.N <= 64 ? launch<5, 1, 1, 2, true>(g, s) : launch<5, 1, 1, 4, true>(g, s);
     }

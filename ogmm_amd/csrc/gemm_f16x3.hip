@@ -35,7 +35,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo, bool
     }
 }
 
-template <int MT, int NT, int WM, int WN, bool POOL>
+template <int MT, int NT, int WM, int WN, bool POOL, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_f16x3_kernel(const ogmm_gemm g, const int rows_per_tile,
                                                                      const int m_tiles, const int n_tiles) {
     constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_f16x3_kernel(const ogmm_
 
     f32x4 ra[A_P];
     f16x8 rbh[B_P], rbl[B_P];
+    unsigned ra_ok = 0, rb_ok = 0;     // zero-selects are applied when the registers are consumed, not right after the load
     bool ovf = false;
     auto load_tile = [&](int t) {
         const bool second = t >= nk1;
@@ -85,26 +86,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_f16x3_kernel(const ogmm_
         const int kbase = second ? (t - nk1) * BKH : t * BKH;
         const int Kp = second ? g.K2 : g.K1;
         const int kB = second ? g.K1 + kbase : kbase;
+        // unconditional loads from clamped (always valid) addresses + select: a branch around a load makes hipcc
+        // serialise the loads behind per-load waits
+        ra_ok = 0;
+        rb_ok = 0;
 #pragma unroll
         for (int i = 0; i < A_P; ++i) {
             const int f = tid + i * T, row = f >> 3, kq = (f & 7) * 4;
             const int gm = m0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((A_PIECES % T == 0 || f < A_PIECES) && gm < m_end && kbase + kq < Kp)
-                v = *reinterpret_cast<const f32x4*>(Ap + (int64_t)gm * ld + kbase + kq);
-            ra[i] = v;
+            const bool ok = (A_PIECES % T == 0 || f < A_PIECES) && gm < m_end && kbase + kq < Kp;
+            const int gmc = min(gm, g.M - 1), kc = ok ? kbase + kq : 0;
+            ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)gmc * ld + kc);
+            ra_ok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < B_P; ++i) {
             const int f = tid + i * T, row = f >> 2, kq = (f & 3) * 8;
             const int gn = n0 + row;
-            f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((B_PIECES % T == 0 || f < B_PIECES) && gn < g.N && kB + kq < g.ldb_h) {
-                h = *reinterpret_cast<const f16x8*>(BH + (int64_t)gn * g.ldb_h + kB + kq);
-                l = *reinterpret_cast<const f16x8*>(BL + (int64_t)gn * g.ldb_h + kB + kq);
-            }
-            rbh[i] = h;
-            rbl[i] = l;
+            const bool ok = (B_PIECES % T == 0 || f < B_PIECES) && gn < g.N && kB + kq < g.ldb_h;
+            const int gnc = min(gn, g.N - 1), kc = ok ? kB + kq : 0;
+            rbh[i] = *reinterpret_cast<const f16x8*>(BH + (int64_t)gnc * g.ldb_h + kc);
+            rbl[i] = *reinterpret_cast<const f16x8*>(BL + (int64_t)gnc * g.ldb_h + kc);
+            rb_ok |= (ok ? 1u : 0u) << i;
         }
     };
 
@@ -116,7 +119,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_f16x3_kernel(const ogmm_
             const int f = tid + i * T;
             if (A_PIECES % T == 0 || f < A_PIECES) {
                 f16x4 hi, lo;
-                split4(ra[i], hi, lo, ovf);
+                if (ABL == 2 || ABL == 3) {            // ablation: no conversion work (bit copies keep the loads alive)
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    const f32x2 p0 = {ra[i][0], ra[i][1]}, p1 = {ra[i][2], ra[i][3]};
+                    hi = __builtin_bit_cast(f16x4, p0);
+                    lo = __builtin_bit_cast(f16x4, p1);
+                } else {
+                    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                    split4(((ra_ok >> i) & 1u) ? ra[i] : zero4, hi, lo, ovf);
+                }
                 const int off = (f >> 3) * LDH + (f & 7) * 4;
                 *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
                 *reinterpret_cast<f16x4*>(&Al[off]) = lo;
@@ -127,12 +138,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_f16x3_kernel(const ogmm_
             const int f = tid + i * T;
             if (B_PIECES % T == 0 || f < B_PIECES) {
                 const int off = (f >> 2) * LDH + (f & 3) * 8;
-                *reinterpret_cast<f16x8*>(&Bh[off]) = rbh[i];
-                *reinterpret_cast<f16x8*>(&Bl[off]) = rbl[i];
+                const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                const bool okb = (rb_ok >> i) & 1u;
+                *reinterpret_cast<f16x8*>(&Bh[off]) = okb ? rbh[i] : zero8;
+                *reinterpret_cast<f16x8*>(&Bl[off]) = okb ? rbl[i] : zero8;
             }
         }
         __syncthreads();
-        if (t + 1 < nk) load_tile(t + 1);
+        if (t + 1 < nk && ABL != 1 && ABL != 3) load_tile(t + 1);
 #pragma unroll
         for (int s = 0; s < BKH / 16; ++s) {
             f16x8 ah[MT], al[MT], bh[NT], bl[NT];
@@ -148,14 +161,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_f16x3_kernel(const ogmm_
                 bh[j] = *reinterpret_cast<const f16x8*>(&Bh[off]);
                 bl[j] = *reinterpret_cast<const f16x8*>(&Bl[off]);
             }
+            // term-major order: consecutive MFMAs hit different accumulators (no dependent-accumulator stalls)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
     if (g.overflow && ovf) atomicOr(g.overflow, 1);
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_f16x3_kernel(const ogmm_
     gemm_epilogue<MT, NT, WM, WN, POOL>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, zo, zi, g.alpha);
 }
 
-template <int MT, int NT, int WM, int WN, bool POOL>
+template <int MT, int NT, int WM, int WN, bool POOL, int ABL = 0>
 int launch_h(const ogmm_gemm& g, hipStream_t stream) {
     constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
     const int rows_per_tile = POOL ? (BM / g.pool_k) * g.pool_k : BM;
@@ -171,7 +189,7 @@ int launch_h(const ogmm_gemm& g, hipStream_t stream) {
     const int n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     dim3 grid((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)(g.batch_outer * g.batch_inner));
-    hipLaunchKernelGGL((gemm_nt_f16x3_kernel<MT, NT, WM, WN, POOL>), grid, dim3(T), 0, stream, g, rows_per_tile, m_tiles, n_tiles);
+    hipLaunchKernelGGL((gemm_nt_f16x3_kernel<MT, NT, WM, WN, POOL, ABL>), grid, dim3(T), 0, stream, g, rows_per_tile, m_tiles, n_tiles);
     return ogmm::check_launch("ogmm_gemm_nt(f16x3)");
 }
 
@@ -186,6 +204,16 @@ int gemm_nt_f16x3(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.sB_o % 8 == 0 && g.sB_i % 8 == 0, "ogmm_gemm_nt(f16x3): B batch strides must be multiples of 8");
     OGMM_REQUIRE(g.K1 + g.K2 <= g.ldb_h, "ogmm_gemm_nt(f16x3): K1+K2=%d exceeds ldb_h=%lld", g.K1 + g.K2, (long long)g.ldb_h);
     if (g.pool_k > 0) return g.N <= 64 ? launch_h<5, 1, 1, 2, true>(g, s) : launch_h<5, 1, 1, 4, true>(g, s);
+    switch (g.precision) {      // codes > 10: tile-shape experiments (tools/gemm_bench.py)
+        case 12: return launch_h<4, 2, 2, 2, false>(g, s);     // 256 x 128, 4 waves of 128 x 64
+        case 13: return launch_h<2, 2, 4, 2, false>(g, s);     // 256 x 128, 8 waves of  64 x 64
+        case 14: return launch_h<4, 2, 2, 4, false>(g, s);     // 256 x 256, 8 waves of 128 x 64
+        case 15: return launch_h<2, 4, 2, 2, false>(g, s);     // 128 x 256, 4 waves of  64 x 128
+        case 16: return launch_h<4, 2, 2, 4, false, 1>(g, s);  // ablation: no global loads after tile 0
+        case 17: return launch_h<4, 2, 2, 4, false, 2>(g, s);  // ablation: no split arithmetic
+        case 18: return launch_h<4, 2, 2, 4, false, 3>(g, s);  // ablation: both
+        default: break;
+    }
     return g.N <= 64 ? launch_h<2, 1, 2, 2, false>(g, s) : launch_h<2, 2, 2, 2, false>(g, s);
 }
 

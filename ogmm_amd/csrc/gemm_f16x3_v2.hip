@@ -1,0 +1,218 @@
+// fp16x3 split GEMM, second structure: B fragments straight from a fragment-major pre-packed weight image,
+// A through a double-buffered LDS image, ONE barrier per K tile.
+//
+// Why (measured on MI355X with tools/gemm_bench.py): in the first structure (gemm_f16x3.hip: A and B both staged
+// through LDS, two barriers per tile) removing every global load still left the matrix pipe ~45 % busy -- the loop is
+// bound by its LDS write phase (64 KB per K tile at the ~80 B/clk/CU ds_write rate, with all waves parked between two
+// barriers) -- and the on-the-fly split arithmetic costs nothing measurable.  Weights are static, so they are packed once
+// in the exact per-lane order of the v_mfma_f32_32x32x16_f16 B operand:
+//     image[plane][n/32][k/16][lane 0..63][8 halfs],  lane = (k % 16 / 8) * 32 + n % 32
+// and every wave fetches its B fragments as fully coalesced 1 KiB loads (L2-resident: <= 4 MB per layer), one k-step ahead,
+// with no LDS traffic and no barrier dependence.  Only A (fp32 activations, shared by the WN waves of a row block) goes
+// through LDS: split on the fly into hi/lo binary16 planes, two buffers, so tile t+1 is written while tile t is read
+// and a single barrier per tile orders both.
+#include "gemm_common.h"
+
+namespace {
+
+using namespace ogmm_gemm_detail;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+constexpr int BKH = 32;
+constexpr int LDH = BKH + 8;
+
+__device__ __forceinline__ void split4v(const f32x4 v, f16x4& hi, f16x4& lo, bool& ovf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        ovf |= fabsf(x) > 65504.0f;
+        x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+        const _Float16 h = (_Float16)x;
+        hi[e] = h;
+        lo[e] = (_Float16)(x - (float)h);
+    }
+}
+
+template <int MT, int NT, int WM, int WN, bool POOL>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_gemm g, const int rows_per_tile, const int m_tiles,
+                                                                     const int n_tiles) {
+    constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
+    constexpr int A_PIECES = BM * 8, A_P = (A_PIECES + T - 1) / T;
+    constexpr int PLANE = BM * LDH;                      // halfs per plane per buffer
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];      // [2 buffers][hi, lo][BM][LDH]
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile_m = (local / n_tiles) * 8 + xcd;
+    const int tile_n = local % n_tiles;
+    if (tile_m >= m_tiles) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const float* __restrict__ A = g.A;
+    const float* __restrict__ A2 = g.A2;
+    const int m0 = tile_m * rows_per_tile, n0 = tile_n * BN;
+    const int m_end = min(g.M, m0 + rows_per_tile);
+    const int nk1 = (g.K1 + BKH - 1) / BKH, nk2 = (g.K2 + BKH - 1) / BKH, nk = nk1 + nk2;
+
+    // B image: k-blocks of 16; piece 2 starts at k = K1 (a multiple of 32)
+    const int KB = (int)(g.ldb_h / 16);
+    const f16x8* __restrict__ BH = reinterpret_cast<const f16x8*>(g.B_hi);
+    const f16x8* __restrict__ BL = reinterpret_cast<const f16x8*>(g.B_lo);
+    int64_t bbase[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bbase[j] = ((int64_t)(n0 / 32 + wn * NT + j) * KB) * 64 + lane;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra[A_P];
+    unsigned ra_ok = 0;          // validity bits of ra[]: the zero-select is applied when the data is CONSUMED (store_a), so the
+    bool ovf = false;            // loads stay in flight across the MFMAs (a select right after the load forces vmcnt(0) there)
+    auto load_a = [&](int t) {
+        const bool second = t >= nk1;
+        const float* Ap = second ? A2 : A;
+        const int64_t ld = second ? g.lda2 : g.lda;
+        const int kbase = second ? (t - nk1) * BKH : t * BKH;
+        const int Kp = second ? g.K2 : g.K1;
+        ra_ok = 0;
+#pragma unroll
+        for (int i = 0; i < A_P; ++i) {
+            const int f = tid + i * T, row = f >> 3, kq = (f & 7) * 4;
+            const int gm = m0 + row;
+            const bool ok = (A_PIECES % T == 0 || f < A_PIECES) && gm < m_end && kbase + kq < Kp;
+            ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)min(gm, g.M - 1) * ld + (ok ? kbase + kq : 0));
+            ra_ok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto store_a = [&](int buf) {
+        _Float16* Ah = smem_h + buf * 2 * PLANE;
+        _Float16* Al = Ah + PLANE;
+#pragma unroll
+        for (int i = 0; i < A_P; ++i) {
+            const int f = tid + i * T;
+            if (A_PIECES % T == 0 || f < A_PIECES) {
+                f16x4 hi, lo;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                split4v(((ra_ok >> i) & 1u) ? ra[i] : zero, hi, lo, ovf);
+                const int off = (f >> 3) * LDH + (f & 7) * 4;
+                *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
+                *reinterpret_cast<f16x4*>(&Al[off]) = lo;
+            }
+        }
+    };
+    // k-block index (in the B image) of k-step s of tile t
+    auto kblk = [&](int t, int s) { return (t < nk1 ? t * 2 : (g.K1 / 16) + (t - nk1) * 2) + s; };
+    auto load_b = [&](f16x8 (&bh)[NT], f16x8 (&bl)[NT], int t, int s) {
+        const int kb = kblk(t, s);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = BH[bbase[j] + (int64_t)kb * 64];
+            bl[j] = BL[bbase[j] + (int64_t)kb * 64];
+        }
+    };
+    auto mma_step = [&](int buf, int s, const f16x8 (&bh)[NT], const f16x8 (&bl)[NT]) {
+        const _Float16* Ah = smem_h + buf * 2 * PLANE;
+        const _Float16* Al = Ah + PLANE;
+        f16x8 ah[MT], al[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int off = ((wm * MT + i) * 32 + lr) * LDH + s * 16 + lh * 8;
+            ah[i] = *reinterpret_cast<const f16x8*>(&Ah[off]);
+            al[i] = *reinterpret_cast<const f16x8*>(&Al[off]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    };
+
+    f16x8 bh0[NT], bl0[NT], bh1[NT], bl1[NT];      // fragments of k-step 0 / k-step 1 (static names: no runtime indexing)
+    load_a(0);
+    load_b(bh0, bl0, 0, 0);
+    store_a(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < nk;
+        // issue order is pinned (sched_barrier): hipcc otherwise sinks the B loads next to their use and then waits
+        // vmcnt(0) for everything in flight.  In-order vmcnt: step 1 needs B(t,1) with only A(t+1) newer, the next
+        // step 0 needs B(t+1,0) with B(t+1,1) and A(t+2) newer, store_a needs A(t+1) with B(t+1,0) newer.
+        load_b(bh1, bl1, t, 1);
+        if (more) load_a(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(buf, 0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_b(bh0, bl0, t + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(buf, 1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_a(buf ^ 1);
+        __syncthreads();
+    }
+    if (g.overflow && ovf) atomicOr(g.overflow, 1);
+    gemm_epilogue<MT, NT, WM, WN, POOL>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
+}
+
+template <int MT, int NT, int WM, int WN, bool POOL>
+int launch_v2(const ogmm_gemm& g, hipStream_t stream) {
+    constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
+    constexpr size_t LDS = (size_t)2 * 2 * BM * LDH * sizeof(_Float16);
+    static_assert(LDS >= (size_t)(BM / 4) * BN * sizeof(int), "pool scratch must fit");
+    const int rows_per_tile = POOL ? (BM / g.pool_k) * g.pool_k : BM;
+    const int m_tiles = (g.M + rows_per_tile - 1) / rows_per_tile;
+    const int n_tiles = (g.N + BN - 1) / BN;
+    const int m_tiles8 = (m_tiles + 7) / 8 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v2_kernel<MT, NT, WM, WN, POOL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(m_tiles8 * n_tiles), 1, 1);
+    hipLaunchKernelGGL((gemm_f16x3_v2_kernel<MT, NT, WM, WN, POOL>), grid, dim3(T), LDS, stream, g, rows_per_tile, m_tiles, n_tiles);
+    return ogmm::check_launch("ogmm_gemm_nt(f16x3 frag)");
+}
+
+}  // namespace
+
+namespace ogmm {
+
+int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
+    OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
+    OGMM_REQUIRE(g.ldb_h > 0 && g.ldb_h % 32 == 0 && (g.K1 + 31) / 32 * 32 + (g.K2 + 31) / 32 * 32 <= g.ldb_h,
+                 "ogmm_gemm_nt(f16x3 frag): ldb_h (padded K) must be a multiple of 32 covering the padded K pieces");
+    OGMM_REQUIRE(g.batch_outer * g.batch_inner == 1, "ogmm_gemm_nt(f16x3 frag): batching not supported");
+    OGMM_REQUIRE(g.K2 == 0 || g.K1 % 32 == 0, "ogmm_gemm_nt(f16x3 frag): two A pieces need K1 %% 32 == 0");
+    if (g.pool_k > 0) return g.N <= 64 ? launch_v2<5, 1, 1, 2, true>(g, s) : launch_v2<5, 1, 1, 4, true>(g, s);
+    switch (g.precision) {
+        case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves
+        case 22: return launch_v2<4, 2, 2, 2, false>(g, s);    // 256 x 128, 4 waves
+        case 23: return launch_v2<2, 2, 4, 2, false>(g, s);    // 256 x 128, 8 waves
+        case 24: return launch_v2<4, 2, 2, 4, false>(g, s);    // 256 x 256, 8 waves
+        default: break;
+    }
+    if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
+    // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)
+    const long long big_tiles = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (g.N >= 256 && big_tiles >= 512) return launch_v2<4, 2, 2, 4, false>(g, s);
+    return launch_v2<2, 2, 2, 2, false>(g, s);
+}
+
+}  // namespace ogmm

@@ -129,7 +129,8 @@ def _add_splits(L):
     for v in L.values():
         if isinstance(v, dict):
             if "W" in v and torch.is_tensor(v["W"]) and v["W"].dim() == 2 and v["W"].shape[1] >= 32:
-                v["split"] = ops.split_f16(v["W"])
+                K = v["W"].shape[1]
+                v["split"] = ops.split_f16(v["W"], frag=True, k1=v.get("k1", K))
             else:
                 _add_splits(v)
 

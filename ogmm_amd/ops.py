@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16X3, PREC_F32, GemmDesc  # noqa: F401
+from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16X3, PREC_F16X3_FRAG, PREC_F32, GemmDesc  # noqa: F401
 
 
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
@@ -85,11 +85,31 @@ def gather_rows(feats, ld, C, N, D, ids, cloud_map=None):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM engine
-def split_f16(W, pad_to=8):
-    """fp32 [N,K] -> dict(W_hi, W_lo binary16 [N, Kpad], inv_scale): W * 2^e = hi + lo with the power of two chosen so
-    that max|W| * 2^e is in [2^11, 2^12) (keeps `lo` a normal binary16 number); inv_scale = 2^-e goes into alpha."""
+def split_f16(W, pad_to=8, frag=False, k1=None):
+    """fp32 [N,K] -> dict(W_hi, W_lo binary16, inv_scale): W * 2^e = hi + lo with the power of two chosen so
+    that max|W| * 2^e is in [2^11, 2^12) (keeps `lo` a normal binary16 number); inv_scale = 2^-e goes into alpha.
+    frag=False: row-major [N, Kpad8] planes (OGMM_PREC_F16X3).  frag=True: the fragment-major image of
+    OGMM_PREC_F16X3_FRAG ([Npad256/32][Kpad32/16][64][8]); k1 = length of the first A piece when the input is a
+    channel concatenation (the second piece is then moved to start at a multiple of 32)."""
     import math
     W = W.float()
+    if frag:
+        N, K = W.shape
+        k1 = K if k1 is None else k1
+        assert k1 % 32 == 0 or k1 == K
+        k2 = K - k1
+        k1p, k2p = (k1 + 31) // 32 * 32, (k2 + 31) // 32 * 32
+        Wp = W.new_zeros((N + 255) // 256 * 256, k1p + k2p)
+        Wp[:N, :k1] = W[:, :k1]
+        if k2:
+            Wp[:N, k1p:k1p + k2] = W[:, k1:]
+        planes = split_f16(Wp, pad_to=32)
+        Np, Kp = Wp.shape
+
+        def image(P):      # [Np, Kp] -> [Np/32][Kp/16][lane = g*32 + r][8]
+            return P.view(Np // 32, 32, Kp // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+        return {"W_hi": image(planes["W_hi"]), "W_lo": image(planes["W_lo"]), "inv_scale": planes["inv_scale"],
+                "variant": PREC_F16X3_FRAG, "ldb_h": Kp}
     amax = float(W.abs().max())
     e = 0 if amax == 0.0 or not math.isfinite(amax) else 11 - math.floor(math.log2(amax))
     e = max(-24, min(24, e))
@@ -113,8 +133,8 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.A2, d.lda2, d.K2 = (A2.data_ptr() if A2 is not None else None), lda2, K2
     d.B, d.ldb = (B.data_ptr() if B is not None else None), ldb
     if split is not None:
-        d.precision = PREC_F16X3
-        d.B_hi, d.B_lo, d.ldb_h = split["W_hi"].data_ptr(), split["W_lo"].data_ptr(), split["W_hi"].shape[-1]
+        d.precision = split.get("variant", PREC_F16X3)
+        d.B_hi, d.B_lo, d.ldb_h = split["W_hi"].data_ptr(), split["W_lo"].data_ptr(), split.get("ldb_h", split["W_hi"].shape[-1])
         d.overflow = overflow.data_ptr() if overflow is not None else None
         alpha = alpha * split["inv_scale"]
     d.C, d.ldc = (C.data_ptr() if C is not None else None), ldc
@@ -140,6 +160,8 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
     e1.record()
     variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
+    if split is not None and split.get("variant", 1) != PREC_F16X3_FRAG and batch == (1, 1) and not pool_k:
+        variant += "_rowmajor"
     GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * batch[0] * batch[1], variant))
 
 

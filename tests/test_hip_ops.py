@@ -97,11 +97,13 @@ def _gemm_ref(A, B):
     return (A.double() @ B.double().t())
 
 
-ENGINES = ["f32", "f16x3"]
+ENGINES = ["f32", "f16x3", "f16x3_frag"]
 
 
 def _split(ops, B, engine):
-    return ops.split_f16(dev(B)) if engine == "f16x3" else None
+    if engine == "f32":
+        return None
+    return ops.split_f16(dev(B), frag=engine == "f16x3_frag")
 
 
 @pytest.mark.parametrize("engine", ENGINES)
@@ -138,7 +140,7 @@ def test_gemm_f16x3_accuracy_is_fp32_class_and_flags_overflow(ops):
     o32, o16 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     ops.gemm_nt(dev(A), K, K, dev(B), K, M, N, C=o32, ldc=N)
-    ops.gemm_nt(dev(A), K, K, None, K, M, N, C=o16, ldc=N, split=ops.split_f16(dev(B)), overflow=flag)
+    ops.gemm_nt(dev(A), K, K, None, K, M, N, C=o16, ldc=N, split=ops.split_f16(dev(B), frag=True), overflow=flag)
     e32 = (o32.cpu().double() - ref).abs().max().item()
     e16 = (o16.cpu().double() - ref).abs().max().item()
     print("max abs error: exact-fp32 engine %.3e, fp16x3 engine %.3e (|C| max %.2f)" % (e32, e16, ref.abs().max().item()))
@@ -189,13 +191,13 @@ def test_gemm_edge_pooling(ops, k, Cout, engine):
     W, s, t = torch.randn(Cout, Cin) / 8, torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
     pool = torch.full((P, 512), -1.0, device="cuda")
     layer = {"W": dev(W), "scale": dev(s), "shift": dev(t), "split": _split(ops, W, engine)}
-    out = ops.edgeconv_layer(dev(h), layer, k, pool[:, 64:64 + Cout], split=engine == "f16x3")
+    out = ops.edgeconv_layer(dev(h), layer, k, pool[:, 64:64 + Cout], split=engine != "f32")
     ref = torch.relu(_gemm_ref(h, W) * s.double() + t.double())
     assert (out.cpu().double() - ref).abs().max().item() < 1e-5
     assert (pool[:, 64:64 + Cout].cpu().double() - ref.view(P, k, Cout).max(1)[0]).abs().max().item() < 1e-5
     assert bool((torch.cat([pool[:, :64], pool[:, 64 + Cout:]], 1) == -1.0).all()), "pooled write left its column slab"
     pool2 = torch.zeros((P, Cout), device="cuda")
-    assert ops.edgeconv_layer(dev(h), layer, k, pool2, store=False, split=engine == "f16x3") is None
+    assert ops.edgeconv_layer(dev(h), layer, k, pool2, store=False, split=engine != "f32") is None
     assert torch.equal(pool2, pool[:, 64:64 + Cout].contiguous())
 
 
