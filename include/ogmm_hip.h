@@ -81,8 +81,8 @@ enum { OGMM_ACT_NONE = 0, OGMM_ACT_RELU = 1, OGMM_ACT_LEAKY02 = 2, OGMM_ACT_SIGM
 enum { OGMM_PREC_F32 = 0, OGMM_PREC_F16X3 = 1, OGMM_PREC_F16X3_FRAG = 2 };
 /* OGMM_PREC_F16X3_FRAG: same arithmetic as F16X3, but B_hi/B_lo are given as the fragment-major image
  *   image[n/32][k/16][lane 0..63][8 halfs], lane = ((k % 16) / 8) * 32 + n % 32, element = k % 8,
- * with n padded to a multiple of 256 and k to a multiple of 32 by zeros (two A pieces: the second piece starts at the
- * k-block K1/16, K1 % 32 == 0); ldb_h = padded K.  Each wave then reads its
+ * with n padded to a multiple of 256 and k to a multiple of 64 by zeros (two A pieces: the second piece starts at the
+ * k-block K1/16, K1 % 64 == 0); ldb_h = padded K.  Each wave then reads its
  * v_mfma_f32_32x32x16_f16 B operands as coalesced 1 KiB loads without touching LDS (no batching in this mode). */
 
 typedef struct ogmm_gemm {

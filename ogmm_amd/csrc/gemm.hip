@@ -172,7 +172,7 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
                      "ogmm_gemm_nt: pooling needs pool_out, ReLU, 4 <= pool_k <= 160, M %% pool_k == 0, no batching");
-    if (g.precision == OGMM_PREC_F16X3_FRAG || g.precision > 20) return ogmm::gemm_nt_f16x3_frag(g, s);
+    if (g.precision == OGMM_PREC_F16X3_FRAG || g.precision >= 18) return ogmm::gemm_nt_f16x3_frag(g, s);
     if (g.precision != OGMM_PREC_F32) return ogmm::gemm_nt_f16x3(g, s);
     if (g.pool_k > 0) {
         return g.N <= 64 ? launch<5, 1, 1, 2, true>(g, s) : launch<5, 1, 1, 4, true>(g, s);

@@ -91,4 +91,67 @@ __device__ __forceinline__ void gemm_epilogue(const ogmm_gemm& g, f32x16 (&acc)[
     }
 }
 
+// Wide epilogue (no pooling): each wave transposes its 32 x (NT*32) accumulator slab through a private LDS patch so
+// that a lane owns 4 CONSECUTIVE columns of one row, then applies alpha*scale+shift / activation / residual on float4s
+// and stores with global_store_dwordx4 (16 lanes = one 256-byte row segment).  4x fewer store instructions than the
+// one-dword-per-lane MFMA layout: the output phase of these GEMMs is store-issue bound (measured: 36 % of a
+// 131072x512x512 launch), see DESIGN.md.  Needs N % 4 == 0, ldc % 4 == 0 (ldr % 4 == 0), 16-byte aligned C / Res.
+// `smem` must provide waves * 32 * (NT*32 + 4) floats and be free (the K loop has passed its last barrier).
+template <int MT, int NT, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0, int m_end,
+                                                   float alpha) {
+    constexpr int LDC = NT * 32 + 4;
+    constexpr int F4_PER_ROW = NT * 8;                      // float4 per patch row
+    constexpr int ITER = 32 * F4_PER_ROW / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    float* patch = smem + wave * (32 * LDC);
+    float* __restrict__ Cm = g.C;
+    const float* __restrict__ Rm = g.Res;
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + j * 32 + lr] = acc[i][j][r];
+        // (same wave: LDS operations complete in order, no barrier needed)
+#pragma unroll
+        for (int q = 0; q < ITER; ++q) {
+            const int idx = q * 64 + lane;
+            const int rl = idx / F4_PER_ROW, c4 = (idx % F4_PER_ROW) * 4;
+            const int row = m0 + (wm * MT + i) * 32 + rl;
+            const int col = n0 + wn * NT * 32 + c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&patch[rl * LDC + c4]);
+            if (row < m_end && col < g.N) {
+                f32x4 sc = one4, sh = zero4;
+                if (g.row_affine) {
+                    const float s1 = g.scale ? g.scale[row] : 1.0f, t1 = g.shift ? g.shift[row] : 0.0f;
+                    sc = f32x4{s1, s1, s1, s1};
+                    sh = f32x4{t1, t1, t1, t1};
+                } else {
+                    if (g.scale) sc = *reinterpret_cast<const f32x4*>(g.scale + col);
+                    if (g.shift) sh = *reinterpret_cast<const f32x4*>(g.shift + col);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(fmaf(v[e] * alpha, sc[e], sh[e]), g.act);
+                if (Rm) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(Rm + (int64_t)row * g.ldr + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                }
+                *reinterpret_cast<f32x4*>(Cm + (int64_t)row * g.ldc + col) = v;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool wide_epilogue_ok(const ogmm_gemm& g) {
+    return g.pool_k == 0 && g.C != nullptr && (g.N & 3) == 0 && (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
+           (g.Res == nullptr || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.Res) & 15) == 0)) &&
+           (g.row_affine || ((g.scale == nullptr || (reinterpret_cast<uintptr_t>(g.scale) & 15) == 0) &&
+                             (g.shift == nullptr || (reinterpret_cast<uintptr_t>(g.shift) & 15) == 0)));
+}
+
 }  // namespace ogmm_gemm_detail

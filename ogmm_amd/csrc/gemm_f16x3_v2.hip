@@ -167,7 +167,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_
         __syncthreads();
     }
     if (g.overflow && ovf) atomicOr(g.overflow, 1);
-    gemm_epilogue<MT, NT, WM, WN, POOL>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
+    if (!POOL && wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha);
+    else gemm_epilogue<MT, NT, WM, WN, POOL>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
 }
 
 template <int MT, int NT, int WM, int WN, bool POOL>
@@ -175,6 +176,7 @@ int launch_v2(const ogmm_gemm& g, hipStream_t stream) {
     constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
     constexpr size_t LDS = (size_t)2 * 2 * BM * LDH * sizeof(_Float16);
     static_assert(LDS >= (size_t)(BM / 4) * BN * sizeof(int), "pool scratch must fit");
+    static_assert(LDS >= (size_t)WM * WN * 32 * (NT * 32 + 4) * sizeof(float), "wide-epilogue patches must fit");
     const int rows_per_tile = POOL ? (BM / g.pool_k) * g.pool_k : BM;
     const int m_tiles = (g.M + rows_per_tile - 1) / rows_per_tile;
     const int n_tiles = (g.N + BN - 1) / BN;
@@ -194,6 +196,9 @@ int launch_v2(const ogmm_gemm& g, hipStream_t stream) {
 
 namespace ogmm {
 
+bool gemm_f16x3_v3_applicable(const ogmm_gemm& g);
+int gemm_nt_f16x3_v3(const ogmm_gemm& g, hipStream_t s);
+
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
     OGMM_REQUIRE(g.ldb_h > 0 && g.ldb_h % 32 == 0 && (g.K1 + 31) / 32 * 32 + (g.K2 + 31) / 32 * 32 <= g.ldb_h,
@@ -206,8 +211,11 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         case 22: return launch_v2<4, 2, 2, 2, false>(g, s);    // 256 x 128, 4 waves
         case 23: return launch_v2<2, 2, 4, 2, false>(g, s);    // 256 x 128, 8 waves
         case 24: return launch_v2<4, 2, 2, 4, false>(g, s);    // 256 x 256, 8 waves
+        case 18: case 19: case 25: case 26: case 27: case 28: case 29:
+            OGMM_REQUIRE(gemm_f16x3_v3_applicable(g), "v3 not applicable"); return gemm_nt_f16x3_v3(g, s);
         default: break;
     }
+    if (gemm_f16x3_v3_applicable(g)) return gemm_nt_f16x3_v3(g, s);
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
     // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)
     const long long big_tiles = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256);

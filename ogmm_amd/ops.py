@@ -96,14 +96,14 @@ def split_f16(W, pad_to=8, frag=False, k1=None):
     if frag:
         N, K = W.shape
         k1 = K if k1 is None else k1
-        assert k1 % 32 == 0 or k1 == K
+        assert k1 % 64 == 0 or k1 == K
         k2 = K - k1
-        k1p, k2p = (k1 + 31) // 32 * 32, (k2 + 31) // 32 * 32
+        k1p, k2p = (k1 + 63) // 64 * 64, (k2 + 63) // 64 * 64      # K tiles of 64 (v3 engine); v2 walks them as 2 x 32
         Wp = W.new_zeros((N + 255) // 256 * 256, k1p + k2p)
         Wp[:N, :k1] = W[:, :k1]
         if k2:
             Wp[:N, k1p:k1p + k2] = W[:, k1:]
-        planes = split_f16(Wp, pad_to=32)
+        planes = split_f16(Wp, pad_to=64)
         Np, Kp = Wp.shape
 
         def image(P):      # [Np, Kp] -> [Np/32][Kp/16][lane = g*32 + r][8]

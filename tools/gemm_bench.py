@@ -19,7 +19,7 @@ for name, m, n, k1, k2 in shapes:
     for v in variants:
         split = None
         if v != 0:
-            split = ops.split_f16(W, frag=(v == 2 or v > 20)); split["variant"] = v
+            split = ops.split_f16(W, frag=(v == 2 or v >= 18)); split["variant"] = v
         def run():
             ops.gemm_nt(A, k1, k1, W, k1 + k2, m, n, C=out, ldc=n, A2=A2, lda2=k2, K2=k2, split=split)
         run(); torch.cuda.synchronize()
