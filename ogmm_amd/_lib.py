@@ -44,6 +44,7 @@ PROTOTYPES = {
     "ogmm_gemm_nt": [POINTER(GemmDesc), c_void_p],
     "ogmm_edgeconv_first": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
+    "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p],
     "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],
     "ogmm_instnorm_relu": [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p],
     "ogmm_l2norm_rows": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],

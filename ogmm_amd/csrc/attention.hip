@@ -1,0 +1,213 @@
+// K9 fused: anchor attention  softmax(Q K^T / sqrt(dh)) V  for one (cloud, head, 128-query tile) per workgroup.
+// Replaces models/attn.py:78-82 (two einsums + softmax) without ever writing the [C,H,N,M] score tensor.
+//
+// Same arithmetic as the weight-GEMM engine: every fp32 operand (Q, K, V, and the probabilities P) is split into two
+// binary16 terms and each product block is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+// (fp32-class accuracy, see gemm_f16x3.hip); the softmax itself runs in fp32 on the accumulator registers.
+//
+// Workgroup = 4 waves; wave w owns 32 query rows.
+//   1. K_h [M keys][dh] and V_h [M keys][dh] (fp32, head-major channel slabs) are split and staged into LDS as
+//      binary16 hi/lo planes: K as [key][dh] (B operand of S = Q K^T: n = key, k = d), V TRANSPOSED as [d][key]
+//      (B operand of O = P V: n = d, k = key).
+//   2. Q rows are loaded straight into registers in A-fragment order (lane: row l&31, 8 consecutive d's per k-step),
+//      split there; S = Q K^T accumulates in MT x (M/32) 32x32 tiles.
+//   3. softmax over the M keys of each row: the row lives in one 32-lane half across the M/32 tiles -> per-register
+//      max / sum with 5 xor-shuffles each.
+//   4. P is written (split) to a per-wave LDS patch in A-operand order -- the patch re-uses the K planes, hence one
+//      barrier -- and O = P V accumulates in dh/32 tiles, stored head-major.
+#include "ogmm_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+constexpr int DH = 128;                 // head dimension (emb_dims 512 / 4 heads)
+constexpr int QT = 128;                 // queries per workgroup
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int MK>      // MK = M / 32 key tiles (1, 2 or 4)
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                        int64_t ldk, const float* __restrict__ v, int64_t ldv, int N, int H,
+                                                        float scale, float* __restrict__ out, int64_t ldo) {
+    constexpr int M = MK * 32;
+    constexpr int LDK = DH + 8;          // halfs per K-plane row   ([key][d])
+    constexpr int LDV = M + 8;           // halfs per V^T-plane row ([d][key])
+    constexpr int LDP = M + 8;           // halfs per P-patch row   ([query][key])
+    constexpr int KPLANE = M * LDK, VPLANE = DH * LDV, PPLANE = 32 * LDP;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    constexpr int KREGION = (2 * KPLANE > 8 * PPLANE) ? 2 * KPLANE : 8 * PPLANE;     // K planes, later the 4 P patches
+    _Float16* Kh = lds;                  // [2 planes][M][LDK]   (later: 4 waves x [2 planes][32][LDP])
+    _Float16* Vt = lds + KREGION;        // [2 planes][DH][LDV]
+
+    const int tile = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const float* __restrict__ kc = k + ((int64_t)c * M) * ldk + h * DH;
+    const float* __restrict__ vc = v + ((int64_t)c * M) * ldv + h * DH;
+
+    // ---- 1. stage K (split) and V (split + transposed)
+    for (int f = tid; f < M * (DH / 4); f += 256) {
+        const int key = f / (DH / 4), d4 = (f % (DH / 4)) * 4;
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kc + (int64_t)key * ldk + d4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vc + (int64_t)key * ldv + d4);
+        f16x4 khi, klo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a, b;
+            split1(kv[e], a, b);
+            khi[e] = a; klo[e] = b;
+            split1(vv[e], a, b);
+            Vt[(d4 + e) * LDV + key] = a;
+            Vt[VPLANE + (d4 + e) * LDV + key] = b;
+        }
+        *reinterpret_cast<f16x4*>(&Kh[key * LDK + d4]) = khi;
+        *reinterpret_cast<f16x4*>(&Kh[KPLANE + key * LDK + d4]) = klo;
+    }
+
+    // ---- 2. Q fragments into registers (row = query, 8 consecutive d per k-step), overlapping the staging above
+    const int q_row = tile * QT + wave * 32 + lr;
+    const bool row_ok = q_row < N;
+    const float* __restrict__ qp = q + ((int64_t)c * N + min(q_row, N - 1)) * ldq + h * DH;
+    f16x8 qh[DH / 16], ql[DH / 16];
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(qp + s * 16 + lh * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(qp + s * 16 + lh * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 x, y;
+            split1(a[e], x, y); qh[s][e] = x; ql[s][e] = y;
+            split1(b[e], x, y); qh[s][4 + e] = x; ql[s][4 + e] = y;
+        }
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T
+    f32x16 sacc[MK];
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        f16x8 bh[MK], bl[MK];
+#pragma unroll
+        for (int j = 0; j < MK; ++j) {
+            const int off = (j * 32 + lr) * LDK + s * 16 + lh * 8;
+            bh[j] = *reinterpret_cast<const f16x8*>(&Kh[off]);
+            bl[j] = *reinterpret_cast<const f16x8*>(&Kh[KPLANE + off]);
+        }
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[s], bh[j], sacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[s], bl[j], sacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[s], bh[j], sacc[j], 0, 0, 0);
+    }
+
+    // ---- 3. softmax over keys: register r of every tile holds row (r&3)+8(r>>2)+4*lh, column = lane&31 (+32 j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < MK; ++j) { sacc[j][r] *= scale; m = fmaxf(m, sacc[j][r]); }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MK; ++j) { sacc[j][r] = expf(sacc[j][r] - m); sum += sacc[j][r]; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j][r] = sacc[j][r] / sum;
+    }
+
+    // ---- 4. P -> per-wave patch (A-operand order) in the K planes; all waves must be done reading K first
+    __syncthreads();
+    _Float16* Ph = lds + wave * 2 * PPLANE;
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            _Float16 a, b;
+            split1(sacc[j][r], a, b);
+            const int off = ((r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + j * 32 + lr;
+            Ph[off] = a;
+            Ph[PPLANE + off] = b;
+        }
+    // (the patch is private to the wave: LDS operations of one wave complete in order)
+
+    // ---- O = P V
+    f32x16 oacc[DH / 32];
+#pragma unroll
+    for (int j = 0; j < DH / 32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < M / 16; ++s) {
+        const int aoff = lr * LDP + s * 16 + lh * 8;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(&Ph[aoff]);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(&Ph[PPLANE + aoff]);
+        f16x8 bh[DH / 32], bl[DH / 32];
+#pragma unroll
+        for (int j = 0; j < DH / 32; ++j) {
+            const int off = (j * 32 + lr) * LDV + s * 16 + lh * 8;
+            bh[j] = *reinterpret_cast<const f16x8*>(&Vt[off]);
+            bl[j] = *reinterpret_cast<const f16x8*>(&Vt[VPLANE + off]);
+        }
+#pragma unroll
+        for (int j = 0; j < DH / 32; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], oacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < DH / 32; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], oacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < DH / 32; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], oacc[j], 0, 0, 0);
+    }
+
+    // ---- store head-major: out[c*N + query][h*dh + d]
+#pragma unroll
+    for (int j = 0; j < DH / 32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tile * QT + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < N) out[((int64_t)c * N + row) * ldo + h * DH + j * 32 + lr] = oacc[j][r];
+        }
+    (void)row_ok;
+}
+
+template <int MK>
+int launch_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H, float scale,
+                     float* out, int64_t ldo, hipStream_t s) {
+    constexpr int M = MK * 32;
+    constexpr int KPL = 2 * M * (DH + 8), PPL = 8 * 32 * (M + 8);
+    const size_t lds = (size_t)((KPL > PPL ? KPL : PPL) + 2 * DH * (M + 8)) * sizeof(_Float16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_kernel<MK>, dim3((N + QT - 1) / QT, H, C), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, N, H, scale, out, ldo);
+    return ogmm::check_launch("ogmm_attention");
+}
+
+}  // namespace
+
+extern "C" int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
+                              int H, int dh, float scale, float* out, int64_t ldo, void* stream) {
+    OGMM_REQUIRE(q && k && v && out && C > 0 && N > 0 && H > 0, "ogmm_attention: null pointer or empty input");
+    OGMM_REQUIRE(dh == DH, "ogmm_attention: head dimension %d not supported (built for %d)", dh, DH);
+    OGMM_REQUIRE(M == 32 || M == 64 || M == 128, "ogmm_attention: %d anchors not supported (32, 64 or 128)", M);
+    OGMM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ogmm::aligned16(q) && ogmm::aligned16(k) && ogmm::aligned16(v),
+                 "ogmm_attention: row strides must be multiples of 4 and pointers 16-byte aligned");
+    hipStream_t s = ogmm::as_stream(stream);
+    if (M == 32) return launch_attention<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
+    if (M == 64) return launch_attention<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
+    return launch_attention<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
+}

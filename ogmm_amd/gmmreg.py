@@ -166,6 +166,7 @@ def pack_weights(sd, D, H):
             w = _w2d(sd, "%s.attn.proj.%d" % (name, i))
             b = sd["%s.attn.proj.%d.bias" % (name, i)].float()
             T[tag] = {"W": w[old_of_new].contiguous(), "shift": b[old_of_new].contiguous()}
+        T["kv"] = {"W": torch.cat([T["k"]["W"], T["v"]["W"]], 0).contiguous(), "shift": torch.cat([T["k"]["shift"], T["v"]["shift"]]).contiguous()}
         wm = _w2d(sd, name + ".attn.merge")
         T["merge"] = {"W": wm[:, old_of_new].contiguous(), "shift": sd[name + ".attn.merge.bias"].float().contiguous()}
         T["mlp0"] = conv_bias(name + ".mlp.0")
@@ -219,6 +220,13 @@ class GMMReg(nn.Module):
         dh, M = D // H, anchors.shape[1]
         dev = x.device
         q = ops.conv1x1(x, L["q"])
+        if ops.attention_supported(M, dh):
+            kv = ops.conv1x1(anchors.view(C * M, D), L["kv"])            # keys | values in one GEMM
+            o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H)
+            msg = ops.conv1x1(o, L["merge"])
+            z = ops.conv1x1(x, L["mlp0"], x2=msg)
+            ops.instnorm_relu_(z, C, N, BN_EPS)
+            return ops.conv1x1(z, L["mlp3"], res=res)
         kk = ops.conv1x1(anchors.view(C * M, D), L["k"])
         vT = torch.empty((C, D, M), dtype=torch.float32, device=dev)            # V^T per cloud: rows = head-major channels
         ops.gemm_nt(L["v"]["W"], D, D, anchors, D, D, M, C=vT, ldc=M, shift=L["v"]["shift"], row_affine=True,

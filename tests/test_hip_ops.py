@@ -201,6 +201,25 @@ def test_gemm_edge_pooling(ops, k, Cout, engine):
     assert torch.equal(pool2, pool[:, 64:64 + Cout].contiguous())
 
 
+@pytest.mark.parametrize("C,N,M", [(3, 1024, 128), (2, 717, 128), (2, 200, 32), (1, 300, 64)])
+def test_fused_attention(ops, C, N, M):
+    """models/attn.py:78-82 with head-major channels (c = h*dh + d)."""
+    torch.manual_seed(N + M)
+    H, dh = 4, 128
+    D = H * dh
+    q, k, v = torch.randn(C * N, D), torch.randn(C * M, D), torch.randn(C * M, D)
+    got = ops.attention(dev(q), dev(k), dev(v), C, N, M, H).cpu().double()
+    qd, kd, vd = q.double().view(C, N, H, dh), k.double().view(C, M, H, dh), v.double().view(C, M, H, dh)
+    prob = torch.softmax(torch.einsum("cnhd,cmhd->chnm", qd, kd) / dh ** .5, dim=-1)
+    ref = torch.einsum("chnm,cmhd->cnhd", prob, vd).reshape(C * N, D)
+    assert (got - ref).abs().max().item() < 2e-6
+    # strided views (keys | values produced by one GEMM)
+    kv = torch.cat([k, v], 1)
+    kvd = dev(kv)
+    got2 = ops.attention(dev(q), kvd[:, :D], kvd[:, D:], C, N, M, H).cpu().double()
+    assert torch.equal(got2, got)
+
+
 # ------------------------------------------------------------------------------------------------ row / column kernels
 def test_softmax_instnorm_l2norm_rowdot(ops):
     torch.manual_seed(2)
