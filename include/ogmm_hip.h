@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 2
+#define OGMM_ABI_VERSION 3
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -99,6 +99,13 @@ typedef struct ogmm_gemm {
     int32_t act;
     int32_t pool_k; float* pool_out; int64_t ldp; int32_t store_c;
     int32_t precision; const void* B_hi; const void* B_lo; int64_t ldb_h; int32_t* overflow;
+    /* InstanceNorm fusion (models/attn.py:24-25), OGMM_PREC_F16X3_FRAG only, rows grouped per cloud (group_rows = N):
+     *   col_stats != NULL: the epilogue also accumulates, per (row group, column), sum and sum of squares of the stored
+     *     values into col_stats[group][column][2] (double, caller-zeroed)            -- the producer of the normalised map
+     *   a_scale/a_shift != NULL ([group][K1+K2] float): A is read as relu(a * a_scale + a_shift) (relu iff a_relu)
+     *     -- the consumer; ogmm_instnorm_finalize turns the statistics into a_scale / a_shift.
+     * group_rows must be a multiple of the row tile (256; 128 for small problems). */
+    double* col_stats; const float* a_scale; const float* a_shift; int32_t a_relu; int32_t group_rows;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
@@ -132,6 +139,9 @@ int ogmm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream
 /* ---- K10 middle: InstanceNorm1d(affine=False, eps) + ReLU in place over the N points of each
  * (cloud, channel).  models/attn.py:24-25.  x [C][N][ld], D channels. */
 int ogmm_instnorm_relu(float* x, int64_t ld, int C, int N, int D, float eps, void* stream);
+
+/* statistics -> affine: mean = s1/rows, var = s2/rows - mean^2 (biased); scale = 1/sqrt(var+eps), shift = -mean*scale. */
+int ogmm_instnorm_finalize(const double* col_stats, int64_t n_entries, int rows, float eps, float* scale, float* shift, void* stream);
 
 /* ---- K13 pieces.  models/gmmreg.py:74: F.normalize over channels (eps 1e-12), rows of length D. */
 int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream);

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG = 0, 1, 2
@@ -31,6 +31,7 @@ class GemmDesc(Structure):
         ("act", c_int32),
         ("pool_k", c_int32), ("pool_out", c_void_p), ("ldp", c_int64), ("store_c", c_int32),
         ("precision", c_int32), ("B_hi", c_void_p), ("B_lo", c_void_p), ("ldb_h", c_int64), ("overflow", c_void_p),
+        ("col_stats", c_void_p), ("a_scale", c_void_p), ("a_shift", c_void_p), ("a_relu", c_int32), ("group_rows", c_int32),
     ]
 
 
@@ -47,6 +48,7 @@ PROTOTYPES = {
     "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p],
     "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],
     "ogmm_instnorm_relu": [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p],
+    "ogmm_instnorm_finalize": [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "ogmm_l2norm_rows": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_rowdot": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_overlap_cross": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p],

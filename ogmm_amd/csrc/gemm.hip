@@ -168,6 +168,8 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.C || g.pool_k > 0, "ogmm_gemm_nt: no output");
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
+    const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision >= 18;
+    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale), "ogmm_gemm_nt: InstanceNorm fusion is only available with OGMM_PREC_F16X3_FRAG");
     if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,

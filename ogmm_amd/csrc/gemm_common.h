@@ -110,6 +110,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
     float* __restrict__ Cm = g.C;
     const float* __restrict__ Rm = g.Res;
     const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 tot1 = zero4, tot2 = zero4;        // column statistics of this wave's MT*32 rows (InstanceNorm fusion)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -142,6 +143,27 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
                     for (int e = 0; e < 4; ++e) v[e] += rr[e];
                 }
                 *reinterpret_cast<f32x4*>(Cm + (int64_t)row * g.ldc + col) = v;
+                if (g.col_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { tot1[e] += v[e]; tot2[e] = fmaf(v[e], v[e], tot2[e]); }
+                }
+            }
+        }
+    }
+    if (g.col_stats) {
+        // lanes that share (lane % F4_PER_ROW) hold the same 4 columns: fold them, then one fp64 atomic per column and statistic
+#pragma unroll
+        for (int o = F4_PER_ROW; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tot1[e] += __shfl_xor(tot1[e], o, 64); tot2[e] += __shfl_xor(tot2[e], o, 64); }
+        const int col = n0 + wn * NT * 32 + (lane % F4_PER_ROW) * 4;
+        const int first_row = m0 + wm * MT * 32;
+        if (lane < F4_PER_ROW && col < g.N && first_row < m_end) {
+            double* st = g.col_stats + ((int64_t)(first_row / g.group_rows) * g.N + col) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(st + 2 * e, (double)tot1[e]);
+                atomicAdd(st + 2 * e + 1, (double)tot2[e]);
             }
         }
     }

@@ -75,6 +75,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     f32x4 ra[A_P];
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4v = {0.f, 0.f, 0.f, 0.f};
+    f32x4 asc = one4, ash = zero4v;      // fused InstanceNorm: A is read as relu(a * asc + ash); one k-quad per thread and tile
+    const int64_t agroup = g.a_scale ? (int64_t)(m0 / g.group_rows) * (g.K1 + g.K2) : 0;
     unsigned ra_ok = 0;          // validity bits of ra[]: the zero-select is applied when the data is CONSUMED (store_a), so the
     bool ovf = false;            // loads stay in flight across the MFMAs (a select right after the load forces vmcnt(0) there)
     auto load_a = [&](int t) {
@@ -84,6 +87,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_
         const int kbase = second ? (t - nk1) * BKH : t * BKH;
         const int Kp = second ? g.K2 : g.K1;
         ra_ok = 0;
+        if (g.a_scale) {
+            const int kq0 = (tid & 7) * 4;
+            const int kk = (kbase + kq0 < Kp) ? (second ? g.K1 : 0) + kbase + kq0 : 0;
+            asc = *reinterpret_cast<const f32x4*>(g.a_scale + agroup + kk);
+            ash = *reinterpret_cast<const f32x4*>(g.a_shift + agroup + kk);
+        }
 #pragma unroll
         for (int i = 0; i < A_P; ++i) {
             const int f = tid + i * T, row = f >> 3, kq = (f & 7) * 4;
@@ -102,7 +111,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_
             if (A_PIECES % T == 0 || f < A_PIECES) {
                 f16x4 hi, lo;
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                split4v(((ra_ok >> i) & 1u) ? ra[i] : zero, hi, lo, ovf);
+                f32x4 val = ra[i];
+                if (g.a_scale) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        val[e] = fmaf(val[e], asc[e], ash[e]);
+                        if (g.a_relu) val[e] = fmaxf(val[e], 0.0f);
+                    }
+                }
+                split4v(((ra_ok >> i) & 1u) ? val : zero, hi, lo, ovf);
                 const int off = (f >> 3) * LDH + (f & 7) * 4;
                 *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
                 *reinterpret_cast<f16x4*>(&Al[off]) = lo;
@@ -205,6 +222,14 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
                  "ogmm_gemm_nt(f16x3 frag): ldb_h (padded K) must be a multiple of 32 covering the padded K pieces");
     OGMM_REQUIRE(g.batch_outer * g.batch_inner == 1, "ogmm_gemm_nt(f16x3 frag): batching not supported");
     OGMM_REQUIRE(g.K2 == 0 || g.K1 % 32 == 0, "ogmm_gemm_nt(f16x3 frag): two A pieces need K1 %% 32 == 0");
+    if (g.col_stats || g.a_scale)
+        OGMM_REQUIRE(g.group_rows > 0 && g.group_rows % 256 == 0 && g.pool_k == 0 && (!g.a_scale || (g.a_shift && aligned16(g.a_scale) && aligned16(g.a_shift))),
+                     "ogmm_gemm_nt(f16x3 frag): InstanceNorm fusion needs group_rows %% 256 == 0, no pooling, aligned a_scale/a_shift");
+    if (g.col_stats) {
+        ogmm_gemm probe = g;
+        OGMM_REQUIRE(g.C && (g.N & 3) == 0 && (g.ldc & 3) == 0 && aligned16(g.C) && !g.Res, "ogmm_gemm_nt(f16x3 frag): col_stats needs the wide epilogue (N, ldc %% 4 == 0, no residual)");
+        (void)probe;
+    }
     if (g.pool_k > 0) return g.N <= 64 ? launch_v2<5, 1, 1, 2, true>(g, s) : launch_v2<5, 1, 1, 4, true>(g, s);
     switch (g.precision) {
         case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves

@@ -71,6 +71,9 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
     f32x4 ra[A_P];
     unsigned ra_ok = 0;
     bool ovf = false;
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4v = {0.f, 0.f, 0.f, 0.f};
+    f32x4 asc = one4, ash = zero4v;      // fused InstanceNorm: A is read as relu(a * asc + ash); one k-quad per thread and tile
+    const int64_t agroup = g.a_scale ? (int64_t)(m0 / g.group_rows) * (g.K1 + g.K2) : 0;
     auto load_a = [&](int t) {
         const bool second = t >= nk1;
         const float* Ap = second ? g.A2 : g.A;
@@ -78,6 +81,12 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
         const int kbase = second ? (t - nk1) * BK3 : t * BK3;
         const int Kp = second ? g.K2 : g.K1;
         ra_ok = 0;
+        if (g.a_scale) {
+            const int kq0 = (tid & 15) * 4;
+            const int kk = (kbase + kq0 < Kp) ? (second ? g.K1 : 0) + kbase + kq0 : 0;
+            asc = *reinterpret_cast<const f32x4*>(g.a_scale + agroup + kk);
+            ash = *reinterpret_cast<const f32x4*>(g.a_shift + agroup + kk);
+        }
 #pragma unroll
         for (int i = 0; i < A_P; ++i) {
             const int f = tid + i * T, row = f >> 4, kq = (f & 15) * 4;
@@ -93,7 +102,15 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
         const int f = tid + i * T;
         f16x4 hi, lo;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        split4w(((ra_ok >> i) & 1u) ? ra[i] : zero, hi, lo, ovf);
+        f32x4 val = ra[i];
+        if (g.a_scale) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                val[e] = fmaf(val[e], asc[e], ash[e]);
+                if (g.a_relu) val[e] = fmaxf(val[e], 0.0f);
+            }
+        }
+        split4w(((ra_ok >> i) & 1u) ? val : zero, hi, lo, ovf);
         const int off = (f >> 4) * LD3 + (f & 15) * 4;
         *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
         *reinterpret_cast<f16x4*>(&Al[off]) = lo;

@@ -75,6 +75,18 @@ __global__ __launch_bounds__(256) void instnorm_relu_kernel(float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- fused-InstanceNorm statistics -> affine (see ogmm_gemm.col_stats)
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const double* __restrict__ st, int64_t n, int rows, float eps,
+                                                                float* __restrict__ scale, float* __restrict__ shift) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double mean = st[2 * i] / rows;
+    const double var = fmax(st[2 * i + 1] / rows - mean * mean, 0.0);
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    scale[i] = (float)inv;
+    shift[i] = (float)(-mean * inv);
+}
+
 // ---------------------------------------------------------------- F.normalize(dim=channels), one wave per row
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int D,
                                                           float* __restrict__ out, int64_t ldo) {
@@ -193,6 +205,13 @@ extern "C" int ogmm_instnorm_relu(float* x, int64_t ld, int C, int N, int D, flo
     OGMM_REQUIRE(x && C > 0 && N > 0 && D > 0 && ld >= D, "ogmm_instnorm_relu: bad sizes C=%d N=%d D=%d", C, N, D);
     hipLaunchKernelGGL(instnorm_relu_kernel, dim3((D + 63) / 64, C), dim3(256), 0, ogmm::as_stream(stream), x, ld, N, D, eps);
     return ogmm::check_launch("ogmm_instnorm_relu");
+}
+
+extern "C" int ogmm_instnorm_finalize(const double* col_stats, int64_t n_entries, int rows, float eps, float* scale, float* shift, void* stream) {
+    OGMM_REQUIRE(col_stats && scale && shift && n_entries > 0 && rows > 0, "ogmm_instnorm_finalize: null pointer or empty input");
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, ogmm::as_stream(stream), col_stats,
+                       n_entries, rows, eps, scale, shift);
+    return ogmm::check_launch("ogmm_instnorm_finalize");
 }
 
 extern "C" int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream) {

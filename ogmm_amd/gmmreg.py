@@ -224,6 +224,12 @@ class GMMReg(nn.Module):
             kv = ops.conv1x1(anchors.view(C * M, D), L["kv"])            # keys | values in one GEMM
             o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H)
             msg = ops.conv1x1(o, L["merge"])
+            if ops.DEFAULT_SPLIT and ops.instnorm_fusable(L["mlp0"].get("split"), N):
+                # InstanceNorm fused: statistics in mlp0's epilogue, normalise + ReLU while mlp3 stages its A operand
+                stats = torch.zeros((C, 2 * D, 2), dtype=torch.float64, device=dev)
+                z = ops.conv1x1(x, L["mlp0"], x2=msg, col_stats=stats, group_rows=N)
+                a_sc, a_sh = ops.instnorm_finalize(stats, N, BN_EPS)
+                return ops.conv1x1(z, L["mlp3"], res=res, a_affine=(a_sc, a_sh, True), group_rows=N)
             z = ops.conv1x1(x, L["mlp0"], x2=msg)
             ops.instnorm_relu_(z, C, N, BN_EPS)
             return ops.conv1x1(z, L["mlp3"], res=res)

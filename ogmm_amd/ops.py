@@ -125,7 +125,7 @@ def split_f16(W, pad_to=8, frag=False, k1=None):
 
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
-            pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None):
+            pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -152,6 +152,11 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.alpha = alpha
     d.act = act
     d.pool_k, d.pool_out, d.ldp, d.store_c = pool_k, (pool_out.data_ptr() if pool_out is not None else None), ldp, 1 if store_c else 0
+    d.group_rows = group_rows
+    if col_stats is not None:
+        d.col_stats = col_stats.data_ptr()
+    if a_affine is not None:
+        d.a_scale, d.a_shift, d.a_relu = a_affine[0].data_ptr(), a_affine[1].data_ptr(), 1 if a_affine[2] else 0
     if GEMM_TIMELINE is None:
         _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
         return
@@ -165,7 +170,21 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * batch[0] * batch[1], variant))
 
 
-def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None):
+def instnorm_fusable(layer_split, N):
+    """The fused InstanceNorm path needs the fragment-major fp16x3 engine and clouds that are whole row tiles."""
+    return layer_split is not None and layer_split.get("variant") == PREC_F16X3_FRAG and N % 256 == 0
+
+
+def instnorm_finalize(col_stats, rows, eps=1e-5):
+    """col_stats [G, cols, 2] float64 -> (scale, shift) float32 [G, cols]."""
+    G, cols, _ = col_stats.shape
+    scale = torch.empty((G, cols), dtype=torch.float32, device=col_stats.device)
+    shift = torch.empty_like(scale)
+    _lib.call("ogmm_instnorm_finalize", _p(col_stats), G * cols, rows, eps, _p(scale), _p(shift), _stream())
+    return scale, shift
+
+
+def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0):
     """y[rows, Cout] = act((x | x2)[rows, K] @ W^T * scale + shift) + res for a packed layer
     (dict with W [Cout, Kpad], scale, shift -- see gmmreg.pack_*).  x, x2, res, out may be column views
     of wider row-major buffers (last stride 1).  split=True uses the layer's pre-split weights (fp16x3 engine)
@@ -191,7 +210,7 @@ def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, ove
             A2=x2, lda2=(x2.stride(0) if x2 is not None else 0), K2=K2,
             scale=layer.get("scale"), shift=layer.get("shift"), act=act,
             res=res, ldr=(res.stride(0) if res is not None else 0),
-            split=(layer.get("split") if split else None), overflow=overflow)
+            split=(layer.get("split") if split else None), overflow=overflow, col_stats=col_stats, a_affine=a_affine, group_rows=group_rows)
     return out
 
 

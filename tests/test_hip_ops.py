@@ -201,6 +201,35 @@ def test_gemm_edge_pooling(ops, k, Cout, engine):
     assert torch.equal(pool2, pool[:, 64:64 + Cout].contiguous())
 
 
+@pytest.mark.parametrize("C,N,Cmid,Cout", [(2, 256, 256, 128), (64, 1024, 1024, 512)])
+def test_gemm_fused_instance_norm(ops, C, N, Cmid, Cout):
+    """conv -> InstanceNorm1d -> ReLU -> conv (models/attn.py:17-27): statistics from the first GEMM's epilogue, the
+    normalisation applied while the second GEMM stages its A operand.  Both the 128x128 and the 256x256 engines."""
+    torch.manual_seed(C + N)
+    Cin = 128
+    x = torch.randn(C * N, Cin)
+    W0, b0 = torch.randn(Cmid, Cin) / 11, torch.randn(Cmid) * 0.5
+    W1, b1 = torch.randn(Cout, Cmid) / 16, torch.randn(Cout) * 0.1
+    L0 = {"W": dev(W0), "shift": dev(b0), "split": ops.split_f16(dev(W0), frag=True)}
+    L1 = {"W": dev(W1), "shift": dev(b1), "split": ops.split_f16(dev(W1), frag=True)}
+    assert ops.instnorm_fusable(L0["split"], N)
+    stats = torch.zeros((C, Cmid, 2), dtype=torch.float64, device="cuda")
+    xd = dev(x)
+    z = ops.conv1x1(xd, L0, col_stats=stats, group_rows=N, split=True)
+    sc, sh = ops.instnorm_finalize(stats, N)
+    y = ops.conv1x1(z, L1, a_affine=(sc, sh, True), group_rows=N, split=True)
+    # unfused path of this library, and an fp64 reference on a few clouds
+    z2 = ops.conv1x1(xd, L0, split=True)
+    ops.instnorm_relu_(z2, C, N)
+    y2 = ops.conv1x1(z2, L1, split=True)
+    assert (y - y2).abs().max().item() < 2e-5 * max(1.0, y2.abs().max().item())
+    nc = min(C, 2)
+    zr = x[:nc * N].double() @ W0.double().t() + b0.double()
+    zr = torch.relu(torch.nn.functional.instance_norm(zr.view(nc, N, Cmid).transpose(1, 2), eps=1e-5)).transpose(1, 2).reshape(nc * N, Cmid)
+    yr = zr @ W1.double().t() + b1.double()
+    assert (y[:nc * N].cpu().double() - yr).abs().max().item() < 2e-5 * max(1.0, yr.abs().max().item())
+
+
 @pytest.mark.parametrize("C,N,M", [(3, 1024, 128), (2, 717, 128), (2, 200, 32), (1, 300, 64)])
 def test_fused_attention(ops, C, N, M):
     """models/attn.py:78-82 with head-major channels (c = h*dh + d)."""
