@@ -117,6 +117,15 @@ int ogmm_edgeconv_first(const float* xyz, const int32_t* idx, int C, int N, int 
                         const float* W /*[64][6]*/, const float* scale, const float* shift,
                         float* h1, float* pool_out, int64_t ldp, void* stream);
 
+/* ---- K2+K3 fused: the whole EdgeConv chain (gather, conv1..conv4 + BN + ReLU, max over k after each layer) for
+ * 7 <= k <= 32; xcat[point][0:64 | 64:128 | 128:256 | 256:512] = x1 | x2 | x3 | x4 (models/dgcnn.py:135-150).  Layers 2-4 take
+ * their weights as OGMM_PREC_F16X3_FRAG images (h*, l*) with folded BN scale/shift (s*, t*) and the image's inverse
+ * power-of-two scale (inv*).  No per-edge tensor is written to memory. */
+int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, int N, int k, const float* W1, const float* s1, const float* t1,
+                        const void* h2, const void* l2, const float* s2, const float* t2, float inv2, const void* h3, const void* l3,
+                        const float* s3, const float* t3, float inv3, const void* h4, const void* l4, const float* s4, const float* t4,
+                        float inv4, float* xcat, int64_t ldx, void* stream);
+
 /* ---- K7 front half: PositionEncoding up to its two 64-channel hidden maps.  models/attn.py:65-73:
  * centroid, g=|p-c|^2 -> conv_dis.0 (1->64)+BN+LeakyReLU -> hid_dis; 5-NN offsets, cosine with the
  * global offset -> conv_ang1 (1->64)+BN+LeakyReLU -> max over k_pos -> hid_ang.  The two 64->D/2

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "ogmm_gather_rows": [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_gemm_nt": [POINTER(GemmDesc), c_void_p],
     "ogmm_edgeconv_first": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_edgeconv_fused": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p] +
+                           [c_void_p, c_void_p, c_void_p, c_void_p, c_float] * 3 + [c_void_p, c_int64, c_void_p],
     "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
     "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p],
     "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],

@@ -297,11 +297,15 @@ class GMMReg(nn.Module):
         # ---- DGCNN (models/dgcnn.py:133-154)
         R = C * N
         xcat = torch.empty((R, 512), dtype=torch.float32, device=dev)
-        h = ops.edgeconv_first(xyz, idx, L["emd1"], xcat[:, 0:64])
-        h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128])
-        h = ops.edgeconv_layer(h, L["emd3"], k, xcat[:, 128:256])
-        ops.edgeconv_layer(h, L["emd4"], k, xcat[:, 256:512], store=False)
-        del h
+        emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
+        if ops.DEFAULT_SPLIT and ops.edgeconv_fused_supported(k, emd):
+            ops.edgeconv_fused(xyz, idx, emd, xcat)                    # per-edge tensors stay on chip
+        else:
+            h = ops.edgeconv_first(xyz, idx, L["emd1"], xcat[:, 0:64])
+            h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128])
+            h = ops.edgeconv_layer(h, L["emd3"], k, xcat[:, 128:256])
+            ops.edgeconv_layer(h, L["emd4"], k, xcat[:, 256:512], store=False)
+            del h
         emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU)
 
         # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)

@@ -223,6 +223,21 @@ def edgeconv_first(xyz, idx, layer, pool_out):
     return h1
 
 
+def edgeconv_fused_supported(k, layers):
+    return 7 <= k <= 32 and all(l.get("split") is not None and l["split"].get("variant") == PREC_F16X3_FRAG for l in layers[1:])
+
+
+def edgeconv_fused(xyz, idx, layers, xcat):
+    """The whole EdgeConv chain in one kernel: layers = [emd1, emd2, emd3, emd4] packed dicts; fills xcat[:, :512]."""
+    C, N, k = idx.shape
+    args = [_p(_f32(xyz, "xyz")), _p(_i32(idx, "idx")), C, N, k, _p(layers[0]["W"]), _p(layers[0]["scale"]), _p(layers[0]["shift"])]
+    for l in layers[1:]:
+        sp = l["split"]
+        args += [_p(sp["W_hi"]), _p(sp["W_lo"]), _p(l["scale"]), _p(l["shift"]), sp["inv_scale"]]
+    _lib.call("ogmm_edgeconv_fused", *args, _p(xcat), xcat.stride(0), _stream())
+    return xcat
+
+
 def edgeconv_layer(h, layer, k, pool_out, store=True, split=None, overflow=None):
     """conv + BN + ReLU on the per-edge tensor h [E, Cin] with max over each point's k edges fused in
     (models/dgcnn.py:141-148).  Returns the un-pooled [E, Cout] (None when store=False)."""

@@ -201,6 +201,32 @@ def test_gemm_edge_pooling(ops, k, Cout, engine):
     assert torch.equal(pool2, pool[:, 64:64 + Cout].contiguous())
 
 
+@pytest.mark.parametrize("C,N,k", [(4, 1024, 20), (3, 200, 12), (2, 717, 20), (1, 333, 32), (2, 64, 7)])
+def test_edgeconv_fused_matches_oracle_dgcnn_front(ops, C, N, k):
+    """models/dgcnn.py:135-150: xcat = cat(x1..x4) against the oracle's EdgeConv chain (same kNN graph)."""
+    from ogmm_amd.gmmreg import pack_weights, state_spec
+    torch.manual_seed(k)
+    sd = {key: torch.zeros(shape, dtype=torch.int64 if key.endswith("num_batches_tracked") else torch.float32) for key, shape in state_spec(512)}
+    synth.fill_state_dict(sd)
+    L = pack_weights({key: v.cuda() for key, v in sd.items()}, 512, 4)
+    xyz = clouds(C, N, seed=61)
+    idx = O.knn_indices(xyz, k)
+    emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
+    assert ops.edgeconv_fused_supported(k, emd)
+    xcat = torch.full((C * N, 512), -1.0, device="cuda")
+    ops.edgeconv_fused(dev(xyz), dev(idx.int()), emd, xcat)
+    # oracle: the four pooled maps (fp64 evaluation of the same chain)
+    Pd = {key: (v.double() if v.is_floating_point() else v) for key, v in sd.items()}
+    h = O.edge_features(xyz.transpose(1, 2).double(), idx)
+    pooled = []
+    for l in (1, 2, 3, 4):
+        h = torch.relu(O._bn(Pd, "emd.bn%d" % l, O._conv(Pd, "emd.conv%d" % l, h)))
+        pooled.append(h.max(dim=-1)[0])
+    ref = torch.cat(pooled, 1).transpose(1, 2).reshape(C * N, 512)
+    err = (xcat.cpu().double() - ref).abs().max().item()
+    assert err < 5e-6 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("C,N,Cmid,Cout", [(2, 256, 256, 128), (64, 1024, 1024, 512)])
 def test_gemm_fused_instance_norm(ops, C, N, Cmid, Cout):
     """conv -> InstanceNorm1d -> ReLU -> conv (models/attn.py:17-27): statistics from the first GEMM's epilogue, the
