@@ -49,18 +49,13 @@ def main():
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from ogmm_amd import dist as odist
+    rank, local_rank, world = odist.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist = odist.init("nccl", rank, world, dev)
 
     from ogmm_amd import ops, synth
     from ogmm_amd.gmmreg import GMMReg
@@ -71,16 +66,13 @@ def main():
     model = model.to(dev).eval()
     model.precision = args.precision
 
-    first = rank * B_PER_GPU                                     # global pair ids of this rank's shard
+    first, _ = odist.shard_pairs(rank, world, B_PER_GPU)         # global pair ids of this rank's shard
     src, tgt, _, _ = synth.make_batch(first, B_PER_GPU, N_POINTS, "partial")
     starts = synth.fps_starts_for(first, B_PER_GPU, N_POINTS)
     src, tgt = src.to(dev), tgt.to(dev)
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        odist.barrier(dist)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -93,10 +85,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         timeline, ops.GEMM_TIMELINE = ops.GEMM_TIMELINE, None
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = odist.max_over_ranks(dist, elapsed, dev)
 
     pairs = B_PER_GPU * world * args.steps
     value = pairs / elapsed

@@ -43,35 +43,72 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     constexpr int LDP = M + 8;           // halfs per P-patch row   ([query][key])
     constexpr int KPLANE = M * LDK, VPLANE = DH * LDV, PPLANE = 32 * LDP;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    constexpr int KREGION = (2 * KPLANE > 8 * PPLANE) ? 2 * KPLANE : 8 * PPLANE;     // K planes, later the 4 P patches
+    constexpr int OPATCH = 32 * (DH + 4) * 2;                                        // fp32 [32][DH+4] output patch, in halfs
+    constexpr int WSTRIDE = (2 * PPLANE > OPATCH) ? 2 * PPLANE : OPATCH;             // per-wave patch (P planes, later O)
+    constexpr int KREGION = (2 * KPLANE > 4 * WSTRIDE) ? 2 * KPLANE : 4 * WSTRIDE;   // K planes, later the 4 wave patches
     _Float16* Kh = lds;                  // [2 planes][M][LDK]   (later: 4 waves x [2 planes][32][LDP])
     _Float16* Vt = lds + KREGION;        // [2 planes][DH][LDV]
 
-    const int tile = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
+    const int h = blockIdx.y, c = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const float* __restrict__ kc = k + ((int64_t)c * M) * ldk + h * DH;
     const float* __restrict__ vc = v + ((int64_t)c * M) * ldv + h * DH;
 
-    // ---- 1. stage K (split) and V (split + transposed)
-    for (int f = tid; f < M * (DH / 4); f += 256) {
-        const int key = f / (DH / 4), d4 = (f % (DH / 4)) * 4;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kc + (int64_t)key * ldk + d4);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(vc + (int64_t)key * ldv + d4);
-        f16x4 khi, klo;
+    // ---- 1. stage K (split) and V (split + transposed).  K: coalesced rows in, rows out.  V: consecutive lanes take
+    // consecutive KEYS of one d-quad, so the transposed 2-byte stores of a wave land on consecutive halfs of one plane row
+    // (the other way round -- consecutive d's per lane -- is a 16-way bank conflict on every store).
+    // (loads are issued in batches of 8 before anything consumes them: with one wave per SIMD a load -> use -> load chain
+    // would expose the full memory latency on every iteration)
+    constexpr int PIECES = M * (DH / 4) / 256;        // float4 per thread and operand: 4, 8 or 16
+    constexpr int BATCH = PIECES < 8 ? PIECES : 8;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 a, b;
-            split1(kv[e], a, b);
-            khi[e] = a; klo[e] = b;
-            split1(vv[e], a, b);
-            Vt[(d4 + e) * LDV + key] = a;
-            Vt[VPLANE + (d4 + e) * LDV + key] = b;
+    for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
+        f32x4 kv[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int f = tid + (b0 + u) * 256;
+            const int key = f / (DH / 4), d4 = (f % (DH / 4)) * 4;
+            kv[u] = *reinterpret_cast<const f32x4*>(kc + (int64_t)key * ldk + d4);
         }
-        *reinterpret_cast<f16x4*>(&Kh[key * LDK + d4]) = khi;
-        *reinterpret_cast<f16x4*>(&Kh[KPLANE + key * LDK + d4]) = klo;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int f = tid + (b0 + u) * 256;
+            const int key = f / (DH / 4), d4 = (f % (DH / 4)) * 4;
+            f16x4 khi, klo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, b;
+                split1(kv[u][e], a, b);
+                khi[e] = a; klo[e] = b;
+            }
+            *reinterpret_cast<f16x4*>(&Kh[key * LDK + d4]) = khi;
+            *reinterpret_cast<f16x4*>(&Kh[KPLANE + key * LDK + d4]) = klo;
+        }
     }
-
+#pragma unroll
+    for (int b0 = 0; b0 < PIECES; b0 += BATCH) {
+        f32x4 vv[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int f = tid + (b0 + u) * 256;
+            const int key = f % M, d4 = (f / M) * 4;
+            vv[u] = *reinterpret_cast<const f32x4*>(vc + (int64_t)key * ldv + d4);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int f = tid + (b0 + u) * 256;
+            const int key = f % M, d4 = (f / M) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, b;
+                split1(vv[u][e], a, b);
+                Vt[(d4 + e) * LDV + key] = a;
+                Vt[VPLANE + (d4 + e) * LDV + key] = b;
+            }
+        }
+    }
+    const int tile = blockIdx.x;
     // ---- 2. Q fragments into registers (row = query, 8 consecutive d per k-step), overlapping the staging above
     const int q_row = tile * QT + wave * 32 + lr;
     const bool row_ok = q_row < N;
@@ -132,7 +169,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 
     // ---- 4. P -> per-wave patch (A-operand order) in the K planes; all waves must be done reading K first
     __syncthreads();
-    _Float16* Ph = lds + wave * 2 * PPLANE;
+    _Float16* Ph = lds + wave * WSTRIDE;
 #pragma unroll
     for (int j = 0; j < MK; ++j)
 #pragma unroll
@@ -171,14 +208,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int j = 0; j < DH / 32; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], oacc[j], 0, 0, 0);
     }
 
-    // ---- store head-major: out[c*N + query][h*dh + d]
+    // ---- store head-major: out[c*N + query][h*dh + d].  The wave's 32 x 128 tile is transposed through its (now free) P
+    // patch so that 16 consecutive lanes write one 512-byte row segment with dwordx4 stores (4x fewer store instructions
+    // than one dword per lane in the MFMA layout; the output phase is store-issue bound).
+    {
+        float* patch = reinterpret_cast<float*>(Ph);              // [32][DH + 4] floats = 16.9 KB <= 2 * PPLANE halfs
 #pragma unroll
-    for (int j = 0; j < DH / 32; ++j)
+        for (int j = 0; j < DH / 32; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tile * QT + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < N) out[((int64_t)c * N + row) * ldo + h * DH + j * 32 + lr] = oacc[j][r];
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * (DH + 4) + j * 32 + lr] = oacc[j][r];
+#pragma unroll
+        for (int qi = 0; qi < 32 * (DH / 4) / 64; ++qi) {
+            const int idx = qi * 64 + lane;
+            const int rl = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+            const int row = tile * QT + wave * 32 + rl;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&patch[rl * (DH + 4) + c4]);
+            if (row < N) *reinterpret_cast<f32x4*>(out + ((int64_t)c * N + row) * ldo + h * DH + c4) = v;
         }
+    }
     (void)row_ok;
 }
 
@@ -186,8 +233,9 @@ template <int MK>
 int launch_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H, float scale,
                      float* out, int64_t ldo, hipStream_t s) {
     constexpr int M = MK * 32;
-    constexpr int KPL = 2 * M * (DH + 8), PPL = 8 * 32 * (M + 8);
-    const size_t lds = (size_t)((KPL > PPL ? KPL : PPL) + 2 * DH * (M + 8)) * sizeof(_Float16);
+    constexpr int KPL = 2 * M * (DH + 8), PPL = 2 * 32 * (M + 8), OPL = 32 * (DH + 4) * 2;
+    constexpr int WST = PPL > OPL ? PPL : OPL;
+    const size_t lds = (size_t)((KPL > 4 * WST ? KPL : 4 * WST) + 2 * DH * (M + 8)) * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -204,7 +252,7 @@ extern "C" int ogmm_attention(const float* q, int64_t ldq, const float* k, int64
     OGMM_REQUIRE(q && k && v && out && C > 0 && N > 0 && H > 0, "ogmm_attention: null pointer or empty input");
     OGMM_REQUIRE(dh == DH, "ogmm_attention: head dimension %d not supported (built for %d)", dh, DH);
     OGMM_REQUIRE(M == 32 || M == 64 || M == 128, "ogmm_attention: %d anchors not supported (32, 64 or 128)", M);
-    OGMM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ogmm::aligned16(q) && ogmm::aligned16(k) && ogmm::aligned16(v),
+    OGMM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ogmm::aligned16(q) && ogmm::aligned16(k) && ogmm::aligned16(v) && ogmm::aligned16(out),
                  "ogmm_attention: row strides must be multiples of 4 and pointers 16-byte aligned");
     hipStream_t s = ogmm::as_stream(stream);
     if (M == 32) return launch_attention<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
