@@ -176,6 +176,126 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
     }
 }
 
+// K15, cached variant (used when the N x J cost matrix fits in LDS, e.g. 64 KB at N=1024, J=16): the cost matrix of an
+// outer iteration is computed once into LDS as [J][N] (both access patterns -- rows on threads, columns on waves -- then
+// touch consecutive words), every Sinkhorn sweep is two passes over it (max, then sum of exp: one exp per entry, no
+// branches), and the unnormalised gamma overwrites it for the M-step.  ~3x fewer instructions per sweep than recomputing
+// sqrt/exp-merge chains; results agree with gmm_em_kernel to rounding.
+__global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __restrict__ xyz, const float* __restrict__ o,
+                                                             const int32_t* __restrict__ ids0, int N, int J, int iters, int sk_iters,
+                                                             float inv_eps, float eps, float inv_tau, float* __restrict__ gamma,
+                                                             float* __restrict__ pi_out, float* __restrict__ mu_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4* pts = reinterpret_cast<float4*>(lds);
+    const int Npad = (N + 3) / 4 * 4;
+    float* u = lds + 4 * (size_t)N;
+    float* logp = u + Npad;
+    float* rclip = logp + Npad;
+    float4* mu = reinterpret_cast<float4*>(rclip + Npad);
+    float* v = reinterpret_cast<float*>(mu + J);
+    float* red = v + J;                                   // [16]
+    float* Cs = red + 16;                                 // [J][N] cost, later unnormalised gamma
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = EM_T / 64;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
+    const float* __restrict__ oc = o + (int64_t)c * N;
+
+    float part = 0.0f;
+    for (int n = tid; n < N; n += EM_T) {
+        const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
+        pts[n] = make_float4(x, y, z, sqnorm3(x, y, z));
+        part += oc[n];
+    }
+    part = wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    float osum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) osum += red[w];
+    osum = fmaxf(osum, 1e-4f);
+    for (int n = tid; n < N; n += EM_T) logp[n] = logf(oc[n] / osum + 1e-8f);
+    for (int j = tid; j < J; j += EM_T) mu[j] = pts[ids0[(int64_t)c * J + j]];
+    const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
+    __syncthreads();
+
+    for (int it = 0; it < iters; ++it) {
+        for (int n = tid; n < N; n += EM_T) {
+            const float4 p = pts[n];
+            u[n] = 0.0f;
+            for (int j = 0; j < J; ++j) {
+                const float4 m = mu[j];
+                Cs[j * N + n] = cdist_mm(p.x, p.y, p.z, p.w, m.x, m.y, m.z, m.w) * inv_tau;
+            }
+        }
+        for (int j = tid; j < J; j += EM_T) v[j] = 0.0f;
+        __syncthreads();
+        for (int sk = 0; sk < sk_iters; ++sk) {
+            for (int n = tid; n < N; n += EM_T) {                     // u^{l+1}: rows on threads
+                const float un = u[n];
+                float mx = -__builtin_inff();
+                for (int j = 0; j < J; ++j) mx = fmaxf(mx, ((-Cs[j * N + n] + un) + v[j]) * inv_eps);
+                float se = 0.0f;
+                for (int j = 0; j < J; ++j) se += expf(((-Cs[j * N + n] + un) + v[j]) * inv_eps - mx);
+                u[n] = eps * (logp[n] - (mx + logf(se))) + un;
+            }
+            __syncthreads();
+            for (int j = wave; j < J; j += NW) {                      // v^{l+1}: columns on waves
+                const float vj = v[j];
+                const float* __restrict__ Cj = Cs + j * N;
+                float mx = -__builtin_inff();
+                for (int n = lane; n < N; n += 64) mx = fmaxf(mx, ((-Cj[n] + u[n]) + vj) * inv_eps);
+                mx = wave_max(mx);
+                float se = 0.0f;
+                for (int n = lane; n < N; n += 64) se += expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
+                se = wave_sum(se);
+                if (lane == 0) v[j] = eps * (logq - (mx + logf(se))) + vj;
+            }
+            __syncthreads();
+        }
+        const bool last = it + 1 == iters;
+        for (int n = tid; n < N; n += EM_T) {                         // gamma = exp(K) (in place), row sums
+            const float un = u[n];
+            float rs = 0.0f;
+            for (int j = 0; j < J; ++j) {
+                float g = expf(((-Cs[j * N + n] + un) + v[j]) * inv_eps);
+                g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+                Cs[j * N + n] = g;
+                rs += g;
+            }
+            const float rc = fmaxf(rs, 1e-3f);
+            rclip[n] = rc;
+            if (last) {
+                float* __restrict__ grow = gamma + ((int64_t)c * N + n) * J;
+                for (int j = 0; j < J; ++j) grow[j] = Cs[j * N + n] / rc;
+            }
+        }
+        __syncthreads();
+        for (int j = wave; j < J; j += NW) {                          // M-step, fp64 column sums
+            const float* __restrict__ Gj = Cs + j * N;
+            double sg = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+            for (int n = lane; n < N; n += 64) {
+                const float4 p = pts[n];
+                const float g = Gj[n] / rclip[n];
+                sg += g;
+                sx += (double)g * p.x; sy += (double)g * p.y; sz += (double)g * p.z;
+            }
+            sg = wave_sum_d(sg); sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
+            if (lane == 0) {
+                const float pj = (float)sg / (float)N;
+                const float npi = pj * (float)N + 1e-5f;
+                const float nx = (float)sx / npi, ny = (float)sy / npi, nz = (float)sz / npi;
+                mu[j] = make_float4(nx, ny, nz, sqnorm3(nx, ny, nz));
+                if (last) {
+                    pi_out[(int64_t)c * J + j] = pj;
+                    float* mo = mu_out + ((int64_t)c * J + j) * 3;
+                    mo[0] = nx; mo[1] = ny; mo[2] = nz;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ================================================================================================
 // K16.  mu_feat[c][j][d] = sum_n gamma[c][n][j] * feats[c][n][d] / (N pi[c][j] + 1e-5)
 // block = (cloud, 64-channel slab, 16-cluster slab): 64 channels x 4 row lanes, 16 accumulators each.
@@ -485,6 +605,17 @@ extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0
     }
     const float inv_eps = (float)(1.0 / (double)epsilon);   // torch divides by a python scalar as multiply-by-reciprocal
     const float inv_tau = (float)(1.0 / (double)tau);
+    const size_t lds_cached = lds + (size_t)N * J * sizeof(float);
+    if (lds_cached <= 128 * 1024) {       // cost matrix resident in LDS
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(gmm_em_cached_kernel, dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters, sk_iters,
+                           inv_eps, epsilon, inv_tau, gamma, pi, mu);
+        return ogmm::check_launch("ogmm_gmm_em(cached)");
+    }
     hipLaunchKernelGGL(gmm_em_kernel, dim3(C), dim3(EM_T), lds, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters, sk_iters, inv_eps,
                        epsilon, inv_tau, gamma, pi, mu);
     return ogmm::check_launch("ogmm_gmm_em");

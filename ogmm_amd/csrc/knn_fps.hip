@@ -43,17 +43,32 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
     int ik[KL];
 #pragma unroll
     for (int p = 0; p < KL; ++p) { dk[p] = __builtin_inff(); ik[p] = 0; }
-    for (int j = 0; j < N; ++j) {
-        const float d = knn_dist(pq, pts[j]);
+    // branch-free stable insertion (selects only; hipcc turns the if/else-if ladder into ~20 branches per insertion);
+    // the only branch left is the wave-level "does any lane insert" test
+    auto insert = [&](float d, int j) {
         if (d < dk[KL - 1]) {
 #pragma unroll
             for (int p = KL - 1; p > 0; --p) {
-                if (d < dk[p - 1]) { dk[p] = dk[p - 1]; ik[p] = ik[p - 1]; }
-                else if (d < dk[p]) { dk[p] = d; ik[p] = j; }
+                const bool shift = d < dk[p - 1];
+                const bool here = !shift && d < dk[p];
+                dk[p] = shift ? dk[p - 1] : (here ? d : dk[p]);
+                ik[p] = shift ? ik[p - 1] : (here ? j : ik[p]);
             }
-            if (d < dk[0]) { dk[0] = d; ik[0] = j; }
+            const bool first = d < dk[0];
+            dk[0] = first ? d : dk[0];
+            ik[0] = first ? j : ik[0];
         }
+    };
+    int j = 0;
+    for (; j + 4 <= N; j += 4) {          // 4 candidates per trip: their LDS reads are in flight together
+        const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
+        const float d0 = knn_dist(pq, p0), d1 = knn_dist(pq, p1), d2 = knn_dist(pq, p2), d3 = knn_dist(pq, p3);
+        insert(d0, j);
+        insert(d1, j + 1);
+        insert(d2, j + 2);
+        insert(d3, j + 3);
     }
+    for (; j < N; ++j) insert(knn_dist(pq, pts[j]), j);
     float d_last = 0.0f, d_next = -1.0f;
 #pragma unroll
     for (int p = 0; p < KL; ++p) {
