@@ -143,14 +143,17 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
     f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];      // B fragments: even / odd k-steps
     f16x8 ah0, al0, ah1, al1;                      // A fragments: even / odd groups
 
+    if ((ABL & 64) && (local & 1)) {          // experiment: stagger half of the workgroups by ~half a main loop
+        for (int z = 0; z < (nk * 3) / 8; ++z) __builtin_amdgcn_s_sleep(127);
+    }
     load_a(0);
     load_b(bhA, blA, 0, 0);
-    if (ABL) { load_b(bhB, blB, 0, 1); }
+    if (ABL & 7) { load_b(bhB, blB, 0, 1); }
 #pragma unroll
     for (int i = 0; i < A_P; ++i) store_a_piece(0, i);
     __syncthreads();
     read_a(ah0, al0, 0, 0, 0);
-    if (ABL) { read_a(ah1, al1, 0, 0, 1); }
+    if (ABL & 7) { read_a(ah1, al1, 0, 0, 1); }
 
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
@@ -165,16 +168,18 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0);
                 // prefetch the next group's A fragments (same tile only: the next tile's first group is read after the barrier)
                 if (!(ABL & 1)) {
                 if (i < MT - 1) { if (i & 1) read_a(ah0, al0, buf, s, i + 1); else read_a(ah1, al1, buf, s, i + 1); }
                 else if (s < 3) read_a(ah0, al0, buf, s + 1, 0);
                 }
                 if (more && s >= 2 && !(ABL & 4)) store_a_piece(buf ^ 1, (s - 2) * 4 + i);
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0);
+                if (ABL & 16) __builtin_amdgcn_s_setprio(1);
                 if (s & 1) { if (i & 1) mma6(i, ah1, al1, bhB, blB); else mma6(i, ah0, al0, bhB, blB); }
                 else       { if (i & 1) mma6(i, ah1, al1, bhA, blA); else mma6(i, ah0, al0, bhA, blA); }
+                if (ABL & 16) __builtin_amdgcn_s_setprio(0);
             }
         }
         __syncthreads();
@@ -223,12 +228,12 @@ static int launch_v3(const ogmm_gemm& g, hipStream_t s) {
 int gemm_nt_f16x3_v3(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {          // 26..29: ablations for tools/gemm_bench.py (wrong results by construction)
         case 26: return launch_v3<7>(g, s);     // MFMA + barrier only
-        case 27: return launch_v3<6>(g, s);     // + LDS A reads
-        case 28: return launch_v3<5>(g, s);     // + B global loads only
         case 29: return launch_v3<3>(g, s);     // + A global loads / split / LDS writes only
+        case 27: return launch_v3<32 + 64>(g, s);    // experiment: no pinning + staggered workgroups
+        case 28: return launch_v3<32>(g, s);    // experiment: no sched_barrier pinning
         case 19: return launch_v3<15>(g, s);    // MFMA only, no epilogue stores
         case 18: return launch_v3<8>(g, s);     // full loop, no epilogue stores
-        default: return launch_v3<0>(g, s);
+        default: return launch_v3<32>(g, s);     // default: no sched_barrier pinning (measured +3-4 %)
     }
 }
 

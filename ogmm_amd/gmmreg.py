@@ -170,6 +170,12 @@ def pack_weights(sd, D, H):
         wm = _w2d(sd, name + ".attn.merge")
         T["merge"] = {"W": wm[:, old_of_new].contiguous(), "shift": sd[name + ".attn.merge.bias"].float().contiguous()}
         T["mlp0"] = conv_bias(name + ".mlp.0")
+        # merge conv folded into the MLP's first conv (SURVEY.md section 7 "legal flop savings"): with msg = o Wm^T + bm,
+        #   mlp0([x | msg]) = x W0a^T + o (W0b Wm)^T + (W0b bm + b0); the product of the two weight matrices is formed in
+        # fp64 and rounded once, so the result differs from the two-step evaluation only by fp32 rounding (parity-tested).
+        w0 = T["mlp0"]["W"].double()
+        T["mlp0_folded"] = {"W": torch.cat([w0[:, :D], w0[:, D:] @ T["merge"]["W"].double()], 1).float().contiguous(),
+                            "shift": (T["mlp0"]["shift"].double() + w0[:, D:] @ T["merge"]["shift"].double()).float().contiguous()}
         T["mlp3"] = conv_bias(name + ".mlp.3")
         L[name] = T
     for name in ("conv1", "conv2", "overlap"):
@@ -203,6 +209,7 @@ class GMMReg(nn.Module):
         # "f16x3": weight GEMMs on the binary16 matrix cores with two-term operand splitting (fp32-class accuracy);
         # "f32": everything on the exact-fp32 MFMA engine.
         self.precision = getattr(config, "precision", "f16x3")
+        self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self._overflow = None
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved
@@ -223,14 +230,17 @@ class GMMReg(nn.Module):
         if ops.attention_supported(M, dh):
             kv = ops.conv1x1(anchors.view(C * M, D), L["kv"])            # keys | values in one GEMM
             o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H)
-            msg = ops.conv1x1(o, L["merge"])
-            if ops.DEFAULT_SPLIT and ops.instnorm_fusable(L["mlp0"].get("split"), N):
+            if self.fold_merge:
+                mlp0, msg = L["mlp0_folded"], o                       # merge conv folded into mlp0's weights
+            else:
+                mlp0, msg = L["mlp0"], ops.conv1x1(o, L["merge"])
+            if ops.DEFAULT_SPLIT and ops.instnorm_fusable(mlp0.get("split"), N):
                 # InstanceNorm fused: statistics in mlp0's epilogue, normalise + ReLU while mlp3 stages its A operand
                 stats = torch.zeros((C, 2 * D, 2), dtype=torch.float64, device=dev)
-                z = ops.conv1x1(x, L["mlp0"], x2=msg, col_stats=stats, group_rows=N)
+                z = ops.conv1x1(x, mlp0, x2=msg, col_stats=stats, group_rows=N)
                 a_sc, a_sh = ops.instnorm_finalize(stats, N, BN_EPS)
                 return ops.conv1x1(z, L["mlp3"], res=res, a_affine=(a_sc, a_sh, True), group_rows=N)
-            z = ops.conv1x1(x, L["mlp0"], x2=msg)
+            z = ops.conv1x1(x, mlp0, x2=msg)
             ops.instnorm_relu_(z, C, N, BN_EPS)
             return ops.conv1x1(z, L["mlp3"], res=res)
         kk = ops.conv1x1(anchors.view(C * M, D), L["k"])
