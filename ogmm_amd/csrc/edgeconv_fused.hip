@@ -6,9 +6,9 @@
 //
 // Tile = P = floor(160 / k) points = P*k <= 160 edge rows (5 MFMA row blocks); 8 waves (2 per SIMD).
 //   layer 1: VALU (K = 6), thread = (channel, edge slot)
-//   layers 2-4: fp16x3 split MFMA (v_mfma_f32_32x32x16_f16, see gemm_f16x3.hip); a wave holds all 5 row blocks of one
-//   32-column block (layer 2: waves 0-1, layer 3: waves 0-3, layer 4: all 8 waves); B fragments come straight from the
-//   fragment-major weight images (L2 resident, 180 KB for the three layers), fetched one k-step ahead.
+//   layers 2-4: fp16x3 split MFMA (v_mfma_f32_32x32x16_f16, see gemm_f16x3.hip); the (row block, 32-column block) grid of a
+//   layer (5 x 2, 5 x 4, 5 x 8) is dealt over the 8 waves; a wave's weight fragments (one column block of a whole layer)
+//   are fetched from the fragment-major images (L2 resident, 180 KB) a full layer ahead of their use.
 // LDS: region A = h1 planes, later h3 planes (87 KB); region B = h2 planes (46 KB); pool scratch 8 x 256 ints.
 #include "ogmm_common.h"
 
@@ -39,36 +39,36 @@ __device__ __forceinline__ void load_weights(f16x8 (&wb)[KS][2], const void* hi,
     }
 }
 
-// One MFMA layer for this wave: rows 0..159 (5 blocks) x the 32-column block nb (weights already in registers).
+// One MFMA layer for this wave: NB row blocks of 32 starting at block rb0 x the 32-column block nb (weights already in registers).
 //   in  : A planes (hi at Ain, lo at Ain + ROWS*LDA), K = 16*KS input channels
 //   out : relu(acc * scale + shift) -> pooled max per point into pool_s[point][column] (int atomicMax), and, if Aout != null,
 //         split into the next layer's A planes.
-template <int KS>
-__device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f16x8 (&wb)[KS][2], int nb, float inv_scale,
+template <int KS, int NB>
+__device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f16x8 (&wb)[KS][2], int nb, int rb0, float inv_scale,
                                            const float* __restrict__ scale, const float* __restrict__ shift, _Float16* Aout, int LDO,
                                            int* pool_s, int pool_ld, unsigned inv_k16, int rows_valid, int lane) {
     const int lr = lane & 31, lh = lane >> 5;
-    f32x16 acc[5];
+    f32x16 acc[NB];
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const int APL = ROWS * LDA;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        f16x8 ah[5], al[5];
+        f16x8 ah[NB], al[NB];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int off = (i * 32 + lr) * LDA + s * 16 + lh * 8;
+        for (int i = 0; i < NB; ++i) {
+            const int off = ((rb0 + i) * 32 + lr) * LDA + s * 16 + lh * 8;
             ah[i] = *reinterpret_cast<const f16x8*>(&Ain[off]);
             al[i] = *reinterpret_cast<const f16x8*>(&Ain[APL + off]);
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wb[s][0], acc[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wb[s][0], acc[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wb[s][1], acc[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wb[s][1], acc[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wb[s][0], acc[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wb[s][0], acc[i], 0, 0, 0);
     }
     const int OPL = ROWS * LDO;
     const int col = nb * 32 + lr;
@@ -76,10 +76,10 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
     int cur_group = -1;
     float cur_max = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int row = (rb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float v = fmaxf(fmaf(acc[i][r], sc, sh), 0.0f);
             if (Aout) {
                 _Float16 a, b;
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
 
     // weight fragments travel from L2 while the gather and layer 1 run (they do not depend on the activations)
     f16x8 wb2[4][2], wb3[4][2], wb4[8][2];
-    if (wave < 2) load_weights<4>(wb2, w.h2, w.l2, wave, lane);
-    if (wave < 4) load_weights<4>(wb3, w.h3, w.l3, wave, lane);
+    load_weights<4>(wb2, w.h2, w.l2, wave & 1, lane);
+    load_weights<4>(wb3, w.h3, w.l3, wave & 3, lane);
 
     // ---- gather: one thread per edge row fetches (x_j - x_i, x_i) once (two dependent global loads per edge, all 160 in flight
     // together) into region B, which is free until layer 2 writes h2
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
 
     // ---- layer 2: 64 -> 64, waves 0 and 1 own 32 columns each
     load_weights<8>(wb4, w.h4, w.l4, wave, lane);       // needed two layers from now
-    if (wave < 2) mfma_layer<4>(regA, LD64, wb2, wave, w.inv2, w.s2, w.t2, regB, LD64, pool_s, 256, inv_k16, rows_valid, lane);
+    // 2 column blocks x 5 row blocks over 8 waves: waves 0-1 take row blocks {0,1}, waves 2-7 one of {2,3,4}
+    if (wave < 2) mfma_layer<4, 2>(regA, LD64, wb2, wave & 1, 0, w.inv2, w.s2, w.t2, regB, LD64, pool_s, 256, inv_k16, rows_valid, lane);
+    else mfma_layer<4, 1>(regA, LD64, wb2, wave & 1, 1 + (wave >> 1), w.inv2, w.s2, w.t2, regB, LD64, pool_s, 256, inv_k16, rows_valid, lane);
     __syncthreads();
     for (int i = tid; i < pts * 64; i += 512) {
         const int p = i >> 6, ch = i & 63;
@@ -184,7 +186,9 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
     __syncthreads();
 
     // ---- layer 3: 64 -> 128, waves 0-3 own 32 columns each; output planes overwrite region A (h1 is dead)
-    if (wave < 4) mfma_layer<4>(regB, LD64, wb3, wave, w.inv3, w.s3, w.t3, regA, LD128, pool_s, 256, inv_k16, rows_valid, lane);
+    // 4 column blocks x 5 row blocks over 8 waves: waves 0-3 take row blocks {0,1,2}, waves 4-7 {3,4}
+    if (wave < 4) mfma_layer<4, 3>(regB, LD64, wb3, wave & 3, 0, w.inv3, w.s3, w.t3, regA, LD128, pool_s, 256, inv_k16, rows_valid, lane);
+    else mfma_layer<4, 2>(regB, LD64, wb3, wave & 3, 3, w.inv3, w.s3, w.t3, regA, LD128, pool_s, 256, inv_k16, rows_valid, lane);
     __syncthreads();
     for (int i = tid; i < pts * 128; i += 512) {
         const int p = i >> 7, ch = i & 127;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
     __syncthreads();
 
     // ---- layer 4: 128 -> 256, every wave 32 columns; only the pooled output is needed
-    mfma_layer<8>(regA, LD128, wb4, wave, w.inv4, w.s4, w.t4, nullptr, 0, pool_s, 256, inv_k16, rows_valid, lane);
+    mfma_layer<8, 5>(regA, LD128, wb4, wave, 0, w.inv4, w.s4, w.t4, nullptr, 0, pool_s, 256, inv_k16, rows_valid, lane);
     __syncthreads();
     for (int i = tid; i < pts * 256; i += 512) {
         const int p = i >> 8, ch = i & 255;
