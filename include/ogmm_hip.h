@@ -138,9 +138,12 @@ int ogmm_pos_hidden(const float* xyz, const int32_t* idx, int idx_ld, int k_pos,
 /* ---- K9 fused: softmax(Q K^T * scale) V per (cloud, head) without materialising the scores.  models/attn.py:78-82.
  * q [C*N][ldq], k and v [C*M][ldk|ldv], out [C*N][ldo]; all head-major: head h owns columns [h*dh, (h+1)*dh)
  * (the host packs the projection weights that way, models/attn.py:96 interleaves d*H + h).  dh = 128, M in {32,64,128}.
- * fp16x3 split arithmetic on the matrix cores, fp32 softmax (see ogmm_gemm_nt). */
+ * fp16x3 split arithmetic on the matrix cores, fp32 softmax (see ogmm_gemm_nt).
+ * workspace (device, ogmm_attention_workspace_bytes(C, M, H, dh) bytes, 16-byte aligned) receives the split fragment-major
+ * K / V images shared by all query tiles of a head; with workspace == NULL every workgroup stages K / V itself (slower). */
+int64_t ogmm_attention_workspace_bytes(int C, int M, int H, int dh);
 int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
-                   int H, int dh, float scale, float* out, int64_t ldo, void* stream);
+                   int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream);
 
 /* ---- K9 middle (unfused fallback): in-place softmax over the last axis (keys).  models/attn.py:80. cols <= 1024. */
 int ogmm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream);

@@ -47,7 +47,8 @@ PROTOTYPES = {
     "ogmm_edgeconv_fused": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p] +
                            [c_void_p, c_void_p, c_void_p, c_void_p, c_float] * 3 + [c_void_p, c_int64, c_void_p],
     "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
-    "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p],
+    "ogmm_attention_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],
     "ogmm_instnorm_relu": [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p],
     "ogmm_instnorm_finalize": [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p],
@@ -80,7 +81,7 @@ def load():
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)      # AttributeError here = missing export
         fn.argtypes = argtypes
-        fn.restype = c_char_p if name == "ogmm_last_error" else c_int
+        fn.restype = c_char_p if name == "ogmm_last_error" else (c_int64 if name.endswith("_bytes") else c_int)
     if lib.ogmm_abi_version() != ABI_VERSION:
         raise OgmmError("libogmm_hip.so ABI %d != binding ABI %d" % (lib.ogmm_abi_version(), ABI_VERSION))
     _lib = lib

@@ -229,6 +229,223 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     (void)row_ok;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Second structure: K and V of every (cloud, head) are split and laid out ONCE per call, by attention_pack_kernel, as
+// fragment-major images (the B-operand order of v_mfma_f32_32x32x16_f16, like the weight images of gemm_f16x3_v2.hip):
+//   Kimg[c][h][plane][key/32][d/16][lane][8]    lane = ((d % 16) / 8) * 32 + key % 32      (S = Q K^T:  n = key, k = d)
+//   Vimg[c][h][plane][d/32][key/16][lane][8]    lane = ((key % 16) / 8) * 32 + d % 32      (O = P V:    n = d,   k = key)
+// The attention workgroups then read their B fragments as coalesced 1 KiB loads (L2/L1 resident, shared by the 8 query
+// tiles of a head) instead of re-splitting and re-transposing 128 KB of K/V per 128 queries; LDS only holds the per-wave
+// P patch (70 KB per workgroup -> two workgroups per CU).
+// ------------------------------------------------------------------------------------------------------------------
+template <int MK>
+__global__ __launch_bounds__(256) void attention_pack_kernel(const float* __restrict__ k, int64_t ldk, const float* __restrict__ v,
+                                                             int64_t ldv, int H, f16x8* __restrict__ kimg, f16x8* __restrict__ vimg) {
+    constexpr int M = MK * 32;
+    constexpr int GROUPS = M * DH / 8;                 // 8-element groups per plane and operand
+    const int h = blockIdx.y, c = blockIdx.z;
+    const float* __restrict__ kc = k + ((int64_t)c * M) * ldk + h * DH;
+    const float* __restrict__ vc = v + ((int64_t)c * M) * ldv + h * DH;
+    f16x8* __restrict__ ko = kimg + ((int64_t)c * H + h) * 2 * GROUPS;
+    f16x8* __restrict__ vo = vimg + ((int64_t)c * H + h) * 2 * GROUPS;
+    for (int gI = blockIdx.x * 256 + threadIdx.x; gI < GROUPS; gI += gridDim.x * 256) {
+        const int lane = gI & 63;
+        {   // K image: [key/32][d/16][lane]
+            const int kb = (gI >> 6) % (DH / 16), nb = (gI >> 6) / (DH / 16);
+            const int key = nb * 32 + (lane & 31), d0 = kb * 16 + (lane >> 5) * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(kc + (int64_t)key * ldk + d0);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(kc + (int64_t)key * ldk + d0 + 4);
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 x, y;
+                split1(a[e], x, y); hi[e] = x; lo[e] = y;
+                split1(b[e], x, y); hi[4 + e] = x; lo[4 + e] = y;
+            }
+            ko[gI] = hi;
+            ko[GROUPS + gI] = lo;
+        }
+        {   // V image: [d/32][key/16][lane]
+            const int kb = (gI >> 6) % (M / 16), nb = (gI >> 6) / (M / 16);
+            const int d = nb * 32 + (lane & 31), key0 = kb * 16 + (lane >> 5) * 8;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x, y;
+                split1(vc[(int64_t)(key0 + e) * ldv + d], x, y);
+                hi[e] = x; lo[e] = y;
+            }
+            vo[gI] = hi;
+            vo[GROUPS + gI] = lo;
+        }
+    }
+}
+
+template <int MK>
+__global__ __launch_bounds__(256, 2) void attention_frag_kernel(const float* __restrict__ q, int64_t ldq, const f16x8* __restrict__ kimg,
+                                                                const f16x8* __restrict__ vimg, int N, int H, float scale,
+                                                                float* __restrict__ out, int64_t ldo) {
+    constexpr int M = MK * 32;
+    constexpr int GROUPS = M * DH / 8;
+    constexpr int LDP = M + 8;
+    constexpr int PPLANE = 32 * LDP;
+    constexpr int OPATCH = 32 * (DH + 4) * 2;
+    constexpr int WSTRIDE = (2 * PPLANE > OPATCH) ? 2 * PPLANE : OPATCH;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tile = blockIdx.x, h = blockIdx.y, c = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const f16x8* __restrict__ KH = kimg + ((int64_t)c * H + h) * 2 * GROUPS + lane;
+    const f16x8* __restrict__ VH = vimg + ((int64_t)c * H + h) * 2 * GROUPS + lane;
+
+    // Q fragments (row = query, 8 consecutive d per k-step), split in registers
+    const int q_row = tile * QT + wave * 32 + lr;
+    const float* __restrict__ qp = q + ((int64_t)c * N + min(q_row, N - 1)) * ldq + h * DH;
+    f32x4 qa[DH / 16], qb[DH / 16];
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        qa[s] = *reinterpret_cast<const f32x4*>(qp + s * 16 + lh * 8);
+        qb[s] = *reinterpret_cast<const f32x4*>(qp + s * 16 + lh * 8 + 4);
+    }
+    // first K fragments travel together with Q
+    f16x8 nbh[MK], nbl[MK];
+#pragma unroll
+    for (int j = 0; j < MK; ++j) { nbh[j] = KH[(j * (DH / 16)) * 64]; nbl[j] = KH[GROUPS + (j * (DH / 16)) * 64]; }
+    f16x8 qh[DH / 16], ql[DH / 16];
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 x, y;
+            split1(qa[s][e], x, y); qh[s][e] = x; ql[s][e] = y;
+            split1(qb[s][e], x, y); qh[s][4 + e] = x; ql[s][4 + e] = y;
+        }
+
+    // ---- S = Q K^T, B fragments one k-step ahead
+    f32x16 sacc[MK];
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+        f16x8 bh[MK], bl[MK];
+#pragma unroll
+        for (int j = 0; j < MK; ++j) { bh[j] = nbh[j]; bl[j] = nbl[j]; }
+        if (s + 1 < DH / 16) {
+#pragma unroll
+            for (int j = 0; j < MK; ++j) { nbh[j] = KH[(j * (DH / 16) + s + 1) * 64]; nbl[j] = KH[GROUPS + (j * (DH / 16) + s + 1) * 64]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MK; ++j) { nbh[j] = VH[(j * (M / 16)) * 64]; nbl[j] = VH[GROUPS + (j * (M / 16)) * 64]; }   // first V step (MK <= DH/32)
+        }
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[s], bh[j], sacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[s], bl[j], sacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[s], bh[j], sacc[j], 0, 0, 0);
+    }
+
+    // ---- softmax over keys (fp32, in the accumulator layout)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < MK; ++j) { sacc[j][r] *= scale; m = fmaxf(m, sacc[j][r]); }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MK; ++j) { sacc[j][r] = __builtin_amdgcn_exp2f((sacc[j][r] - m) * 1.4426950408889634f); sum += sacc[j][r]; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float inv = 1.0f / sum;       // v_exp_f32 (1 ulp) and one reciprocal per row: the kernel is VALU-bound, not MFMA-bound
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j][r] = sacc[j][r] * inv;
+    }
+
+    // ---- P -> private per-wave patch in A-operand order (no barrier: nobody else touches it)
+    _Float16* Ph = lds + wave * WSTRIDE;
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            _Float16 a, b;
+            split1(sacc[j][r], a, b);
+            const int off = ((r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + j * 32 + lr;
+            Ph[off] = a;
+            Ph[PPLANE + off] = b;
+        }
+
+    // ---- O = P V: DH/32 = 4 column blocks, V fragments one k-step ahead (the first MK of the first step are already here)
+    constexpr int NV = DH / 32;
+    f32x16 oacc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = 0.0f;
+    f16x8 vh[NV], vl[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (j < MK) { vh[j] = nbh[j]; vl[j] = nbl[j]; }
+        else { vh[j] = VH[(j * (M / 16)) * 64]; vl[j] = VH[GROUPS + (j * (M / 16)) * 64]; }
+    }
+#pragma unroll
+    for (int s = 0; s < M / 16; ++s) {
+        f16x8 bh[NV], bl[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { bh[j] = vh[j]; bl[j] = vl[j]; }
+        if (s + 1 < M / 16) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { vh[j] = VH[(j * (M / 16) + s + 1) * 64]; vl[j] = VH[GROUPS + (j * (M / 16) + s + 1) * 64]; }
+        }
+        const int aoff = lr * LDP + s * 16 + lh * 8;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(&Ph[aoff]);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(&Ph[PPLANE + aoff]);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], oacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], oacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], oacc[j], 0, 0, 0);
+    }
+
+    // ---- transposed wide store (see attention_kernel)
+    float* patch = reinterpret_cast<float*>(Ph);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * (DH + 4) + j * 32 + lr] = oacc[j][r];
+#pragma unroll
+    for (int qi = 0; qi < 32 * (DH / 4) / 64; ++qi) {
+        const int idx = qi * 64 + lane;
+        const int rl = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+        const int row = tile * QT + wave * 32 + rl;
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&patch[rl * (DH + 4) + c4]);
+        if (row < N) *reinterpret_cast<f32x4*>(out + ((int64_t)c * N + row) * ldo + h * DH + c4) = v4;
+    }
+}
+
+template <int MK>
+int launch_attention_frag(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H,
+                          float scale, float* out, int64_t ldo, void* workspace, hipStream_t s) {
+    constexpr int M = MK * 32;
+    constexpr int GROUPS = M * DH / 8;
+    constexpr int PPL = 2 * 32 * (M + 8), OPL = 32 * (DH + 4) * 2;
+    const size_t lds = (size_t)4 * (PPL > OPL ? PPL : OPL) * sizeof(_Float16);
+    f16x8* kimg = reinterpret_cast<f16x8*>(workspace);
+    f16x8* vimg = kimg + (int64_t)C * H * 2 * GROUPS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_frag_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_pack_kernel<MK>, dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
+    hipLaunchKernelGGL(attention_frag_kernel<MK>, dim3((N + QT - 1) / QT, H, C), dim3(256), lds, s, q, ldq, kimg, vimg, N, H, scale, out, ldo);
+    return ogmm::check_launch("ogmm_attention(frag)");
+}
+
 template <int MK>
 int launch_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H, float scale,
                      float* out, int64_t ldo, hipStream_t s) {
@@ -247,14 +464,24 @@ int launch_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, c
 
 }  // namespace
 
+extern "C" int64_t ogmm_attention_workspace_bytes(int C, int M, int H, int dh) {
+    return (int64_t)C * H * 2 /*K,V*/ * 2 /*hi,lo*/ * M * dh * (int64_t)sizeof(_Float16);
+}
+
 extern "C" int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
-                              int H, int dh, float scale, float* out, int64_t ldo, void* stream) {
+                              int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream) {
     OGMM_REQUIRE(q && k && v && out && C > 0 && N > 0 && H > 0, "ogmm_attention: null pointer or empty input");
     OGMM_REQUIRE(dh == DH, "ogmm_attention: head dimension %d not supported (built for %d)", dh, DH);
     OGMM_REQUIRE(M == 32 || M == 64 || M == 128, "ogmm_attention: %d anchors not supported (32, 64 or 128)", M);
     OGMM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ogmm::aligned16(q) && ogmm::aligned16(k) && ogmm::aligned16(v) && ogmm::aligned16(out),
                  "ogmm_attention: row strides must be multiples of 4 and pointers 16-byte aligned");
     hipStream_t s = ogmm::as_stream(stream);
+    if (workspace) {
+        OGMM_REQUIRE(ogmm::aligned16(workspace), "ogmm_attention: workspace must be 16-byte aligned");
+        if (M == 32) return launch_attention_frag<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+        if (M == 64) return launch_attention_frag<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+        return launch_attention_frag<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+    }
     if (M == 32) return launch_attention<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
     if (M == 64) return launch_attention<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
     return launch_attention<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);

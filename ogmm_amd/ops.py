@@ -262,7 +262,7 @@ def pos_hidden(xyz, idx, k_pos, p):
     return hd, ha
 
 
-def attention(q, k, v, C, N, M, H, out=None):
+def attention(q, k, v, C, N, M, H, out=None, use_workspace=True):
     """Fused anchor attention (models/attn.py:78-82).  q [C*N, D], k, v [C*M, D] (row-major views, last stride 1), head-major
     channels; returns [C*N, D]."""
     D = q.shape[1]
@@ -270,8 +270,12 @@ def attention(q, k, v, C, N, M, H, out=None):
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and q.shape[0] == C * N and k.shape[0] == C * M
     if out is None:
         out = torch.empty((C * N, D), dtype=torch.float32, device=q.device)
+    ws = None
+    if use_workspace:
+        nbytes = _lib.load().ogmm_attention_workspace_bytes(C, M, H, dh)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
     _lib.call("ogmm_attention", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0), C, N, M, H, dh,
-              1.0 / dh ** .5, _p(out), out.stride(0), _stream())
+              1.0 / dh ** .5, _p(out), out.stride(0), _p(ws), _stream())
     return out
 
 

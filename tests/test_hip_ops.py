@@ -273,6 +273,9 @@ def test_fused_attention(ops, C, N, M):
     kvd = dev(kv)
     got2 = ops.attention(dev(q), kvd[:, :D], kvd[:, D:], C, N, M, H).cpu().double()
     assert torch.equal(got2, got)
+    # the variant that stages K / V per workgroup instead of reading the packed images
+    got3 = ops.attention(dev(q), dev(k), dev(v), C, N, M, H, use_workspace=False).cpu().double()
+    assert (got3 - ref).abs().max().item() < 2e-6
 
 
 # ------------------------------------------------------------------------------------------------ row / column kernels
