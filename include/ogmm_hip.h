@@ -155,6 +155,12 @@ int ogmm_instnorm_relu(float* x, int64_t ld, int C, int N, int D, float eps, voi
 /* statistics -> affine: mean = s1/rows, var = s2/rows - mean^2 (biased); scale = 1/sqrt(var+eps), shift = -mean*scale. */
 int ogmm_instnorm_finalize(const double* col_stats, int64_t n_entries, int rows, float eps, float* scale, float* shift, void* stream);
 
+/* activation rows x [rows][ld] (fp32) -> split fragment-major image (OGMM_PREC_F16X3_FRAG B operand: [ceil(rows/32)][K/16][64][8]
+ * binary16, hi and lo), so that an activation can be the B side of ogmm_gemm_nt (the similarity of models/gmmreg.py:75).
+ * Rows beyond `rows` are zero.  K % 16 == 0.  For the 256-column tiles of the large engine pad rows to a multiple of 256 by
+ * zero-filling the image (the caller owns the buffer: ceil(rows/32)*32 * K halfs per plane are written). */
+int ogmm_pack_frag(const float* x, int64_t ld, int64_t rows, int K, void* hi, void* lo, void* stream);
+
 /* ---- K13 pieces.  models/gmmreg.py:74: F.normalize over channels (eps 1e-12), rows of length D. */
 int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream);
 /* Cout = 1 convolutions (proj.net.3, overlap.net.6): y[m] = act(dot(x[m][:], w) + b). */

@@ -52,16 +52,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
 
-    const float* __restrict__ A = g.A;
-    const float* __restrict__ A2 = g.A2;
+    const int zb = blockIdx.z;                                   // batch index (outer): whole-problem strides
+    const float* __restrict__ A = g.A + zb * g.sA_o;
+    const float* __restrict__ A2 = g.A2 ? g.A2 + zb * g.sA2_o : nullptr;
     const int m0 = tile_m * rows_per_tile, n0 = tile_n * BN;
     const int m_end = min(g.M, m0 + rows_per_tile);
     const int nk1 = (g.K1 + BKH - 1) / BKH, nk2 = (g.K2 + BKH - 1) / BKH, nk = nk1 + nk2;
 
     // B image: k-blocks of 16; piece 2 starts at k = K1 (a multiple of 32)
     const int KB = (int)(g.ldb_h / 16);
-    const f16x8* __restrict__ BH = reinterpret_cast<const f16x8*>(g.B_hi);
-    const f16x8* __restrict__ BL = reinterpret_cast<const f16x8*>(g.B_lo);
+    const f16x8* __restrict__ BH = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_hi) + zb * g.sB_o);
+    const f16x8* __restrict__ BL = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_lo) + zb * g.sB_o);
     int64_t bbase[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bbase[j] = ((int64_t)(n0 / 32 + wn * NT + j) * KB) * 64 + lane;
@@ -184,8 +185,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_
         __syncthreads();
     }
     if (g.overflow && ovf) atomicOr(g.overflow, 1);
-    if (!POOL && wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha);
-    else gemm_epilogue<MT, NT, WM, WN, POOL>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
+    ogmm_gemm gz = g;                  // per-batch views for the epilogue
+    if (gz.C) gz.C += zb * g.sC_o;
+    if (gz.Res) gz.Res += zb * g.sR_o;
+    if (!POOL && wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha);
+    else gemm_epilogue<MT, NT, WM, WN, POOL>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
 }
 
 template <int MT, int NT, int WM, int WN, bool POOL>
@@ -204,7 +208,7 @@ int launch_v2(const ogmm_gemm& g, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_set = true;
     }
-    dim3 grid((unsigned)(m_tiles8 * n_tiles), 1, 1);
+    dim3 grid((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer);
     hipLaunchKernelGGL((gemm_f16x3_v2_kernel<MT, NT, WM, WN, POOL>), grid, dim3(T), LDS, stream, g, rows_per_tile, m_tiles, n_tiles);
     return ogmm::check_launch("ogmm_gemm_nt(f16x3 frag)");
 }
@@ -220,7 +224,9 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
     OGMM_REQUIRE(g.ldb_h > 0 && g.ldb_h % 32 == 0 && (g.K1 + 31) / 32 * 32 + (g.K2 + 31) / 32 * 32 <= g.ldb_h,
                  "ogmm_gemm_nt(f16x3 frag): ldb_h (padded K) must be a multiple of 32 covering the padded K pieces");
-    OGMM_REQUIRE(g.batch_outer * g.batch_inner == 1, "ogmm_gemm_nt(f16x3 frag): batching not supported");
+    OGMM_REQUIRE(g.batch_inner == 1 && (g.batch_outer == 1 || (!g.col_stats && !g.a_scale && g.pool_k == 0)),
+                 "ogmm_gemm_nt(f16x3 frag): only outer batching (whole-problem strides sA_o, sB_o in binary16 elements, sC_o, sR_o), no fusion flags");
+    OGMM_REQUIRE(g.sB_o % 8 == 0, "ogmm_gemm_nt(f16x3 frag): sB_o must be a multiple of 8 halfs");
     OGMM_REQUIRE(g.K2 == 0 || g.K1 % 32 == 0, "ogmm_gemm_nt(f16x3 frag): two A pieces need K1 %% 32 == 0");
     if (g.col_stats || g.a_scale)
         OGMM_REQUIRE(g.group_rows > 0 && g.group_rows % 256 == 0 && g.pool_k == 0 && (!g.a_scale || (g.a_shift && aligned16(g.a_scale) && aligned16(g.a_shift))),
@@ -243,7 +249,7 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     if (gemm_f16x3_v3_applicable(g)) return gemm_nt_f16x3_v3(g, s);
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
     // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)
-    const long long big_tiles = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const long long big_tiles = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch_outer;
     if (g.N >= 256 && big_tiles >= 512) return launch_v2<4, 2, 2, 4, false>(g, s);
     return launch_v2<2, 2, 2, 2, false>(g, s);
 }

@@ -49,13 +49,16 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
+    const int zb = blockIdx.z;                                   // batch index (outer)
+    const float* __restrict__ Abase = g.A + zb * g.sA_o;
+    const float* __restrict__ A2base = g.A2 ? g.A2 + zb * g.sA2_o : nullptr;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int m_end = min(g.M, m0 + BM);
     const int nk1 = (g.K1 + BK3 - 1) / BK3, nk2 = (g.K2 + BK3 - 1) / BK3, nk = nk1 + nk2;
 
     const int KB = (int)(g.ldb_h / 16);
-    const f16x8* __restrict__ BH = reinterpret_cast<const f16x8*>(g.B_hi);
-    const f16x8* __restrict__ BL = reinterpret_cast<const f16x8*>(g.B_lo);
+    const f16x8* __restrict__ BH = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_hi) + zb * g.sB_o);
+    const f16x8* __restrict__ BL = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_lo) + zb * g.sB_o);
     int64_t bbase[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bbase[j] = ((int64_t)(n0 / 32 + wn * NT + j) * KB) * 64 + lane;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
     const int64_t agroup = g.a_scale ? (int64_t)(m0 / g.group_rows) * (g.K1 + g.K2) : 0;
     auto load_a = [&](int t) {
         const bool second = t >= nk1;
-        const float* Ap = second ? g.A2 : g.A;
+        const float* Ap = second ? A2base : Abase;
         const int64_t ld = second ? g.lda2 : g.lda;
         const int kbase = second ? (t - nk1) * BK3 : t * BK3;
         const int Kp = second ? g.K2 : g.K1;
@@ -197,8 +200,11 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
         if (sum == 1.2345f) g.C[0] = sum;
         return;
     }
-    if (wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha);
-    else gemm_epilogue<MT, NT, WM, WN, false>(g, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
+    ogmm_gemm gz = g;                  // per-batch views for the epilogue
+    if (gz.C) gz.C += zb * g.sC_o;
+    if (gz.Res) gz.Res += zb * g.sR_o;
+    if (wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha);
+    else gemm_epilogue<MT, NT, WM, WN, false>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
 }
 
 }  // namespace
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v3_kernel(const ogmm_gemm g, con
 namespace ogmm {
 
 bool gemm_f16x3_v3_applicable(const ogmm_gemm& g) {
-    const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch_outer;
     return g.pool_k == 0 && g.N >= 256 && tiles >= 512 && g.ldb_h % 64 == 0 && (g.K2 == 0 || g.K1 % 64 == 0) &&
            (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h;
 }
@@ -221,7 +227,7 @@ static int launch_v3(const ogmm_gemm& g, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v3_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_f16x3_v3_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles)), dim3(T), LDS, s, g, m_tiles, n_tiles);
+    hipLaunchKernelGGL(gemm_f16x3_v3_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, m_tiles, n_tiles);
     return check_launch("ogmm_gemm_nt(f16x3 v3)");
 }
 

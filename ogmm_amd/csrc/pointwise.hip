@@ -5,6 +5,7 @@
 // One wavefront per row with 16-byte lane loads where rows are contiguous; column reductions put 64
 // consecutive channels on 64 consecutive lanes so every global access is a full 256-byte line.
 #include "ogmm_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -85,6 +86,39 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const double* __
     const double inv = 1.0 / sqrt(var + (double)eps);
     scale[i] = (float)inv;
     shift[i] = (float)(-mean * inv);
+}
+
+// ---------------------------------------------------------------- activation rows -> split fragment-major B image
+// x [rows][ld] fp32 -> hi/lo images [rows/32][K/16][64 lanes][8 halfs] (OGMM_PREC_F16X3_FRAG operand order), so that an
+// ACTIVATION can be the B operand of the fp16x3 engine (the N x N similarity of models/gmmreg.py:75).  rows % 32 == 0 is
+// not required: missing rows are zero.  K % 16 == 0.
+using f16x8p = __attribute__((ext_vector_type(8))) _Float16;
+__global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, int64_t rows_pad,
+                                                        f16x8p* __restrict__ hi, f16x8p* __restrict__ lo) {
+    const int64_t total = rows_pad / 32 * (K / 16) * 64;
+    for (int64_t gI = (int64_t)blockIdx.x * 256 + threadIdx.x; gI < total; gI += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(gI & 63);
+        const int64_t blk = gI >> 6;
+        const int kb = (int)(blk % (K / 16));
+        const int64_t nb = blk / (K / 16);
+        const int64_t row = nb * 32 + (lane & 31);
+        const int k0 = kb * 16 + (lane >> 5) * 8;
+        f16x8p h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < rows) {
+            const float4 a = *reinterpret_cast<const float4*>(x + row * ld + k0);
+            const float4 b = *reinterpret_cast<const float4*>(x + row * ld + k0 + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xx = __builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+                const _Float16 hh = (_Float16)xx;
+                h[e] = hh;
+                l[e] = (_Float16)(xx - (float)hh);
+            }
+        }
+        hi[gI] = h;
+        lo[gI] = l;
+    }
 }
 
 // ---------------------------------------------------------------- F.normalize(dim=channels), one wave per row
@@ -212,6 +246,17 @@ extern "C" int ogmm_instnorm_finalize(const double* col_stats, int64_t n_entries
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, ogmm::as_stream(stream), col_stats,
                        n_entries, rows, eps, scale, shift);
     return ogmm::check_launch("ogmm_instnorm_finalize");
+}
+
+extern "C" int ogmm_pack_frag(const float* x, int64_t ld, int64_t rows, int K, void* hi, void* lo, void* stream) {
+    OGMM_REQUIRE(x && hi && lo && rows > 0 && K > 0 && K % 16 == 0 && ld % 4 == 0 && ogmm::aligned16(x) && ogmm::aligned16(hi) && ogmm::aligned16(lo),
+                 "ogmm_pack_frag: K %% 16 == 0, ld %% 4 == 0 and 16-byte aligned pointers required");
+    const int64_t rows_pad = (rows + 31) / 32 * 32;
+    const int64_t total = rows_pad / 32 * (K / 16) * 64;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, ogmm::as_stream(stream), x, ld, rows, K, rows_pad,
+                       reinterpret_cast<f16x8p*>(hi), reinterpret_cast<f16x8p*>(lo));
+    return ogmm::check_launch("ogmm_pack_frag");
 }
 
 extern "C" int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream) {

@@ -336,7 +336,11 @@ class GMMReg(nn.Module):
         # ---- overlap scores (gmmreg.py:74-89)
         fn = ops.l2norm_rows(f)
         S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-        ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
+        if ops.DEFAULT_SPLIT and D % 64 == 0:
+            tgt_img = ops.pack_frag_batched(fn[B * N:], B, N)              # the tgt side as a split fragment-major B operand
+            ops.gemm_nt(fn, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img, overflow=self._overflow)
+        else:
+            ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
         ph = ops.conv1x1(f, L["proj"]["0"], ACT_RELU)
         extra = torch.zeros((R, 4), dtype=torch.float32, device=dev)             # conv2 input channels 512 (wo), 513 (o), zero pad
         ops.rowdot(ph, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=4)

@@ -137,6 +137,8 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
         d.B_hi, d.B_lo, d.ldb_h = split["W_hi"].data_ptr(), split["W_lo"].data_ptr(), split.get("ldb_h", split["W_hi"].shape[-1])
         d.overflow = overflow.data_ptr() if overflow is not None else None
         alpha = alpha * split["inv_scale"]
+        if "sB" in split:
+            sB = (split["sB"], 0)
     d.C, d.ldc = (C.data_ptr() if C is not None else None), ldc
     d.Res, d.ldr = (res.data_ptr() if res is not None else None), ldr
     d.M, d.N = M, N
@@ -260,6 +262,21 @@ def pos_hidden(xyz, idx, k_pos, p):
     _lib.call("ogmm_pos_hidden", _p(xyz), _p(_i32(idx, "idx")), idx.shape[2], k_pos, C, N, _p(p["w_dis"]), _p(p["s_dis"]), _p(p["t_dis"]),
               _p(p["w_ang"]), _p(p["s_ang"]), _p(p["t_ang"]), _p(hd), _p(ha), _stream())
     return hd, ha
+
+
+def pack_frag_batched(x, batch, rows):
+    """x [(batch*rows), K] fp32 -> split dict for gemm_nt(batch=(batch,1)): per-batch fragment images of `rows` rows (zero-padded to a
+    multiple of 256), laid out back to back; `sB` (halfs) is the stride between them."""
+    K = x.shape[1]
+    assert x.stride(1) == 1 and x.shape[0] == batch * rows and K % 64 == 0
+    rp = (rows + 255) // 256 * 256
+    hi = torch.zeros((batch, rp * K), dtype=torch.float16, device=x.device) if rp != rows else torch.empty((batch, rp * K), dtype=torch.float16, device=x.device)
+    lo = torch.zeros_like(hi) if rp != rows else torch.empty_like(hi)
+    for b in range(batch) if rp != rows else ():
+        _lib.call("ogmm_pack_frag", _p(x[b * rows:]), x.stride(0), rows, K, _p(hi[b]), _p(lo[b]), _stream())
+    if rp == rows:      # images are contiguous row blocks: one launch packs every batch element
+        _lib.call("ogmm_pack_frag", _p(x), x.stride(0), batch * rows, K, _p(hi), _p(lo), _stream())
+    return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K}
 
 
 def attention(q, k, v, C, N, M, H, out=None, use_workspace=True):

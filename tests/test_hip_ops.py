@@ -182,6 +182,25 @@ def test_gemm_batched_strided_row_affine(ops):
     assert (vT.cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("Bn,N,D", [(3, 256, 128), (2, 200, 64), (64, 1024, 512)])
+def test_gemm_activation_times_activation_batched(ops, Bn, N, D):
+    """models/gmmreg.py:75: S[b] = src_fn[b] tgt_fn[b]^T with the tgt side packed into split fragment images per pair."""
+    torch.manual_seed(N)
+    a, b = torch.randn(Bn * N, D), torch.randn(Bn * N, D)
+    ad, bd = dev(a), dev(b)
+    S = torch.empty(Bn, N, N, device="cuda")
+    img = ops.pack_frag_batched(bd, Bn, N)
+    ops.gemm_nt(ad, D, D, None, D, N, N, C=S, ldc=N, batch=(Bn, 1), sA=(N * D, 0), sC=(N * N, 0), split=img)
+    nb = min(Bn, 3)
+    ref = torch.einsum("bmd,bnd->bmn", a.view(Bn, N, D)[:nb].double(), b.view(Bn, N, D)[:nb].double())
+    bound = 6e-7 * torch.einsum("bmd,bnd->bmn", a.view(Bn, N, D)[:nb].double().abs(), b.view(Bn, N, D)[:nb].double().abs()) + 1e-7
+    assert ((S[:nb].cpu().double() - ref).abs() / bound).max().item() < 1.0
+    if Bn > 3:
+        S32 = torch.empty(Bn, N, N, device="cuda")
+        ops.gemm_nt(ad, D, D, bd, D, N, N, C=S32, ldc=N, batch=(Bn, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
+        assert (S - S32).abs().max().item() < 3e-4          # |S| up to ~100 here: both engines are ~1e-6 relative
+
+
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("k,Cout", [(20, 64), (20, 128), (12, 256), (7, 64)])
 def test_gemm_edge_pooling(ops, k, Cout, engine):
