@@ -132,6 +132,7 @@ def main():
                             "t_err_max": O.translation_error(got[1].cpu(), ref[1]).max().item(),
                             "overlap_err_max": max((got[2].cpu() - ref[2]).abs().max().item(), (got[3].cpu() - ref[3]).abs().max().item()),
                             "pairs_checked": n, "against": "CPU oracle (bit-identical to the reference on its golden fixtures)"}
+    result["fp16_split_overflowed"] = bool(model.fp16_overflowed())      # |activation| > 65504 clamped anywhere in the run?
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
