@@ -95,7 +95,7 @@ def main():
     gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
-    kernel = ("gemm_f16x3_v2_kernel<4,2,2,4,false> / <2,2,2,2,false> (3x v_mfma_f32_32x32x16_f16 per block)" if args.precision == "f16x3"
+    kernel = ("gemm_f16x3_v4_kernel (256x256x64, 3x v_mfma_f32_32x32x16_f16 per block; v2 <2,2,2,2> for small shapes)" if args.precision == "f16x3"
               else "gemm_nt_kernel<2,2,2,2,false> (v_mfma_f32_32x32x2_f32)")
 
     result = {

@@ -219,6 +219,7 @@ namespace ogmm {
 
 bool gemm_f16x3_v3_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v3(const ogmm_gemm& g, hipStream_t s);
+int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s);
 
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
@@ -240,13 +241,13 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {
         case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves
         case 22: return launch_v2<4, 2, 2, 2, false>(g, s);    // 256 x 128, 4 waves
-        case 23: return launch_v2<2, 2, 4, 2, false>(g, s);    // 256 x 128, 8 waves
         case 24: return launch_v2<4, 2, 2, 4, false>(g, s);    // 256 x 256, 8 waves
+        case 23: OGMM_REQUIRE(gemm_f16x3_v3_applicable(g), "v4 not applicable"); return gemm_nt_f16x3_v4(g, s);     // 1 x 8 wave arrangement
         case 18: case 19: case 25: case 26: case 27: case 28: case 29:
             OGMM_REQUIRE(gemm_f16x3_v3_applicable(g), "v3 not applicable"); return gemm_nt_f16x3_v3(g, s);
         default: break;
     }
-    if (gemm_f16x3_v3_applicable(g)) return gemm_nt_f16x3_v3(g, s);
+    if (gemm_f16x3_v3_applicable(g)) return gemm_nt_f16x3_v4(g, s);     // 1 x 8 wave arrangement: +2-4 % over v3's 2 x 4
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
     // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)
     const long long big_tiles = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch_outer;

@@ -1,0 +1,253 @@
+// fp16x3 split GEMM, fourth structure (large shapes): 256 x 256 tile, 8 waves of 256 x 32 (all rows, one 32-column block
+// each), K tile of 64, one barrier per 96 MFMAs per wave.  Same pipeline as gemm_f16x3_v3.hip; the difference is the wave
+// arrangement: with one column block per wave every B fragment (1 KiB straight from the L2-resident weight image) is
+// fetched by exactly ONE wave of the workgroup instead of two, halving the L2 -> CU weight traffic that the ablations of
+// v3 showed to cost ~20 % of the loop; the price is twice the A-fragment LDS reads (16 per k-step), which LDS has room for.
+//
+// Per K tile (4 k-steps of 16) a wave runs 4 x 4 groups of 6 MFMAs (row block i against both column blocks: lo*hi, hi*lo,
+// hi*hi).  Between groups it issues, in program order pinned with sched_barrier:
+//   * the two ds_read_b128 of the NEXT group's A fragments (hi, lo)      -> LDS latency hidden behind 6 MFMAs (192 cycles)
+//   * once per k-step the four 1 KiB loads of the next k-step's B fragments from the fragment-major weight image
+//   * during the last two k-steps one eighth of the NEXT tile's A staging (fp32 -> hi/lo split -> ds_write into the
+//     other LDS buffer), whose global loads were issued at the start of the tile
+// so the only full stop is the single barrier at the end of the tile.  A and B operand formats are those of
+// gemm_f16x3_v2.hip (which remains the engine for small N, small M and the EdgeConv pooling epilogue).
+#include "gemm_common.h"
+
+namespace {
+
+using namespace ogmm_gemm_detail;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+constexpr int BK3 = 64;
+constexpr int LD3 = BK3 + 8;          // 144-byte rows: conflict-free ds_read_b128 / ds_write_b64
+constexpr int MT = 8, NT = 1, WM = 1, WN = 8;
+constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;      // 256, 256, 512
+constexpr int A_P = BM * (BK3 / 4) / T;                                      // 8 float4 per thread per tile
+constexpr int PLANE = BM * LD3;
+
+__device__ __forceinline__ void split4w(const f32x4 v, f16x4& hi, f16x4& lo, bool& ovf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        ovf |= fabsf(x) > 65504.0f;
+        x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+        const _Float16 h = (_Float16)x;
+        hi[e] = h;
+        lo[e] = (_Float16)(x - (float)h);
+    }
+}
+
+template <int ABL>
+__global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, const int m_tiles, const int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];      // [2 buffers][hi, lo][BM][LD3]
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile_m = (local / n_tiles) * 8 + xcd;
+    const int tile_n = local % n_tiles;
+    if (tile_m >= m_tiles) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int zb = blockIdx.z;                                   // batch index (outer)
+    const float* __restrict__ Abase = g.A + zb * g.sA_o;
+    const float* __restrict__ A2base = g.A2 ? g.A2 + zb * g.sA2_o : nullptr;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m_end = min(g.M, m0 + BM);
+    const int nk1 = (g.K1 + BK3 - 1) / BK3, nk2 = (g.K2 + BK3 - 1) / BK3, nk = nk1 + nk2;
+
+    const int KB = (int)(g.ldb_h / 16);
+    const f16x8* __restrict__ BH = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_hi) + zb * g.sB_o);
+    const f16x8* __restrict__ BL = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_lo) + zb * g.sB_o);
+    int64_t bbase[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bbase[j] = ((int64_t)(n0 / 32 + wn * NT + j) * KB) * 64 + lane;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra[A_P];
+    unsigned ra_ok = 0;
+    bool ovf = false;
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4v = {0.f, 0.f, 0.f, 0.f};
+    f32x4 asc = one4, ash = zero4v;      // fused InstanceNorm: A is read as relu(a * asc + ash); one k-quad per thread and tile
+    const int64_t agroup = g.a_scale ? (int64_t)(m0 / g.group_rows) * (g.K1 + g.K2) : 0;
+    auto load_a = [&](int t) {
+        const bool second = t >= nk1;
+        const float* Ap = second ? A2base : Abase;
+        const int64_t ld = second ? g.lda2 : g.lda;
+        const int kbase = second ? (t - nk1) * BK3 : t * BK3;
+        const int Kp = second ? g.K2 : g.K1;
+        ra_ok = 0;
+        if (g.a_scale) {
+            const int kq0 = (tid & 15) * 4;
+            const int kk = (kbase + kq0 < Kp) ? (second ? g.K1 : 0) + kbase + kq0 : 0;
+            asc = *reinterpret_cast<const f32x4*>(g.a_scale + agroup + kk);
+            ash = *reinterpret_cast<const f32x4*>(g.a_shift + agroup + kk);
+        }
+#pragma unroll
+        for (int i = 0; i < A_P; ++i) {
+            const int f = tid + i * T, row = f >> 4, kq = (f & 15) * 4;
+            const int gm = m0 + row;
+            const bool ok = gm < m_end && kbase + kq < Kp;
+            ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)min(gm, g.M - 1) * ld + (ok ? kbase + kq : 0));
+            ra_ok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto store_a_piece = [&](int buf, int i) {
+        _Float16* Ah = smem_h + buf * 2 * PLANE;
+        _Float16* Al = Ah + PLANE;
+        const int f = tid + i * T;
+        f16x4 hi, lo;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 val = ra[i];
+        if (g.a_scale) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                val[e] = fmaf(val[e], asc[e], ash[e]);
+                if (g.a_relu) val[e] = fmaxf(val[e], 0.0f);
+            }
+        }
+        split4w(((ra_ok >> i) & 1u) ? val : zero, hi, lo, ovf);
+        const int off = (f >> 4) * LD3 + (f & 15) * 4;
+        *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
+        *reinterpret_cast<f16x4*>(&Al[off]) = lo;
+    };
+    auto kblk = [&](int t, int s) { return (t < nk1 ? t * 4 : (g.K1 / 16) + (t - nk1) * 4) + s; };
+    auto load_b = [&](f16x8 (&bh)[NT], f16x8 (&bl)[NT], int t, int s) {
+        const int64_t kb = (int64_t)kblk(t, s) * 64;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = BH[bbase[j] + kb];
+            bl[j] = BL[bbase[j] + kb];
+        }
+    };
+    auto read_a = [&](f16x8 (&ah)[2], f16x8 (&al)[2], int buf, int s, int gI) {
+        const _Float16* Ah = smem_h + buf * 2 * PLANE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int off = ((2 * gI + u) * 32 + lr) * LD3 + s * 16 + lh * 8;
+            ah[u] = *reinterpret_cast<const f16x8*>(&Ah[off]);
+            al[u] = *reinterpret_cast<const f16x8*>(&Ah[PLANE + off]);
+        }
+    };
+    // group gI = row blocks 2*gI and 2*gI+1: six MFMAs alternating between their two accumulators
+    auto mma6 = [&](int gI, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[NT], const f16x8 (&bl)[NT]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[2 * gI + u][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u], bh[0], acc[2 * gI + u][0], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[2 * gI + u][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bl[0], acc[2 * gI + u][0], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[2 * gI + u][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bh[0], acc[2 * gI + u][0], 0, 0, 0);
+    };
+
+    // one k-step: 4 groups of two row blocks; A fragments of the next group (or of step s+1's first group) are read one group ahead
+    f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];      // B fragments: even / odd k-steps
+    f16x8 ah0[2], al0[2], ah1[2], al1[2];          // A fragments: even / odd groups (two row blocks each)
+
+    if ((ABL & 64) && (local & 1)) {          // experiment: stagger half of the workgroups by ~half a main loop
+        for (int z = 0; z < (nk * 3) / 8; ++z) __builtin_amdgcn_s_sleep(127);
+    }
+    load_a(0);
+    load_b(bhA, blA, 0, 0);
+    if (ABL & 7) { load_b(bhB, blB, 0, 1); }
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) store_a_piece(0, i);
+    __syncthreads();
+    read_a(ah0, al0, 0, 0, 0);
+    if (ABL & 7) { read_a(ah1, al1, 0, 0, 1); }
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < nk;
+        if (more && !(ABL & 4)) load_a(t + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // B fragments of the next k-step (next tile's first step after the last one)
+            if (!(ABL & 2)) {
+            if (s < 3) { if (s & 1) load_b(bhA, blA, t, s + 1); else load_b(bhB, blB, t, s + 1); }
+            else if (more) load_b(bhA, blA, t + 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT / 2; ++i) {
+                if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0);
+                // prefetch the next group's A fragments (same tile only: the next tile's first group is read after the barrier)
+                if (!(ABL & 1)) {
+                if (i < MT / 2 - 1) { if (i & 1) read_a(ah0, al0, buf, s, i + 1); else read_a(ah1, al1, buf, s, i + 1); }
+                else if (s < 3) read_a(ah0, al0, buf, s + 1, 0);
+                }
+                if (more && s >= 2 && !(ABL & 4)) store_a_piece(buf ^ 1, (s - 2) * 4 + i);
+                if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0);
+                if (ABL & 16) __builtin_amdgcn_s_setprio(1);
+                if (s & 1) { if (i & 1) mma6(i, ah1, al1, bhB, blB); else mma6(i, ah0, al0, bhB, blB); }
+                else       { if (i & 1) mma6(i, ah1, al1, bhA, blA); else mma6(i, ah0, al0, bhA, blA); }
+                if (ABL & 16) __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        __syncthreads();
+        if (more && !(ABL & 1)) read_a(ah0, al0, buf ^ 1, 0, 0);
+    }
+    if (g.overflow && ovf) atomicOr(g.overflow, 1);
+    if (ABL & 8) {          // ablation: no output stores (one dummy store keeps the accumulators live)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        if (sum == 1.2345f) g.C[0] = sum;
+        return;
+    }
+    ogmm_gemm gz = g;                  // per-batch views for the epilogue
+    if (gz.C) gz.C += zb * g.sC_o;
+    if (gz.Res) gz.Res += zb * g.sR_o;
+    if (wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha);
+    else gemm_epilogue<MT, NT, WM, WN, false>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
+}
+
+}  // namespace
+
+namespace ogmm {
+
+bool gemm_f16x3_v4_applicable(const ogmm_gemm& g) {
+    const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch_outer;
+    return g.pool_k == 0 && g.N >= 256 && tiles >= 512 && g.ldb_h % 64 == 0 && (g.K2 == 0 || g.K1 % 64 == 0) &&
+           (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h;
+}
+
+template <int ABL>
+static int launch_v4(const ogmm_gemm& g, hipStream_t s) {
+    constexpr size_t LDS = (size_t)2 * 2 * PLANE * sizeof(_Float16);      // 147456 B
+    const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
+    const int m_tiles8 = (m_tiles + 7) / 8 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v4_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, m_tiles, n_tiles);
+    return check_launch("ogmm_gemm_nt(f16x3 v4)");
+}
+
+int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
+    switch (g.precision) {          // 26..29: ablations for tools/gemm_bench.py (wrong results by construction)
+        case 26: return launch_v4<7>(g, s);     // MFMA + barrier only
+        case 29: return launch_v4<3>(g, s);     // + A global loads / split / LDS writes only
+        case 27: return launch_v4<32 + 64>(g, s);    // experiment: no pinning + staggered workgroups
+        case 28: return launch_v4<32>(g, s);    // experiment: no sched_barrier pinning
+        case 19: return launch_v4<15>(g, s);    // MFMA only, no epilogue stores
+        case 18: return launch_v4<8>(g, s);     // full loop, no epilogue stores
+        default: return launch_v4<32>(g, s);     // default: no sched_barrier pinning (measured +3-4 %)
+    }
+}
+
+}  // namespace ogmm

@@ -211,6 +211,7 @@ class GMMReg(nn.Module):
         self.precision = getattr(config, "precision", "f16x3")
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self._overflow = None
+        self._side = None
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved
     def _layers(self):
@@ -299,10 +300,22 @@ class GMMReg(nn.Module):
         fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()   # [stage][src clouds | tgt clouds]
 
         xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()         # [C,N,3]
-        idx = ops.knn(xyz, k)
-        ids_a = ops.fps(xyz, M, fps_starts)                                       # [3,C,M]: all three random-start samplings at once
-        ids_j = ops.fps(xyz, J, None)                                             # centre-start sampling for the GMM init
         swap = torch.cat([torch.arange(B, C), torch.arange(0, B)]).to(device=dev, dtype=torch.int32)
+        # Latency-bound selection kernels (one workgroup per cloud: FPS chains, the k=5 graph, later the E/M loop) run on a
+        # side stream next to the GEMM-bound main stream: they occupy <= C of the 256 CUs.  Every tensor they touch stays
+        # referenced until the streams are joined again.
+        main = torch.cuda.current_stream()
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
+            ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
+            idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
+            sel_done = torch.cuda.Event()
+            sel_done.record(side)
+        idx = ops.knn(xyz, k)
 
         # ---- DGCNN (models/dgcnn.py:133-154)
         R = C * N
@@ -319,7 +332,7 @@ class GMMReg(nn.Module):
         emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU)
 
         # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)
-        idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
+        main.wait_event(sel_done)
         hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])
         x0 = torch.empty((R, D), dtype=torch.float32, device=dev)
         ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2])
@@ -352,12 +365,17 @@ class GMMReg(nn.Module):
         o = torch.empty((C, N), dtype=torch.float32, device=dev)
         ops.rowdot(g, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1)
 
-        # ---- self-attention 2 (gmmreg.py:92-97)
+        # ---- GMM E/M (needs only xyz and the overlap scores) on the side stream, next to self-attention 2 (gmmreg.py:92-101)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            gamma, pi, mu = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0)
+            em_done = torch.cuda.Event()
+            em_done.record(side)
         a2 = ops.gather_rows(f, D, C, N, D, ids_a[2])
         f2 = self._transformer(L["sattn2"], f, a2, C, N, res=f)
+        main.wait_event(em_done)
 
-        # ---- GMM E/M, cluster matching, rigid solve, clustering loss (gmmreg.py:100-114)
-        gamma, pi, mu = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0)
+        # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)
         muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)
         rot, trans = ops.match_kabsch(mu[:B].contiguous(), mu[B:].contiguous(), muf[:B].contiguous(), muf[B:].contiguous(), 0.05)
         row_loss, near = ops.clu_infonce(xyz, mu, f2, muf, C, N, 0.1)
