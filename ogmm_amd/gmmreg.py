@@ -315,6 +315,9 @@ class GMMReg(nn.Module):
             idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
             sel_done = torch.cuda.Event()
             sel_done.record(side)
+        xyz.record_stream(side)
+        for t_ in (ids_a, ids_j, idx5):
+            t_.record_stream(main)
         idx = ops.knn(xyz, k)
 
         # ---- DGCNN (models/dgcnn.py:133-154)
@@ -371,6 +374,9 @@ class GMMReg(nn.Module):
             gamma, pi, mu = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0)
             em_done = torch.cuda.Event()
             em_done.record(side)
+        o.record_stream(side)
+        for t_ in (gamma, pi, mu):
+            t_.record_stream(main)
         a2 = ops.gather_rows(f, D, C, N, D, ids_a[2])
         f2 = self._transformer(L["sattn2"], f, a2, C, N, res=f)
         main.wait_event(em_done)

@@ -4,15 +4,27 @@ import re
 import sqlite3
 import sys
 
+
+def short(name):
+    """kernel name without the argument list (cut at the first '(' outside template brackets)"""
+    name = name.replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else "kernel_name"
 rows = db.execute("select %s, start, end from kernels" % name_col).fetchall()
 agg = {}
 for name, s, e in rows:
-    short = re.sub(r"\(anonymous namespace\)::", "", name)
-    short = re.sub(r"\(.*$", "", short) if not short.startswith("void") else re.sub(r"\(ogmm_gemm.*$|\(float.*$|\(.*$", "", short)
-    a = agg.setdefault(short, [0, 0, 10 ** 18, 0])
+    a = agg.setdefault(short(name), [0, 0, 10 ** 18, 0])
     d = e - s
     a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
 total = sum(a[1] for a in agg.values())
