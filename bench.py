@@ -47,9 +47,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3")
+    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3"], default="cfg1",
+                    help="cfg1 = BASELINE configs[1] (headline); cfg2 = configs[2] shape (N=2048, J=64, B=256); cfg3 = configs[3] shape per GPU (room clouds, N=2048, J=64, B=64)")
     args = ap.parse_args()
 
     from ogmm_amd import dist as odist
+    global B_PER_GPU, N_POINTS, J, GFLOP_PER_PAIR
+    kind = "partial"
+    if args.workload == "cfg2":
+        B_PER_GPU, N_POINTS, J, GFLOP_PER_PAIR = 256, 2048, 64, 107.50
+    elif args.workload == "cfg3":
+        B_PER_GPU, N_POINTS, J, GFLOP_PER_PAIR, kind = 64, 2048, 64, 107.50, "room"
+    CFG.n_clusters = J
     rank, local_rank, world = odist.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
@@ -67,7 +76,7 @@ def main():
     model.precision = args.precision
 
     first, _ = odist.shard_pairs(rank, world, B_PER_GPU)         # global pair ids of this rank's shard
-    src, tgt, _, _ = synth.make_batch(first, B_PER_GPU, N_POINTS, "partial")
+    src, tgt, _, _ = synth.make_batch(first, B_PER_GPU, N_POINTS, kind)
     starts = synth.fps_starts_for(first, B_PER_GPU, N_POINTS)
     src, tgt = src.to(dev), tgt.to(dev)
 
@@ -102,8 +111,10 @@ def main():
         "metric": "pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "engine": args.precision,
-        "config": {"workload": "BASELINE configs[1]: ModelNet40-shaped partial-overlap+noise pairs, N=1024 points, J=16 mixtures, "
-                               "batch 64 per GPU, GMMReg.forward eval (D=512, k=20, M=128, H=4), closed-form weights",
+        "config": {"workload": {"cfg1": "BASELINE configs[1]: ModelNet40-shaped partial-overlap+noise pairs, N=1024 points, J=16 mixtures, "
+                                        "batch 64 per GPU, GMMReg.forward eval (D=512, k=20, M=128, H=4), closed-form weights",
+                                "cfg2": "BASELINE configs[2] shape: unseen-category-like pairs, N=2048, J=64, batch 256 per GPU (fp32-class arithmetic, not bf16)",
+                                "cfg3": "BASELINE configs[3] shape per GPU: ICL-NUIM-like room pairs, N=2048, J=64, batch 64 per GPU"}[args.workload],
                    "pairs_per_gpu_step": B_PER_GPU, "n_points": N_POINTS, "n_clusters": J, "parallelism": "pairs sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": None,
