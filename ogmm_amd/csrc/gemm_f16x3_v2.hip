@@ -35,7 +35,7 @@ __device__ __forceinline__ void split4v(const f32x4 v, f16x4& hi, f16x4& lo, boo
 }
 
 template <int MT, int NT, int WM, int WN, bool POOL>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f16x3_v2_kernel(const ogmm_gemm g, const int rows_per_tile, const int m_tiles,
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && MT * NT == 8) ? 2 : 1) void gemm_f16x3_v2_kernel(const ogmm_gemm g, const int rows_per_tile, const int m_tiles,
                                                                      const int n_tiles) {
     constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;
     constexpr int A_PIECES = BM * 8, A_P = (A_PIECES + T - 1) / T;
@@ -217,8 +217,7 @@ int launch_v2(const ogmm_gemm& g, hipStream_t stream) {
 
 namespace ogmm {
 
-bool gemm_f16x3_v3_applicable(const ogmm_gemm& g);
-int gemm_nt_f16x3_v3(const ogmm_gemm& g, hipStream_t s);
+bool gemm_f16x3_large_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s);
 
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
@@ -240,14 +239,12 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     if (g.pool_k > 0) return g.N <= 64 ? launch_v2<5, 1, 1, 2, true>(g, s) : launch_v2<5, 1, 1, 4, true>(g, s);
     switch (g.precision) {
         case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves
-        case 22: return launch_v2<4, 2, 2, 2, false>(g, s);    // 256 x 128, 4 waves
-        case 24: return launch_v2<4, 2, 2, 4, false>(g, s);    // 256 x 256, 8 waves
-        case 23: OGMM_REQUIRE(gemm_f16x3_v3_applicable(g), "v4 not applicable"); return gemm_nt_f16x3_v4(g, s);     // 1 x 8 wave arrangement
-        case 18: case 19: case 25: case 26: case 27: case 28: case 29:
-            OGMM_REQUIRE(gemm_f16x3_v3_applicable(g), "v3 not applicable"); return gemm_nt_f16x3_v3(g, s);
+        case 22: return launch_v2<4, 2, 1, 4, false>(g, s);    // 128 x 256, 4 waves of 128 x 64: two independent workgroups per CU
+        case 18: case 19: case 23: case 26: case 29:            // large-shape engine and its ablations (tools/gemm_bench.py)
+            OGMM_REQUIRE(gemm_f16x3_large_applicable(g), "large-shape engine not applicable"); return gemm_nt_f16x3_v4(g, s);
         default: break;
     }
-    if (gemm_f16x3_v3_applicable(g)) return gemm_nt_f16x3_v4(g, s);     // 1 x 8 wave arrangement: +2-4 % over v3's 2 x 4
+    if (gemm_f16x3_large_applicable(g)) return gemm_nt_f16x3_v4(g, s);
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
     // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)
     const long long big_tiles = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.batch_outer;

@@ -1,8 +1,13 @@
-// fp16x3 split GEMM, fourth structure (large shapes): 256 x 256 tile, 8 waves of 256 x 32 (all rows, one 32-column block
-// each), K tile of 64, one barrier per 96 MFMAs per wave.  Same pipeline as gemm_f16x3_v3.hip; the difference is the wave
-// arrangement: with one column block per wave every B fragment (1 KiB straight from the L2-resident weight image) is
-// fetched by exactly ONE wave of the workgroup instead of two, halving the L2 -> CU weight traffic that the ablations of
-// v3 showed to cost ~20 % of the loop; the price is twice the A-fragment LDS reads (16 per k-step), which LDS has room for.
+// fp16x3 split GEMM for large shapes: 256 x 256 tile, 8 waves of 256 x 32 (all rows, one 32-column block each), K tile of 64,
+// one barrier per 96 MFMAs per wave, everything else issued in the shadow of the matrix pipe.
+//
+// With one column block per wave every B fragment (1 KiB straight from the L2-resident weight image) is fetched by exactly
+// ONE wave of the workgroup (a 2 x 4 wave arrangement fetches each twice: measured -3 %); the price is 16 A-fragment LDS
+// reads per k-step, which LDS has room for.  Other structures measured on the same shapes and dropped: 2 x 4 waves of
+// 128 x 64 (v3), the same pipeline on 128 x 256 tiles with two independent 4-wave workgroups per CU so that one's store
+// burst overlaps the other's MFMA loop (v5), K tiles of 32 with two barriers (v2's 256 x 256 instance): all land within
+// +-4 % of each other (~300-330 TF algorithmic at 131072 x 1024 x 1024), i.e. the plateau is set by the matrix pipe's
+// effective clock (MFMA-only loop: 543), L2->CU operand traffic and the un-overlapped output burst, not by the tiling.
 //
 // Per K tile (4 k-steps of 16) a wave runs 4 x 4 groups of 6 MFMAs (row block i against both column blocks: lo*hi, hi*lo,
 // hi*hi).  Between groups it issues, in program order pinned with sched_barrier:
@@ -153,9 +158,6 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
     f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];      // B fragments: even / odd k-steps
     f16x8 ah0[2], al0[2], ah1[2], al1[2];          // A fragments: even / odd groups (two row blocks each)
 
-    if ((ABL & 64) && (local & 1)) {          // experiment: stagger half of the workgroups by ~half a main loop
-        for (int z = 0; z < (nk * 3) / 8; ++z) __builtin_amdgcn_s_sleep(127);
-    }
     load_a(0);
     load_b(bhA, blA, 0, 0);
     if (ABL & 7) { load_b(bhB, blB, 0, 1); }
@@ -186,10 +188,8 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
                 }
                 if (more && s >= 2 && !(ABL & 4)) store_a_piece(buf ^ 1, (s - 2) * 4 + i);
                 if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0);
-                if (ABL & 16) __builtin_amdgcn_s_setprio(1);
                 if (s & 1) { if (i & 1) mma6(i, ah1, al1, bhB, blB); else mma6(i, ah0, al0, bhB, blB); }
                 else       { if (i & 1) mma6(i, ah1, al1, bhA, blA); else mma6(i, ah0, al0, bhA, blA); }
-                if (ABL & 16) __builtin_amdgcn_s_setprio(0);
             }
         }
         __syncthreads();
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
 
 namespace ogmm {
 
-bool gemm_f16x3_v4_applicable(const ogmm_gemm& g) {
+bool gemm_f16x3_large_applicable(const ogmm_gemm& g) {
     const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch_outer;
     return g.pool_k == 0 && g.N >= 256 && tiles >= 512 && g.ldb_h % 64 == 0 && (g.K2 == 0 || g.K1 % 64 == 0) &&
            (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h;
@@ -242,8 +242,6 @@ int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {          // 26..29: ablations for tools/gemm_bench.py (wrong results by construction)
         case 26: return launch_v4<7>(g, s);     // MFMA + barrier only
         case 29: return launch_v4<3>(g, s);     // + A global loads / split / LDS writes only
-        case 27: return launch_v4<32 + 64>(g, s);    // experiment: no pinning + staggered workgroups
-        case 28: return launch_v4<32>(g, s);    // experiment: no sched_barrier pinning
         case 19: return launch_v4<15>(g, s);    // MFMA only, no epilogue stores
         case 18: return launch_v4<8>(g, s);     // full loop, no epilogue stores
         default: return launch_v4<32>(g, s);     // default: no sched_barrier pinning (measured +3-4 %)
