@@ -7,6 +7,33 @@ namespace ogmm_gemm_detail {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+// fp32 x4 -> binary16 hi x4 + lo x4 with hi = rn16(x), lo = rn16(x - hi), in 8 VALU instructions:
+//   2 x v_cvt_pk_f16_f32 (hi pairs), 4 x v_fma_mix{lo,hi}_f16 (lo = rn16(fma(hi, -1, x)): the f16 source is read in place
+//   and the fp32 result x - hi, which is exact, is rounded straight into the packed destination), 2 x v_max3_f32 |x| for
+//   the overflow flag (|x| > 65504 makes hi infinite and the product garbage: the caller raises the device flag).
+// hipcc's own lowering of the same arithmetic is 13 instructions + 12 for clamp/overflow tests; the staging of A is the
+// largest non-MFMA cost of the loop (measured: 22 %), almost all of it VALU issue.
+__device__ __forceinline__ void split4_f16(const f32x4 v, f16x4& hi, f16x4& lo, float& amax) {
+    f16x2 h01, h23, l01, l23;
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    hi = f16x4{h01[0], h01[1], h23[0], h23[1]};
+    lo = f16x4{l01[0], l01[1], l23[0], l23[1]};
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case OGMM_ACT_RELU: return fmaxf(v, 0.0f);

@@ -17,7 +17,6 @@ namespace {
 
 using namespace ogmm_gemm_detail;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 constexpr int BKH = 32;
 constexpr int LDH = BKH + 8;
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && MT * NT == 8) ? 2 : 
     f32x4 asc = one4, ash = zero4v;      // fused InstanceNorm: A is read as relu(a * asc + ash); one k-quad per thread and tile
     const int64_t agroup = g.a_scale ? (int64_t)(m0 / g.group_rows) * (g.K1 + g.K2) : 0;
     unsigned ra_ok = 0;          // validity bits of ra[]: the zero-select is applied when the data is CONSUMED (store_a), so the
-    bool ovf = false;            // loads stay in flight across the MFMAs (a select right after the load forces vmcnt(0) there)
+    float amax = 0.0f;          // running max |a| of everything this thread staged (fp16 overflow flag)            // loads stay in flight across the MFMAs (a select right after the load forces vmcnt(0) there)
     auto load_a = [&](int t) {
         const bool second = t >= nk1;
         const float* Ap = second ? A2 : A;
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && MT * NT == 8) ? 2 : 
                         if (g.a_relu) val[e] = fmaxf(val[e], 0.0f);
                     }
                 }
-                split4v(((ra_ok >> i) & 1u) ? val : zero, hi, lo, ovf);
+                split4_f16(((ra_ok >> i) & 1u) ? val : zero, hi, lo, amax);
                 const int off = (f >> 3) * LDH + (f & 7) * 4;
                 *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
                 *reinterpret_cast<f16x4*>(&Al[off]) = lo;
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && MT * NT == 8) ? 2 : 
         if (more) store_a(buf ^ 1);
         __syncthreads();
     }
-    if (g.overflow && ovf) atomicOr(g.overflow, 1);
+    if (g.overflow && amax > 65504.0f) atomicOr(g.overflow, 1);
     ogmm_gemm gz = g;                  // per-batch views for the epilogue
     if (gz.C) gz.C += zb * g.sC_o;
     if (gz.Res) gz.Res += zb * g.sR_o;
@@ -240,7 +239,7 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {
         case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves
         case 22: return launch_v2<4, 2, 1, 4, false>(g, s);    // 128 x 256, 4 waves of 128 x 64: two independent workgroups per CU
-        case 18: case 19: case 23: case 26: case 29:            // large-shape engine and its ablations (tools/gemm_bench.py)
+        case 18: case 19: case 23: case 26: case 27: case 28: case 29:            // large-shape engine and its ablations (tools/gemm_bench.py)
             OGMM_REQUIRE(gemm_f16x3_large_applicable(g), "large-shape engine not applicable"); return gemm_nt_f16x3_v4(g, s);
         default: break;
     }

@@ -23,7 +23,6 @@ namespace {
 
 using namespace ogmm_gemm_detail;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 constexpr int BK3 = 64;
 constexpr int LD3 = BK3 + 8;          // 144-byte rows: conflict-free ds_read_b128 / ds_write_b64
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
 
     f32x4 ra[A_P];
     unsigned ra_ok = 0;
-    bool ovf = false;
+    float amax = 0.0f;          // running max |a| of everything this thread staged (fp16 overflow flag)
     const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4v = {0.f, 0.f, 0.f, 0.f};
     f32x4 asc = one4, ash = zero4v;      // fused InstanceNorm: A is read as relu(a * asc + ash); one k-quad per thread and tile
     const int64_t agroup = g.a_scale ? (int64_t)(m0 / g.group_rows) * (g.K1 + g.K2) : 0;
@@ -121,8 +120,12 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
                 if (g.a_relu) val[e] = fmaxf(val[e], 0.0f);
             }
         }
-        split4w(((ra_ok >> i) & 1u) ? val : zero, hi, lo, ovf);
+        split4_f16(((ra_ok >> i) & 1u) ? val : zero, hi, lo, amax);
         const int off = (f >> 4) * LD3 + (f & 15) * 4;
+        if (ABL & 256) {            // ablation 256: no LDS writes (loads + split kept alive)
+            asm volatile("" :: "v"(hi), "v"(lo));
+            return;
+        }
         *reinterpret_cast<f16x4*>(&Ah[off]) = hi;
         *reinterpret_cast<f16x4*>(&Al[off]) = lo;
     };
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             bh[j] = BH[bbase[j] + kb];
-            bl[j] = BL[bbase[j] + kb];
+            bl[j] = (ABL & 64) ? bh[j] : BL[bbase[j] + kb];          // ablation 64: half the weight traffic (wrong results)
         }
     };
     auto read_a = [&](f16x8 (&ah)[2], f16x8 (&al)[2], int buf, int s, int gI) {
@@ -170,13 +173,20 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
         const bool more = t + 1 < nk;
-        if (more && !(ABL & 4)) load_a(t + 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // B fragments of the next k-step (next tile's first step after the last one)
             if (!(ABL & 2)) {
             if (s < 3) { if (s & 1) load_b(bhA, blA, t, s + 1); else load_b(bhB, blB, t, s + 1); }
             else if (more) load_b(bhA, blA, t + 1, 0);
+            }
+            // The next tile's A loads go out AFTER step 0's B-fragment loads: vmcnt retires in order, so every fragment
+            // consumed after this point waits for these (HBM-latency) loads too; issued here the first such consumer is
+            // step 2's, two k-steps (~3 us) away, instead of step 1's (measured: the A loads cost 20 % of the loop).
+            if (s == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && !(ABL & 4) && !(ABL & 128)) load_a(t + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int i = 0; i < MT / 2; ++i) {
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
         __syncthreads();
         if (more && !(ABL & 1)) read_a(ah0, al0, buf ^ 1, 0, 0);
     }
-    if (g.overflow && ovf) atomicOr(g.overflow, 1);
+    if (g.overflow && amax > 65504.0f) atomicOr(g.overflow, 1);
     if (ABL & 8) {          // ablation: no output stores (one dummy store keeps the accumulators live)
         float sum = 0.f;
 #pragma unroll
@@ -243,6 +253,8 @@ int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
         case 26: return launch_v4<7>(g, s);     // MFMA + barrier only
         case 29: return launch_v4<3>(g, s);     // + A global loads / split / LDS writes only
         case 19: return launch_v4<15>(g, s);    // MFMA only, no epilogue stores
+        case 27: return launch_v4<32 + 8 + 128>(g, s);   // no stores, no A global loads
+        case 28: return launch_v4<32 + 8 + 256>(g, s);   // no stores, no A LDS writes
         case 18: return launch_v4<8>(g, s);     // full loop, no epilogue stores
         default: return launch_v4<32>(g, s);     // default: no sched_barrier pinning (measured +3-4 %)
     }
