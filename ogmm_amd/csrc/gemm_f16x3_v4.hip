@@ -173,6 +173,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
         const bool more = t + 1 < nk;
+        if ((ABL & 512) && more && !(ABL & 4) && !(ABL & 128)) load_a(t + 1);      // A/B switch: A loads at the tile start
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // B fragments of the next k-step (next tile's first step after the last one)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
             // The next tile's A loads go out AFTER step 0's B-fragment loads: vmcnt retires in order, so every fragment
             // consumed after this point waits for these (HBM-latency) loads too; issued here the first such consumer is
             // step 2's, two k-steps (~3 us) away, instead of step 1's (measured: the A loads cost 20 % of the loop).
-            if (s == 0) {
+            if (s == 0 && !(ABL & 512)) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && !(ABL & 4) && !(ABL & 128)) load_a(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -254,7 +255,7 @@ int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
         case 29: return launch_v4<3>(g, s);     // + A global loads / split / LDS writes only
         case 19: return launch_v4<15>(g, s);    // MFMA only, no epilogue stores
         case 27: return launch_v4<32 + 8 + 128>(g, s);   // no stores, no A global loads
-        case 28: return launch_v4<32 + 8 + 256>(g, s);   // no stores, no A LDS writes
+        case 28: return launch_v4<32 + 512>(g, s);   // A loads at the tile start (older order)
         case 18: return launch_v4<8>(g, s);     // full loop, no epilogue stores
         default: return launch_v4<32>(g, s);     // default: no sched_barrier pinning (measured +3-4 %)
     }

@@ -7,7 +7,8 @@ does not travel to the GPU box in any form.
 
 Two third-party modules that the reference imports at module scope but never touches on the
 hot path (`open3d` via lib/o3dutils.py:11, `transforms3d` via lib/se3.py:10) are absent from
-this image; empty stub modules are registered for them.
+this image; empty stub modules are registered for them.  `h5py` (file loader only,
+datasets/datautils.py:15) is stubbed the same way so that lib/metric.py and lib/loss.py import.
 """
 import os
 import sys
@@ -25,7 +26,7 @@ def import_reference():
     """Returns the reference's `models.gmmreg` module (and makes `lib.*` importable)."""
     if not reference_available():
         raise RuntimeError("reference not mounted at %s" % REFERENCE_ROOT)
-    for name in ("open3d", "transforms3d", "transforms3d.quaternions"):
+    for name in ("open3d", "transforms3d", "transforms3d.quaternions", "h5py"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
     sys.modules["transforms3d"].quaternions = sys.modules["transforms3d.quaternions"]

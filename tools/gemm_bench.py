@@ -8,7 +8,7 @@ from ogmm_amd import ops
 
 variants = [int(v) for v in sys.argv[1:]] or [0, 1]
 M = 131072
-shapes = [("mlp0 1024x(512+512)", M, 1024, 512, 512), ("mlp3 512x1024", M, 512, 1024, 0), ("conv.0 1024x512", M, 1024, 512, 0),
+shapes = [("mlp0 1024x(512+512)", M, 1024, 512, 512), ("conv.3 1024x1024", M, 1024, 1024, 0), ("conv2.0 1024x(512+4)", M, 1024, 512, 4), ("mlp3 512x1024", M, 512, 1024, 0), ("conv.0 1024x512", M, 1024, 512, 0),
           ("q/merge 512x512", M, 512, 512, 0), ("proj 256x512", M, 256, 512, 0), ("pos 256x64", M, 256, 64, 0)]
 torch.manual_seed(0)
 for name, m, n, k1, k2 in shapes:
