@@ -114,6 +114,29 @@ def make_batch(first_pair, batch, n_points, kind="partial", seed=1234):
     return tuple(torch.from_numpy(np.stack([p[j] for p in parts])) for j in range(4))
 
 
+def overlap_labels(src, tgt, R, t, thresh=0.05):
+    """Ground-truth overlap labels of one pair the way the reference's loader derives them (lib/o3dutils.py:217-226 <-
+    datasets/modelnet.py:212): a src point is 1 when some tgt point lies within `thresh` of it after the ground-truth
+    motion, and symmetrically for tgt.  src, tgt [3,N] -> two float32 [N] arrays.  Brute force in fp64 (N <= a few k)."""
+    moved = src.T.astype(np.float64) @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
+    d2 = ((moved[:, None, :] - tgt.T.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    hit = d2 < thresh * thresh
+    return hit.any(1).astype(np.float32), hit.any(0).astype(np.float32)
+
+
+def make_train_batch(first_pair, batch, n_points, kind="partial", seed=1234, thresh=0.05):
+    """Training inputs of train.py:38-56 for pairs [first_pair, first_pair+batch): src, tgt [B,3,N], transform_gt
+    [B,4,4], src_overlap, tgt_overlap [B,N]."""
+    src, tgt, R, t = make_batch(first_pair, batch, n_points, kind, seed)
+    T = torch.eye(4).repeat(batch, 1, 1)
+    T[:, :3, :3] = R
+    T[:, :3, 3] = t
+    labels = [overlap_labels(src[i].numpy(), tgt[i].numpy(), R[i].numpy(), t[i].numpy(), thresh) for i in range(batch)]
+    so = torch.from_numpy(np.stack([l[0] for l in labels]))
+    to = torch.from_numpy(np.stack([l[1] for l in labels]))
+    return src, tgt, T, so, to
+
+
 def fps_starts_for(first_pair, batch, n_points, seed=1234):
     """The six random FPS start indices per pair (lib/utils.py:190 draws them from the global
     generator; here they are a pure function of the global pair id) -> int64 [6,B]."""

@@ -133,17 +133,19 @@ def weighted_em(xyz, feats, o_scores, n_clusters, iters=10, tau=1.0, stats=None)
     `stats` (optional list) receives the Sinkhorn iteration count of every E-step."""
     ids = fps(xyz, n_clusters, None)
     mu = gather_rows(xyz, ids)
+    o_scores = o_scores.detach()                              # lib/utils.py:275: no gradient reaches the overlap scores from here
     o = o_scores / o_scores.sum(-1, keepdim=True).clip(min=1e-4)
     gamma = None
-    for _ in range(iters):
-        cost = torch.cdist(xyz, mu).clip(min=0.0) / tau
-        g, n_it = sinkhorn_log(cost, o, None, max_iter=10)
-        if stats is not None:
-            stats.append(n_it)
-        g = torch.nan_to_num(g, nan=0.0)
-        gamma = g / g.sum(-1, keepdim=True).clip(min=1e-3)
-        pi, mu = gmm_moments(gamma, xyz)
-    mu_feat = gmm_moments(gamma, feats)[1]
+    with torch.no_grad():                                     # lib/utils.py:278
+        for _ in range(iters):
+            cost = torch.cdist(xyz, mu).clip(min=0.0) / tau
+            g, n_it = sinkhorn_log(cost, o, None, max_iter=10)
+            if stats is not None:
+                stats.append(n_it)
+            g = torch.nan_to_num(g, nan=0.0)
+            gamma = g / g.sum(-1, keepdim=True).clip(min=1e-3)
+            pi, mu = gmm_moments(gamma, xyz)
+    mu_feat = gmm_moments(gamma, feats)[1]                    # with grad w.r.t. feats (lib/utils.py:289-290)
     return gamma, pi, mu, mu_feat, ids
 
 
@@ -198,9 +200,14 @@ def info_nce(x, y, tau):
 # --------------------------------------------------------------------------------------
 # L2 model blocks (models/dgcnn.py, models/attn.py, models/gmmreg.py), eval mode
 # --------------------------------------------------------------------------------------
+_BN_TRAINING = False   # set by forward(train=True): batch statistics + in-place running-stat updates (momentum 0.1)
+
+
 def _bn(P, name, x):
+    if _BN_TRAINING and (name + '.num_batches_tracked') in P:
+        P[name + '.num_batches_tracked'] += 1                 # nn.BatchNorm bookkeeping (unused by the arithmetic: momentum is fixed)
     return F.batch_norm(x, P[name + '.running_mean'], P[name + '.running_var'],
-                        P[name + '.weight'], P[name + '.bias'], False, 0.1, BN_EPS)
+                        P[name + '.weight'], P[name + '.bias'], _BN_TRAINING, 0.1, BN_EPS)
 
 
 def _conv(P, name, x):
@@ -286,13 +293,25 @@ def draw_fps_starts(B, N):
     return torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
 
 
-def forward(P, cfg, src, tgt, fps_starts=None, cap=None, inject=None):
-    """models/gmmreg.py:50-119 (`GMMReg.forward`, is_test=False), eval mode.
+def forward(P, cfg, src, tgt, fps_starts=None, cap=None, inject=None, train=False):
+    """models/gmmreg.py:50-119 (`GMMReg.forward`, is_test=False); eval mode, or with train=True the `.train()`
+    behaviour: every BatchNorm normalises with the statistics of its own call (src and tgt are separate calls) and
+    updates P's running statistics in place, src call first.  Autograd runs through everything except kNN / FPS / the
+    E-M loop, as in the reference.
 
     P: the reference state_dict (153 keys); cfg: gnn_k, num_heads, km_clusters (+ n_clusters);
     src, tgt [B,3,N].  fps_starts [6,B] pins the random FPS starts (drawn like the reference
     when None).  `cap` (dict) receives intermediates; `inject` may carry 'knn_idx_src/tgt' to
     pin the kNN graph.  Returns (R [B,3,3], t [B,3], src_o [B,N], tgt_o [B,N], loss [])."""
+    global _BN_TRAINING
+    _BN_TRAINING = bool(train)
+    try:
+        return _forward(P, cfg, src, tgt, fps_starts, cap, inject)
+    finally:
+        _BN_TRAINING = False
+
+
+def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
     B, _, N = src.shape
     k, H, M, J = cfg.gnn_k, cfg.num_heads, cfg.km_clusters, cfg.n_clusters
     if fps_starts is None:
@@ -364,6 +383,44 @@ def forward(P, cfg, src, tgt, fps_starts=None, cap=None, inject=None):
         loss = loss + info_nce(anchors_f, positives, 0.1)
     loss = 0.5 * loss
     return R, t, o['src'], o['tgt'], loss
+
+
+# --------------------------------------------------------------------------------------
+# training losses (lib/loss.py, train.py:54-74) -- SURVEY section 8 a22
+# --------------------------------------------------------------------------------------
+def dcp_loss(R, R_gt, t, t_gt):
+    """lib/loss.py:121-126: mse(R^T R_gt, I) + mse(t, t_gt)."""
+    B = t_gt.shape[0]
+    eye = torch.eye(3, dtype=R.dtype)[None].repeat(B, 1, 1)
+    return F.mse_loss(torch.matmul(R.transpose(2, 1), R_gt), eye) + F.mse_loss(t.view(B, 3), t_gt.view(B, 3))
+
+
+def welsch_loss(src, tgt, T, src_o, tgt_o, alpha=10.0, top_k=512):
+    """lib/loss.py:83-106 (`WelschLoss`): src, tgt [B,N,3]; T [B,4,4]; the top_k points by (ground-truth) overlap of
+    each cloud are matched to their nearest neighbour in the other cloud after moving src by T."""
+    moved = torch.matmul(src, T[:, :3, :3].transpose(-1, -2)) + T[:, :3, 3][:, None, :]      # lib/se3.py:105-109
+    s_ids = torch.topk(src_o, k=top_k, dim=-1)[1][:, :, None].expand(-1, -1, 3)
+    t_ids = torch.topk(tgt_o, k=top_k, dim=-1)[1][:, :, None].expand(-1, -1, 3)
+    z1 = torch.cdist(torch.gather(moved, 1, s_ids), tgt).min(dim=-1)[0]
+    z2 = torch.cdist(torch.gather(tgt, 1, t_ids), moved).min(dim=-1)[0]
+    a2 = alpha * alpha
+    return (2.0 - torch.exp(-0.5 * z1 ** 2.0 / a2) - torch.exp(-0.5 * z2 ** 2.0 / a2)).sum(dim=1).mean()
+
+
+def training_loss(out, src, tgt, T_gt, src_overlap, tgt_overlap, alpha=10.0, top_k=512):
+    """train.py:54-72: 10 dcp + clu + mse(overlap) + 0.01 welsch, nan -> 0.  `out` = forward(...)'s 5-tuple;
+    src, tgt [B,3,N]; T_gt [B,4,4]; *_overlap [B,N] ground-truth labels."""
+    R, t, so, to, clu = out
+    B = T_gt.shape[0]
+    R_gt, t_gt = T_gt[:, :3, :3], T_gt[:, :3, 3:4].reshape(B, 3)
+    o_pred = torch.nan_to_num(torch.cat([so, to], dim=-1), nan=0.0).clip(min=0.0)
+    o_gt = torch.nan_to_num(torch.cat([src_overlap, tgt_overlap], dim=-1), nan=0.0).clip(min=0.0)
+    T_pred = torch.eye(4, dtype=R.dtype)[None].repeat(B, 1, 1)          # lib/se3.py:29-52 (in-place writes into a leaf-free eye)
+    T_pred[:, :3, :3] = R
+    T_pred[:, :3, 3:4] = t.view(-1, 3, 1)
+    loss = 10 * dcp_loss(R, R_gt, t, t_gt) + clu + F.mse_loss(o_pred, o_gt) \
+        + 0.01 * welsch_loss(src.transpose(1, 2), tgt.transpose(1, 2), T_pred, src_overlap, tgt_overlap, alpha, top_k)
+    return torch.nan_to_num(loss, nan=0.0)
 
 
 # --------------------------------------------------------------------------------------
