@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 3
+#define OGMM_ABI_VERSION 4
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -201,6 +201,35 @@ int ogmm_kabsch(const float* src, const float* corr, const float* w, int B, int 
  * the 0.5 of models/gmmreg.py:110); near[c][j] = chosen point index. */
 int ogmm_clu_infonce(const float* xyz, const float* mu, const float* feats, int64_t ld, const float* mu_feat,
                      int C, int N, int J, int D, float tau, float* row_loss_sum /*[C]*/, int32_t* near /*[C][J]*/, void* stream);
+
+/* =====================================================================================================
+ * Training mode (`model.train()`): forward kernels that differ from eval, and the backward kernels.
+ * The reference has no hand-written backward: autograd differentiates the model files; each entry cites the
+ * forward expression whose derivative it computes.
+ * ===================================================================================================== */
+
+/* ---- T1: train-mode BatchNorm (models/dgcnn.py:126-130, :21-27; models/attn.py:34-57) and InstanceNorm1d
+ * (models/attn.py:24) over row groups of a point-major map x [rows][cols] (row stride ldx): group g = rows
+ * [g*group_rows, (g+1)*group_rows).  A BatchNorm group is one call of the shared layer (the src or the tgt half of the
+ * stacked batch); an InstanceNorm group is one cloud.
+ *   ogmm_colstats:        stats[g][c] = {sum x, sum x^2} in fp64 (zeroed by the call)
+ *   ogmm_affine_act:      y = act(x * scale[g][c] + shift[g][c]),  act in {NONE, RELU, LEAKY02}
+ *   ogmm_norm_bwd_reduce: sums[g][c] = {sum dz, sum dz * xhat}, dz = dy * act'(y), xhat = (x - mean) * rstd  (fp64, zeroed by the call)
+ *   ogmm_norm_bwd_apply:  dx = scale * (dz - sums0/n - xhat * sums1/n),  n = group_rows
+ * The host turns stats into mean / rstd / scale = gamma*rstd / shift = beta - mean*scale and sums into dgamma, dbeta. */
+int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, double* stats /*[G][cols][2]*/, void* stream);
+int ogmm_affine_act(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, const float* scale /*[G][cols]*/,
+                    const float* shift, int act, float* y, int64_t ldy, void* stream);
+int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int cols,
+                         int64_t group_rows, const float* mean /*[G][cols]*/, const float* rstd, int act, double* sums /*[G][cols][2]*/, void* stream);
+int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int cols,
+                        int64_t group_rows, const float* scale, const float* mean, const float* rstd, int act, const double* sums,
+                        float* dx, int64_t lddx, void* stream);
+
+/* ---- T2: max over the k edges of a point on an un-fused per-edge map (models/dgcnn.py:139,142,145,148; models/attn.py:72):
+ * out[p][c] = max_j h[p*k + j][c], arg[p][c] = first maximising j; backward routes dout to that edge and writes zeros elsewhere. */
+int ogmm_maxpool_k(const float* h, int64_t ldh, int64_t points, int k, int cols, float* out, int64_t ldo, uint8_t* arg /*[points][cols]*/, void* stream);
+int ogmm_maxpool_k_bwd(const float* dout, int64_t ldo, const uint8_t* arg, int64_t points, int k, int cols, float* dh, int64_t ldh, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG = 0, 1, 2
@@ -61,6 +61,14 @@ PROTOTYPES = {
     "ogmm_match_kabsch": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_kabsch": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_clu_infonce": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    # training mode
+    "ogmm_colstats": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p],
+    "ogmm_affine_act": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
+    "ogmm_norm_bwd_reduce": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "ogmm_norm_bwd_apply": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                            c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_maxpool_k": [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p],
+    "ogmm_maxpool_k_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p],
 }
 
 _lib = None

@@ -9,8 +9,9 @@ What runs where: this file is host orchestration only (the reference's forward i
 operation of the forward is a kernel of libogmm_hip.so reached through ogmm_amd/ops.py; PyTorch provides
 device buffers and the stream.  There is no CPU fallback: CPU tensors raise.
 
-Scope of this round: eval-mode forward (`model.eval()`, `is_test=False`).  Training-mode BatchNorm statistics /
-autograd and the open3d ICP refinement of `is_test=True` (models/gmmreg.py:115-117) raise NotImplementedError.
+Scope: `model.eval()` runs the fused inference kernels; `model.train()` runs the training graph (batch-statistics
+BatchNorm, autograd; ogmm_amd/train_graph.py).  The open3d ICP refinement of `is_test=True` (models/gmmreg.py:115-117)
+raises NotImplementedError.
 
 Layout: clouds are stacked as C = 2B (src clouds, then tgt clouds: in eval mode the shared-weight src/tgt calls of
 the reference are independent, models/gmmreg.py:52-53) and feature maps are point-major [C*N, channels].
@@ -272,8 +273,6 @@ class GMMReg(nn.Module):
         so the same `torch.manual_seed` gives the same anchors as the reference."""
         if not (isinstance(src, torch.Tensor) and src.is_cuda and tgt.is_cuda):
             raise OgmmError("GMMReg.forward needs CUDA/ROCm tensors: the MI355X path has no CPU fallback")
-        if self.training:
-            raise NotImplementedError("training-mode forward/backward is not built yet (eval-mode inference only); call .eval()")
         if is_test:
             raise NotImplementedError("is_test=True needs the open3d ICP refinement (models/gmmreg.py:115-117): out of scope")
         if src.dim() != 3 or src.shape[1] != 3 or src.shape != tgt.shape or src.dtype != torch.float32 or tgt.dtype != torch.float32:
@@ -290,6 +289,8 @@ class GMMReg(nn.Module):
             self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         if self.emd.conv1.weight.device != dev:
             raise OgmmError("GMMReg parameters live on %s but the inputs on %s: call model.to(device) first" % (self.emd.conv1.weight.device, dev))
+        if self.training:
+            return self._forward_train(src, tgt, fps_starts, capture)
         L = self._layers()
         cap = {} if capture else None
         ops.DEFAULT_SPLIT = self.precision == "f16x3"
@@ -392,6 +393,22 @@ class GMMReg(nn.Module):
                        o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss)
             self.last_intermediates = cap
         return rot, trans, o[:B], o[B:], loss
+
+    def _forward_train(self, src, tgt, fps_starts, capture):
+        """`.train()` mode: batch-statistics BatchNorm with running-stat updates and autograd through every differentiable
+        stage (ogmm_amd/train_graph.py over the kernels of ogmm_amd/train_ops.py)."""
+        from . import train_graph, train_ops
+        B, _, N = src.shape
+        if fps_starts is None:
+            fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
+        P = dict(self.named_parameters())
+        P.update(dict(self.named_buffers()))
+        cap = {} if capture else None
+        out = train_graph.forward_train(train_ops.TrainOps(self.precision, self._overflow), P, self.config, self.n_clusters,
+                                        src, tgt, fps_starts.to(src.device), cap)
+        if capture:
+            self.last_intermediates = cap
+        return out
 
     def fp16_overflowed(self):
         """True if any fp16x3 GEMM since the last call clamped an activation beyond +-65504 (synchronises)."""

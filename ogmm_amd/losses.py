@@ -1,0 +1,66 @@
+"""Losses of the training step: the clustering InfoNCE that `GMMReg.forward` itself returns
+(lib/loss.py:16-57, :109-118) and the three terms train.py:69-71 adds -- all on small tensors ([B,J,D], [B,3,3], [B,2N],
+[B,top_k,N]), written with differentiable torch tensor ops on whatever device the inputs live on.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def info_nce(anchor, positive, tau):
+    """`ConLoss.forward` (lib/loss.py:22-57) for one cloud set.  anchor, positive [B,n,D] -> scalar.
+    Each of the B*2n rows is a softmax classification whose class 0 is the matching pair (x_i, y_i) and whose other
+    2n-2 classes are the same-set and cross-set similarities with the diagonal removed, all divided by tau."""
+    B, n, _ = anchor.shape
+    x = F.normalize(anchor, p=2, dim=-1)
+    y = F.normalize(positive, p=2, dim=-1)
+    both = torch.cat([x, y], dim=1)                                   # [B,2n,D]
+    sim = torch.bmm(both, both.transpose(1, 2)) / tau                 # blocks [[xx, xy], [yx, yy]]
+    i = torch.arange(n, device=anchor.device)
+    pos = torch.cat([sim[:, i, n + i], sim[:, n + i, i]], dim=1)      # [B,2n]: xy_ii for the x rows, yx_ii for the y rows
+    # the negatives are every entry of a row except the two "diagonals" (self-similarity and the positive)
+    mask = torch.ones(2 * n, 2 * n, dtype=torch.bool, device=anchor.device)
+    mask[torch.arange(2 * n), torch.arange(2 * n)] = False
+    mask[i, n + i] = False
+    mask[n + i, i] = False
+    neg = sim[:, mask].view(B, 2 * n, 2 * n - 2)
+    logits = torch.cat([pos[:, :, None], neg], dim=2).reshape(B * 2 * n, 2 * n - 1)
+    return F.cross_entropy(logits, torch.zeros(logits.shape[0], dtype=torch.long, device=anchor.device))
+
+
+def dcp_loss(R, R_gt, t, t_gt):
+    """lib/loss.py:121-126"""
+    B = R.shape[0]
+    eye = torch.eye(3, dtype=R.dtype, device=R.device).expand(B, 3, 3)
+    return F.mse_loss(torch.bmm(R.transpose(1, 2), R_gt), eye) + F.mse_loss(t.reshape(B, 3), t_gt.reshape(B, 3))
+
+
+def overlap_mse(src_o, tgt_o, src_overlap, tgt_overlap):
+    """train.py:59-62 + lib/loss.py:137-138 (`get_weighted_bce_loss` is a plain MSE)"""
+    pred = torch.nan_to_num(torch.cat([src_o, tgt_o], dim=-1), nan=0.0).clip(min=0.0)
+    gt = torch.nan_to_num(torch.cat([src_overlap, tgt_overlap], dim=-1), nan=0.0).clip(min=0.0)
+    return F.mse_loss(pred, gt)
+
+
+def welsch_loss(src, tgt, R, t, src_overlap, tgt_overlap, alpha=10.0, top_k=512):
+    """`WelschLoss.forward` (lib/loss.py:83-106) with the predicted motion given as (R, t) instead of the 4x4 the
+    reference packs first (lib/se3.py:29-52).  src, tgt [B,N,3]."""
+    moved = torch.bmm(src, R.transpose(1, 2)) + t.reshape(-1, 1, 3)
+    s_ids = torch.topk(src_overlap, k=top_k, dim=-1)[1]
+    t_ids = torch.topk(tgt_overlap, k=top_k, dim=-1)[1]
+    take = lambda p, ids: torch.gather(p, 1, ids[:, :, None].expand(-1, -1, 3))          # noqa: E731
+    z1 = torch.cdist(take(moved, s_ids), tgt).min(dim=-1)[0]
+    z2 = torch.cdist(take(tgt, t_ids), moved).min(dim=-1)[0]
+    a2 = alpha * alpha
+    return (2.0 - torch.exp(-0.5 * z1 * z1 / a2) - torch.exp(-0.5 * z2 * z2 / a2)).sum(dim=1).mean()
+
+
+def training_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap, alpha=10.0, top_k=512):
+    """train.py:54-72: 10*dcp + clu + mse + 0.01*welsch with NaN -> 0.  out = GMMReg.forward's 5-tuple; src, tgt [B,3,N];
+    transform_gt [B,4,4]; *_overlap [B,N].  Returns (loss, dict of the four parts)."""
+    R, t, so, to, clu = out
+    B = R.shape[0]
+    R_gt, t_gt = transform_gt[:, :3, :3], transform_gt[:, :3, 3].reshape(B, 3)
+    parts = {"dcp": dcp_loss(R, R_gt, t, t_gt), "clu": clu, "mse": overlap_mse(so, to, src_overlap, tgt_overlap),
+             "welsch": welsch_loss(src.transpose(1, 2), tgt.transpose(1, 2), R, t, src_overlap, tgt_overlap, alpha, top_k)}
+    loss = torch.nan_to_num(10 * parts["dcp"] + parts["clu"] + parts["mse"] + 0.01 * parts["welsch"], nan=0.0)
+    return loss, parts

@@ -389,3 +389,56 @@ def clu_infonce(xyz, mu, feats, mu_feat, C, N, tau=0.1):
     _lib.call("ogmm_clu_infonce", _p(_f32(xyz, "xyz")), _p(_f32(mu, "mu")), _p(_f32(feats, "feats")), feats.stride(0), _p(mu_feat), C, N, J, D,
               tau, _p(row_loss), _p(near), _stream())
     return row_loss, near
+
+
+# ---------------------------------------------------------------------------------------------- training mode
+def colstats(x, group_rows):
+    """x [rows, cols] (last stride 1) -> float64 [G, cols, 2] = {sum, sum of squares} per row group"""
+    assert x.stride(1) == 1
+    rows, cols = x.shape
+    st = torch.empty((rows // group_rows, cols, 2), dtype=torch.float64, device=x.device)
+    _lib.call("ogmm_colstats", _p(_f32(x, "x")), x.stride(0), rows, cols, group_rows, _p(st), _stream())
+    return st
+
+
+def affine_act(x, group_rows, scale, shift, act, out=None):
+    """act(x * scale[g] + shift[g]) with per-(group, column) float32 scale / shift [G, cols]"""
+    assert x.stride(1) == 1 and scale.is_contiguous() and shift.is_contiguous()
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    _lib.call("ogmm_affine_act", _p(_f32(x, "x")), x.stride(0), rows, cols, group_rows, _p(_f32(scale, "scale")), _p(_f32(shift, "shift")), act,
+              _p(out), out.stride(0), _stream())
+    return out
+
+
+def norm_bwd(x, y, dy, group_rows, scale, mean, rstd, act):
+    """backward of y = act((x - mean) * rstd * gamma + beta) -> (dx, sums float64 [G, cols, 2] = {sum dz, sum dz*xhat})"""
+    rows, cols = x.shape
+    assert x.stride(1) == 1 and y.stride(1) == 1 and dy.stride(1) == 1
+    G = rows // group_rows
+    sums = torch.empty((G, cols, 2), dtype=torch.float64, device=x.device)
+    _lib.call("ogmm_norm_bwd_reduce", _p(_f32(x, "x")), x.stride(0), _p(_f32(y, "y")), y.stride(0), _p(_f32(dy, "dy")), dy.stride(0), rows, cols,
+              group_rows, _p(_f32(mean, "mean")), _p(_f32(rstd, "rstd")), act, _p(sums), _stream())
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    _lib.call("ogmm_norm_bwd_apply", _p(x), x.stride(0), _p(y), y.stride(0), _p(dy), dy.stride(0), rows, cols, group_rows,
+              _p(_f32(scale, "scale")), _p(mean), _p(rstd), act, _p(sums), _p(dx), dx.stride(0), _stream())
+    return dx, sums
+
+
+def maxpool_k(h, k):
+    """-> (out [P, cols], arg uint8 [P, cols])"""
+    assert h.stride(1) == 1 and h.shape[0] % k == 0
+    P, cols = h.shape[0] // k, h.shape[1]
+    out = torch.empty((P, cols), dtype=torch.float32, device=h.device)
+    arg = torch.empty((P, cols), dtype=torch.uint8, device=h.device)
+    _lib.call("ogmm_maxpool_k", _p(_f32(h, "h")), h.stride(0), P, k, cols, _p(out), out.stride(0), _p(arg), _stream())
+    return out, arg
+
+
+def maxpool_k_bwd(dout, arg, k):
+    assert dout.stride(1) == 1 and arg.is_contiguous()
+    P, cols = dout.shape
+    dh = torch.empty((P * k, cols), dtype=torch.float32, device=dout.device)
+    _lib.call("ogmm_maxpool_k_bwd", _p(_f32(dout, "dout")), dout.stride(0), _p(arg), P, k, cols, _p(dh), dh.stride(0), _stream())
+    return dh

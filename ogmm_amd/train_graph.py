@@ -1,0 +1,122 @@
+"""Training-mode forward of GMMReg as a differentiable graph over `TrainOps` (ogmm_amd/train_ops.py).
+
+Follows models/gmmreg.py:50-119 with the module in `.train()`: every BatchNorm normalises with the statistics of its
+own call -- the reference calls each shared block once for src and once for tgt, so statistics are per HALF of the
+stacked batch -- and updates its running statistics (momentum 0.1, unbiased variance) src call first
+(models/dgcnn.py:126-130, :21-27; models/attn.py:34-57).  InstanceNorm is per cloud as in eval.  Gradients flow through
+everything except the discrete selections (kNN, FPS, nearest point) and the E/M loop (lib/utils.py:275-288).
+
+Layout as in the eval path: clouds stacked C = 2B (src clouds, then tgt clouds), feature maps point-major
+[C*N, channels]; per-edge maps [C*N*k, channels].  `ops` supplies every tensor operation; this file only wires them.
+"""
+import torch
+
+from . import losses
+
+GROUPS = 2          # BatchNorm statistics groups: the src call and the tgt call of the reference
+
+
+def _w(P, key):
+    w = P[key + ".weight"]
+    return w.reshape(w.shape[0], w.shape[1])
+
+
+def _b(P, key):
+    return P.get(key + ".bias")
+
+
+def _bn(ops, P, name, y, act, rows_per_point=1):
+    return ops.batchnorm_act(y, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"], P[name + ".running_var"],
+                             P[name + ".num_batches_tracked"], GROUPS, act)
+
+
+def dgcnn(ops, P, xyz, idx):
+    """models/dgcnn.py:133-154.  -> [C*N, D]"""
+    C, N, k = idx.shape
+    h = ops.edge_features(xyz, idx)                                   # [C*N*k, 6], constant
+    pooled = []
+    for l in (1, 2, 3, 4):
+        y = ops.linear(h, _w(P, "emd.conv%d" % l), None)
+        h = _bn(ops, P, "emd.bn%d" % l, y, "relu")
+        pooled.append(ops.maxpool_k(h, k))                               # max over the k edges of a point, after the ReLU
+    xcat = torch.cat(pooled, dim=1)
+    return _bn(ops, P, "emd.bn5", ops.linear(xcat, _w(P, "emd.conv5"), None), "relu")
+
+
+def pos_encoding(ops, P, xyz, idx5):
+    """models/attn.py:59-75 (`pos.conv` is never applied).  -> [C*N, D]"""
+    d2, alpha = ops.pos_features(xyz, idx5)                              # [C*N, 1], [C*N*5, 1]: constants of the input
+    h = _bn(ops, P, "pos.conv_dis.1", ops.linear(d2, _w(P, "pos.conv_dis.0"), None), "leaky")
+    dis = _bn(ops, P, "pos.conv_dis.4", ops.linear(h, _w(P, "pos.conv_dis.3"), None), "leaky")
+    a = _bn(ops, P, "pos.conv_ang1.1", ops.linear(alpha, _w(P, "pos.conv_ang1.0"), None), "leaky")
+    a = ops.maxpool_k(a, idx5.shape[2])
+    ang = _bn(ops, P, "pos.conv_ang2.1", ops.linear(a, _w(P, "pos.conv_ang2.0"), None), "leaky")
+    return torch.cat([dis, ang], dim=1)
+
+
+def transformer(ops, P, name, x, anchors, C, N, M, H):
+    """models/attn.py:78-111 without the residual.  x [C*N, D], anchors [C*M, D].  The reference splits heads as channel
+    c = d*H + h (models/attn.py:96); the projections are re-ordered head-major (c' = h*dh + d) by permuting weight rows,
+    and the merge convolution's input columns the same way, so that a head is a contiguous slice."""
+    D = x.shape[1]
+    dh = D // H
+    cp = torch.arange(D, device=x.device)
+    perm = (cp % dh) * H + (cp // dh)
+    q = ops.linear(x, _w(P, name + ".attn.proj.0")[perm], _b(P, name + ".attn.proj.0")[perm])
+    kk = ops.linear(anchors, _w(P, name + ".attn.proj.1")[perm], _b(P, name + ".attn.proj.1")[perm])
+    vv = ops.linear(anchors, _w(P, name + ".attn.proj.2")[perm], _b(P, name + ".attn.proj.2")[perm])
+    o = ops.attention(q, kk, vv, C, N, M, H)
+    msg = ops.linear(o, _w(P, name + ".attn.merge")[:, perm], _b(P, name + ".attn.merge"))
+    z = ops.linear(x, _w(P, name + ".mlp.0"), _b(P, name + ".mlp.0"), x2=msg)
+    z = ops.instnorm_relu(z, C, N)
+    return ops.linear(z, _w(P, name + ".mlp.3"), _b(P, name + ".mlp.3"))
+
+
+def conv_stack(ops, P, name, x, three, x2=None):
+    """models/dgcnn.py:16-38"""
+    h = _bn(ops, P, name + ".net.1", ops.linear(x, _w(P, name + ".net.0"), _b(P, name + ".net.0"), x2=x2), "relu")
+    if not three:
+        return ops.linear(h, _w(P, name + ".net.3"), _b(P, name + ".net.3"))
+    h = _bn(ops, P, name + ".net.4", ops.linear(h, _w(P, name + ".net.3"), _b(P, name + ".net.3")), "relu")
+    return ops.linear(h, _w(P, name + ".net.6"), _b(P, name + ".net.6"))
+
+
+def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):
+    """P: name -> tensor (parameters with requires_grad, buffers updated in place).  src, tgt [B,3,N];
+    fps_starts int [6,B] in the reference's draw order.  Returns (R [B,3,3], t [B,3], src_o [B,N], tgt_o [B,N], clu_loss [])."""
+    B, _, N = src.shape
+    C, k, H, M, J = 2 * B, cfg.gnn_k, cfg.num_heads, cfg.km_clusters, n_clusters
+    D = P["emd.conv5.weight"].shape[0]
+    xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()              # [C,N,3]
+    starts = fps_starts.reshape(3, 2 * B)                                         # [stage][src clouds | tgt clouds]
+    idx, idx5 = ops.knn(xyz, k), ops.knn(xyz, 5)
+    ids_a = ops.fps(xyz, M, starts)                                               # [3,C,M]
+    ids_j = ops.fps(xyz, J, None)                                                 # [C,J]
+    swap = torch.cat([torch.arange(B, C), torch.arange(0, B)]).to(xyz.device)
+
+    emb = dgcnn(ops, P, xyz, idx)
+    a0 = ops.gather_points(emb, C, N, ids_a[0])                                   # gmmreg.py:54-57
+    x0 = emb + pos_encoding(ops, P, xyz, idx5)                                    # gmmreg.py:58-61
+    ft = conv_stack(ops, P, "conv1", transformer(ops, P, "sattn1", x0, a0, C, N, M, H) + x0, True)
+    a1 = ops.gather_points(ft, C, N, ids_a[1], cloud_map=swap)                    # the OTHER cloud's anchors (gmmreg.py:67-72)
+    f = transformer(ops, P, "cattn", ft, a1, C, N, M, H) + ft
+
+    fn = ops.l2norm_rows(f)                                                       # gmmreg.py:74
+    ol = conv_stack(ops, P, "proj", f, False)                                     # [C*N, 1] overlap logits
+    wo = ops.overlap_cross(fn, ol, B, N)                                          # [C*N, 1]  (gmmreg.py:75-80)
+    fo = conv_stack(ops, P, "conv2", f, True, x2=torch.cat([wo, ol], dim=1))
+    o = torch.sigmoid(conv_stack(ops, P, "overlap", fo, True)).view(C, N)         # gmmreg.py:85-89
+
+    a2 = ops.gather_points(f, C, N, ids_a[2])
+    f2 = transformer(ops, P, "sattn2", f, a2, C, N, M, H) + f                     # gmmreg.py:92-97
+
+    gamma, pi, mu = ops.gmm_em(xyz, o.detach(), ids_j)                            # no gradient (lib/utils.py:275-288)
+    muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)                                  # [C,J,D], gradient to f2 only
+    R, t = ops.match_kabsch(mu[:B], mu[B:], muf[:B], muf[B:], 0.05)               # gmmreg.py:102-103
+    near = ops.nearest_point(xyz, mu)                                             # [C,J] (lib/utils.py:244-254)
+    anchors_f = ops.gather_points(f2, C, N, near).view(C, J, D)
+    clu = 0.5 * (losses.info_nce(anchors_f[:B], muf[:B], 0.1) + losses.info_nce(anchors_f[B:], muf[B:], 0.1))
+    if cap is not None:
+        cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, o=o, gamma=gamma, pi=pi, mu=mu,
+                   muf=muf, near=near)
+    return R, t, o[:B], o[B:], clu

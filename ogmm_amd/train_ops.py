@@ -1,0 +1,243 @@
+"""Operations of the training graph (ogmm_amd/train_graph.py), each differentiable where the reference is.
+
+`TrainOps` is the product implementation: discrete selections and the E/M loop run on the HIP kernels of
+libogmm_hip.so (no gradient flows through them in the reference either); dense layers run forward on the GEMM engine;
+normalisation, pooling, attention and the overlap block have hand-written forward AND backward kernels wrapped in
+`torch.autograd.Function`; backward GEMMs (dX = dY W, dW = dY^T X) are plain library GEMMs (torch.matmul -> hipBLASLt).
+CPU tensors are rejected by the kernels' wrappers: there is no CPU path here.  The plain-PyTorch statement of the same
+operations that the tests use as the numerical reference lives in tests/train_ref.py.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+_ACT = {"relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY02, "none": ops.ACT_NONE}
+
+
+class _NormAct(torch.autograd.Function):
+    """act((y - mean_g) * rstd_g * weight + bias) over row groups: kernels T1 of include/ogmm_hip.h.
+    Also returns the fp64 group means / biased variances for the running-statistics update."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, group_rows, act):
+        y = y.contiguous()
+        st = ops.colstats(y, group_rows)
+        mean64 = st[..., 0] / group_rows
+        var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
+        rstd64 = torch.rsqrt(var64 + BN_EPS)
+        scale64 = rstd64 if weight is None else rstd64 * weight.detach().double()
+        shift64 = -mean64 * scale64 if bias is None else bias.detach().double() - mean64 * scale64
+        scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
+        mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
+        h = ops.affine_act(y, group_rows, scale, shift, act)
+        ctx.save_for_backward(y, h, scale, mean, rstd)
+        ctx.group_rows, ctx.act, ctx.affine = group_rows, act, weight is not None
+        ctx.mark_non_differentiable(mean64, var64)
+        return h, mean64, var64
+
+    @staticmethod
+    def backward(ctx, dh, _dm, _dv):
+        y, h, scale, mean, rstd = ctx.saved_tensors
+        dy, sums = ops.norm_bwd(y, h, dh.contiguous(), ctx.group_rows, scale, mean, rstd, ctx.act)
+        if not ctx.affine:
+            return dy, None, None, None, None
+        return dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float(), None, None
+
+
+class _MaxPoolK(torch.autograd.Function):
+    """kernels T2 of include/ogmm_hip.h"""
+
+    @staticmethod
+    def forward(ctx, h, k):
+        out, arg = ops.maxpool_k(h.contiguous(), k)
+        ctx.save_for_backward(arg)
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        return ops.maxpool_k_bwd(dout.contiguous(), arg, ctx.k), None
+
+
+class _Linear(torch.autograd.Function):
+    """y = [x | x2] W^T + b.  Forward on the GEMM engine (fp16x3 split of the CURRENT weights, or exact fp32); backward
+    dX = dY W and dW = dY^T X are plain library GEMMs (hipBLASLt through torch.matmul), db a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, x2, W, b, precision, overflow):
+        K1 = x.shape[1]
+        K2 = 0 if x2 is None else x2.shape[1]
+        Wd = W.detach()
+        if K2 % 4:                                        # 16-byte rows for the second piece (conv2.net.0: 512 + 2 channels)
+            pad = 4 - K2 % 4
+            x2p = torch.cat([x2, x2.new_zeros(x2.shape[0], pad)], dim=1)
+            Wd = torch.cat([Wd, Wd.new_zeros(Wd.shape[0], pad)], dim=1)
+        else:
+            x2p = x2
+        layer = {"W": Wd.contiguous()}
+        if b is not None:
+            layer["shift"] = b.detach().contiguous()
+        if precision == "f16x3":
+            layer["split"] = ops.split_f16(layer["W"], frag=True, k1=K1)
+        y = ops.conv1x1(x.contiguous(), layer, ops.ACT_NONE, x2=None if x2p is None else x2p.contiguous(),
+                        split=precision == "f16x3", overflow=overflow)
+        ctx.save_for_backward(x, x2, W)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, W = ctx.saved_tensors
+        K1 = x.shape[1]
+        dx = dx2 = dW = db = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            dall = dy @ W
+            dx = dall[:, :K1]
+            dx2 = dall[:, K1:] if x2 is not None else None
+        if ctx.needs_input_grad[2]:
+            dyt = dy.t()
+            dW = dyt @ x if x2 is None else torch.cat([dyt @ x, dyt @ x2], dim=1)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = dy.sum(dim=0)
+        return dx, dx2, dW, db, None, None
+
+
+class TrainOps:
+    """precision: "f16x3" (dense forward layers on the split-binary16 matrix-core engine) or "f32" (exact-fp32 engine)."""
+
+    def __init__(self, precision="f16x3", overflow=None):
+        if precision not in ("f16x3", "f32"):
+            raise ValueError("precision must be 'f16x3' or 'f32'")
+        self.precision, self.overflow = precision, overflow
+
+    # ------------------------------------------------------------------ selections (no gradient)
+    def knn(self, xyz, k):
+        return ops.knn(xyz, k).long()
+
+    def fps(self, xyz, npoint, starts):
+        if starts is None:
+            return ops.fps(xyz, npoint, None).long()
+        return ops.fps(xyz, npoint, starts.to(device=xyz.device, dtype=torch.int32).contiguous()).long()
+
+    def gmm_em(self, xyz, o, ids_j):
+        return ops.gmm_em(xyz, o.contiguous(), ids_j.to(torch.int32).contiguous(), iters=10, sk_iters=10, epsilon=1e-2, tau=1.0)
+
+    def nearest_point(self, xyz, mu):
+        """index of the point nearest to each mu (lib/utils.py:244-254) -> [C,J] int64"""
+        return torch.cdist(mu, xyz).argmin(dim=2)
+
+    # ------------------------------------------------------------------ constants of the input
+    def edge_features(self, xyz, idx):
+        """lib/utils.py:47-66: [x_j - x_i ; x_i] per edge -> [C*N*k, 6]"""
+        C, N, k = idx.shape
+        nb = torch.gather(xyz, 1, idx.reshape(C, N * k, 1).expand(-1, -1, 3)).view(C, N, k, 3)
+        ctr = xyz[:, :, None, :].expand(-1, -1, k, -1)
+        return torch.cat([nb - ctr, ctr], dim=3).reshape(C * N * k, 6)
+
+    def pos_features(self, xyz, idx5):
+        """models/attn.py:60-70: squared distance to the cloud centroid [C*N,1]; cosine between each 5-NN offset and the
+        centroid offset [C*N*5,1] (the self neighbour gives a zero vector, hence cosine 0)."""
+        C, N, k = idx5.shape
+        g = xyz - xyz.mean(dim=1, keepdim=True)
+        d2 = (g * g).sum(dim=2).reshape(C * N, 1)
+        nb = torch.gather(xyz, 1, idx5.reshape(C, N * k, 1).expand(-1, -1, 3)).view(C, N, k, 3)
+        loc = F.normalize(nb - xyz[:, :, None, :], dim=3)
+        alpha = (loc * F.normalize(g, dim=2)[:, :, None, :]).sum(dim=3)
+        return d2, alpha.reshape(C * N * k, 1)
+
+    # ------------------------------------------------------------------ dense layers
+    def linear(self, x, W, b, x2=None):
+        """y = [x | x2] W^T + b.   x [R,K1], x2 [R,K2] or None, W [Cout, K1+K2].  Layers too thin for a matrix-core tile
+        (the 6->64 edge layer, the 1->64 positional layers, the Cout=1 heads) are HBM-bound outer products / row dots."""
+        K1, Cout = x.shape[1], W.shape[0]
+        if K1 < 32 or Cout < 32 or (K1 % 64 and x2 is not None):
+            xin = x if x2 is None else torch.cat([x, x2], dim=1)
+            y = xin @ W.t()
+            return y if b is None else y + b
+        return _Linear.apply(x, x2, W, b, self.precision, self.overflow)
+
+    def batchnorm_act(self, y, weight, bias, running_mean, running_var, num_batches, groups, act):
+        """Train-mode BatchNorm over each of the `groups` equal row blocks of y (one block per call of the reference's
+        shared layer), then ReLU or LeakyReLU(0.2).  Running statistics are updated in place, block 0 first."""
+        n = y.shape[0] // groups
+        h, mean64, var64 = _NormAct.apply(y, weight, bias, n, _ACT[act])
+        with torch.no_grad():
+            unbiased = var64 * (n / max(n - 1, 1))
+            for g in range(groups):
+                running_mean.mul_(1 - BN_MOMENTUM).add_(mean64[g].to(running_mean.dtype), alpha=BN_MOMENTUM)
+                running_var.mul_(1 - BN_MOMENTUM).add_(unbiased[g].to(running_var.dtype), alpha=BN_MOMENTUM)
+            num_batches += groups
+        return h
+
+    def instnorm_relu(self, z, C, N):
+        """InstanceNorm1d (no affine, biased variance, eps 1e-5) over the N points of each cloud, then ReLU"""
+        return _NormAct.apply(z, None, None, N, ops.ACT_RELU)[0]
+
+    def maxpool_k(self, h, k):
+        """max over the k consecutive rows of each point: [P*k, c] -> [P, c]"""
+        return _MaxPoolK.apply(h, k)
+
+    def gather_points(self, feats, C, N, ids, cloud_map=None):
+        """rows ids[c, s] of cloud map(c) -> [C*S, D]  (lib/utils.py:111-127)"""
+        S = ids.shape[1]
+        clouds = torch.arange(C, device=feats.device) if cloud_map is None else cloud_map
+        rows = (clouds[:, None] * N + ids[clouds]).reshape(C * S)
+        return feats.index_select(0, rows)
+
+    def attention(self, q, k, v, C, N, M, H):
+        """softmax(q k^T / sqrt(dh)) v per cloud and head; head-major channels.  q [C*N,D], k, v [C*M,D] -> [C*N,D]"""
+        D = q.shape[1]
+        dh = D // H
+        qh = q.view(C, N, H, dh).transpose(1, 2)
+        kh = k.view(C, M, H, dh).transpose(1, 2)
+        vh = v.view(C, M, H, dh).transpose(1, 2)
+        p = torch.softmax(qh @ kh.transpose(2, 3) / dh ** .5, dim=-1)
+        return (p @ vh).transpose(1, 2).reshape(C * N, D)
+
+    def l2norm_rows(self, f):
+        return F.normalize(f, dim=1)
+
+    def overlap_cross(self, fn, ol, B, N):
+        """models/gmmreg.py:75-80, literally: with S[b,m,n] = <fn_src[b,m], fn_tgt[b,n]>,
+        wo_src[b,m] = sum_n softmax_n(S[b,m,:])[n] * ol_src[b,n]   (the src logits indexed along the tgt axis) and
+        wo_tgt[b,n] = sum_m softmax_m(S[b,:,n])[m] * ol_tgt[b,m].   fn [2B*N, D], ol [2B*N, 1] -> [2B*N, 1]"""
+        fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
+        S = fs @ ft.transpose(1, 2)
+        os_, ot = ol[:B * N].view(B, N), ol[B * N:].view(B, N)
+        wo_s = (torch.softmax(S, dim=2) * os_[:, None, :]).sum(dim=2)
+        wo_t = (torch.softmax(S, dim=1) * ot[:, :, None]).sum(dim=1)
+        return torch.cat([wo_s.reshape(B * N, 1), wo_t.reshape(B * N, 1)], dim=0)
+
+    # ------------------------------------------------------------------ GMM head
+    def gmm_feat_mean(self, gamma, pi, f, C, N):
+        """lib/utils.py:130-140 on features: mu_f = gamma^T f / (pi N + 1e-5)  -> [C,J,D]"""
+        return gamma.transpose(1, 2) @ f.view(C, N, -1) / (pi * N + 1e-5)[:, :, None]
+
+    def match_kabsch(self, mu_s, mu_t, f_s, f_t, temperature):
+        """models/dgcnn.py:96-115 + lib/se3.py:256-289"""
+        sim = F.normalize(f_s, dim=-1) @ F.normalize(f_t, dim=-1).transpose(1, 2)
+        sc = torch.softmax(sim / temperature, dim=2)                    # [B,J,J]
+        corr = sc @ mu_t                                                # [B,J,3]
+        w = sc.sum(dim=2)                                               # == 1 up to rounding
+        return self.kabsch(mu_s, corr, w)
+
+    def kabsch(self, src, corr, w):
+        """weighted rigid fit src -> corr, points as rows: src, corr [B,J,3], w [B,J] -> R [B,3,3], t [B,3]"""
+        ws = w.sum(dim=1, keepdim=True)
+        c_s = (src * w[:, :, None]).sum(dim=1) / ws
+        c_c = (corr * w[:, :, None]).sum(dim=1) / ws
+        cov = ((src - c_s[:, None, :]) * w[:, :, None]).transpose(1, 2) @ (corr - c_c[:, None, :])
+        cov = torch.nan_to_num(cov, nan=0.0) + 1e-5 * torch.eye(3, dtype=cov.dtype, device=cov.device)
+        U, _, Vh = torch.linalg.svd(cov)
+        V = Vh.transpose(1, 2)
+        flip = torch.det(V @ U.transpose(1, 2)) <= 0
+        V = torch.where(flip[:, None, None] & (torch.arange(3, device=V.device) == 2)[None, None, :], -V, V)
+        R = V @ U.transpose(1, 2)
+        t = c_c - (R @ c_s[:, :, None])[:, :, 0]
+        return R, t

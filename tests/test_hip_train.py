@@ -1,0 +1,123 @@
+"""Training mode on the GPU: every HIP-backed training operation against its plain-PyTorch statement (tests/train_ref.py),
+and the whole training step (loss parts, outputs, gradients of all parameters, BatchNorm running statistics) against the
+fixtures of the reference's own training step."""
+import numpy as np
+import pytest
+import torch
+
+from ogmm_amd import losses, metric, synth
+from ogmm_amd.gmmreg import GMMReg
+from ogmm_amd.train_ops import TrainOps
+from train_ref import RefTrainOps
+from train_util import TRAIN_CASES, check_grads, load_train_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("rows,cols,groups,act,affine", [(2 * 1500, 64, 2, "relu", True), (2 * 777, 256, 2, "leaky", True),
+                                                         (4 * 320, 1024, 4, "relu", False), (2 * 40960, 128, 2, "relu", True)])
+def test_norm_act_forward_backward(rows, cols, groups, act, affine):
+    g = torch.Generator().manual_seed(rows + cols)
+    y = (torch.randn(rows, cols, generator=g) * 2 + 0.5).to(DEV).requires_grad_(True)
+    w = (torch.rand(cols, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    b = (torch.rand(cols, generator=g) - 0.5).to(DEV).requires_grad_(True)
+    dh = torch.randn(rows, cols, generator=g).to(DEV)
+    hip, ref = TrainOps(), RefTrainOps()
+    out = {}
+    for tag, o in (("hip", hip), ("ref", ref)):
+        rm, rv, nb = torch.zeros(cols, device=DEV), torch.ones(cols, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+        for t_ in (y, w, b):
+            t_.grad = None
+        if affine:
+            h = o.batchnorm_act(y, w, b, rm, rv, nb, groups, act)
+        else:
+            h = o.instnorm_relu(y, groups, rows // groups)
+        h.backward(dh)
+        out[tag] = (h.detach(), y.grad.clone(), w.grad.clone() if affine else None, b.grad.clone() if affine else None, rm, rv, nb)
+    assert _rel(out["hip"][0], out["ref"][0]) < 2e-6
+    assert _rel(out["hip"][1], out["ref"][1]) < 2e-5
+    if affine:
+        assert _rel(out["hip"][2], out["ref"][2]) < 2e-5 and _rel(out["hip"][3], out["ref"][3]) < 2e-5
+        assert _rel(out["hip"][4], out["ref"][4]) < 1e-5 and _rel(out["hip"][5], out["ref"][5]) < 1e-5
+        assert int(out["hip"][6]) == int(out["ref"][6]) == groups
+
+
+@pytest.mark.parametrize("points,k,cols", [(1000, 20, 64), (333, 5, 64), (4096, 12, 256)])
+def test_maxpool_k(points, k, cols):
+    g = torch.Generator().manual_seed(points)
+    h = torch.relu(torch.randn(points * k, cols, generator=g)).to(DEV).requires_grad_(True)     # many exact ties at 0
+    d = torch.randn(points, cols, generator=g).to(DEV)
+    a = TrainOps().maxpool_k(h, k)
+    a.backward(d)
+    ga = h.grad.clone()
+    h.grad = None
+    r = RefTrainOps().maxpool_k(h, k)
+    r.backward(d)
+    assert torch.equal(a, r)
+    live = (r > 0)[:, None, :].expand(-1, k, -1).reshape(points * k, cols)      # gradients routed to a zero are killed by the ReLU in the model
+    assert torch.equal(ga[live], h.grad[live])
+    assert float(ga.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("rows,k1,k2,cout,bias", [(3000, 512, 0, 1024, True), (2048, 512, 512, 1024, True), (1111, 512, 2, 1024, True),
+                                                   (5000, 64, 0, 128, False), (700, 1024, 0, 512, True)])
+def test_linear_forward_backward(precision, rows, k1, k2, cout, bias):
+    g = torch.Generator().manual_seed(rows + k1)
+    x = torch.randn(rows, k1, generator=g).to(DEV).requires_grad_(True)
+    x2 = torch.randn(rows, k2, generator=g).to(DEV).requires_grad_(True) if k2 else None
+    W = (torch.randn(cout, k1 + k2, generator=g) / (k1 + k2) ** .5).to(DEV).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(DEV).requires_grad_(True) if bias else None
+    dy = torch.randn(rows, cout, generator=g).to(DEV)
+    res = {}
+    for tag, o in (("hip", TrainOps(precision)), ("ref", RefTrainOps())):
+        for t_ in (x, x2, W, b):
+            if t_ is not None:
+                t_.grad = None
+        y = o.linear(x.double() if tag == "ref" else x, W.double() if tag == "ref" else W,
+                     None if b is None else (b.double() if tag == "ref" else b),
+                     x2=None if x2 is None else (x2.double() if tag == "ref" else x2))
+        y.backward(dy.double() if tag == "ref" else dy)
+        res[tag] = [y.detach()] + [t_.grad.clone() for t_ in (x, x2, W, b) if t_ is not None]
+    tol = 3e-6 if precision == "f16x3" else 2e-6
+    for a, r in zip(res["hip"], res["ref"]):
+        assert _rel(a, r) < tol * 3, (_rel(a, r))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_training_step_matches_reference(name, precision):
+    fx, cfg, (B, N, J, D, top_k) = load_train_case(name)
+    cfg.precision = precision
+    model = GMMReg(D, J, cfg)
+    synth.fill_state_dict(model.state_dict())
+    model = model.to(DEV).train()
+    src, tgt = torch.from_numpy(fx["src"]).to(DEV), torch.from_numpy(fx["tgt"]).to(DEV)
+    out = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]))
+    loss, parts = losses.training_loss(out, src, tgt, torch.from_numpy(fx["T_gt"]).to(DEV), torch.from_numpy(fx["src_overlap"]).to(DEV),
+                                       torch.from_numpy(fx["tgt_overlap"]).to(DEV), 10.0, top_k)
+    loss.backward()
+    rep = {kpart: abs(parts[kpart].item() - float(fx["loss_" + kpart])) for kpart in parts}
+    rep["R"] = metric.rotation_error_rad(out[0].detach().cpu(), torch.from_numpy(fx["R"])).max().item()
+    rep["t"] = metric.translation_error(out[1].detach().cpu(), torch.from_numpy(fx["t"])).max().item()
+    rep["o"] = max(np.abs(out[2].detach().cpu().numpy() - fx["src_o"]).max(), np.abs(out[3].detach().cpu().numpy() - fx["tgt_o"]).max())
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    errs = {}
+    worst = check_grads(fx, grads, report=errs)
+    print("TRAIN-PARITY %s %s loss=%.8f (ref %.8f) %s worst_grad_err_over_allowed=%.2f" % (
+        precision, name, loss.item(), float(fx["loss"]), " ".join("%s=%.2e" % kv for kv in rep.items()), worst))
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    for kpart in parts:
+        # the Welsch term sums 2 - exp(-a) - exp(-b) with a, b ~ 1e-6: every summand carries the 6e-8 rounding of "1 - tiny",
+        # so the fp32 value itself is only defined to ~1e-5 (it enters the loss with weight 0.01)
+        assert rep[kpart] <= (1e-4 if kpart == "welsch" else 1e-5) * max(1.0, abs(float(fx["loss_" + kpart]))), kpart
+    assert rep["R"] < 1e-5 and rep["t"] < 1e-5 and rep["o"] < 1e-5
+    sd = model.state_dict()
+    for key in (f[len("stat/"):] for f in fx.files if f.startswith("stat/")):
+        np.testing.assert_allclose(sd[key].cpu().numpy(), fx["stat/" + key], rtol=1e-5, atol=1e-6, err_msg=key)
+    assert not model.fp16_overflowed()

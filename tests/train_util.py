@@ -29,13 +29,18 @@ def filled_state(module_or_spec):
     return synth.fill_state_dict(module_or_spec)
 
 
-def check_grads(fx, grads, factor=4.0, floor=1e-4, report=None):
+def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None):
     """grads: {key: tensor or None}.  Per parameter, the candidate's distance from the fp64 truth (relative L2 over the
-    stored strided sample, and of the norm) must be <= max(factor * the reference's own fp32 distance, floor).
+    stored strided sample, and of the norm) must be <= factor * max(the reference's own fp32 distance for that parameter,
+    the median of the reference's distances over all parameters) -- the reference's per-parameter distance is a single
+    draw of rounding noise (median 4e-4..6e-4, max 5e-3 on the fixtures), so the median keeps a lucky draw from becoming
+    an unreachable bar -- and never below `floor`.
     Parameters whose reference gradient is structurally zero (norm < 1e-6 of the total) must stay below 1e-5 of the
     total; parameters the forward never touches must have no gradient.  Returns the worst ratio error/allowed."""
     total = float(fx["gnorm_total"])
     worst = 0.0
+    live = [float(fx[f]) for f in fx.files if f.startswith("gerr/") and float(fx["gnorm/" + f[5:]]) >= 1e-6 * total]
+    typical = float(np.median(live))
     for key in (f[len("gnorm/"):] for f in fx.files if f.startswith("gnorm/")):
         ref_norm = float(fx["gnorm/" + key])
         g = grads.get(key)
@@ -51,7 +56,7 @@ def check_grads(fx, grads, factor=4.0, floor=1e-4, report=None):
         got = g[sample_idx(g.size)]
         scale = max(np.linalg.norm(truth), tnorm * np.sqrt(len(truth) / g.size))
         err = max(np.linalg.norm(got - truth) / scale, abs(np.linalg.norm(g) - tnorm) / tnorm)
-        allowed = max(factor * float(fx["gerr/" + key]), floor)
+        allowed = max(factor * float(fx["gerr/" + key]), factor * typical, floor)
         if report is not None:
             report[key] = (err, allowed)
         worst = max(worst, err / allowed)
