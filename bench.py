@@ -47,9 +47,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3")
-    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3"], default="cfg1",
-                    help="cfg1 = BASELINE configs[1] (headline); cfg2 = configs[2] shape (N=2048, J=64, B=256); cfg3 = configs[3] shape per GPU (room clouds, N=2048, J=64, B=64)")
+    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "train"], default="cfg1",
+                    help="cfg1 = BASELINE configs[1] (headline); cfg2 = configs[2] shape (N=2048, J=64, B=256); cfg3 = configs[3] shape per GPU "
+                         "(room clouds, N=2048, J=64, B=64); train = configs[4]: full training step, N=1024, J=16, 128 pairs per GPU (global 1024 on 8)")
+    ap.add_argument("--train-batch", type=int, default=128, help="pairs per GPU and step for --workload train")
     args = ap.parse_args()
+    if args.workload == "train":
+        return train_main(args)
 
     from ogmm_amd import dist as odist
     global B_PER_GPU, N_POINTS, J, GFLOP_PER_PAIR
@@ -144,6 +148,80 @@ def main():
                             "overlap_err_max": max((got[2].cpu() - ref[2]).abs().max().item(), (got[3].cpu() - ref[3]).abs().max().item()),
                             "pairs_checked": n, "against": "CPU oracle (bit-identical to the reference on its golden fixtures)"}
     result["fp16_split_overflowed"] = bool(model.fp16_overflowed())      # |activation| > 65504 clamped anywhere in the run?
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def train_main(args):
+    """BASELINE configs[4]: one step = forward (train-mode BatchNorm) + the loss of train.py:54-72 + backward + one flat
+    gradient all-reduce (RCCL; skipped at N=1) + Adam + BatchNorm-buffer broadcast, on 128 synthetic pairs per GPU."""
+    from ogmm_amd import dist as odist, ops, synth
+    from ogmm_amd.gmmreg import GMMReg
+    from ogmm_amd.trainer import Trainer
+    B, N, J_ = args.train_batch, 1024, 16
+    CFG.n_clusters = J_
+    rank, local_rank, world = odist.env_rank_world()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = odist.init("nccl", rank, world, dev)
+    model = GMMReg(512, J_, CFG)
+    synth.fill_state_dict(model.state_dict())
+    params_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    model.precision = args.precision
+    first, _ = odist.shard_pairs(rank, world, B)
+    batch = [t.to(dev) for t in synth.make_train_batch(first, B, N, "partial")]
+    starts = synth.fps_starts_for(first, B, N)
+    trainer = Trainer(model, dist=dist, world=world)
+    for _ in range(args.warmup):
+        info = trainer.step(*batch, fps_starts=starts)
+    odist.barrier(dist)
+    ops.GEMM_TIMELINE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = trainer.step(*batch, fps_starts=starts)
+    odist.barrier(dist)
+    elapsed = time.perf_counter() - t0
+    timeline, ops.GEMM_TIMELINE = ops.GEMM_TIMELINE, None
+    elapsed = odist.max_over_ranks(dist, elapsed, dev)
+    value = B * world * args.steps / elapsed
+    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v in timeline if v == args.precision]
+    gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
+    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.precision]
+    result = {
+        "metric": "train_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "engine": args.precision,
+        "config": {"workload": "BASELINE configs[4]: end-to-end training step (forward in train mode, loss of train.py, backward, gradient "
+                               "all-reduce, Adam), ModelNet40-shaped partial-overlap pairs, N=1024, J=16, %d pairs per GPU" % B,
+                   "pairs_per_gpu_step": B, "n_points": N, "n_clusters": J_,
+                   "parallelism": "data parallel x%d: per-rank BatchNorm statistics, one 52 MB gradient all-reduce per step" % world},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "kernel": "forward GEMM engine launches of the training step (backward GEMMs are library calls)", "launches": len(dom),
+                     "kernel_share_of_step": gemm_ms / (1e3 * elapsed)},
+        "final_loss": float(info["loss"]), "loss_parts": {k: float(v) for k, v in info["parts"].items()},
+    }
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import ogmm_oracle as O
+        n = min(args.cpu_sample, 2)
+        P = {k: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in params_cpu.items()}
+        cb = [t[:n].cpu() for t in batch]
+        times = []
+        for _ in range(2):
+            for v in P.values():
+                v.grad = None
+            c0 = time.perf_counter()
+            out = O.forward(P, CFG, cb[0], cb[1], starts[:, :n], train=True)
+            O.training_loss(out, cb[0], cb[1], cb[2], cb[3], cb[4], 10.0, 512).backward()
+            times.append(time.perf_counter() - c0)
+        result["cpu_baseline"] = {"value": n / times[-1], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": "forward+loss+backward of the CPU oracle on the first %d pairs (no optimizer step), second of two runs" % n}
+    result["fp16_split_overflowed"] = bool(model.fp16_overflowed())
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -213,6 +213,7 @@ class GMMReg(nn.Module):
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self._overflow = None
         self._side = None
+        self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved
     def _layers(self):
@@ -271,7 +272,9 @@ class GMMReg(nn.Module):
         """models/gmmreg.py:50-119.  `fps_starts` (int64/int32 [6,B], optional) pins the six `torch.randint` draws of
         lib/utils.py:190; when None they are drawn from torch's global CPU generator in the reference's call order,
         so the same `torch.manual_seed` gives the same anchors as the reference."""
-        if not (isinstance(src, torch.Tensor) and src.is_cuda and tgt.is_cuda):
+        if not (isinstance(src, torch.Tensor) and isinstance(tgt, torch.Tensor)):
+            raise OgmmError("src and tgt must be tensors")
+        if not (src.is_cuda and tgt.is_cuda) and not (self.training and self._train_ops is not None):
             raise OgmmError("GMMReg.forward needs CUDA/ROCm tensors: the MI355X path has no CPU fallback")
         if is_test:
             raise NotImplementedError("is_test=True needs the open3d ICP refinement (models/gmmreg.py:115-117): out of scope")
@@ -285,7 +288,7 @@ class GMMReg(nn.Module):
         dev = src.device
         if self.precision not in ("f16x3", "f32"):
             raise OgmmError("precision must be 'f16x3' or 'f32'")
-        if self._overflow is None or self._overflow.device != dev:
+        if dev.type == "cuda" and (self._overflow is None or self._overflow.device != dev):
             self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         if self.emd.conv1.weight.device != dev:
             raise OgmmError("GMMReg parameters live on %s but the inputs on %s: call model.to(device) first" % (self.emd.conv1.weight.device, dev))
@@ -404,8 +407,8 @@ class GMMReg(nn.Module):
         P = dict(self.named_parameters())
         P.update(dict(self.named_buffers()))
         cap = {} if capture else None
-        out = train_graph.forward_train(train_ops.TrainOps(self.precision, self._overflow), P, self.config, self.n_clusters,
-                                        src, tgt, fps_starts.to(src.device), cap)
+        backend = self._train_ops if self._train_ops is not None else train_ops.TrainOps(self.precision, self._overflow)
+        out = train_graph.forward_train(backend, P, self.config, self.n_clusters, src, tgt, fps_starts.to(src.device), cap)
         if capture:
             self.last_intermediates = cap
         return out
