@@ -231,6 +231,18 @@ int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* y, int64_t ldy
 int ogmm_maxpool_k(const float* h, int64_t ldh, int64_t points, int k, int cols, float* out, int64_t ldo, uint8_t* arg /*[points][cols]*/, void* stream);
 int ogmm_maxpool_k_bwd(const float* dout, int64_t ldo, const uint8_t* arg, int64_t points, int k, int cols, float* dh, int64_t ldh, void* stream);
 
+/* ---- T3: operands of the weight-gradient GEMM dW[n][k] = sum_r dY[r][n] X[r][k] (derivative of y = x W^T w.r.t. W) for
+ * ogmm_gemm_nt, which contracts over the last axis of both operands.  The contraction is cut into S chunks of `chunk` rows
+ * (chunk %% 64 == 0, r zero-padded to S*chunk) that run as the batch dimension of ogmm_gemm_nt (split-K); every chunk's
+ * operand is stored compactly with row pitch `pitch` = chunk + 64 (a non power of two: HBM channel spread):
+ *   ogmm_transpose_pad: out[s][c][rr] = x[s*chunk + rr][c]                       (A = dY^T, fp32; sA_o = cols*pitch floats, lda = pitch)
+ *   ogmm_pack_frag_t:   per chunk the OGMM_PREC_F16X3_FRAG image of X^T, [n_pad/32][pitch/16][64 lanes][8 halfs], hi and lo
+ *                       planes (ldb_h = pitch, sB_o = n_pad*pitch halfs); *overflow |= 1 if a finite |x| > 65504 was clamped.
+ * The S partial products (sC_o = n*k) are summed afterwards. */
+int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out, void* stream);
+int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
+                     int* overflow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+// Operand preparation for the weight-gradient GEMM of the training step:  dW[n][k] = sum_r dY[r][n] * X[r][k]
+// (the derivative of y = x W^T in every dense layer of models/dgcnn.py, models/attn.py, models/gmmreg.py).
+//
+// The GEMM engine contracts over the LAST axis of both operands (C = A B^T), so the contraction over the row axis r is
+// fed as A = dY^T (fp32, [n][r]) and B = X^T in the engine's pre-split fragment-major binary16 image ([k/32][r/16][64][8]).
+// Both kernels are single-pass HBM-bound relayouts.  The contraction is cut into S chunks of `chunk` rows (split-K over the
+// batch dimension of ogmm_gemm_nt; r is zero-padded to S*chunk) and each chunk's operand is stored compactly, chunk-major,
+// with a row pitch of chunk + 64 elements: rows of one long [n][r_pad] matrix would sit a power of two apart (512 KB at
+// r_pad = 131072), which puts every row of a tile on the same HBM channel.
+#include "ogmm_common.h"
+#include <algorithm>
+
+namespace {
+
+using namespace ogmm;
+using f16x8t = __attribute__((ext_vector_type(8))) _Float16;
+
+// out[s][c][rr] = x[s*chunk + rr][c] (0 beyond `rows`), row pitch `pitch`.  64x64 tiles through LDS, both sides 256-byte lines.
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols, int64_t r_pad,
+                                                            int64_t chunk, int64_t pitch, float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i;
+        tile[i][tx] = (r < rows && c0 + tx < cols) ? x[r * ldx + c0 + tx] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i;
+        const int64_t r = r0 + tx;
+        if (c < cols && r < r_pad) {
+            const int64_t sb = r / chunk;
+            out[(sb * cols + c) * pitch + (r - sb * chunk)] = tile[tx][i];
+        }
+    }
+}
+
+// Fragment-major split images of X^T, one per chunk s: entry (((s * n_pad/32 + nb) * (pitch/16) + kb) * 64 + lane) holds the 8
+// binary16 values X[s*chunk + kb*16 + (lane>>5)*8 + j][nb*32 + (lane&31)], j = 0..7 (hi and lo planes); zero outside the
+// matrix and in the pitch padding (kb*16 >= chunk).
+__global__ __launch_bounds__(256) void pack_frag_t_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols, int64_t chunk,
+                                                          int64_t pitch, int S, int n_pad, f16x8t* __restrict__ hi, f16x8t* __restrict__ lo,
+                                                          int* __restrict__ overflow) {
+    const int64_t kblocks = pitch / 16;
+    const int64_t total = (int64_t)S * (n_pad / 32) * kblocks * 64;
+    bool clipped = false;
+    for (int64_t gI = (int64_t)blockIdx.x * 256 + threadIdx.x; gI < total; gI += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(gI & 63);
+        const int64_t blk = gI >> 6;
+        const int64_t kb = blk % kblocks;
+        const int64_t snb = blk / kblocks;
+        const int nb = (int)(snb % (n_pad / 32));
+        const int64_t sb = snb / (n_pad / 32);
+        const int n = nb * 32 + (lane & 31);
+        const int64_t k0 = sb * chunk + kb * 16 + (lane >> 5) * 8;
+        f16x8t h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n < cols && kb * 16 < chunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t r = k0 + j;
+                float v = r < rows ? x[r * ldx + n] : 0.0f;
+                const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+                clipped |= c != v && v == v;
+                const _Float16 hh = (_Float16)c;
+                h[j] = hh;
+                l[j] = (_Float16)(c - (float)hh);
+            }
+        }
+        hi[gI] = h;
+        lo[gI] = l;
+    }
+    if (clipped && overflow) atomicOr(overflow, 1);
+}
+
+}  // namespace
+
+extern "C" int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out, void* stream) {
+    OGMM_REQUIRE(x && out && rows > 0 && cols > 0 && chunk > 0 && S > 0 && (int64_t)S * chunk >= rows && pitch >= chunk, "ogmm_transpose_pad: bad shape");
+    const int64_t r_pad = (int64_t)S * chunk;
+    dim3 grid((unsigned)((r_pad + 63) / 64), (cols + 63) / 64);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, as_stream(stream), x, ldx, rows, cols, r_pad, chunk, pitch, out);
+    return check_launch("ogmm_transpose_pad");
+}
+
+extern "C" int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
+                                int* overflow, void* stream) {
+    OGMM_REQUIRE(x && hi && lo && rows > 0 && cols > 0 && S > 0 && (int64_t)S * chunk >= rows && chunk % 16 == 0 && pitch % 16 == 0 && pitch >= chunk &&
+                 n_pad >= cols && n_pad % 32 == 0 && aligned16(hi) && aligned16(lo),
+                 "ogmm_pack_frag_t: chunk, pitch %% 16 == 0, n_pad %% 32 == 0, 16-byte aligned images required");
+    const int64_t total = (int64_t)S * (n_pad / 32) * (pitch / 16) * 64;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(pack_frag_t_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, chunk, pitch, S, n_pad,
+                       reinterpret_cast<f16x8t*>(hi), reinterpret_cast<f16x8t*>(lo), overflow);
+    return check_launch("ogmm_pack_frag_t");
+}

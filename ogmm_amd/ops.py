@@ -442,3 +442,31 @@ def maxpool_k_bwd(dout, arg, k):
     dh = torch.empty((P * k, cols), dtype=torch.float32, device=dout.device)
     _lib.call("ogmm_maxpool_k_bwd", _p(_f32(dout, "dout")), dout.stride(0), _p(arg), P, k, cols, _p(dh), dh.stride(0), _stream())
     return dh
+
+
+def weight_grad(dy, xs, overflow=None):
+    """dW = dY^T [x_0 | x_1 | ...] on the fp16x3 engine: dy [R, n], xs = list of [R, k_i] (last stride 1) -> [n, sum k_i].
+    dY^T is materialised once (fp32, chunk-major), every x_i becomes per-chunk split fragment images of x_i^T, the contraction
+    over r runs as split-K batches of the engine and the partial products are summed (kernels T3 of include/ogmm_hip.h)."""
+    R, n = dy.shape
+    assert dy.stride(1) == 1
+    tiles_mn = ((n + 255) // 256) * max((max(x.shape[1] for x in xs) + 255) // 256, 1)
+    S = max(1, min((384 + tiles_mn - 1) // tiles_mn, (R + 255) // 256))
+    chunk = ((R + S - 1) // S + 63) // 64 * 64
+    S = (R + chunk - 1) // chunk
+    pitch = chunk + 64
+    dyt = torch.empty((S, n, pitch), dtype=torch.float32, device=dy.device)
+    _lib.call("ogmm_transpose_pad", _p(_f32(dy, "dy")), dy.stride(0), R, n, chunk, pitch, S, _p(dyt), _stream())
+    outs = []
+    for x in xs:
+        assert x.stride(1) == 1 and x.shape[0] == R
+        k = x.shape[1]
+        n_pad = (k + 255) // 256 * 256
+        hi = torch.empty(S * n_pad * pitch, dtype=torch.float16, device=dy.device)
+        lo = torch.empty_like(hi)
+        _lib.call("ogmm_pack_frag_t", _p(_f32(x, "x")), x.stride(0), R, k, chunk, pitch, S, n_pad, _p(hi), _p(lo), _p(overflow), _stream())
+        part = torch.empty((S, n, k), dtype=torch.float32, device=dy.device)
+        split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
+        gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow)
+        outs.append(part.sum(dim=0) if S > 1 else part[0])
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)

@@ -66,8 +66,10 @@ class _MaxPoolK(torch.autograd.Function):
 
 
 class _Linear(torch.autograd.Function):
-    """y = [x | x2] W^T + b.  Forward on the GEMM engine (fp16x3 split of the CURRENT weights, or exact fp32); backward
-    dX = dY W and dW = dY^T X are plain library GEMMs (hipBLASLt through torch.matmul), db a column sum."""
+    """y = [x | x2] W^T + b.  Forward and dX = dY W on the GEMM engine (fp16x3 split of the CURRENT weights, or exact fp32
+    forward + library dX with precision "f32"); dW = dY^T X runs on the engine as a split-K GEMM over transposed operands
+    (kernels T3) for the wide layers and as a plain library GEMM (hipBLASLt through torch.matmul) for the thin ones; db is a
+    column sum."""
 
     @staticmethod
     def forward(ctx, x, x2, W, b, precision, overflow):
@@ -88,7 +90,7 @@ class _Linear(torch.autograd.Function):
         y = ops.conv1x1(x.contiguous(), layer, ops.ACT_NONE, x2=None if x2p is None else x2p.contiguous(),
                         split=precision == "f16x3", overflow=overflow)
         ctx.save_for_backward(x, x2, W)
-        ctx.has_bias = b is not None
+        ctx.has_bias, ctx.precision, ctx.overflow = b is not None, precision, overflow
         return y
 
     @staticmethod
@@ -97,12 +99,27 @@ class _Linear(torch.autograd.Function):
         K1 = x.shape[1]
         dx = dx2 = dW = db = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
-            dall = dy @ W
+            if ctx.precision == "f16x3":
+                # dX = dY W on the engine: the weight operand is W^T [K, Cout], split per step.  Activation gradients sit far
+                # below binary16's normal range (max 1e-6 .. 0.2 per layer at loss scale 1); the trainer's power-of-two loss
+                # scale (exact in fp32) lifts them into it, the overflow flag reports a scale that is too large.
+                Wt = W.detach().t().contiguous()
+                if Wt.shape[0] % 4:
+                    Wt = torch.cat([Wt, Wt.new_zeros(4 - Wt.shape[0] % 4, Wt.shape[1])], dim=0)
+                layer = {"W": Wt, "split": ops.split_f16(Wt, frag=True)}
+                dall = ops.conv1x1(dy.contiguous(), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
+            else:
+                dall = dy @ W
             dx = dall[:, :K1]
-            dx2 = dall[:, K1:] if x2 is not None else None
+            dx2 = dall[:, K1:K1 + x2.shape[1]] if x2 is not None else None
         if ctx.needs_input_grad[2]:
-            dyt = dy.t()
-            dW = dyt @ x if x2 is None else torch.cat([dyt @ x, dyt @ x2], dim=1)
+            if ctx.precision == "f16x3" and W.shape[0] >= 1024 and K1 >= 256 and (x2 is None or x2.shape[1] >= 256):
+                # kernels T3.  Measured at R = 131072 (tools/dw_bench.py, ms engine incl. relayouts vs library): 1024x1024 1.59 vs
+                # 2.74, 1024x512 0.98 vs 1.07, 512x1024 1.34 vs 1.07, 512x512 0.80 vs 0.70 -> the engine takes the 1024-wide layers
+                dW = ops.weight_grad(dy.contiguous(), [x] if x2 is None else [x, x2], ctx.overflow)
+            else:       # narrower layers and the HBM-bound per-edge maps: library GEMM
+                dyt = dy.t()
+                dW = dyt @ x if x2 is None else torch.cat([dyt @ x, dyt @ x2], dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = dy.sum(dim=0)
         return dx, dx2, dW, db, None, None

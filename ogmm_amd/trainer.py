@@ -61,11 +61,27 @@ def broadcast_buffers(model, dist, world, src=0):
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, weight_decay=1e-4, welsch_alpha=10.0, welsch_top_k=512, dist=None, world=1):
-        """lr / alpha / top_k defaults: configs/cfgs.py:55,41,44; weight decay: train.py:199"""
+    def __init__(self, model, lr=1e-4, weight_decay=1e-4, welsch_alpha=10.0, welsch_top_k=512, dist=None, world=1, loss_scale=None):
+        """lr / alpha / top_k defaults: configs/cfgs.py:55,41,44; weight decay: train.py:199.
+        loss_scale: power of two the loss is multiplied by before backward (gradients are divided by it again before the
+        optimizer; both exact in fp32).  It exists for the fp16x3 engine's backward GEMMs, whose operands are split into
+        binary16 terms: unscaled activation gradients (1e-6 .. 0.2) would fall into binary16's subnormal range.  Default
+        2^16 with precision "f16x3", 1 with "f32".  If a scaled gradient exceeds 65504 the engine raises its overflow flag:
+        the step is skipped and the scale halved."""
         self.model, self.dist, self.world = model, dist, world
         self.alpha, self.top_k = welsch_alpha, welsch_top_k
         self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        if loss_scale is None:
+            loss_scale = 65536.0 if getattr(model, "precision", "f32") == "f16x3" else 1.0
+        self.loss_scale = float(loss_scale)
+        self.skipped_steps = 0
+
+    def _any_rank(self, flag):
+        if self.dist is None or self.world <= 1:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=next(self.model.parameters()).device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
 
     def local_loss(self, out, src, tgt, transform_gt, src_overlap, tgt_overlap):
         loss, parts = losses.training_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap, self.alpha, self.top_k)
@@ -79,12 +95,23 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         out = self.model(src, tgt, fps_starts=fps_starts)
         loss, parts = self.local_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap)
-        loss.backward()
-        allreduce_gradients(self.model, self.dist, self.world)
-        self.optimizer.step()
+        (loss * self.loss_scale).backward()
+        overflowed = self.loss_scale != 1.0 and self._any_rank(self.model.fp16_overflowed())
+        if overflowed:
+            self.skipped_steps += 1
+            self.loss_scale *= 0.5
+            self.optimizer.zero_grad(set_to_none=True)
+        else:
+            allreduce_gradients(self.model, self.dist, self.world)
+            if self.loss_scale != 1.0:
+                inv = 1.0 / self.loss_scale
+                for p in self.model.parameters():
+                    if p.grad is not None:
+                        p.grad.mul_(inv)
+            self.optimizer.step()
         broadcast_buffers(self.model, self.dist, self.world)
         with torch.no_grad():
             B = src.shape[0]
             r_err = metric.rotation_error(out[0], transform_gt[:, :3, :3]).mean()
             t_err = metric.translation_error(out[1], transform_gt[:, :3, 3].reshape(B, 3)).mean()
-        return {"loss": loss.detach(), "parts": {k: v.detach() for k, v in parts.items()}, "r_err_deg": r_err, "t_err": t_err, "out": out}
+        return {"loss": loss.detach(), "skipped": overflowed, "parts": {k: v.detach() for k, v in parts.items()}, "r_err_deg": r_err, "t_err": t_err, "out": out}

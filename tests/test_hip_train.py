@@ -101,12 +101,13 @@ def test_training_step_matches_reference(name, precision):
     out = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]))
     loss, parts = losses.training_loss(out, src, tgt, torch.from_numpy(fx["T_gt"]).to(DEV), torch.from_numpy(fx["src_overlap"]).to(DEV),
                                        torch.from_numpy(fx["tgt_overlap"]).to(DEV), 10.0, top_k)
-    loss.backward()
+    scale = 65536.0 if precision == "f16x3" else 1.0          # the trainer's default loss scale (exact power of two)
+    (loss * scale).backward()
     rep = {kpart: abs(parts[kpart].item() - float(fx["loss_" + kpart])) for kpart in parts}
     rep["R"] = metric.rotation_error_rad(out[0].detach().cpu(), torch.from_numpy(fx["R"])).max().item()
     rep["t"] = metric.translation_error(out[1].detach().cpu(), torch.from_numpy(fx["t"])).max().item()
     rep["o"] = max(np.abs(out[2].detach().cpu().numpy() - fx["src_o"]).max(), np.abs(out[3].detach().cpu().numpy() - fx["tgt_o"]).max())
-    grads = {k: p.grad for k, p in model.named_parameters()}
+    grads = {k: (p.grad / scale if p.grad is not None else None) for k, p in model.named_parameters()}
     errs = {}
     worst = check_grads(fx, grads, report=errs)
     print("TRAIN-PARITY %s %s loss=%.8f (ref %.8f) %s worst_grad_err_over_allowed=%.2f" % (
