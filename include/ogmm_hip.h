@@ -243,6 +243,25 @@ int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int6
 int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
                      int* overflow, void* stream);
 
+/* ---- T4: backward of K18 (lib/se3.py:256-289): gradients w.r.t. src, corr [B][3][J] and w [B][J] given dL/dR [B][3][3] and
+ * dL/dt [B][3] (either may be NULL = zero).  One lane per pair in fp64; the derivative of V D U^T through the 3x3 SVD in
+ * closed form (no 1/(s_i^2 - s_j^2) blow-up for equal singular values).  Any of g_src / g_corr / g_w may be NULL. */
+int ogmm_kabsch_bwd(const float* src, const float* corr, const float* w, int B, int J, const float* gR, const float* gt,
+                    float* g_src, float* g_corr, float* g_w, void* stream);
+
+/* ---- T5: index of the point nearest to each centre (lib/utils.py:244-254, torch.cdist + top-1): near [C][J]. */
+int ogmm_nearest_point(const float* xyz, const float* mu /*[C][J][3]*/, int C, int N, int J, int32_t* near, void* stream);
+
+/* ---- T6: constants of the input that feed trainable thin layers, un-fused for training:
+ *   ogmm_edge_features: out[(c*N+i)*k + j][0..5] = (x_j - x_i, x_i), j over idx[c][i][:]          (lib/utils.py:47-66)
+ *   ogmm_pos_features:  d2[c*N+i] = |p_i - centroid_c|^2;  alpha[(c*N+i)*k + j] = cos angle between the unit offset to the
+ *                       j-th neighbour and the unit centroid offset (eps 1e-12)                     (models/attn.py:60-70) */
+int ogmm_edge_features(const float* xyz, const int32_t* idx, int C, int N, int k, float* out /*[C*N*k][6]*/, void* stream);
+int ogmm_pos_features(const float* xyz, const int32_t* idx, int C, int N, int k, const float* centroid /*[C][3]*/, float* d2, float* alpha, void* stream);
+
+/* ---- T7: backward of ogmm_l2norm_rows (models/gmmreg.py:74): dx = g/n - x (x.g)/n^3, n = max(|x|, 1e-12). */
+int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t rows, int D, float* dx, int64_t lddx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,11 @@ PROTOTYPES = {
                             c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_maxpool_k": [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_maxpool_k_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p],
+    "ogmm_kabsch_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogmm_nearest_point": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ogmm_edge_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ogmm_pos_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogmm_l2norm_rows_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_transpose_pad": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p],
     "ogmm_pack_frag_t": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }

@@ -445,6 +445,120 @@ __global__ void kabsch_kernel(const float* __restrict__ src, const float* __rest
 }
 
 // ================================================================================================
+// Backward of K18 (training): gradients of a loss w.r.t. src, corr, w given dL/dR, dL/dt.  One lane per pair, fp64.
+//   H = cov = U S V^T,  R = V D U^T,  D = diag(1,1,d),  t = cc - R cs.
+//   With A = U^T dH V:  U^T dU = wU, V^T dV = wV skew,  A_ij = wU_ij s_j - s_i wV_ij  =>  for i != j
+//     wU_ij = (s_j A_ij + s_i A_ji) / (s_j^2 - s_i^2),   wV_ij = (s_i A_ij + s_j A_ji) / (s_j^2 - s_i^2),
+//   and V^T dR U = wV D - D wU.  Contracting with G = V^T (dL/dR) U gives dL/dA; where d_i = d_j the singular
+//   denominators cancel:  dL/dA_ij = (G_ji - G_ij) / (s_i + s_j)  (no blow-up for equal singular values);
+//   for the reflected pair (d_i = 1, d_j = -1):  dL/dA_ij = dL/dA_ji = -(G_ij + G_ji) / (s_j - s_i).
+//   dL/dH = U (dL/dA) V^T.  This is torch's svd_backward specialised to the product V D U^T (lib/se3.py:276-289).
+// ================================================================================================
+__global__ void kabsch_bwd_kernel(const float* __restrict__ src, const float* __restrict__ corr, const float* __restrict__ w, int B, int J,
+                                  const float* __restrict__ gR_in, const float* __restrict__ gt_in,
+                                  float* __restrict__ g_src, float* __restrict__ g_corr, float* __restrict__ g_w) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* s = src + (int64_t)b * 3 * J;
+    const float* q = corr + (int64_t)b * 3 * J;
+    const float* ww = w + (int64_t)b * J;
+    double ws = 0.0, cs[3] = {0, 0, 0}, cc[3] = {0, 0, 0};
+    for (int n = 0; n < J; ++n) {
+        const double wn = ww[n];
+        ws += wn;
+        for (int a = 0; a < 3; ++a) { cs[a] += wn * s[a * J + n]; cc[a] += wn * q[a * J + n]; }
+    }
+    for (int a = 0; a < 3; ++a) { cs[a] /= ws; cc[a] /= ws; }
+    double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int n = 0; n < J; ++n) {
+        const double wn = ww[n];
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) H[a][c] += (s[a * J + n] - cs[a]) * wn * (q[c * J + n] - cc[c]);
+    }
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) {
+        if (H[a][c] != H[a][c]) H[a][c] = 0.0;
+        if (a == c) H[a][c] += 1e-5;
+    }
+    // SVD pieces exactly as the forward builds them
+    double AtA[3][3], Vj[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double t_ = 0.0;
+        for (int k = 0; k < 3; ++k) t_ += H[k][i] * H[k][j];
+        AtA[i][j] = t_;
+    }
+    jacobi_eig3(AtA, Vj);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a) for (int c = a + 1; c < 3; ++c)
+        if (AtA[ord[c]][ord[c]] > AtA[ord[a]][ord[a]]) { const int t_ = ord[a]; ord[a] = ord[c]; ord[c] = t_; }
+    double V[3][3], U[3][3], sv[3], D[3] = {1.0, 1.0, 1.0};      // columns: V[k][i] = v_i[k]
+    for (int i = 0; i < 2; ++i) for (int k = 0; k < 3; ++k) V[k][i] = Vj[k][ord[i]];
+    V[0][2] = V[1][0] * V[2][1] - V[2][0] * V[1][1];
+    V[1][2] = V[2][0] * V[0][1] - V[0][0] * V[2][1];
+    V[2][2] = V[0][0] * V[1][1] - V[1][0] * V[0][1];
+    double hv[3][3];                                              // hv[i] = H v_i
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) hv[i][k] = H[k][0] * V[0][i] + H[k][1] * V[1][i] + H[k][2] * V[2][i];
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1) {
+            const double dd = hv[1][0] * U[0][0] + hv[1][1] * U[1][0] + hv[1][2] * U[2][0];
+            for (int k = 0; k < 3; ++k) hv[1][k] -= dd * U[k][0];
+        }
+        const double nrm = sqrt(hv[i][0] * hv[i][0] + hv[i][1] * hv[i][1] + hv[i][2] * hv[i][2]);
+        sv[i] = nrm;
+        const double inv = nrm > 0 ? 1.0 / nrm : 0.0;
+        for (int k = 0; k < 3; ++k) U[k][i] = hv[i][k] * inv;
+    }
+    const double u3p[3] = {U[1][0] * U[2][1] - U[2][0] * U[1][1], U[2][0] * U[0][1] - U[0][0] * U[2][1], U[0][0] * U[1][1] - U[1][0] * U[0][1]};
+    const double proj = u3p[0] * hv[2][0] + u3p[1] * hv[2][1] + u3p[2] * hv[2][2];        // = d * s_3
+    D[2] = proj >= 0 ? 1.0 : -1.0;
+    sv[2] = fabs(proj);
+    for (int k = 0; k < 3; ++k) U[k][2] = D[2] * u3p[k];
+    double R[3][3];
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) R[a][c] = V[a][0] * U[c][0] + V[a][1] * U[c][1] + D[2] * V[a][2] * U[c][2];
+    // upstream gradients; t = cc - R cs
+    double gR[3][3], gt[3], gcs[3], G[3][3], gA[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gH[3][3];
+    for (int a = 0; a < 3; ++a) gt[a] = gt_in ? (double)gt_in[b * 3 + a] : 0.0;
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) gR[a][c] = (gR_in ? (double)gR_in[b * 9 + a * 3 + c] : 0.0) - gt[a] * cs[c];
+    for (int c = 0; c < 3; ++c) gcs[c] = -(R[0][c] * gt[0] + R[1][c] * gt[1] + R[2][c] * gt[2]);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {      // G = V^T gR U
+        double t_ = 0.0;
+        for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) t_ += V[a][i] * gR[a][c] * U[c][j];
+        G[i][j] = t_;
+    }
+    for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) {
+        if (D[i] == D[j]) {
+            const double den = sv[i] + sv[j];
+            const double inv = den > 1e-300 ? 1.0 / den : 0.0;
+            gA[i][j] = (G[j][i] - G[i][j]) * inv;
+            gA[j][i] = -gA[i][j];
+        } else {
+            const double den = sv[j] - sv[i];
+            const double inv = fabs(den) > 1e-300 ? 1.0 / den : 0.0;
+            gA[i][j] = gA[j][i] = -(G[i][j] + G[j][i]) * inv;
+        }
+    }
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) {      // gH = U gA V^T
+        double t_ = 0.0;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t_ += U[a][i] * gA[i][j] * V[c][j];
+        gH[a][c] = t_;
+    }
+    for (int n = 0; n < J; ++n) {
+        const double wn = ww[n];
+        double sc[3], qc[3], hq[3], hs[3];
+        for (int a = 0; a < 3; ++a) { sc[a] = s[a * J + n] - cs[a]; qc[a] = q[a * J + n] - cc[a]; }
+        for (int a = 0; a < 3; ++a) {
+            hq[a] = gH[a][0] * qc[0] + gH[a][1] * qc[1] + gH[a][2] * qc[2];      // gH qc
+            hs[a] = gH[0][a] * sc[0] + gH[1][a] * sc[1] + gH[2][a] * sc[2];      // gH^T sc
+        }
+        double gw = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            if (g_src) g_src[(int64_t)b * 3 * J + a * J + n] = (float)(wn * hq[a] + wn / ws * gcs[a]);
+            if (g_corr) g_corr[(int64_t)b * 3 * J + a * J + n] = (float)(wn * hs[a] + wn / ws * gt[a]);
+            gw += sc[a] * hq[a] + (gcs[a] * sc[a] + gt[a] * qc[a]) / ws;
+        }
+        if (g_w) g_w[(int64_t)b * J + n] = (float)gw;
+    }
+}
+
+// ================================================================================================
 // K17+K18.  One workgroup of 256 threads per pair: cosine similarity J x J (each wave reduces one entry
 // at a time over D with coalesced 16-byte lane loads), softmax(sim / T) over target clusters, soft
 // correspondences, then the rigid solve on lane 0.   models/dgcnn.py:96-115.
@@ -659,4 +773,17 @@ extern "C" int ogmm_clu_infonce(const float* xyz, const float* mu, const float* 
     hipLaunchKernelGGL(infonce_rows_kernel, dim3(J, C), dim3(256), 4 * (size_t)J * sizeof(float), s, feats, ld, mu_feat, near, N, J, D,
                        (float)(1.0 / (double)tau), row_loss);
     return ogmm::check_launch("ogmm_clu_infonce");
+}
+
+extern "C" int ogmm_kabsch_bwd(const float* src, const float* corr, const float* w, int B, int J, const float* gR, const float* gt,
+                               float* g_src, float* g_corr, float* g_w, void* stream) {
+    OGMM_REQUIRE(src && corr && w && B > 0 && J > 0, "ogmm_kabsch_bwd: null pointer or empty input");
+    hipLaunchKernelGGL(kabsch_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, ogmm::as_stream(stream), src, corr, w, B, J, gR, gt, g_src, g_corr, g_w);
+    return ogmm::check_launch("ogmm_kabsch_bwd");
+}
+
+extern "C" int ogmm_nearest_point(const float* xyz, const float* mu, int C, int N, int J, int32_t* near, void* stream) {
+    OGMM_REQUIRE(xyz && mu && near && C > 0 && N > 0 && J > 0, "ogmm_nearest_point: null pointer or empty input");
+    hipLaunchKernelGGL(nearest_point_kernel, dim3(J, C), dim3(256), 0, ogmm::as_stream(stream), xyz, mu, N, J, near);
+    return ogmm::check_launch("ogmm_nearest_point");
 }

@@ -1,0 +1,92 @@
+// Small training-mode kernels: constants of the input that feed trainable thin layers, and the backward of the channel
+// L2-normalisation.
+//   edge features  [x_j - x_i ; x_i]                      lib/utils.py:47-66 (input of emd.conv1, models/dgcnn.py:137)
+//   positional inputs |p - centroid|^2 and cos(angle)     models/attn.py:60-70 (inputs of pos.conv_dis.0 / pos.conv_ang1.0)
+//   d/dx of x / max(|x|, 1e-12)                           models/gmmreg.py:74 (F.normalize over channels)
+#include "ogmm_common.h"
+
+namespace {
+
+using namespace ogmm;
+
+__global__ __launch_bounds__(256) void edge_features_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, int N, int k,
+                                                            int64_t edges, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= edges) return;
+    const int64_t p = e / k;                         // global point row = cloud * N + i
+    const int64_t cloud = p / N;
+    const float* __restrict__ ctr = xyz + p * 3;
+    const float* __restrict__ nb = xyz + (cloud * N + idx[e]) * 3;
+    const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+    float* __restrict__ o = out + e * 6;
+    o[0] = nb[0] - cx; o[1] = nb[1] - cy; o[2] = nb[2] - cz;
+    o[3] = cx; o[4] = cy; o[5] = cz;
+}
+
+__global__ __launch_bounds__(256) void pos_features_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, int N, int k,
+                                                           int64_t points, const float* __restrict__ centroid,
+                                                           float* __restrict__ d2, float* __restrict__ alpha) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= points) return;
+    const int64_t cloud = p / N;
+    const float* __restrict__ me = xyz + p * 3;
+    const float* __restrict__ cen = centroid + cloud * 3;
+    const float gx = me[0] - cen[0], gy = me[1] - cen[1], gz = me[2] - cen[2];
+    const float g2 = gx * gx + gy * gy + gz * gz;
+    d2[p] = g2;
+    const float gi = 1.0f / fmaxf(sqrtf(g2), 1e-12f);
+    for (int j = 0; j < k; ++j) {
+        const float* __restrict__ nb = xyz + (cloud * N + idx[p * k + j]) * 3;
+        const float lx = nb[0] - me[0], ly = nb[1] - me[1], lz = nb[2] - me[2];
+        const float li = 1.0f / fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), 1e-12f);
+        alpha[p * k + j] = (lx * li) * (gx * gi) + (ly * li) * (gy * gi) + (lz * li) * (gz * gi);
+    }
+}
+
+// dx = g / n - x (x.g) / n^3,  n = max(|x|, 1e-12); one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g, int64_t ldg,
+                                                              int64_t rows, int D, float* __restrict__ dx, int64_t lddx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* __restrict__ px = x + row * ldx;
+    const float* __restrict__ pg = g + row * ldg;
+    float ss = 0.0f, dot = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        const float xv = px[d];
+        ss += xv * xv;
+        dot += xv * pg[d];
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float nrm = sqrtf(ss);
+    float* __restrict__ q = dx + row * lddx;
+    if (nrm > 1e-12f) {
+        const float inv = 1.0f / nrm, c = dot * inv * inv * inv;
+        for (int d = lane; d < D; d += 64) q[d] = pg[d] * inv - px[d] * c;
+    } else {                                           // clamped denominator: y = x / 1e-12 is linear in x
+        for (int d = lane; d < D; d += 64) q[d] = pg[d] * 1e12f;
+    }
+}
+
+}  // namespace
+
+extern "C" int ogmm_edge_features(const float* xyz, const int32_t* idx, int C, int N, int k, float* out, void* stream) {
+    OGMM_REQUIRE(xyz && idx && out && C > 0 && N > 0 && k > 0, "ogmm_edge_features: null pointer or empty input");
+    const int64_t edges = (int64_t)C * N * k;
+    hipLaunchKernelGGL(edge_features_kernel, dim3((unsigned)((edges + 255) / 256)), dim3(256), 0, as_stream(stream), xyz, idx, N, k, edges, out);
+    return check_launch("ogmm_edge_features");
+}
+
+extern "C" int ogmm_pos_features(const float* xyz, const int32_t* idx, int C, int N, int k, const float* centroid, float* d2, float* alpha, void* stream) {
+    OGMM_REQUIRE(xyz && idx && centroid && d2 && alpha && C > 0 && N > 0 && k > 0, "ogmm_pos_features: null pointer or empty input");
+    const int64_t points = (int64_t)C * N;
+    hipLaunchKernelGGL(pos_features_kernel, dim3((unsigned)((points + 255) / 256)), dim3(256), 0, as_stream(stream), xyz, idx, N, k, points, centroid, d2, alpha);
+    return check_launch("ogmm_pos_features");
+}
+
+extern "C" int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t rows, int D, float* dx, int64_t lddx, void* stream) {
+    OGMM_REQUIRE(x && g && dx && rows > 0 && D > 0, "ogmm_l2norm_rows_bwd: null pointer or empty input");
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, ldx, g, ldg, rows, D, dx, lddx);
+    return check_launch("ogmm_l2norm_rows_bwd");
+}

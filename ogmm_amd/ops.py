@@ -470,3 +470,44 @@ def weight_grad(dy, xs, overflow=None):
         gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow)
         outs.append(part.sum(dim=0) if S > 1 else part[0])
     return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+
+
+def kabsch_bwd(src, corr, w, gR, gt):
+    """backward of `kabsch` (layout [B,3,J]): -> (g_src, g_corr [B,3,J], g_w [B,J])"""
+    B, _, J = src.shape
+    src, corr, w = _f32(src, "src").contiguous(), _f32(corr, "corr").contiguous(), _f32(w, "w").reshape(B, J).contiguous()
+    g_src, g_corr = torch.empty_like(src), torch.empty_like(corr)
+    g_w = torch.empty((B, J), dtype=torch.float32, device=src.device)
+    _lib.call("ogmm_kabsch_bwd", _p(src), _p(corr), _p(w), B, J, _p(None if gR is None else _f32(gR, "gR").contiguous()),
+              _p(None if gt is None else _f32(gt, "gt").contiguous()), _p(g_src), _p(g_corr), _p(g_w), _stream())
+    return g_src, g_corr, g_w
+
+
+def nearest_point(xyz, mu):
+    C, N, _ = xyz.shape
+    J = mu.shape[1]
+    near = torch.empty((C, J), dtype=torch.int32, device=xyz.device)
+    _lib.call("ogmm_nearest_point", _p(_f32(xyz, "xyz")), _p(_f32(mu, "mu").contiguous()), C, N, J, _p(near), _stream())
+    return near
+
+
+def edge_features(xyz, idx):
+    C, N, k = idx.shape
+    out = torch.empty((C * N * k, 6), dtype=torch.float32, device=xyz.device)
+    _lib.call("ogmm_edge_features", _p(_f32(xyz, "xyz")), _p(_i32(idx, "idx")), C, N, k, _p(out), _stream())
+    return out
+
+
+def pos_features(xyz, idx, centroid):
+    C, N, k = idx.shape
+    d2 = torch.empty((C * N, 1), dtype=torch.float32, device=xyz.device)
+    alpha = torch.empty((C * N * k, 1), dtype=torch.float32, device=xyz.device)
+    _lib.call("ogmm_pos_features", _p(_f32(xyz, "xyz")), _p(_i32(idx, "idx")), C, N, k, _p(_f32(centroid, "centroid").contiguous()), _p(d2), _p(alpha), _stream())
+    return d2, alpha
+
+
+def l2norm_rows_bwd(x, g):
+    assert x.stride(1) == 1 and g.stride(1) == 1
+    dx = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.call("ogmm_l2norm_rows_bwd", _p(_f32(x, "x")), x.stride(0), _p(_f32(g, "g")), g.stride(0), x.shape[0], x.shape[1], _p(dx), dx.stride(0), _stream())
+    return dx

@@ -125,6 +125,54 @@ class _Linear(torch.autograd.Function):
         return dx, dx2, dW, db, None, None
 
 
+class _L2Norm(torch.autograd.Function):
+    """F.normalize over channels (models/gmmreg.py:74): ogmm_l2norm_rows / ogmm_l2norm_rows_bwd"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.l2norm_rows(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.l2norm_rows_bwd(x, g.contiguous())
+
+
+class _FeatMean(torch.autograd.Function):
+    """mu_f = gamma^T f / (pi N + 1e-5) (lib/utils.py:130-140): ogmm_gmm_feat_mean forward; the gradient reaches f only
+    (gamma, pi come out of the no-grad E/M loop): df = gamma (dmu / (pi N + 1e-5)), a small batched library GEMM."""
+
+    @staticmethod
+    def forward(ctx, gamma, pi, f, C, N):
+        ctx.save_for_backward(gamma, pi)
+        ctx.N = N
+        return ops.gmm_feat_mean(gamma.contiguous(), pi.contiguous(), f.contiguous(), C, N)
+
+    @staticmethod
+    def backward(ctx, dmu):
+        gamma, pi = ctx.saved_tensors
+        df = torch.bmm(gamma, dmu / (pi * ctx.N + 1e-5)[:, :, None])
+        return None, None, df.reshape(-1, dmu.shape[2]), None, None
+
+
+class _Kabsch(torch.autograd.Function):
+    """lib/se3.py:256-289 on the fp64 in-register 3x3 solver (ogmm_kabsch) with its closed-form backward (ogmm_kabsch_bwd).
+    Tensors in the kernels' layout: src, corr [B,3,J], w [B,J]."""
+
+    @staticmethod
+    def forward(ctx, src, corr, w):
+        ctx.save_for_backward(src, corr, w)
+        R, t = ops.kabsch(src, corr, w)
+        return R, t.reshape(-1, 3)
+
+    @staticmethod
+    def backward(ctx, gR, gt):
+        src, corr, w = ctx.saved_tensors
+        return ops.kabsch_bwd(src, corr, w, gR, gt)
+
+
 class TrainOps:
     """precision: "f16x3" (dense forward layers on the split-binary16 matrix-core engine) or "f32" (exact-fp32 engine)."""
 
@@ -147,26 +195,17 @@ class TrainOps:
 
     def nearest_point(self, xyz, mu):
         """index of the point nearest to each mu (lib/utils.py:244-254) -> [C,J] int64"""
-        return torch.cdist(mu, xyz).argmin(dim=2)
+        return ops.nearest_point(xyz, mu).long()
 
     # ------------------------------------------------------------------ constants of the input
     def edge_features(self, xyz, idx):
         """lib/utils.py:47-66: [x_j - x_i ; x_i] per edge -> [C*N*k, 6]"""
-        C, N, k = idx.shape
-        nb = torch.gather(xyz, 1, idx.reshape(C, N * k, 1).expand(-1, -1, 3)).view(C, N, k, 3)
-        ctr = xyz[:, :, None, :].expand(-1, -1, k, -1)
-        return torch.cat([nb - ctr, ctr], dim=3).reshape(C * N * k, 6)
+        return ops.edge_features(xyz, idx.to(torch.int32).contiguous())
 
     def pos_features(self, xyz, idx5):
         """models/attn.py:60-70: squared distance to the cloud centroid [C*N,1]; cosine between each 5-NN offset and the
         centroid offset [C*N*5,1] (the self neighbour gives a zero vector, hence cosine 0)."""
-        C, N, k = idx5.shape
-        g = xyz - xyz.mean(dim=1, keepdim=True)
-        d2 = (g * g).sum(dim=2).reshape(C * N, 1)
-        nb = torch.gather(xyz, 1, idx5.reshape(C, N * k, 1).expand(-1, -1, 3)).view(C, N, k, 3)
-        loc = F.normalize(nb - xyz[:, :, None, :], dim=3)
-        alpha = (loc * F.normalize(g, dim=2)[:, :, None, :]).sum(dim=3)
-        return d2, alpha.reshape(C * N * k, 1)
+        return ops.pos_features(xyz, idx5.to(torch.int32).contiguous(), xyz.mean(dim=1))
 
     # ------------------------------------------------------------------ dense layers
     def linear(self, x, W, b, x2=None):
@@ -218,7 +257,7 @@ class TrainOps:
         return (p @ vh).transpose(1, 2).reshape(C * N, D)
 
     def l2norm_rows(self, f):
-        return F.normalize(f, dim=1)
+        return _L2Norm.apply(f)
 
     def overlap_cross(self, fn, ol, B, N):
         """models/gmmreg.py:75-80, literally: with S[b,m,n] = <fn_src[b,m], fn_tgt[b,n]>,
@@ -234,7 +273,7 @@ class TrainOps:
     # ------------------------------------------------------------------ GMM head
     def gmm_feat_mean(self, gamma, pi, f, C, N):
         """lib/utils.py:130-140 on features: mu_f = gamma^T f / (pi N + 1e-5)  -> [C,J,D]"""
-        return gamma.transpose(1, 2) @ f.view(C, N, -1) / (pi * N + 1e-5)[:, :, None]
+        return _FeatMean.apply(gamma, pi, f, C, N)
 
     def match_kabsch(self, mu_s, mu_t, f_s, f_t, temperature):
         """models/dgcnn.py:96-115 + lib/se3.py:256-289"""
@@ -246,15 +285,4 @@ class TrainOps:
 
     def kabsch(self, src, corr, w):
         """weighted rigid fit src -> corr, points as rows: src, corr [B,J,3], w [B,J] -> R [B,3,3], t [B,3]"""
-        ws = w.sum(dim=1, keepdim=True)
-        c_s = (src * w[:, :, None]).sum(dim=1) / ws
-        c_c = (corr * w[:, :, None]).sum(dim=1) / ws
-        cov = ((src - c_s[:, None, :]) * w[:, :, None]).transpose(1, 2) @ (corr - c_c[:, None, :])
-        cov = torch.nan_to_num(cov, nan=0.0) + 1e-5 * torch.eye(3, dtype=cov.dtype, device=cov.device)
-        U, _, Vh = torch.linalg.svd(cov)
-        V = Vh.transpose(1, 2)
-        flip = torch.det(V @ U.transpose(1, 2)) <= 0
-        V = torch.where(flip[:, None, None] & (torch.arange(3, device=V.device) == 2)[None, None, :], -V, V)
-        R = V @ U.transpose(1, 2)
-        t = c_c - (R @ c_s[:, :, None])[:, :, 0]
-        return R, t
+        return _Kabsch.apply(src.transpose(1, 2).contiguous(), corr.transpose(1, 2).contiguous(), w.contiguous())

@@ -89,6 +89,61 @@ def test_linear_forward_backward(precision, rows, k1, k2, cout, bias):
         assert _rel(a, r) < tol * 3, (_rel(a, r))
 
 
+@pytest.mark.parametrize("B,J,reflect", [(5, 16, False), (3, 8, True), (4, 128, False)])
+def test_kabsch_forward_backward(B, J, reflect):
+    g = torch.Generator().manual_seed(B * J)
+    src = torch.randn(B, J, 3, generator=g)
+    Rg = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+    Rg = Rg * torch.sign(torch.det(Rg))[:, None, None]
+    corr = src @ Rg.transpose(1, 2) + 0.05 * torch.randn(B, J, 3, generator=g) + torch.randn(B, 1, 3, generator=g)
+    if reflect:
+        corr[0, :, 2] *= -1.0        # mirrored correspondences: the det <= 0 branch of lib/se3.py:281-285
+        src[1, :, 2] = 0.0           # planar cluster centres: smallest singular value ~ 1e-5
+    w = torch.rand(B, J, generator=g) + 0.1
+    gR, gt = torch.randn(B, 3, 3, generator=g), torch.randn(B, 3, generator=g)
+    outs = {}
+    for tag, o, dt in (("hip", TrainOps(), torch.float32), ("ref", RefTrainOps(), torch.float64)):
+        a = [t_.to(DEV, dt).requires_grad_(True) for t_ in (src, corr, w)]
+        R, t = o.kabsch(*a)
+        ((R * gR.to(DEV, dt)).sum() + (t * gt.to(DEV, dt)).sum()).backward()
+        outs[tag] = [R.detach(), t.detach()] + [t_.grad for t_ in a]
+    for i, (a, r) in enumerate(zip(outs["hip"], outs["ref"])):
+        assert _rel(a, r) < (2e-5 if reflect else 5e-6), (i, _rel(a, r))
+
+
+def test_small_ops_match_reference():
+    g = torch.Generator().manual_seed(5)
+    C, N, k, J, D = 4, 300, 12, 8, 64
+    xyz = torch.rand(C, N, 3, generator=g).to(DEV)
+    hip, ref = TrainOps(), RefTrainOps()
+    idx = hip.knn(xyz, k)
+    assert torch.allclose(hip.edge_features(xyz, idx), ref.edge_features(xyz, idx), atol=1e-7)
+    for a, r in zip(hip.pos_features(xyz, idx[:, :, :5].contiguous()), ref.pos_features(xyz, idx[:, :, :5].contiguous())):
+        assert torch.allclose(a, r, atol=2e-6)
+    mu = torch.rand(C, J, 3, generator=g).to(DEV)
+    assert torch.equal(hip.nearest_point(xyz, mu), ref.nearest_point(xyz, mu))
+    f = torch.randn(C * N, D, generator=g).to(DEV).requires_grad_(True)
+    up = torch.randn(C * N, D, generator=g).to(DEV)
+    res = []
+    for o in (hip, ref):
+        f.grad = None
+        y = o.l2norm_rows(f)
+        y.backward(up)
+        res.append((y.detach(), f.grad.clone()))
+    assert _rel(res[0][0], res[1][0]) < 1e-6 and _rel(res[0][1], res[1][1]) < 2e-6
+    gamma = torch.rand(C, N, J, generator=g).to(DEV)
+    gamma = gamma / gamma.sum(-1, keepdim=True) * 0.7
+    pi = gamma.mean(dim=1)
+    upm = torch.randn(C, J, D, generator=g).to(DEV)
+    res = []
+    for o in (hip, ref):
+        f.grad = None
+        m = o.gmm_feat_mean(gamma, pi, f, C, N)
+        m.backward(upm)
+        res.append((m.detach(), f.grad.clone()))
+    assert _rel(res[0][0], res[1][0]) < 2e-6 and _rel(res[0][1], res[1][1]) < 2e-6
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_training_step_matches_reference(name, precision):

@@ -44,6 +44,44 @@ class RefTrainOps(TrainOps):
     def maxpool_k(self, h, k):
         return h.view(-1, k, h.shape[1]).max(dim=1)[0]
 
+    def nearest_point(self, xyz, mu):
+        return torch.cdist(mu, xyz).argmin(dim=2)
+
+    def edge_features(self, xyz, idx):
+        C, N, k = idx.shape
+        nb = torch.gather(xyz, 1, idx.reshape(C, N * k, 1).expand(-1, -1, 3)).view(C, N, k, 3)
+        ctr = xyz[:, :, None, :].expand(-1, -1, k, -1)
+        return torch.cat([nb - ctr, ctr], dim=3).reshape(C * N * k, 6)
+
+    def pos_features(self, xyz, idx5):
+        C, N, k = idx5.shape
+        g = xyz - xyz.mean(dim=1, keepdim=True)
+        d2 = (g * g).sum(dim=2).reshape(C * N, 1)
+        nb = torch.gather(xyz, 1, idx5.reshape(C, N * k, 1).expand(-1, -1, 3)).view(C, N, k, 3)
+        loc = F.normalize(nb - xyz[:, :, None, :], dim=3)
+        alpha = (loc * F.normalize(g, dim=2)[:, :, None, :]).sum(dim=3)
+        return d2, alpha.reshape(C * N * k, 1)
+
+    def l2norm_rows(self, f):
+        return F.normalize(f, dim=1)
+
+    def gmm_feat_mean(self, gamma, pi, f, C, N):
+        return gamma.transpose(1, 2) @ f.view(C, N, -1) / (pi * N + 1e-5)[:, :, None]
+
+    def kabsch(self, src, corr, w):
+        ws = w.sum(dim=1, keepdim=True)
+        c_s = (src * w[:, :, None]).sum(dim=1) / ws
+        c_c = (corr * w[:, :, None]).sum(dim=1) / ws
+        cov = ((src - c_s[:, None, :]) * w[:, :, None]).transpose(1, 2) @ (corr - c_c[:, None, :])
+        cov = torch.nan_to_num(cov, nan=0.0) + 1e-5 * torch.eye(3, dtype=cov.dtype, device=cov.device)
+        U, _, Vh = torch.linalg.svd(cov)
+        V = Vh.transpose(1, 2)
+        flip = torch.det(V @ U.transpose(1, 2)) <= 0
+        V = torch.where(flip[:, None, None] & (torch.arange(3, device=V.device) == 2)[None, None, :], -V, V)
+        R = V @ U.transpose(1, 2)
+        t = c_c - (R @ c_s[:, :, None])[:, :, 0]
+        return R, t
+
     def gmm_em(self, xyz, o, ids_j):
         C, N, _ = xyz.shape
         gamma, pi, mu, _, ids = O.weighted_em(xyz, xyz.new_zeros(C, N, 1), o, ids_j.shape[1], iters=10, tau=1.0)

