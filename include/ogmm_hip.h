@@ -202,6 +202,16 @@ int ogmm_kabsch(const float* src, const float* corr, const float* w, int B, int 
 int ogmm_clu_infonce(const float* xyz, const float* mu, const float* feats, int64_t ld, const float* mu_feat,
                      int C, int N, int J, int D, float tau, float* row_loss_sum /*[C]*/, int32_t* near /*[C][J]*/, void* stream);
 
+/* ---- K20: point-to-point ICP refinement of `forward(is_test=True)`.  lib/o3dutils.py:172-214 (reg_solver ->
+ * refine_registration -> open3d registration_icp with TransformationEstimationPointToPoint), called at models/gmmreg.py:115-117
+ * with max_corr_dist = 2 * overlap_radius and the network's (R, t) as the initial motion.  open3d's published algorithm,
+ * default convergence criteria (pass max_iter 30, rel_fitness = rel_rmse = 1e-6), fp64, the whole loop for one pair on
+ * one workgroup.  src [B][N][3], tgt [B][Nt][3] (Nt <= 8192), R0 [B][3][3], t0 [B][3] (NULL = identity) -> R, t;
+ * fitness / rmse / iters [B] are optional. */
+int ogmm_icp_point_to_point(const float* src, const float* tgt, int B, int N, int Nt, const float* R0, const float* t0,
+                            float max_corr_dist, int max_iter, double rel_fitness, double rel_rmse,
+                            float* R, float* t, float* fitness, float* rmse, int* iters, void* stream);
+
 /* =====================================================================================================
  * Training mode (`model.train()`): forward kernels that differ from eval, and the backward kernels.
  * The reference has no hand-written backward: autograd differentiates the model files; each entry cites the

@@ -2,7 +2,7 @@
 symbol does not resolve, importing the ops fails loudly -- the product path has no CPU route."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
@@ -61,6 +61,8 @@ PROTOTYPES = {
     "ogmm_match_kabsch": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_kabsch": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_clu_infonce": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "ogmm_icp_point_to_point": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_double, c_double,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     # training mode
     "ogmm_colstats": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p],
     "ogmm_affine_act": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],

@@ -10,8 +10,8 @@ operation of the forward is a kernel of libogmm_hip.so reached through ogmm_amd/
 device buffers and the stream.  There is no CPU fallback: CPU tensors raise.
 
 Scope: `model.eval()` runs the fused inference kernels; `model.train()` runs the training graph (batch-statistics
-BatchNorm, autograd; ogmm_amd/train_graph.py).  The open3d ICP refinement of `is_test=True` (models/gmmreg.py:115-117)
-raises NotImplementedError.
+BatchNorm, autograd; ogmm_amd/train_graph.py).  `is_test=True` adds the point-to-point ICP refinement of
+models/gmmreg.py:115-117 as a GPU kernel (open3d's published algorithm; parity unpinned, see oracle/icp_oracle.py).
 
 Layout: clouds are stacked as C = 2B (src clouds, then tgt clouds: in eval mode the shared-weight src/tgt calls of
 the reference are independent, models/gmmreg.py:52-53) and feature maps are point-major [C*N, channels].
@@ -276,8 +276,6 @@ class GMMReg(nn.Module):
             raise OgmmError("src and tgt must be tensors")
         if not (src.is_cuda and tgt.is_cuda) and not (self.training and self._train_ops is not None):
             raise OgmmError("GMMReg.forward needs CUDA/ROCm tensors: the MI355X path has no CPU fallback")
-        if is_test:
-            raise NotImplementedError("is_test=True needs the open3d ICP refinement (models/gmmreg.py:115-117): out of scope")
         if src.dim() != 3 or src.shape[1] != 3 or src.shape != tgt.shape or src.dtype != torch.float32 or tgt.dtype != torch.float32:
             raise OgmmError("src and tgt must be float32 [B,3,N] of equal shape (models/gmmreg.py:79-80 needs N_src == N_tgt)")
         cfg = self.config
@@ -293,7 +291,7 @@ class GMMReg(nn.Module):
         if self.emd.conv1.weight.device != dev:
             raise OgmmError("GMMReg parameters live on %s but the inputs on %s: call model.to(device) first" % (self.emd.conv1.weight.device, dev))
         if self.training:
-            return self._forward_train(src, tgt, fps_starts, capture)
+            return self._forward_train(src, tgt, fps_starts, capture, is_test)
         L = self._layers()
         cap = {} if capture else None
         ops.DEFAULT_SPLIT = self.precision == "f16x3"
@@ -395,9 +393,13 @@ class GMMReg(nn.Module):
             cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0], o_logit=extra[:, 1],
                        o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss)
             self.last_intermediates = cap
+        if is_test:
+            # models/gmmreg.py:115-117: point-to-point ICP from the network's motion, correspondence radius 2 * overlap_radius
+            # (lib/o3dutils.py:176).  The reference hands every pair to open3d on the CPU; here the whole batch stays on the GPU.
+            rot, trans = ops.icp_point_to_point(xyz[:B], xyz[B:], rot, trans, 2.0 * cfg.overlap_radius)
         return rot, trans, o[:B], o[B:], loss
 
-    def _forward_train(self, src, tgt, fps_starts, capture):
+    def _forward_train(self, src, tgt, fps_starts, capture, is_test=False):
         """`.train()` mode: batch-statistics BatchNorm with running-stat updates and autograd through every differentiable
         stage (ogmm_amd/train_graph.py over the kernels of ogmm_amd/train_ops.py)."""
         from . import train_graph, train_ops
@@ -411,6 +413,10 @@ class GMMReg(nn.Module):
         out = train_graph.forward_train(backend, P, self.config, self.n_clusters, src, tgt, fps_starts.to(src.device), cap)
         if capture:
             self.last_intermediates = cap
+        if is_test:                                            # models/gmmreg.py:115-117 (no gradient through open3d there either)
+            rot, trans = ops.icp_point_to_point(src.transpose(1, 2).contiguous(), tgt.transpose(1, 2).contiguous(),
+                                                out[0].detach(), out[1].detach(), 2.0 * self.config.overlap_radius)
+            out = (rot, trans) + tuple(out[2:])
         return out
 
     def fp16_overflowed(self):
