@@ -212,6 +212,10 @@ int ogmm_icp_point_to_point(const float* src, const float* tgt, int B, int N, in
                             float max_corr_dist, int max_iter, double rel_fitness, double rel_rmse,
                             float* R, float* t, float* fitness, float* rmse, int* iters, void* stream);
 
+/* ---- K21: out[b][i] = min_j |a[b][i] - b[b][j]|^2 (direct-difference form), the reduction the evaluation metrics
+ * take over lib/metric.py:193-194's [B][Na][Nb] matrix (chamfer / clipped chamfer / source error, lib/metric.py:221-236). */
+int ogmm_min_sqdist(const float* a /*[B][Na][3]*/, const float* b /*[B][Nb][3]*/, int B, int Na, int Nb, float* out /*[B][Na]*/, void* stream);
+
 /* =====================================================================================================
  * Training mode (`model.train()`): forward kernels that differ from eval, and the backward kernels.
  * The reference has no hand-written backward: autograd differentiates the model files; each entry cites the

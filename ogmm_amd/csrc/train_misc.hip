@@ -90,3 +90,36 @@ extern "C" int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g,
     hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, ldx, g, ldg, rows, D, dx, lddx);
     return check_launch("ogmm_l2norm_rows_bwd");
 }
+
+// ---------------------------------------------------------------- nearest squared distance, brute force (evaluation metrics)
+// lib/metric.py:193-194 (`square_distance`, direct form sum (a - b)^2) followed by min over the other cloud (:221-236): the
+// [B,Na,Nb] matrix of the reference is never formed.  The other cloud is staged through LDS in tiles; one thread per query.
+namespace {
+constexpr int MSD_TILE = 1024;
+__global__ __launch_bounds__(256) void min_sqdist_kernel(const float* __restrict__ a, const float* __restrict__ b, int Na, int Nb,
+                                                         float* __restrict__ out) {
+    __shared__ float tile[MSD_TILE * 3];
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float* __restrict__ pa = a + ((int64_t)c * Na + (i < Na ? i : 0)) * 3;
+    const float x = pa[0], y = pa[1], z = pa[2];
+    float best = __builtin_inff();
+    for (int j0 = 0; j0 < Nb; j0 += MSD_TILE) {
+        const int n = min(MSD_TILE, Nb - j0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < n * 3; t += 256) tile[t] = b[((int64_t)c * Nb + j0) * 3 + t];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const float dx = x - tile[3 * j], dy = y - tile[3 * j + 1], dz = z - tile[3 * j + 2];
+            best = fminf(best, ogmm::add_rn(ogmm::add_rn(ogmm::mul_rn(dx, dx), ogmm::mul_rn(dy, dy)), ogmm::mul_rn(dz, dz)));
+        }
+    }
+    if (i < Na) out[(int64_t)c * Na + i] = best;
+}
+}  // namespace
+
+extern "C" int ogmm_min_sqdist(const float* a, const float* b, int B, int Na, int Nb, float* out, void* stream) {
+    OGMM_REQUIRE(a && b && out && B > 0 && Na > 0 && Nb > 0, "ogmm_min_sqdist: null pointer or empty input");
+    hipLaunchKernelGGL(min_sqdist_kernel, dim3((Na + 255) / 256, B), dim3(256), 0, ogmm::as_stream(stream), a, b, Na, Nb, out);
+    return ogmm::check_launch("ogmm_min_sqdist");
+}

@@ -408,6 +408,14 @@ def icp_point_to_point(src, tgt, R0, t0, max_corr_dist, max_iter=30, rel_fitness
     return (R, t, fit, rmse, iters) if want_stats else (R, t)
 
 
+def min_sqdist(a, b):
+    """a [B,Na,3], b [B,Nb,3] -> [B,Na] squared distance to the nearest point of b (lib/metric.py:193-194 + min)"""
+    a, b = _f32(a, "a").contiguous(), _f32(b, "b").contiguous()
+    out = torch.empty(a.shape[:2], dtype=torch.float32, device=a.device)
+    _lib.call("ogmm_min_sqdist", _p(a), _p(b), a.shape[0], a.shape[1], b.shape[1], _p(out), _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- training mode
 def colstats(x, group_rows):
     """x [rows, cols] (last stride 1) -> float64 [G, cols, 2] = {sum, sum of squares} per row group"""

@@ -68,3 +68,22 @@ def test_against_reference():
     assert torch.equal(se3.integrate_trans(R1[0], t1[0, :, None]), ref_se3.integrate_trans(R1[0], t1[0, :, None]))
     for a, b in zip(se3.decompose_trans(T), ref_se3.decompose_trans(T)):
         assert torch.equal(a, b)
+
+
+def test_euler_zyx_matches_scipy():
+    from scipy.spatial.transform import Rotation
+    R = Rotation.random(200, random_state=4).as_matrix()
+    want = Rotation.from_matrix(R).as_euler("zyx", degrees=True)
+    got = metric.euler_zyx_deg(torch.from_numpy(R)).numpy()
+    assert np.abs(got - want).max() < 1e-9
+
+
+def test_summarize_metrics_matches_reference_fixture():
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_b4_n300.npz"))
+    m = {k[2:]: torch.from_numpy(np.asarray(fx[k])) for k in fx.files if k.startswith("m/")}
+    got = metric.summarize_metrics(m)
+    want = {k[2:]: float(fx[k]) for k in fx.files if k.startswith("s/")}
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), k
