@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 4
+#define OGMM_ABI_VERSION 5
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -228,16 +228,18 @@ int ogmm_min_sqdist(const float* a /*[B][Na][3]*/, const float* b /*[B][Nb][3]*/
  * stacked batch); an InstanceNorm group is one cloud.
  *   ogmm_colstats:        stats[g][c] = {sum x, sum x^2} in fp64 (zeroed by the call)
  *   ogmm_affine_act:      y = act(x * scale[g][c] + shift[g][c]),  act in {NONE, RELU, LEAKY02}
- *   ogmm_norm_bwd_reduce: sums[g][c] = {sum dz, sum dz * xhat}, dz = dy * act'(y), xhat = (x - mean) * rstd  (fp64, zeroed by the call)
+ *   ogmm_norm_bwd_reduce: sums[g][c] = {sum dz, sum dz * xhat}, dz = dy * act'(x*scale + shift), xhat = (x - mean) * rstd  (fp64, zeroed by the call)
  *   ogmm_norm_bwd_apply:  dx = scale * (dz - sums0/n - xhat * sums1/n),  n = group_rows
+ * (the activation derivative is taken from the recomputed pre-activation, so the stored output is not re-read)
  * The host turns stats into mean / rstd / scale = gamma*rstd / shift = beta - mean*scale and sums into dgamma, dbeta. */
 int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, double* stats /*[G][cols][2]*/, void* stream);
 int ogmm_affine_act(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, const float* scale /*[G][cols]*/,
                     const float* shift, int act, float* y, int64_t ldy, void* stream);
-int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int cols,
-                         int64_t group_rows, const float* mean /*[G][cols]*/, const float* rstd, int act, double* sums /*[G][cols][2]*/, void* stream);
-int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int cols,
-                        int64_t group_rows, const float* scale, const float* mean, const float* rstd, int act, const double* sums,
+int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+                         const float* scale /*[G][cols]*/, const float* shift, const float* mean, const float* rstd, int act,
+                         double* sums /*[G][cols][2]*/, void* stream);
+int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+                        const float* scale, const float* shift, const float* mean, const float* rstd, int act, const double* sums,
                         float* dx, int64_t lddx, void* stream);
 
 /* ---- T2: max over the k edges of a point on an un-fused per-edge map (models/dgcnn.py:139,142,145,148; models/attn.py:72):

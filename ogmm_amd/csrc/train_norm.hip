@@ -11,7 +11,6 @@
 //   ill-conditioned in fp32 (tests/golden/make_golden_train.py), so the reductions must not add noise of their own.
 //
 //   Grid: row blocks on x (can exceed 65535), 64-column slabs on y, groups on z.
-//   Thread mapping everywhere: 64 consecutive columns on the 64 lanes of a wave (256-byte lines), 4 waves = 4 row lanes.
 #include "ogmm_common.h"
 
 namespace {
@@ -20,7 +19,7 @@ using namespace ogmm;
 
 constexpr int ROW_CHUNK = 512;       // rows of one group handled by one workgroup of the reduction kernels
 
-__device__ __forceinline__ float act_grad(float y, int act) {      // derivative of the activation, from its OUTPUT
+__device__ __forceinline__ float act_grad(float y, int act) {      // derivative of the activation, from its output or its pre-activation (same sign)
     if (act == OGMM_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
     if (act == OGMM_ACT_LEAKY02) return y > 0.0f ? 1.0f : 0.2f;
     return 1.0f;
@@ -31,7 +30,161 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
     return v;
 }
 
+// All four kernels move float4 per lane: a wave covers 256 consecutive columns of one row (or 64 / 128 columns of 4 / 2 rows),
+// a block of 256 threads = 4 waves covers `ROWS_PER_PASS` rows per pass.  cols % 4 == 0 and 16-byte aligned rows are required
+// by the vector kernels; the scalar kernels below them take any shape.
+template <int CV>   // CV = lanes per row = min(cols / 4, 64), a power of two
+struct Map {
+    static constexpr int rows_per_wave = 64 / CV;
+    static constexpr int rows_per_pass = 4 * rows_per_wave;
+};
+
 // ---------------------------------------------------------------- column statistics: stats[g][c] = {sum x, sum x^2}
+template <int CV>
+__global__ __launch_bounds__(256) void colstats_v4_kernel(const float* __restrict__ x, int64_t ldx, int cols, int64_t group_rows,
+                                                          double* __restrict__ stats) {
+    __shared__ double red[4][64][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane % CV, rl = wave * Map<CV>::rows_per_wave + lane / CV;
+    const int col = (blockIdx.y * CV + cl) * 4;
+    const int g = blockIdx.z;
+    const int64_t r0 = (int64_t)blockIdx.x * ROW_CHUNK, r1 = min(r0 + ROW_CHUNK, group_rows);
+    const float* __restrict__ base = x + ((int64_t)g * group_rows) * ldx + col;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    if (col < cols)
+        for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
+            const float4 v = *reinterpret_cast<const float4*>(base + r * ldx);
+            const double a = v.x, b = v.y, c = v.z, d = v.w;
+            s[0] += a; s[1] += b; s[2] += c; s[3] += d;
+            ss[0] += a * a; ss[1] += b * b; ss[2] += c * c; ss[3] += d * d;
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][lane][e] = s[e]; red[wave][lane][4 + e] = ss[e]; }
+    __syncthreads();
+    // lanes (wave 0, lane < CV) gather the partial sums of every row lane that shares their columns
+    if (wave == 0 && lane < CV && col < cols) {
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 4; ++w)
+            for (int l = lane; l < 64; l += CV)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += red[w][l][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (col + e < cols) {
+                atomicAdd(&stats[((int64_t)g * cols + col + e) * 2], t[e]);
+                atomicAdd(&stats[((int64_t)g * cols + col + e) * 2 + 1], t[4 + e]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- y = act(x * scale[g][c] + shift[g][c])
+template <int CV>
+__global__ __launch_bounds__(256) void affine_act_v4_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols, int64_t group_rows,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                            float* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane % CV, rl = wave * Map<CV>::rows_per_wave + lane / CV;
+    const int col = (blockIdx.y * CV + cl) * 4;
+    if (col >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = min(r0 + 64, rows);
+    for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
+        const int64_t gc = (r / group_rows) * cols + col;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + col);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + gc), sh = *reinterpret_cast<const float4*>(shift + gc);
+        float4 o;
+        o.x = act_fwd(fmaf(v.x, sc.x, sh.x), act); o.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
+        o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act); o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
+        *reinterpret_cast<float4*>(y + r * ldy + col) = o;
+    }
+}
+
+// ---------------------------------------------------------------- backward reduction: sums[g][c] = {sum dz, sum dz * xhat}
+// The activation derivative comes from the recomputed pre-activation x * scale + shift (the stored output is not re-read).
+template <int CV>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                                                                 int cols, int64_t group_rows, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, int act, double* __restrict__ sums) {
+    __shared__ double red[4][64][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane % CV, rl = wave * Map<CV>::rows_per_wave + lane / CV;
+    const int col = (blockIdx.y * CV + cl) * 4;
+    const int g = blockIdx.z;
+    const int64_t r0 = (int64_t)blockIdx.x * ROW_CHUNK, r1 = min(r0 + ROW_CHUNK, group_rows);
+    const int64_t gr = (int64_t)g * group_rows;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (col < cols) {
+        const int64_t gc = (int64_t)g * cols + col;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + gc), sh = *reinterpret_cast<const float4*>(shift + gc);
+        const float4 m = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc);
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+        for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
+            const float4 xv4 = *reinterpret_cast<const float4*>(x + (gr + r) * ldx + col);
+            const float4 dv4 = *reinterpret_cast<const float4*>(dy + (gr + r) * lddy + col);
+            const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dz = dv[e] * act_grad(fmaf(xv[e], scv[e], shv[e]), act);
+                const float xh = (xv[e] - mv[e]) * rv[e];
+                s1[e] += (double)dz;
+                s2[e] += (double)dz * (double)xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][lane][e] = s1[e]; red[wave][lane][4 + e] = s2[e]; }
+    __syncthreads();
+    if (wave == 0 && lane < CV && col < cols) {
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 4; ++w)
+            for (int l = lane; l < 64; l += CV)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += red[w][l][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (col + e < cols) {
+                atomicAdd(&sums[((int64_t)g * cols + col + e) * 2], t[e]);
+                atomicAdd(&sums[((int64_t)g * cols + col + e) * 2 + 1], t[4 + e]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dx = scale * (dz - S1/n - xhat * S2/n)
+template <int CV>
+__global__ __launch_bounds__(256) void norm_bwd_apply_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                                                                int64_t rows, int cols, int64_t group_rows, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, int act, const double* __restrict__ sums,
+                                                                float* __restrict__ dx, int64_t lddx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane % CV, rl = wave * Map<CV>::rows_per_wave + lane / CV;
+    const int col = (blockIdx.y * CV + cl) * 4;
+    if (col >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = min(r0 + 64, rows);
+    const double inv_n = 1.0 / (double)group_rows;
+    for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
+        const int64_t gc = (r / group_rows) * cols + col;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + gc), sh = *reinterpret_cast<const float4*>(shift + gc);
+        const float4 m = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc);
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+        const float4 xv4 = *reinterpret_cast<const float4*>(x + r * ldx + col);
+        const float4 dv4 = *reinterpret_cast<const float4*>(dy + r * lddy + col);
+        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m1 = (float)(sums[(gc + e) * 2] * inv_n), m2 = (float)(sums[(gc + e) * 2 + 1] * inv_n);
+            const float dz = dv[e] * act_grad(fmaf(xv[e], scv[e], shv[e]), act);
+            const float xh = (xv[e] - mv[e]) * rv[e];
+            o[e] = scv[e] * (dz - m1 - xh * m2);
+        }
+        *reinterpret_cast<float4*>(dx + r * lddx + col) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------- scalar fallbacks (cols % 4 != 0 or unaligned rows)
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int64_t ldx, int cols, int64_t group_rows,
                                                        double* __restrict__ stats) {
     __shared__ double red[2][4][64];
@@ -56,7 +209,6 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     }
 }
 
-// ---------------------------------------------------------------- y = act(x * scale[g][c] + shift[g][c])
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols, int64_t group_rows,
                                                          const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                          float* __restrict__ y, int64_t ldy) {
@@ -70,11 +222,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
 }
 
-// ---------------------------------------------------------------- backward reduction: sums[g][c] = {sum dz, sum dz * xhat}
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy,
-                                                              const float* __restrict__ dy, int64_t lddy, int cols, int64_t group_rows,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd, int act,
-                                                              double* __restrict__ sums) {
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                                                              int cols, int64_t group_rows, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, int act, double* __restrict__ sums) {
     __shared__ double red[2][4][64];
     const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.y * 64 + ch;
@@ -83,13 +234,14 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     const int64_t gr = (int64_t)g * group_rows;
     double s1 = 0.0, s2 = 0.0;
     if (col < cols) {
-        const float m = mean[(int64_t)g * cols + col], rs = rstd[(int64_t)g * cols + col];
+        const int64_t gc = (int64_t)g * cols + col;
+        const float m = mean[gc], rs = rstd[gc], sc = scale[gc], sh = shift[gc];
         for (int64_t r = r0 + rl; r < r1; r += 4) {
             const int64_t rr = gr + r;
-            const float dz = dy[rr * lddy + col] * act_grad(y[rr * ldy + col], act);
-            const float xh = (x[rr * ldx + col] - m) * rs;
+            const float xv = x[rr * ldx + col];
+            const float dz = dy[rr * lddy + col] * act_grad(fmaf(xv, sc, sh), act);
             s1 += (double)dz;
-            s2 += (double)dz * (double)xh;
+            s2 += (double)dz * (double)((xv - m) * rs);
         }
     }
     red[0][rl][ch] = s1;
@@ -101,10 +253,9 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     }
 }
 
-// ---------------------------------------------------------------- dx = scale * (dz - S1/n - xhat * S2/n)
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy,
-                                                             const float* __restrict__ dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
-                                                             const float* __restrict__ scale, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                                                             int64_t rows, int cols, int64_t group_rows, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int act, const double* __restrict__ sums,
                                                              float* __restrict__ dx, int64_t lddx) {
     const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -113,11 +264,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = min(r0 + 64, rows);
     const double inv_n = 1.0 / (double)group_rows;
     for (int64_t r = r0 + rl; r < r1; r += 4) {
-        const int64_t g = r / group_rows;
-        const int64_t gc = g * cols + col;
+        const int64_t gc = (r / group_rows) * cols + col;
         const float m1 = (float)(sums[gc * 2] * inv_n), m2 = (float)(sums[gc * 2 + 1] * inv_n);
-        const float dz = dy[r * lddy + col] * act_grad(y[r * ldy + col], act);
-        const float xh = (x[r * ldx + col] - mean[gc]) * rstd[gc];
+        const float xv = x[r * ldx + col];
+        const float dz = dy[r * lddy + col] * act_grad(fmaf(xv, scale[gc], shift[gc]), act);
+        const float xh = (xv - mean[gc]) * rstd[gc];
         dx[r * lddx + col] = scale[gc] * (dz - m1 - xh * m2);
     }
 }
@@ -160,15 +311,40 @@ __global__ __launch_bounds__(256) void maxpool_k_bwd_kernel(const float* __restr
 
 extern "C" {
 
+// lanes per row for the float4 kernels: cols/4 rounded up to a power of two, at most 64
+static int lanes_per_row(int cols) {
+    int cv = 1;
+    while (cv < 64 && cv * 4 < cols) cv <<= 1;
+    return cv;
+}
+static bool vec_ok(const void* p, int64_t ld, int cols) { return cols % 4 == 0 && ld % 4 == 0 && aligned16(p); }
+
+#define OGMM_DISPATCH_CV(cv, CALL)                 \
+    switch (cv) {                                  \
+        case 1: { constexpr int CV = 1; CALL; } break;   \
+        case 2: { constexpr int CV = 2; CALL; } break;   \
+        case 4: { constexpr int CV = 4; CALL; } break;   \
+        case 8: { constexpr int CV = 8; CALL; } break;   \
+        case 16: { constexpr int CV = 16; CALL; } break; \
+        case 32: { constexpr int CV = 32; CALL; } break; \
+        default: { constexpr int CV = 64; CALL; } break; \
+    }
+
 int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, double* stats, void* stream) {
     OGMM_REQUIRE(rows >= 0 && cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_colstats: rows=%lld must be a multiple of group_rows=%lld",
                  (long long)rows, (long long)group_rows);
     if (rows == 0) return 0;
     const int64_t G = rows / group_rows;
     OGMM_REQUIRE(G <= 65535, "ogmm_colstats: too many groups (%lld)", (long long)G);
-    hipMemsetAsync(stats, 0, sizeof(double) * 2 * G * cols, as_stream(stream));
-    dim3 grid((unsigned)((group_rows + ROW_CHUNK - 1) / ROW_CHUNK), (cols + 63) / 64, (unsigned)G);
-    hipLaunchKernelGGL(colstats_kernel, grid, dim3(256), 0, as_stream(stream), x, ldx, cols, group_rows, stats);
+    (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * G * cols, as_stream(stream));
+    const unsigned chunks = (unsigned)((group_rows + ROW_CHUNK - 1) / ROW_CHUNK);
+    if (vec_ok(x, ldx, cols)) {
+        const int cv = lanes_per_row(cols);
+        dim3 grid(chunks, (cols / 4 + cv - 1) / cv, (unsigned)G);
+        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(colstats_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, cols, group_rows, stats));
+    } else {
+        hipLaunchKernelGGL(colstats_kernel, dim3(chunks, (cols + 63) / 64, (unsigned)G), dim3(256), 0, as_stream(stream), x, ldx, cols, group_rows, stats);
+    }
     return check_launch("ogmm_colstats");
 }
 
@@ -177,31 +353,54 @@ int ogmm_affine_act(const float* x, int64_t ldx, int64_t rows, int cols, int64_t
     OGMM_REQUIRE(cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_affine_act: bad shape");
     OGMM_REQUIRE(act == OGMM_ACT_NONE || act == OGMM_ACT_RELU || act == OGMM_ACT_LEAKY02, "ogmm_affine_act: activation %d not supported", act);
     if (rows == 0) return 0;
-    dim3 grid((unsigned)((rows + 63) / 64), (cols + 63) / 64);
-    hipLaunchKernelGGL(affine_act_kernel, grid, dim3(256), 0, as_stream(stream), x, ldx, rows, cols, group_rows, scale, shift, act, y, ldy);
+    const unsigned rblocks = (unsigned)((rows + 63) / 64);
+    if (vec_ok(x, ldx, cols) && vec_ok(y, ldy, cols) && aligned16(scale) && aligned16(shift)) {
+        const int cv = lanes_per_row(cols);
+        dim3 grid(rblocks, (cols / 4 + cv - 1) / cv);
+        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(affine_act_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, rows, cols, group_rows, scale,
+                                                shift, act, y, ldy));
+    } else {
+        hipLaunchKernelGGL(affine_act_kernel, dim3(rblocks, (cols + 63) / 64), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, group_rows, scale,
+                           shift, act, y, ldy);
+    }
     return check_launch("ogmm_affine_act");
 }
 
-int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int cols,
-                         int64_t group_rows, const float* mean, const float* rstd, int act, double* sums, void* stream) {
+int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+                         const float* scale, const float* shift, const float* mean, const float* rstd, int act, double* sums, void* stream) {
     OGMM_REQUIRE(cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_norm_bwd_reduce: bad shape");
     if (rows == 0) return 0;
     const int64_t G = rows / group_rows;
     OGMM_REQUIRE(G <= 65535, "ogmm_norm_bwd_reduce: too many groups");
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * G * cols, as_stream(stream));
-    dim3 grid((unsigned)((group_rows + ROW_CHUNK - 1) / ROW_CHUNK), (cols + 63) / 64, (unsigned)G);
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, ldx, y, ldy, dy, lddy, cols, group_rows, mean, rstd, act, sums);
+    (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * G * cols, as_stream(stream));
+    const unsigned chunks = (unsigned)((group_rows + ROW_CHUNK - 1) / ROW_CHUNK);
+    if (vec_ok(x, ldx, cols) && vec_ok(dy, lddy, cols) && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(rstd)) {
+        const int cv = lanes_per_row(cols);
+        dim3 grid(chunks, (cols / 4 + cv - 1) / cv, (unsigned)G);
+        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(norm_bwd_reduce_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, cols, group_rows,
+                                                scale, shift, mean, rstd, act, sums));
+    } else {
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(chunks, (cols + 63) / 64, (unsigned)G), dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, cols,
+                           group_rows, scale, shift, mean, rstd, act, sums);
+    }
     return check_launch("ogmm_norm_bwd_reduce");
 }
 
-int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* dy, int64_t lddy, int64_t rows, int cols,
-                        int64_t group_rows, const float* scale, const float* mean, const float* rstd, int act, const double* sums,
+int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+                        const float* scale, const float* shift, const float* mean, const float* rstd, int act, const double* sums,
                         float* dx, int64_t lddx, void* stream) {
     OGMM_REQUIRE(cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_norm_bwd_apply: bad shape");
     if (rows == 0) return 0;
-    dim3 grid((unsigned)((rows + 63) / 64), (cols + 63) / 64);
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, grid, dim3(256), 0, as_stream(stream), x, ldx, y, ldy, dy, lddy, rows, cols, group_rows, scale, mean,
-                       rstd, act, sums, dx, lddx);
+    const unsigned rblocks = (unsigned)((rows + 63) / 64);
+    if (vec_ok(x, ldx, cols) && vec_ok(dy, lddy, cols) && vec_ok(dx, lddx, cols) && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(rstd)) {
+        const int cv = lanes_per_row(cols);
+        dim3 grid(rblocks, (cols / 4 + cv - 1) / cv);
+        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(norm_bwd_apply_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, rows, cols,
+                                                group_rows, scale, shift, mean, rstd, act, sums, dx, lddx));
+    } else {
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(rblocks, (cols + 63) / 64), dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, rows, cols,
+                           group_rows, scale, shift, mean, rstd, act, sums, dx, lddx);
+    }
     return check_launch("ogmm_norm_bwd_apply");
 }
 

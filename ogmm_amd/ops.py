@@ -437,17 +437,17 @@ def affine_act(x, group_rows, scale, shift, act, out=None):
     return out
 
 
-def norm_bwd(x, y, dy, group_rows, scale, mean, rstd, act):
-    """backward of y = act((x - mean) * rstd * gamma + beta) -> (dx, sums float64 [G, cols, 2] = {sum dz, sum dz*xhat})"""
+def norm_bwd(x, dy, group_rows, scale, shift, mean, rstd, act):
+    """backward of y = act(x * scale + shift), scale = gamma * rstd, shift = beta - mean * scale
+    -> (dx, sums float64 [G, cols, 2] = {sum dz, sum dz*xhat})"""
     rows, cols = x.shape
-    assert x.stride(1) == 1 and y.stride(1) == 1 and dy.stride(1) == 1
+    assert x.stride(1) == 1 and dy.stride(1) == 1
     G = rows // group_rows
     sums = torch.empty((G, cols, 2), dtype=torch.float64, device=x.device)
-    _lib.call("ogmm_norm_bwd_reduce", _p(_f32(x, "x")), x.stride(0), _p(_f32(y, "y")), y.stride(0), _p(_f32(dy, "dy")), dy.stride(0), rows, cols,
-              group_rows, _p(_f32(mean, "mean")), _p(_f32(rstd, "rstd")), act, _p(sums), _stream())
+    args = (_p(_f32(scale, "scale")), _p(_f32(shift, "shift")), _p(_f32(mean, "mean")), _p(_f32(rstd, "rstd")), act)
+    _lib.call("ogmm_norm_bwd_reduce", _p(_f32(x, "x")), x.stride(0), _p(_f32(dy, "dy")), dy.stride(0), rows, cols, group_rows, *args, _p(sums), _stream())
     dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
-    _lib.call("ogmm_norm_bwd_apply", _p(x), x.stride(0), _p(y), y.stride(0), _p(dy), dy.stride(0), rows, cols, group_rows,
-              _p(_f32(scale, "scale")), _p(mean), _p(rstd), act, _p(sums), _p(dx), dx.stride(0), _stream())
+    _lib.call("ogmm_norm_bwd_apply", _p(x), x.stride(0), _p(dy), dy.stride(0), rows, cols, group_rows, *args, _p(sums), _p(dx), dx.stride(0), _stream())
     return dx, sums
 
 

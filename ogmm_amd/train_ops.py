@@ -35,15 +35,15 @@ class _NormAct(torch.autograd.Function):
         scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
         mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
         h = ops.affine_act(y, group_rows, scale, shift, act)
-        ctx.save_for_backward(y, h, scale, mean, rstd)
+        ctx.save_for_backward(y, scale, shift, mean, rstd)
         ctx.group_rows, ctx.act, ctx.affine = group_rows, act, weight is not None
         ctx.mark_non_differentiable(mean64, var64)
         return h, mean64, var64
 
     @staticmethod
     def backward(ctx, dh, _dm, _dv):
-        y, h, scale, mean, rstd = ctx.saved_tensors
-        dy, sums = ops.norm_bwd(y, h, dh.contiguous(), ctx.group_rows, scale, mean, rstd, ctx.act)
+        y, scale, shift, mean, rstd = ctx.saved_tensors
+        dy, sums = ops.norm_bwd(y, dh.contiguous(), ctx.group_rows, scale, shift, mean, rstd, ctx.act)
         if not ctx.affine:
             return dy, None, None, None, None
         return dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float(), None, None

@@ -20,7 +20,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("rows,cols,groups,act,affine", [(2 * 1500, 64, 2, "relu", True), (2 * 777, 256, 2, "leaky", True),
-                                                         (4 * 320, 1024, 4, "relu", False), (2 * 40960, 128, 2, "relu", True)])
+                                                         (4 * 320, 1024, 4, "relu", False), (2 * 40960, 128, 2, "relu", True),
+                                                         (2 * 500, 20, 2, "leaky", True), (2 * 64, 6, 2, "relu", True), (3 * 1000, 516, 3, "relu", False)])
 def test_norm_act_forward_backward(rows, cols, groups, act, affine):
     g = torch.Generator().manual_seed(rows + cols)
     y = (torch.randn(rows, cols, generator=g) * 2 + 0.5).to(DEV).requires_grad_(True)
