@@ -28,7 +28,9 @@ import sys
 import time
 from argparse import Namespace
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required by RCCL on this pool's driver (multi-process runs)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
