@@ -259,6 +259,16 @@ int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int6
 int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
                      int* overflow, void* stream);
 
+/* ---- T8: the overlap block (models/gmmreg.py:75-80) in training: ogmm_overlap_cross that also saves the row / column softmax
+ * statistics (stats [B][4][N] = row max, row sum, column max, column sum), and its backward: given a = dL/dwo_src, b = dL/dwo_tgt
+ * (element stride ldg) it writes dS [B][N][N], g_o_src [B][N] (gradient of the logits the row pass reads, accumulated per column)
+ * and g_o_tgt [B][N] in one pass over S.  dL/dfn then follows from dS by two GEMMs. */
+int ogmm_overlap_cross_train(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in, float* wo_src, float* wo_tgt,
+                             int64_t ldo, float* stats, void* stream);
+int ogmm_overlap_cross_bwd(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in, const float* wo_src,
+                           const float* wo_tgt, int64_t ldo, const float* stats, const float* g_wo_src, const float* g_wo_tgt, int64_t ldg,
+                           float* dS, float* g_o_src, float* g_o_tgt, int64_t ldgo, void* stream);
+
 /* ---- T4: backward of K18 (lib/se3.py:256-289): gradients w.r.t. src, corr [B][3][J] and w [B][J] given dL/dR [B][3][3] and
  * dL/dt [B][3] (either may be NULL = zero).  One lane per pair in fp64; the derivative of V D U^T through the 3x3 SVD in
  * closed form (no 1/(s_i^2 - s_j^2) blow-up for equal singular values).  Any of g_src / g_corr / g_w may be NULL. */

@@ -72,6 +72,9 @@ PROTOTYPES = {
                             c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_maxpool_k": [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_maxpool_k_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p],
+    "ogmm_overlap_cross_train": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+    "ogmm_overlap_cross_bwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_kabsch_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_nearest_point": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_edge_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

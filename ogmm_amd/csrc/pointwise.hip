@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------- overlap block, row direction (one wave per row m)
 //   wo_src[b][m] = sum_n softmax_n(S[b][m][:])[n] * o_src[b][n]
 __global__ __launch_bounds__(256) void overlap_rows_kernel(const float* __restrict__ S, int N, const float* __restrict__ o_src,
-                                                           int64_t ldo_in, float* __restrict__ wo_src, int64_t ldo) {
+                                                           int64_t ldo_in, float* __restrict__ wo_src, int64_t ldo,
+                                                           float* __restrict__ stats /* [B][4][N] or NULL: rows 0,1 = row max, row sum */) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= N) return;
@@ -183,13 +184,17 @@ __global__ __launch_bounds__(256) void overlap_rows_kernel(const float* __restri
     }
     se = wave_sum(se);
     so = wave_sum(so);
-    if (lane == 0) wo_src[((int64_t)b * N + m) * ldo] = so / se;
+    if (lane == 0) {
+        wo_src[((int64_t)b * N + m) * ldo] = so / se;
+        if (stats) { stats[((int64_t)b * 4 + 0) * N + m] = mx; stats[((int64_t)b * 4 + 1) * N + m] = se; }
+    }
 }
 
 // ---------------------------------------------------------------- overlap block, column direction
 //   wo_tgt[b][n] = sum_m softmax_m(S[b][:][n])[m] * o_tgt[b][m]; block = 64 columns x 4 row lanes, online softmax
 __global__ __launch_bounds__(256) void overlap_cols_kernel(const float* __restrict__ S, int N, const float* __restrict__ o_tgt,
-                                                           int64_t ldo_in, float* __restrict__ wo_tgt, int64_t ldo) {
+                                                           int64_t ldo_in, float* __restrict__ wo_tgt, int64_t ldo,
+                                                           float* __restrict__ stats /* rows 2,3 = column max, column sum */) {
     __shared__ float sm[4][64], ss[4][64], st[4][64];
     const int b = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + cl;
@@ -224,7 +229,51 @@ __global__ __launch_bounds__(256) void overlap_cols_kernel(const float* __restri
             T = fmaf(st[i][cl], r, T);
         }
         wo_tgt[((int64_t)b * N + n) * ldo] = T / E;
+        if (stats) { stats[((int64_t)b * 4 + 2) * N + n] = M; stats[((int64_t)b * 4 + 3) * N + n] = E; }
     }
+}
+
+// ---------------------------------------------------------------- overlap block, backward (training)
+// With P1 = softmax_n(S[m][:]) and P2 = softmax_m(S[:][n]) rebuilt from the saved row / column max and sum:
+//   dS[m][n]   = P1 a[m] (o_src[n] - wo_src[m]) + P2 b[n] (o_tgt[m] - wo_tgt[n]),   a = dL/dwo_src, b = dL/dwo_tgt
+//   g_osrc[n] += sum_m a[m] P1[m][n]      (o_src is indexed along the tgt axis, models/gmmreg.py:79)
+//   g_otgt[m]  = sum_n b[n] P2[m][n]
+// One pass over S; a block owns ROWS_B rows (one wave per row at a time), column sums go through LDS and one global atomic
+// per column and block.
+constexpr int OVB_ROWS = 32;
+__global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restrict__ S, int N, const float* __restrict__ o_src,
+                                                          const float* __restrict__ o_tgt, int64_t ldo_in, const float* __restrict__ wo_src,
+                                                          const float* __restrict__ wo_tgt, int64_t ldo, const float* __restrict__ stats,
+                                                          const float* __restrict__ g_wo_src, const float* __restrict__ g_wo_tgt, int64_t ldg,
+                                                          float* __restrict__ dS, float* __restrict__ g_osrc, float* __restrict__ g_otgt, int64_t ldgo) {
+    extern __shared__ float colacc[];                     // [N]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const float* __restrict__ st = stats + (int64_t)b * 4 * N;
+    for (int n = threadIdx.x; n < N; n += 256) colacc[n] = 0.0f;
+    __syncthreads();
+    const int m_hi = min(N, (int)(blockIdx.x + 1) * OVB_ROWS);
+    for (int m = blockIdx.x * OVB_ROWS + wave; m < m_hi; m += 4) {
+        const int64_t gm = (int64_t)b * N + m;
+        const float a = g_wo_src[gm * ldg], wos = wo_src[gm * ldo], rmax = st[m], rinv = 1.0f / st[N + m];
+        const float otm = o_tgt[gm * ldo_in];
+        const float* __restrict__ row = S + gm * N;
+        float* __restrict__ drow = dS + gm * N;
+        float dot = 0.0f;
+        for (int n = lane; n < N; n += 64) {
+            const int64_t gn = (int64_t)b * N + n;
+            const float s = row[n];
+            const float p1 = expf(s - rmax) * rinv;
+            const float p2 = expf(s - st[2 * N + n]) / st[3 * N + n];
+            const float bn = g_wo_tgt[gn * ldg];
+            drow[n] = p1 * a * (o_src[gn * ldo_in] - wos) + p2 * bn * (otm - wo_tgt[gn * ldo]);
+            dot = fmaf(bn, p2, dot);
+            atomicAdd(&colacc[n], a * p1);
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) g_otgt[gm * ldgo] = dot;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) atomicAdd(&g_osrc[((int64_t)b * N + n) * ldgo], colacc[n]);
 }
 
 }  // namespace
@@ -278,7 +327,30 @@ extern "C" int ogmm_overlap_cross(const float* S, int B, int N, const float* o_s
                                   float* wo_tgt, int64_t ldo, void* stream) {
     OGMM_REQUIRE(S && o_src && o_tgt && wo_src && wo_tgt && B > 0 && N > 0 && ldo_in >= 1 && ldo >= 1, "ogmm_overlap_cross: null pointer or empty input");
     hipStream_t s = ogmm::as_stream(stream);
-    hipLaunchKernelGGL(overlap_rows_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, S, N, o_src, ldo_in, wo_src, ldo);
-    hipLaunchKernelGGL(overlap_cols_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, S, N, o_tgt, ldo_in, wo_tgt, ldo);
+    hipLaunchKernelGGL(overlap_rows_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, S, N, o_src, ldo_in, wo_src, ldo, (float*)nullptr);
+    hipLaunchKernelGGL(overlap_cols_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, S, N, o_tgt, ldo_in, wo_tgt, ldo, (float*)nullptr);
     return ogmm::check_launch("ogmm_overlap_cross");
+}
+
+extern "C" int ogmm_overlap_cross_train(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in, float* wo_src,
+                                        float* wo_tgt, int64_t ldo, float* stats, void* stream) {
+    OGMM_REQUIRE(S && o_src && o_tgt && wo_src && wo_tgt && stats && B > 0 && N > 0 && ldo_in >= 1 && ldo >= 1, "ogmm_overlap_cross_train: null pointer or empty input");
+    hipStream_t s = ogmm::as_stream(stream);
+    hipLaunchKernelGGL(overlap_rows_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, S, N, o_src, ldo_in, wo_src, ldo, stats);
+    hipLaunchKernelGGL(overlap_cols_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, S, N, o_tgt, ldo_in, wo_tgt, ldo, stats);
+    return ogmm::check_launch("ogmm_overlap_cross_train");
+}
+
+extern "C" int ogmm_overlap_cross_bwd(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in, const float* wo_src,
+                                      const float* wo_tgt, int64_t ldo, const float* stats, const float* g_wo_src, const float* g_wo_tgt, int64_t ldg,
+                                      float* dS, float* g_o_src, float* g_o_tgt, int64_t ldgo, void* stream) {
+    OGMM_REQUIRE(S && o_src && o_tgt && wo_src && wo_tgt && stats && g_wo_src && g_wo_tgt && dS && g_o_src && g_o_tgt && B > 0 && N > 0,
+                 "ogmm_overlap_cross_bwd: null pointer or empty input");
+    OGMM_REQUIRE(ldgo == 1, "ogmm_overlap_cross_bwd: g_o_src / g_o_tgt must be dense [B][N] (zeroed here)");
+    OGMM_REQUIRE(N <= 16384, "ogmm_overlap_cross_bwd: N <= 16384 (column accumulators live in LDS)");
+    hipStream_t s = ogmm::as_stream(stream);
+    (void)hipMemsetAsync(g_o_src, 0, sizeof(float) * (size_t)B * N, s);
+    hipLaunchKernelGGL(overlap_bwd_kernel, dim3((N + OVB_ROWS - 1) / OVB_ROWS, B), dim3(256), (size_t)N * sizeof(float), s, S, N, o_src, o_tgt, ldo_in,
+                       wo_src, wo_tgt, ldo, stats, g_wo_src, g_wo_tgt, ldg, dS, g_o_src, g_o_tgt, ldgo);
+    return ogmm::check_launch("ogmm_overlap_cross_bwd");
 }

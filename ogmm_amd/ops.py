@@ -536,3 +536,35 @@ def l2norm_rows_bwd(x, g):
     dx = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
     _lib.call("ogmm_l2norm_rows_bwd", _p(_f32(x, "x")), x.stride(0), _p(_f32(g, "g")), g.stride(0), x.shape[0], x.shape[1], _p(dx), dx.stride(0), _stream())
     return dx
+
+
+def similarity(fn, B, N, split=True, overflow=None):
+    """S[b] = fn_src[b] fn_tgt[b]^T for the stacked, channel-normalised map fn [(2B*N), D] -> [B,N,N]  (models/gmmreg.py:75)"""
+    D = fn.shape[1]
+    S = torch.empty((B, N, N), dtype=torch.float32, device=fn.device)
+    if split and D % 64 == 0:
+        img = pack_frag_batched(fn[B * N:], B, N)
+        gemm_nt(fn, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=img, overflow=overflow)
+    else:
+        gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
+    return S
+
+
+def overlap_cross_train(S, ol):
+    """ol [(2B*N), 1] logits -> (wo [(2B*N), 1], stats [B,4,N])"""
+    B, N, _ = S.shape
+    wo = torch.empty((2 * B * N, 1), dtype=torch.float32, device=S.device)
+    stats = torch.empty((B, 4, N), dtype=torch.float32, device=S.device)
+    _lib.call("ogmm_overlap_cross_train", _p(_f32(S, "S")), B, N, _p(_f32(ol, "ol")), _p(ol[B * N:]), 1, _p(wo), _p(wo[B * N:]), 1, _p(stats), _stream())
+    return wo, stats
+
+
+def overlap_cross_bwd(S, ol, wo, stats, g_wo):
+    """-> (dS [B,N,N], g_ol [(2B*N), 1])"""
+    B, N, _ = S.shape
+    dS = torch.empty_like(S)
+    g_ol = torch.empty((2 * B * N, 1), dtype=torch.float32, device=S.device)
+    g_wo = _f32(g_wo, "g_wo").contiguous()
+    _lib.call("ogmm_overlap_cross_bwd", _p(S), B, N, _p(ol), _p(ol[B * N:]), 1, _p(wo), _p(wo[B * N:]), 1, _p(stats), _p(g_wo), _p(g_wo[B * N:]), 1,
+              _p(dS), _p(g_ol), _p(g_ol[B * N:]), 1, _stream())
+    return dS, g_ol

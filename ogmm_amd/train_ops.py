@@ -157,6 +157,29 @@ class _FeatMean(torch.autograd.Function):
         return None, None, df.reshape(-1, dmu.shape[2]), None, None
 
 
+class _OverlapCross(torch.autograd.Function):
+    """models/gmmreg.py:75-80: N x N similarity on the GEMM engine, row / column softmax-dots (kernels K13 + T8); backward: one
+    pass over S gives dS and the logit gradients, dL/dfn = (dS fn_tgt, dS^T fn_src) are two batched library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, fn, ol, B, N, precision, overflow):
+        fn, ol = fn.contiguous(), ol.contiguous()
+        S = ops.similarity(fn, B, N, split=precision == "f16x3", overflow=overflow)
+        wo, stats = ops.overlap_cross_train(S, ol)
+        ctx.save_for_backward(S, fn, ol, wo, stats)
+        ctx.B, ctx.N = B, N
+        return wo
+
+    @staticmethod
+    def backward(ctx, g_wo):
+        S, fn, ol, wo, stats = ctx.saved_tensors
+        B, N = ctx.B, ctx.N
+        dS, g_ol = ops.overlap_cross_bwd(S, ol, wo, stats, g_wo)
+        fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
+        g_fn = torch.cat([torch.bmm(dS, ft), torch.bmm(dS.transpose(1, 2), fs)], dim=0).view(2 * B * N, -1)
+        return g_fn, g_ol, None, None, None, None
+
+
 class _Kabsch(torch.autograd.Function):
     """lib/se3.py:256-289 on the fp64 in-register 3x3 solver (ogmm_kabsch) with its closed-form backward (ogmm_kabsch_bwd).
     Tensors in the kernels' layout: src, corr [B,3,J], w [B,J]."""
@@ -263,12 +286,7 @@ class TrainOps:
         """models/gmmreg.py:75-80, literally: with S[b,m,n] = <fn_src[b,m], fn_tgt[b,n]>,
         wo_src[b,m] = sum_n softmax_n(S[b,m,:])[n] * ol_src[b,n]   (the src logits indexed along the tgt axis) and
         wo_tgt[b,n] = sum_m softmax_m(S[b,:,n])[m] * ol_tgt[b,m].   fn [2B*N, D], ol [2B*N, 1] -> [2B*N, 1]"""
-        fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
-        S = fs @ ft.transpose(1, 2)
-        os_, ot = ol[:B * N].view(B, N), ol[B * N:].view(B, N)
-        wo_s = (torch.softmax(S, dim=2) * os_[:, None, :]).sum(dim=2)
-        wo_t = (torch.softmax(S, dim=1) * ot[:, :, None]).sum(dim=1)
-        return torch.cat([wo_s.reshape(B * N, 1), wo_t.reshape(B * N, 1)], dim=0)
+        return _OverlapCross.apply(fn, ol, B, N, self.precision, self.overflow)
 
     # ------------------------------------------------------------------ GMM head
     def gmm_feat_mean(self, gamma, pi, f, C, N):

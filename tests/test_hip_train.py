@@ -146,6 +146,25 @@ def test_small_ops_match_reference():
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("B,N,D", [(2, 512, 512), (3, 200, 128), (1, 1024, 512)])
+def test_overlap_cross_forward_backward(precision, B, N, D):
+    g = torch.Generator().manual_seed(B * N)
+    fn = torch.nn.functional.normalize(torch.randn(2 * B * N, D, generator=g), dim=1).to(DEV).requires_grad_(True)
+    ol = torch.randn(2 * B * N, 1, generator=g).to(DEV).requires_grad_(True)
+    up = torch.randn(2 * B * N, 1, generator=g).to(DEV)
+    res = {}
+    for tag, o in (("hip", TrainOps(precision)), ("ref", RefTrainOps())):
+        fn.grad = ol.grad = None
+        dt = torch.float64 if tag == "ref" else torch.float32
+        a, b_ = fn.to(dt), ol.to(dt)
+        wo = o.overlap_cross(a, b_, B, N)
+        wo.backward(up.to(dt))
+        res[tag] = (wo.detach(), fn.grad.clone(), ol.grad.clone())
+    for a, r in zip(res["hip"], res["ref"]):
+        assert _rel(a, r) < 5e-6, _rel(a, r)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_training_step_matches_reference(name, precision):
     fx, cfg, (B, N, J, D, top_k) = load_train_case(name)

@@ -65,6 +65,14 @@ class RefTrainOps(TrainOps):
     def l2norm_rows(self, f):
         return F.normalize(f, dim=1)
 
+    def overlap_cross(self, fn, ol, B, N):
+        fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
+        S = fs @ ft.transpose(1, 2)
+        os_, ot = ol[:B * N].view(B, N), ol[B * N:].view(B, N)
+        wo_s = (torch.softmax(S, dim=2) * os_[:, None, :]).sum(dim=2)
+        wo_t = (torch.softmax(S, dim=1) * ot[:, :, None]).sum(dim=1)
+        return torch.cat([wo_s.reshape(B * N, 1), wo_t.reshape(B * N, 1)], dim=0)
+
     def gmm_feat_mean(self, gamma, pi, f, C, N):
         return gamma.transpose(1, 2) @ f.view(C, N, -1) / (pi * N + 1e-5)[:, :, None]
 
