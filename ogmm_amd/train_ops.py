@@ -157,6 +157,37 @@ class _FeatMean(torch.autograd.Function):
         return None, None, df.reshape(-1, dmu.shape[2]), None, None
 
 
+def _attention_torch(q, k, v, C, N, M, H):
+    D = q.shape[1]
+    dh = D // H
+    qh = q.view(C, N, H, dh).transpose(1, 2)
+    kh = k.view(C, M, H, dh).transpose(1, 2)
+    vh = v.view(C, M, H, dh).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(2, 3) / dh ** .5, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(C * N, D)
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) v (models/attn.py:78-82): forward on the fused attention kernel (scores never reach HBM);
+    backward re-forms the scores with batched library GEMMs + softmax and differentiates them (no hand-written backward
+    kernel yet)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, C, N, M, H):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        ctx.save_for_backward(q, k, v)
+        ctx.dims = (C, N, M, H)
+        return ops.attention(q, k, v, C, N, M, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v = (t_.detach().requires_grad_(True) for t_ in ctx.saved_tensors)
+        with torch.enable_grad():
+            o = _attention_torch(q, k, v, *ctx.dims)
+        gq, gk, gv = torch.autograd.grad(o, (q, k, v), g)
+        return gq, gk, gv, None, None, None, None
+
+
 class _OverlapCross(torch.autograd.Function):
     """models/gmmreg.py:75-80: N x N similarity on the GEMM engine, row / column softmax-dots (kernels K13 + T8); backward: one
     pass over S gives dS and the logit gradients, dL/dfn = (dS fn_tgt, dS^T fn_src) are two batched library GEMMs."""
@@ -271,13 +302,9 @@ class TrainOps:
 
     def attention(self, q, k, v, C, N, M, H):
         """softmax(q k^T / sqrt(dh)) v per cloud and head; head-major channels.  q [C*N,D], k, v [C*M,D] -> [C*N,D]"""
-        D = q.shape[1]
-        dh = D // H
-        qh = q.view(C, N, H, dh).transpose(1, 2)
-        kh = k.view(C, M, H, dh).transpose(1, 2)
-        vh = v.view(C, M, H, dh).transpose(1, 2)
-        p = torch.softmax(qh @ kh.transpose(2, 3) / dh ** .5, dim=-1)
-        return (p @ vh).transpose(1, 2).reshape(C * N, D)
+        if ops.attention_supported(M, q.shape[1] // H):
+            return _Attention.apply(q, k, v, C, N, M, H)
+        return _attention_torch(q, k, v, C, N, M, H)
 
     def l2norm_rows(self, f):
         return _L2Norm.apply(f)

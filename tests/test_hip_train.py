@@ -145,6 +145,25 @@ def test_small_ops_match_reference():
     assert _rel(res[0][0], res[1][0]) < 2e-6 and _rel(res[0][1], res[1][1]) < 2e-6
 
 
+@pytest.mark.parametrize("C,N,M", [(4, 512, 128), (2, 300, 32)])
+def test_attention_forward_backward(C, N, M):
+    H, D = 4, 512
+    g = torch.Generator().manual_seed(C * N)
+    q = torch.randn(C * N, D, generator=g).to(DEV).requires_grad_(True)
+    k = torch.randn(C * M, D, generator=g).to(DEV).requires_grad_(True)
+    v = torch.randn(C * M, D, generator=g).to(DEV).requires_grad_(True)
+    up = torch.randn(C * N, D, generator=g).to(DEV)
+    res = {}
+    for tag, o in (("hip", TrainOps()), ("ref", RefTrainOps())):
+        q.grad = k.grad = v.grad = None
+        dt = torch.float64 if tag == "ref" else torch.float32
+        out = o.attention(q.to(dt), k.to(dt), v.to(dt), C, N, M, H)
+        out.backward(up.to(dt))
+        res[tag] = (out.detach(), q.grad.clone(), k.grad.clone(), v.grad.clone())
+    for a, r in zip(res["hip"], res["ref"]):
+        assert _rel(a, r) < 1e-5, _rel(a, r)
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("B,N,D", [(2, 512, 512), (3, 200, 128), (1, 1024, 512)])
 def test_overlap_cross_forward_backward(precision, B, N, D):

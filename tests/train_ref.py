@@ -65,6 +65,15 @@ class RefTrainOps(TrainOps):
     def l2norm_rows(self, f):
         return F.normalize(f, dim=1)
 
+    def attention(self, q, k, v, C, N, M, H):
+        D = q.shape[1]
+        dh = D // H
+        qh = q.view(C, N, H, dh).transpose(1, 2)
+        kh = k.view(C, M, H, dh).transpose(1, 2)
+        vh = v.view(C, M, H, dh).transpose(1, 2)
+        p = torch.softmax(qh @ kh.transpose(2, 3) / dh ** .5, dim=-1)
+        return (p @ vh).transpose(1, 2).reshape(C * N, D)
+
     def overlap_cross(self, fn, ol, B, N):
         fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
         S = fs @ ft.transpose(1, 2)
