@@ -216,6 +216,10 @@ int ogmm_icp_point_to_point(const float* src, const float* tgt, int B, int N, in
  * take over lib/metric.py:193-194's [B][Na][Nb] matrix (chamfer / clipped chamfer / source error, lib/metric.py:221-236). */
 int ogmm_min_sqdist(const float* a /*[B][Na][3]*/, const float* b /*[B][Nb][3]*/, int B, int Na, int Nb, float* out /*[B][Na]*/, void* stream);
 
+/* ---- K22: R = V diag(1, 1, det(V U^T)) U^T for M = U S V^T, M [B][3][3] (NaN -> 0): the SVD step of the DeepGMR
+ * baseline's `gmm_register` (baseline/deepgmr.py:28-34), fp64 Jacobi in registers like K18. */
+int ogmm_rotation_from_cov(const float* M, int B, float* R, void* stream);
+
 /* =====================================================================================================
  * Training mode (`model.train()`): forward kernels that differ from eval, and the backward kernels.
  * The reference has no hand-written backward: autograd differentiates the model files; each entry cites the

@@ -444,6 +444,16 @@ __global__ void kabsch_kernel(const float* __restrict__ src, const float* __rest
                  [&](int n) { return (double)ww[n]; }, R + (int64_t)b * 9, t + (int64_t)b * 3);
 }
 
+// proper rotation of a given 3x3 cross-covariance (DeepGMR's gmm_register, baseline/deepgmr.py:28-34): R = V diag(1,1,det(V U^T)) U^T
+__global__ void rotation_from_cov_kernel(const float* __restrict__ M, int B, float* __restrict__ R) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double cov[3][3], Rd[3][3];
+    for (int i = 0; i < 9; ++i) { const float v = M[(int64_t)b * 9 + i]; cov[i / 3][i % 3] = (v != v) ? 0.0 : (double)v; }
+    rotation_from_cov(cov, Rd);
+    for (int i = 0; i < 9; ++i) R[(int64_t)b * 9 + i] = (float)Rd[i / 3][i % 3];
+}
+
 // ================================================================================================
 // Backward of K18 (training): gradients of a loss w.r.t. src, corr, w given dL/dR, dL/dt.  One lane per pair, fp64.
 //   H = cov = U S V^T,  R = V D U^T,  D = diag(1,1,d),  t = cc - R cs.
@@ -786,4 +796,10 @@ extern "C" int ogmm_nearest_point(const float* xyz, const float* mu, int C, int 
     OGMM_REQUIRE(xyz && mu && near && C > 0 && N > 0 && J > 0, "ogmm_nearest_point: null pointer or empty input");
     hipLaunchKernelGGL(nearest_point_kernel, dim3(J, C), dim3(256), 0, ogmm::as_stream(stream), xyz, mu, N, J, near);
     return ogmm::check_launch("ogmm_nearest_point");
+}
+
+extern "C" int ogmm_rotation_from_cov(const float* M, int B, float* R, void* stream) {
+    OGMM_REQUIRE(M && R && B > 0, "ogmm_rotation_from_cov: null pointer or empty input");
+    hipLaunchKernelGGL(rotation_from_cov_kernel, dim3((B + 63) / 64), dim3(64), 0, ogmm::as_stream(stream), M, B, R);
+    return ogmm::check_launch("ogmm_rotation_from_cov");
 }

@@ -102,7 +102,8 @@ def _default_init(module, spec):
                 bound = 1.0 / math.sqrt(max(1, int(torch.tensor(w_shape[1:]).prod())))
                 p.uniform_(-bound, bound)
         for name in ("sattn1", "cattn", "sattn2"):
-            sd[name + ".mlp.3.bias"].zero_()
+            if name + ".mlp.3.bias" in sd:
+                sd[name + ".mlp.3.bias"].zero_()
 
 
 # ------------------------------------------------------------------------------------------ weight packing

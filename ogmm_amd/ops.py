@@ -408,6 +408,14 @@ def icp_point_to_point(src, tgt, R0, t0, max_corr_dist, max_iter=30, rel_fitness
     return (R, t, fit, rmse, iters) if want_stats else (R, t)
 
 
+def rotation_from_cov(M):
+    """M [B,3,3] -> R = V diag(1,1,det(V U^T)) U^T of its SVD (baseline/deepgmr.py:28-34)"""
+    M = _f32(M, "M").contiguous()
+    R = torch.empty_like(M)
+    _lib.call("ogmm_rotation_from_cov", _p(M), M.shape[0], _p(R), _stream())
+    return R
+
+
 def min_sqdist(a, b):
     """a [B,Na,3], b [B,Nb,3] -> [B,Na] squared distance to the nearest point of b (lib/metric.py:193-194 + min)"""
     a, b = _f32(a, "a").contiguous(), _f32(b, "b").contiguous()
