@@ -25,9 +25,15 @@ def _b(P, key):
     return P.get(key + ".bias")
 
 
-def _bn(ops, P, name, y, act, rows_per_point=1):
+def _bn(ops, P, name, y, act, stats=None):
     return ops.batchnorm_act(y, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"], P[name + ".running_var"],
-                             P[name + ".num_batches_tracked"], GROUPS, act)
+                             P[name + ".num_batches_tracked"], GROUPS, act, stats=stats)
+
+
+def _conv_bn(ops, P, conv, bn, x, act, x2=None):
+    """1x1 conv -> train-mode BatchNorm -> activation; the conv also delivers the column sums the BatchNorm needs"""
+    y, st = ops.linear_stats(x, _w(P, conv), _b(P, conv), x2=x2, groups=GROUPS)
+    return _bn(ops, P, bn, y, act, st)
 
 
 def dgcnn(ops, P, xyz, idx):
@@ -36,21 +42,20 @@ def dgcnn(ops, P, xyz, idx):
     h = ops.edge_features(xyz, idx)                                   # [C*N*k, 6], constant
     pooled = []
     for l in (1, 2, 3, 4):
-        y = ops.linear(h, _w(P, "emd.conv%d" % l), None)
-        h = _bn(ops, P, "emd.bn%d" % l, y, "relu")
+        h = _conv_bn(ops, P, "emd.conv%d" % l, "emd.bn%d" % l, h, "relu")
         pooled.append(ops.maxpool_k(h, k))                               # max over the k edges of a point, after the ReLU
     xcat = torch.cat(pooled, dim=1)
-    return _bn(ops, P, "emd.bn5", ops.linear(xcat, _w(P, "emd.conv5"), None), "relu")
+    return _conv_bn(ops, P, "emd.conv5", "emd.bn5", xcat, "relu")
 
 
 def pos_encoding(ops, P, xyz, idx5):
     """models/attn.py:59-75 (`pos.conv` is never applied).  -> [C*N, D]"""
     d2, alpha = ops.pos_features(xyz, idx5)                              # [C*N, 1], [C*N*5, 1]: constants of the input
-    h = _bn(ops, P, "pos.conv_dis.1", ops.linear(d2, _w(P, "pos.conv_dis.0"), None), "leaky")
-    dis = _bn(ops, P, "pos.conv_dis.4", ops.linear(h, _w(P, "pos.conv_dis.3"), None), "leaky")
-    a = _bn(ops, P, "pos.conv_ang1.1", ops.linear(alpha, _w(P, "pos.conv_ang1.0"), None), "leaky")
+    h = _conv_bn(ops, P, "pos.conv_dis.0", "pos.conv_dis.1", d2, "leaky")
+    dis = _conv_bn(ops, P, "pos.conv_dis.3", "pos.conv_dis.4", h, "leaky")
+    a = _conv_bn(ops, P, "pos.conv_ang1.0", "pos.conv_ang1.1", alpha, "leaky")
     a = ops.maxpool_k(a, idx5.shape[2])
-    ang = _bn(ops, P, "pos.conv_ang2.1", ops.linear(a, _w(P, "pos.conv_ang2.0"), None), "leaky")
+    ang = _conv_bn(ops, P, "pos.conv_ang2.0", "pos.conv_ang2.1", a, "leaky")
     return torch.cat([dis, ang], dim=1)
 
 
@@ -67,17 +72,17 @@ def transformer(ops, P, name, x, anchors, C, N, M, H):
     vv = ops.linear(anchors, _w(P, name + ".attn.proj.2")[perm], _b(P, name + ".attn.proj.2")[perm])
     o = ops.attention(q, kk, vv, C, N, M, H)
     msg = ops.linear(o, _w(P, name + ".attn.merge")[:, perm], _b(P, name + ".attn.merge"))
-    z = ops.linear(x, _w(P, name + ".mlp.0"), _b(P, name + ".mlp.0"), x2=msg)
-    z = ops.instnorm_relu(z, C, N)
+    z, st = ops.linear_stats(x, _w(P, name + ".mlp.0"), _b(P, name + ".mlp.0"), x2=msg, groups=C)
+    z = ops.instnorm_relu(z, C, N, stats=st)
     return ops.linear(z, _w(P, name + ".mlp.3"), _b(P, name + ".mlp.3"))
 
 
 def conv_stack(ops, P, name, x, three, x2=None):
     """models/dgcnn.py:16-38"""
-    h = _bn(ops, P, name + ".net.1", ops.linear(x, _w(P, name + ".net.0"), _b(P, name + ".net.0"), x2=x2), "relu")
+    h = _conv_bn(ops, P, name + ".net.0", name + ".net.1", x, "relu", x2=x2)
     if not three:
         return ops.linear(h, _w(P, name + ".net.3"), _b(P, name + ".net.3"))
-    h = _bn(ops, P, name + ".net.4", ops.linear(h, _w(P, name + ".net.3"), _b(P, name + ".net.3")), "relu")
+    h = _conv_bn(ops, P, name + ".net.3", name + ".net.4", h, "relu")
     return ops.linear(h, _w(P, name + ".net.6"), _b(P, name + ".net.6"))
 
 

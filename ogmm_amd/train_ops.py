@@ -24,9 +24,10 @@ class _NormAct(torch.autograd.Function):
     Also returns the fp64 group means / biased variances for the running-statistics update."""
 
     @staticmethod
-    def forward(ctx, y, weight, bias, group_rows, act):
+    def forward(ctx, y, weight, bias, group_rows, act, st=None):
         y = y.contiguous()
-        st = ops.colstats(y, group_rows)
+        if st is None:                     # otherwise: column sums that the producing GEMM's epilogue already accumulated
+            st = ops.colstats(y, group_rows)
         mean64 = st[..., 0] / group_rows
         var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
         rstd64 = torch.rsqrt(var64 + BN_EPS)
@@ -45,8 +46,8 @@ class _NormAct(torch.autograd.Function):
         y, scale, shift, mean, rstd = ctx.saved_tensors
         dy, sums = ops.norm_bwd(y, dh.contiguous(), ctx.group_rows, scale, shift, mean, rstd, ctx.act)
         if not ctx.affine:
-            return dy, None, None, None, None
-        return dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float(), None, None
+            return dy, None, None, None, None, None
+        return dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float(), None, None, None
 
 
 class _MaxPoolK(torch.autograd.Function):
@@ -72,7 +73,7 @@ class _Linear(torch.autograd.Function):
     column sum."""
 
     @staticmethod
-    def forward(ctx, x, x2, W, b, precision, overflow):
+    def forward(ctx, x, x2, W, b, precision, overflow, stats_rows=0):
         K1 = x.shape[1]
         K2 = 0 if x2 is None else x2.shape[1]
         Wd = W.detach()
@@ -87,14 +88,25 @@ class _Linear(torch.autograd.Function):
             layer["shift"] = b.detach().contiguous()
         if precision == "f16x3":
             layer["split"] = ops.split_f16(layer["W"], frag=True, k1=K1)
+        stats = None
+        if stats_rows and precision == "f16x3" and stats_rows % 256 == 0 and W.shape[0] % 4 == 0 and stats_rows <= 131072:
+            # the normalisation that follows needs sum / sum of squares per (row group, column): the engine's epilogue adds them up
+            # (one fp64 atomic per tile and column: fine for <= 512 row tiles per group, measured 12x slower than a separate
+            # pass on the 2.6 M-row per-edge maps, whose 5120 tiles per group all hit the same few addresses)
+            stats = torch.zeros((x.shape[0] // stats_rows, W.shape[0], 2), dtype=torch.float64, device=x.device)
         y = ops.conv1x1(x.contiguous(), layer, ops.ACT_NONE, x2=None if x2p is None else x2p.contiguous(),
-                        split=precision == "f16x3", overflow=overflow)
+                        split=precision == "f16x3", overflow=overflow, col_stats=stats, group_rows=stats_rows if stats is not None else 0)
         ctx.save_for_backward(x, x2, W)
         ctx.has_bias, ctx.precision, ctx.overflow = b is not None, precision, overflow
+        if stats_rows:
+            if stats is None:
+                stats = ops.colstats(y, stats_rows)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, x2, W = ctx.saved_tensors
         K1 = x.shape[1]
         dx = dx2 = dW = db = None
@@ -122,7 +134,7 @@ class _Linear(torch.autograd.Function):
                 dW = dyt @ x if x2 is None else torch.cat([dyt @ x, dyt @ x2], dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = dy.sum(dim=0)
-        return dx, dx2, dW, db, None, None
+        return dx, dx2, dW, db, None, None, None
 
 
 class _L2Norm(torch.autograd.Function):
@@ -272,11 +284,21 @@ class TrainOps:
             return y if b is None else y + b
         return _Linear.apply(x, x2, W, b, self.precision, self.overflow)
 
-    def batchnorm_act(self, y, weight, bias, running_mean, running_var, num_batches, groups, act):
+    def linear_stats(self, x, W, b, x2=None, groups=1):
+        """linear() for a layer that feeds a normalisation over `groups` equal row blocks: also returns the fp64 column sums
+        [groups, Cout, 2] = {sum, sum of squares} (accumulated by the GEMM epilogue when the shape allows it)."""
+        K1, Cout = x.shape[1], W.shape[0]
+        rows = x.shape[0] // groups
+        if K1 < 32 or Cout < 32 or (K1 % 64 and x2 is not None):
+            y = self.linear(x, W, b, x2)
+            return y, ops.colstats(y.contiguous(), rows)
+        return _Linear.apply(x, x2, W, b, self.precision, self.overflow, rows)
+
+    def batchnorm_act(self, y, weight, bias, running_mean, running_var, num_batches, groups, act, stats=None):
         """Train-mode BatchNorm over each of the `groups` equal row blocks of y (one block per call of the reference's
         shared layer), then ReLU or LeakyReLU(0.2).  Running statistics are updated in place, block 0 first."""
         n = y.shape[0] // groups
-        h, mean64, var64 = _NormAct.apply(y, weight, bias, n, _ACT[act])
+        h, mean64, var64 = _NormAct.apply(y, weight, bias, n, _ACT[act], stats)
         with torch.no_grad():
             unbiased = var64 * (n / max(n - 1, 1))
             for g in range(groups):
@@ -285,9 +307,9 @@ class TrainOps:
             num_batches += groups
         return h
 
-    def instnorm_relu(self, z, C, N):
+    def instnorm_relu(self, z, C, N, stats=None):
         """InstanceNorm1d (no affine, biased variance, eps 1e-5) over the N points of each cloud, then ReLU"""
-        return _NormAct.apply(z, None, None, N, ops.ACT_RELU)[0]
+        return _NormAct.apply(z, None, None, N, ops.ACT_RELU, stats)[0]
 
     def maxpool_k(self, h, k):
         """max over the k consecutive rows of each point: [P*k, c] -> [P, c]"""

@@ -27,7 +27,10 @@ class RefTrainOps(TrainOps):
         y = x @ W.t()
         return y if b is None else y + b
 
-    def batchnorm_act(self, y, weight, bias, running_mean, running_var, num_batches, groups, act):
+    def linear_stats(self, x, W, b, x2=None, groups=1):
+        return self.linear(x, W, b, x2), None
+
+    def batchnorm_act(self, y, weight, bias, running_mean, running_var, num_batches, groups, act, stats=None):
         n = y.shape[0] // groups
         outs = []
         for g in range(groups):                       # one F.batch_norm call per call of the reference's shared layer, src first
@@ -37,7 +40,7 @@ class RefTrainOps(TrainOps):
         h = torch.cat(outs, dim=0)
         return F.relu(h) if act == "relu" else F.leaky_relu(h, 0.2)
 
-    def instnorm_relu(self, z, C, N):
+    def instnorm_relu(self, z, C, N, stats=None):
         zc = z.view(C, N, -1).transpose(1, 2)
         return F.relu(F.instance_norm(zc, eps=1e-5)).transpose(1, 2).reshape(C * N, -1)
 
