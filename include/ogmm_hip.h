@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 5
+#define OGMM_ABI_VERSION 6
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -239,12 +239,20 @@ int ogmm_rotation_from_cov(const float* M, int B, float* R, void* stream);
 int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, double* stats /*[G][cols][2]*/, void* stream);
 int ogmm_affine_act(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, const float* scale /*[G][cols]*/,
                     const float* shift, int act, float* y, int64_t ldy, void* stream);
-int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+/* Upstream gradient of the two backward kernels: dy (dense, may be NULL) plus, for a map that was max-pooled over the k rows of a
+ * point, the gradient of the pooled map dpool [rows/k][cols] routed to the winning row arg [rows/k][cols] (NULL = none).
+ * ogmm_affine_act_pool is the matching forward: y = act(x*scale + shift) (y may be NULL when only the pooled map is used) and
+ * pooled[p][c] = max_j y[p*k + j][c] with the first maximising j in arg; group_points = group_rows / k. */
+int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* dpool, int64_t ldp, const uint8_t* arg, int k,
+                         int64_t rows, int cols, int64_t group_rows,
                          const float* scale /*[G][cols]*/, const float* shift, const float* mean, const float* rstd, int act,
                          double* sums /*[G][cols][2]*/, void* stream);
-int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* dpool, int64_t ldp, const uint8_t* arg, int k,
+                        int64_t rows, int cols, int64_t group_rows,
                         const float* scale, const float* shift, const float* mean, const float* rstd, int act, const double* sums,
                         float* dx, int64_t lddx, void* stream);
+int ogmm_affine_act_pool(const float* x, int64_t ldx, int64_t points, int k, int cols, int64_t group_points, const float* scale, const float* shift,
+                         int act, float* y, int64_t ldy, float* pooled, int64_t ldp, uint8_t* arg, void* stream);
 
 /* ---- T2: max over the k edges of a point on an un-fused per-edge map (models/dgcnn.py:139,142,145,148; models/attn.py:72):
  * out[p][c] = max_j h[p*k + j][c], arg[p][c] = first maximising j; backward routes dout to that edge and writes zeros elsewhere. */

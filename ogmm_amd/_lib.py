@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG = 0, 1, 2
@@ -68,9 +68,12 @@ PROTOTYPES = {
     # training mode
     "ogmm_colstats": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p],
     "ogmm_affine_act": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
-    "ogmm_norm_bwd_reduce": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
-    "ogmm_norm_bwd_apply": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                            c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_norm_bwd_reduce": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int64,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "ogmm_norm_bwd_apply": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int64,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_affine_act_pool": [c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                             c_void_p, c_void_p],
     "ogmm_maxpool_k": [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_maxpool_k_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_overlap_cross_train": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],

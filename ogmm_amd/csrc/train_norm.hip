@@ -99,10 +99,70 @@ __global__ __launch_bounds__(256) void affine_act_v4_kernel(const float* __restr
     }
 }
 
+// Upstream gradient of one element of a normalised map: the dense part dy (may be absent) plus, for maps that were max-pooled
+// over the k rows of a point (EdgeConv, models/dgcnn.py:139-148), the pooled gradient routed to the winning row (`arg`).
+struct Routed {
+    const float* dy; int64_t lddy;          // dense upstream gradient or NULL
+    const float* dpool; int64_t ldp;        // [points][cols] gradient of the pooled map or NULL
+    const uint8_t* arg; int k; int cols;    // winning row per (point, column)
+};
+__device__ __forceinline__ float4 routed_load4(const Routed& u, int64_t r, int col) {
+    float4 v = u.dy ? *reinterpret_cast<const float4*>(u.dy + r * u.lddy + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u.dpool) {
+        const int64_t p = r / u.k;
+        const int j = (int)(r - p * u.k);
+        const uchar4 a = *reinterpret_cast<const uchar4*>(u.arg + p * u.cols + col);
+        const float4 g = *reinterpret_cast<const float4*>(u.dpool + p * u.ldp + col);
+        v.x += a.x == j ? g.x : 0.f; v.y += a.y == j ? g.y : 0.f; v.z += a.z == j ? g.z : 0.f; v.w += a.w == j ? g.w : 0.f;
+    }
+    return v;
+}
+__device__ __forceinline__ float routed_load1(const Routed& u, int64_t r, int col) {
+    float v = u.dy ? u.dy[r * u.lddy + col] : 0.f;
+    if (u.dpool) {
+        const int64_t p = r / u.k;
+        if (u.arg[p * u.cols + col] == (int)(r - p * u.k)) v += u.dpool[p * u.ldp + col];
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------- y = act(x * scale + shift) (optional) and its max over the k rows of a point
+// One lane owns (point, 4 columns) and walks the point's k rows: the normalised per-edge map is written only if a later layer
+// reads it (the last EdgeConv layer and the positional angle branch only use the pooled map).
+template <int CV>
+__global__ __launch_bounds__(256) void affine_act_pool_v4_kernel(const float* __restrict__ x, int64_t ldx, int64_t points, int k, int cols,
+                                                                 int64_t group_points, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 int act, float* __restrict__ y, int64_t ldy, float* __restrict__ pooled, int64_t ldp,
+                                                                 uint8_t* __restrict__ arg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane % CV, pl = wave * Map<CV>::rows_per_wave + lane / CV;
+    const int col = (blockIdx.y * CV + cl) * 4;
+    if (col >= cols) return;
+    const int64_t p0 = (int64_t)blockIdx.x * 16, p1 = min(p0 + 16, points);
+    for (int64_t p = p0 + pl; p < p1; p += Map<CV>::rows_per_pass) {
+        const int64_t gc = (p / group_points) * cols + col;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + gc), sh = *reinterpret_cast<const float4*>(shift + gc);
+        float best[4];
+        int bj[4] = {0, 0, 0, 0};
+        for (int j = 0; j < k; ++j) {
+            const int64_t r = p * k + j;
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + col);
+            const float o[4] = {act_fwd(fmaf(v.x, sc.x, sh.x), act), act_fwd(fmaf(v.y, sc.y, sh.y), act),
+                                act_fwd(fmaf(v.z, sc.z, sh.z), act), act_fwd(fmaf(v.w, sc.w, sh.w), act)};
+            if (y) *reinterpret_cast<float4*>(y + r * ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j == 0 || o[e] > best[e]) { best[e] = o[e]; bj[e] = j; }          // first maximum wins, like torch.max
+        }
+        *reinterpret_cast<float4*>(pooled + p * ldp + col) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<uchar4*>(arg + p * cols + col) = make_uchar4((uint8_t)bj[0], (uint8_t)bj[1], (uint8_t)bj[2], (uint8_t)bj[3]);
+    }
+}
+
 // ---------------------------------------------------------------- backward reduction: sums[g][c] = {sum dz, sum dz * xhat}
 // The activation derivative comes from the recomputed pre-activation x * scale + shift (the stored output is not re-read).
 template <int CV>
-__global__ __launch_bounds__(256) void norm_bwd_reduce_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+__global__ __launch_bounds__(256) void norm_bwd_reduce_v4_kernel(const float* __restrict__ x, int64_t ldx, const Routed up,
                                                                  int cols, int64_t group_rows, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, int act, double* __restrict__ sums) {
@@ -121,7 +181,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_v4_kernel(const float* __
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
         for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
             const float4 xv4 = *reinterpret_cast<const float4*>(x + (gr + r) * ldx + col);
-            const float4 dv4 = *reinterpret_cast<const float4*>(dy + (gr + r) * lddy + col);
+            const float4 dv4 = routed_load4(up, gr + r, col);
             const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -153,7 +213,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_v4_kernel(const float* __
 
 // ---------------------------------------------------------------- dx = scale * (dz - S1/n - xhat * S2/n)
 template <int CV>
-__global__ __launch_bounds__(256) void norm_bwd_apply_v4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+__global__ __launch_bounds__(256) void norm_bwd_apply_v4_kernel(const float* __restrict__ x, int64_t ldx, const Routed up,
                                                                 int64_t rows, int cols, int64_t group_rows, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, int act, const double* __restrict__ sums,
@@ -170,7 +230,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_v4_kernel(const float* __r
         const float4 m = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc);
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
         const float4 xv4 = *reinterpret_cast<const float4*>(x + r * ldx + col);
-        const float4 dv4 = *reinterpret_cast<const float4*>(dy + r * lddy + col);
+        const float4 dv4 = routed_load4(up, r, col);
         const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
         float o[4];
 #pragma unroll
@@ -222,7 +282,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, int64_t ldx, const Routed up,
                                                               int cols, int64_t group_rows, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, double* __restrict__ sums) {
@@ -239,7 +299,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
         for (int64_t r = r0 + rl; r < r1; r += 4) {
             const int64_t rr = gr + r;
             const float xv = x[rr * ldx + col];
-            const float dz = dy[rr * lddy + col] * act_grad(fmaf(xv, sc, sh), act);
+            const float dz = routed_load1(up, rr, col) * act_grad(fmaf(xv, sc, sh), act);
             s1 += (double)dz;
             s2 += (double)dz * (double)((xv - m) * rs);
         }
@@ -253,7 +313,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     }
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const Routed up,
                                                              int64_t rows, int cols, int64_t group_rows, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int act, const double* __restrict__ sums,
@@ -267,7 +327,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
         const int64_t gc = (r / group_rows) * cols + col;
         const float m1 = (float)(sums[gc * 2] * inv_n), m2 = (float)(sums[gc * 2 + 1] * inv_n);
         const float xv = x[r * ldx + col];
-        const float dz = dy[r * lddy + col] * act_grad(fmaf(xv, scale[gc], shift[gc]), act);
+        const float dz = routed_load1(up, r, col) * act_grad(fmaf(xv, scale[gc], shift[gc]), act);
         const float xh = (xv - mean[gc]) * rstd[gc];
         dx[r * lddx + col] = scale[gc] * (dz - m1 - xh * m2);
     }
@@ -366,42 +426,73 @@ int ogmm_affine_act(const float* x, int64_t ldx, int64_t rows, int cols, int64_t
     return check_launch("ogmm_affine_act");
 }
 
-int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+static int make_routed(Routed& up, const char* who, const float* dy, int64_t lddy, const float* dpool, int64_t ldp, const uint8_t* arg, int k,
+                       int64_t rows, int cols) {
+    OGMM_REQUIRE(dy || dpool, "%s: no upstream gradient (dy and dpool both NULL)", who);
+    OGMM_REQUIRE(!dpool || (arg && k >= 1 && k <= 255 && rows % k == 0), "%s: pooled gradient needs arg and 1 <= k <= 255 dividing rows", who);
+    up = Routed{dy, lddy, dpool, ldp, arg, k > 0 ? k : 1, cols};
+    return 0;
+}
+static bool routed_vec_ok(const Routed& up, int cols) {
+    return (!up.dy || vec_ok(up.dy, up.lddy, cols)) && (!up.dpool || (vec_ok(up.dpool, up.ldp, cols) && (reinterpret_cast<uintptr_t>(up.arg) & 3) == 0));
+}
+
+int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* dpool, int64_t ldp, const uint8_t* arg, int k,
+                         int64_t rows, int cols, int64_t group_rows,
                          const float* scale, const float* shift, const float* mean, const float* rstd, int act, double* sums, void* stream) {
     OGMM_REQUIRE(cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_norm_bwd_reduce: bad shape");
     if (rows == 0) return 0;
+    Routed up;
+    if (make_routed(up, "ogmm_norm_bwd_reduce", dy, lddy, dpool, ldp, arg, k, rows, cols)) return 1;
     const int64_t G = rows / group_rows;
     OGMM_REQUIRE(G <= 65535, "ogmm_norm_bwd_reduce: too many groups");
     (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * G * cols, as_stream(stream));
     const unsigned chunks = (unsigned)((group_rows + ROW_CHUNK - 1) / ROW_CHUNK);
-    if (vec_ok(x, ldx, cols) && vec_ok(dy, lddy, cols) && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(rstd)) {
+    if (vec_ok(x, ldx, cols) && routed_vec_ok(up, cols) && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(rstd)) {
         const int cv = lanes_per_row(cols);
         dim3 grid(chunks, (cols / 4 + cv - 1) / cv, (unsigned)G);
-        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(norm_bwd_reduce_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, cols, group_rows,
+        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(norm_bwd_reduce_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, up, cols, group_rows,
                                                 scale, shift, mean, rstd, act, sums));
     } else {
-        hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(chunks, (cols + 63) / 64, (unsigned)G), dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, cols,
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(chunks, (cols + 63) / 64, (unsigned)G), dim3(256), 0, as_stream(stream), x, ldx, up, cols,
                            group_rows, scale, shift, mean, rstd, act, sums);
     }
     return check_launch("ogmm_norm_bwd_reduce");
 }
 
-int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int cols, int64_t group_rows,
+int ogmm_norm_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* dpool, int64_t ldp, const uint8_t* arg, int k,
+                        int64_t rows, int cols, int64_t group_rows,
                         const float* scale, const float* shift, const float* mean, const float* rstd, int act, const double* sums,
                         float* dx, int64_t lddx, void* stream) {
     OGMM_REQUIRE(cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_norm_bwd_apply: bad shape");
     if (rows == 0) return 0;
+    Routed up;
+    if (make_routed(up, "ogmm_norm_bwd_apply", dy, lddy, dpool, ldp, arg, k, rows, cols)) return 1;
     const unsigned rblocks = (unsigned)((rows + 63) / 64);
-    if (vec_ok(x, ldx, cols) && vec_ok(dy, lddy, cols) && vec_ok(dx, lddx, cols) && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(rstd)) {
+    if (vec_ok(x, ldx, cols) && routed_vec_ok(up, cols) && vec_ok(dx, lddx, cols) && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(rstd)) {
         const int cv = lanes_per_row(cols);
         dim3 grid(rblocks, (cols / 4 + cv - 1) / cv);
-        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(norm_bwd_apply_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, rows, cols,
+        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(norm_bwd_apply_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, up, rows, cols,
                                                 group_rows, scale, shift, mean, rstd, act, sums, dx, lddx));
     } else {
-        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(rblocks, (cols + 63) / 64), dim3(256), 0, as_stream(stream), x, ldx, dy, lddy, rows, cols,
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(rblocks, (cols + 63) / 64), dim3(256), 0, as_stream(stream), x, ldx, up, rows, cols,
                            group_rows, scale, shift, mean, rstd, act, sums, dx, lddx);
     }
     return check_launch("ogmm_norm_bwd_apply");
+}
+
+int ogmm_affine_act_pool(const float* x, int64_t ldx, int64_t points, int k, int cols, int64_t group_points, const float* scale, const float* shift,
+                         int act, float* y, int64_t ldy, float* pooled, int64_t ldp, uint8_t* arg, void* stream) {
+    OGMM_REQUIRE(x && pooled && arg && cols > 0 && k >= 1 && k <= 255 && group_points > 0 && points % group_points == 0, "ogmm_affine_act_pool: bad shape");
+    OGMM_REQUIRE(act == OGMM_ACT_NONE || act == OGMM_ACT_RELU || act == OGMM_ACT_LEAKY02, "ogmm_affine_act_pool: activation %d not supported", act);
+    OGMM_REQUIRE(vec_ok(x, ldx, cols) && vec_ok(pooled, ldp, cols) && (!y || vec_ok(y, ldy, cols)) && aligned16(scale) && aligned16(shift) &&
+                 (reinterpret_cast<uintptr_t>(arg) & 3) == 0, "ogmm_affine_act_pool: cols %% 4 == 0 and 16-byte aligned rows required");
+    if (points == 0) return 0;
+    const int cv = lanes_per_row(cols);
+    dim3 grid((unsigned)((points + 15) / 16), (cols / 4 + cv - 1) / cv);
+    OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(affine_act_pool_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, points, k, cols, group_points,
+                                            scale, shift, act, y, ldy, pooled, ldp, arg));
+    return check_launch("ogmm_affine_act_pool");
 }
 
 int ogmm_maxpool_k(const float* h, int64_t ldh, int64_t points, int k, int cols, float* out, int64_t ldo, uint8_t* arg, void* stream) {

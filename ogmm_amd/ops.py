@@ -445,18 +445,34 @@ def affine_act(x, group_rows, scale, shift, act, out=None):
     return out
 
 
-def norm_bwd(x, dy, group_rows, scale, shift, mean, rstd, act):
-    """backward of y = act(x * scale + shift), scale = gamma * rstd, shift = beta - mean * scale
+def norm_bwd(x, dy, group_rows, scale, shift, mean, rstd, act, dpool=None, arg=None, k=0):
+    """backward of y = act(x * scale + shift), scale = gamma * rstd, shift = beta - mean * scale; the upstream gradient is dy
+    (may be None) plus, for a map that was max-pooled over k rows, dpool routed to the rows `arg`
     -> (dx, sums float64 [G, cols, 2] = {sum dz, sum dz*xhat})"""
     rows, cols = x.shape
-    assert x.stride(1) == 1 and dy.stride(1) == 1
+    assert x.stride(1) == 1 and (dy is None or dy.stride(1) == 1) and (dpool is None or dpool.stride(1) == 1)
     G = rows // group_rows
     sums = torch.empty((G, cols, 2), dtype=torch.float64, device=x.device)
-    args = (_p(_f32(scale, "scale")), _p(_f32(shift, "shift")), _p(_f32(mean, "mean")), _p(_f32(rstd, "rstd")), act)
-    _lib.call("ogmm_norm_bwd_reduce", _p(_f32(x, "x")), x.stride(0), _p(_f32(dy, "dy")), dy.stride(0), rows, cols, group_rows, *args, _p(sums), _stream())
+    up = (_p(None if dy is None else _f32(dy, "dy")), 0 if dy is None else dy.stride(0),
+          _p(None if dpool is None else _f32(dpool, "dpool")), 0 if dpool is None else dpool.stride(0), _p(arg), k)
+    tail = (_p(_f32(scale, "scale")), _p(_f32(shift, "shift")), _p(_f32(mean, "mean")), _p(_f32(rstd, "rstd")), act)
+    _lib.call("ogmm_norm_bwd_reduce", _p(_f32(x, "x")), x.stride(0), *up, rows, cols, group_rows, *tail, _p(sums), _stream())
     dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
-    _lib.call("ogmm_norm_bwd_apply", _p(x), x.stride(0), _p(dy), dy.stride(0), rows, cols, group_rows, *args, _p(sums), _p(dx), dx.stride(0), _stream())
+    _lib.call("ogmm_norm_bwd_apply", _p(x), x.stride(0), *up, rows, cols, group_rows, *tail, _p(sums), _p(dx), dx.stride(0), _stream())
     return dx, sums
+
+
+def affine_act_pool(x, k, group_rows, scale, shift, act, want_y=True):
+    """-> (y or None, pooled [P, cols], arg uint8 [P, cols]) with P = rows / k"""
+    rows, cols = x.shape
+    assert x.stride(1) == 1 and rows % k == 0 and group_rows % k == 0
+    P = rows // k
+    y = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_y else None
+    pooled = torch.empty((P, cols), dtype=torch.float32, device=x.device)
+    arg = torch.empty((P, cols), dtype=torch.uint8, device=x.device)
+    _lib.call("ogmm_affine_act_pool", _p(_f32(x, "x")), x.stride(0), P, k, cols, group_rows // k, _p(_f32(scale, "scale")), _p(_f32(shift, "shift")), act,
+              _p(y), cols, _p(pooled), cols, _p(arg), _stream())
+    return y, pooled, arg
 
 
 def maxpool_k(h, k):

@@ -36,14 +36,23 @@ def _conv_bn(ops, P, conv, bn, x, act, x2=None):
     return _bn(ops, P, bn, y, act, st)
 
 
+def _conv_bn_pool(ops, P, conv, bn, x, act, k, want_h):
+    """1x1 conv -> train-mode BatchNorm -> activation -> max over the k rows of every point, normalisation and pooling in one pass;
+    -> (per-row map or None when nothing reads it, pooled map)"""
+    y, st = ops.linear_stats(x, _w(P, conv), _b(P, conv), groups=GROUPS)
+    return ops.batchnorm_act_pool(y, P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"], P[bn + ".running_var"],
+                                  P[bn + ".num_batches_tracked"], GROUPS, act, k, want_h, stats=st)
+
+
 def dgcnn(ops, P, xyz, idx):
     """models/dgcnn.py:133-154.  -> [C*N, D]"""
     C, N, k = idx.shape
     h = ops.edge_features(xyz, idx)                                   # [C*N*k, 6], constant
     pooled = []
     for l in (1, 2, 3, 4):
-        h = _conv_bn(ops, P, "emd.conv%d" % l, "emd.bn%d" % l, h, "relu")
-        pooled.append(ops.maxpool_k(h, k))                               # max over the k edges of a point, after the ReLU
+        # max over the k edges of a point, after the ReLU; the last layer's per-edge map is only pooled
+        h, pl = _conv_bn_pool(ops, P, "emd.conv%d" % l, "emd.bn%d" % l, h, "relu", k, want_h=l < 4)
+        pooled.append(pl)
     xcat = torch.cat(pooled, dim=1)
     return _conv_bn(ops, P, "emd.conv5", "emd.bn5", xcat, "relu")
 
@@ -53,8 +62,7 @@ def pos_encoding(ops, P, xyz, idx5):
     d2, alpha = ops.pos_features(xyz, idx5)                              # [C*N, 1], [C*N*5, 1]: constants of the input
     h = _conv_bn(ops, P, "pos.conv_dis.0", "pos.conv_dis.1", d2, "leaky")
     dis = _conv_bn(ops, P, "pos.conv_dis.3", "pos.conv_dis.4", h, "leaky")
-    a = _conv_bn(ops, P, "pos.conv_ang1.0", "pos.conv_ang1.1", alpha, "leaky")
-    a = ops.maxpool_k(a, idx5.shape[2])
+    _, a = _conv_bn_pool(ops, P, "pos.conv_ang1.0", "pos.conv_ang1.1", alpha, "leaky", idx5.shape[2], want_h=False)
     ang = _conv_bn(ops, P, "pos.conv_ang2.0", "pos.conv_ang2.1", a, "leaky")
     return torch.cat([dis, ang], dim=1)
 

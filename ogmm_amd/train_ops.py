@@ -50,6 +50,46 @@ class _NormAct(torch.autograd.Function):
         return dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float(), None, None, None
 
 
+class _NormActPool(torch.autograd.Function):
+    """_NormAct followed by the max over the k rows of every point in ONE pass (ogmm_affine_act_pool); the normalised per-edge
+    map itself is written only when a later layer reads it.  Backward: the pooled gradient is routed to the winning rows
+    inside the normalisation's backward kernels (no scattered per-edge gradient map, no separate add)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, group_rows, act, k, want_h, st=None):
+        y = y.contiguous()
+        if st is None:
+            st = ops.colstats(y, group_rows)
+        mean64 = st[..., 0] / group_rows
+        var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
+        rstd64 = torch.rsqrt(var64 + BN_EPS)
+        scale64 = rstd64 if weight is None else rstd64 * weight.detach().double()
+        shift64 = -mean64 * scale64 if bias is None else bias.detach().double() - mean64 * scale64
+        scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
+        mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
+        h, pooled, arg = ops.affine_act_pool(y, k, group_rows, scale, shift, act, want_y=want_h)
+        ctx.save_for_backward(y, scale, shift, mean, rstd, arg)
+        ctx.group_rows, ctx.act, ctx.affine, ctx.k = group_rows, act, weight is not None, k
+        ctx.set_materialize_grads(False)
+        if h is None:
+            h = y.new_empty(0)
+        ctx.mark_non_differentiable(mean64, var64)
+        return h, pooled, mean64, var64
+
+    @staticmethod
+    def backward(ctx, dh, dpooled, _dm, _dv):
+        y, scale, shift, mean, rstd, arg = ctx.saved_tensors
+        if dh is not None and dh.numel() == 0:
+            dh = None
+        if dh is None and dpooled is None:
+            return (None,) * 8
+        dy, sums = ops.norm_bwd(y, None if dh is None else dh.contiguous(), ctx.group_rows, scale, shift, mean, rstd, ctx.act,
+                                dpool=None if dpooled is None else dpooled.contiguous(), arg=arg, k=ctx.k)
+        if not ctx.affine:
+            return (dy,) + (None,) * 7
+        return (dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float()) + (None,) * 5
+
+
 class _MaxPoolK(torch.autograd.Function):
     """kernels T2 of include/ogmm_hip.h"""
 
@@ -306,6 +346,21 @@ class TrainOps:
                 running_var.mul_(1 - BN_MOMENTUM).add_(unbiased[g].to(running_var.dtype), alpha=BN_MOMENTUM)
             num_batches += groups
         return h
+
+    def batchnorm_act_pool(self, y, weight, bias, running_mean, running_var, num_batches, groups, act, k, want_h, stats=None):
+        """batchnorm_act + max over the k rows of every point: -> (h or None, pooled [rows/k, c])"""
+        n = y.shape[0] // groups
+        if y.shape[1] % 4:
+            h = self.batchnorm_act(y, weight, bias, running_mean, running_var, num_batches, groups, act, stats)
+            return (h if want_h else None), self.maxpool_k(h, k)
+        h, pooled, mean64, var64 = _NormActPool.apply(y, weight, bias, n, _ACT[act], k, want_h, stats)
+        with torch.no_grad():
+            unbiased = var64 * (n / max(n - 1, 1))
+            for g in range(groups):
+                running_mean.mul_(1 - BN_MOMENTUM).add_(mean64[g].to(running_mean.dtype), alpha=BN_MOMENTUM)
+                running_var.mul_(1 - BN_MOMENTUM).add_(unbiased[g].to(running_var.dtype), alpha=BN_MOMENTUM)
+            num_batches += groups
+        return (h if want_h else None), pooled
 
     def instnorm_relu(self, z, C, N, stats=None):
         """InstanceNorm1d (no affine, biased variance, eps 1e-5) over the N points of each cloud, then ReLU"""

@@ -40,6 +40,10 @@ class RefTrainOps(TrainOps):
         h = torch.cat(outs, dim=0)
         return F.relu(h) if act == "relu" else F.leaky_relu(h, 0.2)
 
+    def batchnorm_act_pool(self, y, weight, bias, running_mean, running_var, num_batches, groups, act, k, want_h, stats=None):
+        h = self.batchnorm_act(y, weight, bias, running_mean, running_var, num_batches, groups, act)
+        return (h if want_h else None), self.maxpool_k(h, k)
+
     def instnorm_relu(self, z, C, N, stats=None):
         zc = z.view(C, N, -1).transpose(1, 2)
         return F.relu(F.instance_norm(zc, eps=1e-5)).transpose(1, 2).reshape(C * N, -1)
