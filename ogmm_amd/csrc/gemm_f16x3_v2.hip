@@ -42,10 +42,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && MT * NT == 8) ? 2 : 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];      // [2 buffers][hi, lo][BM][LDH]
 
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int tile_m = (local / n_tiles) * 8 + xcd;
-    const int tile_n = local % n_tiles;
-    if (tile_m >= m_tiles) return;
+    int tile_m, tile_n;
+    if (m_tiles < 0) {                  // few M panels (see gemm_f16x3_v4.hip): plain tile order keeps every XCD busy
+        tile_m = bid / n_tiles;
+        tile_n = bid % n_tiles;
+    } else {
+        const int xcd = bid & 7, local = bid >> 3;
+        tile_m = (local / n_tiles) * 8 + xcd;
+        tile_n = local % n_tiles;
+        if (tile_m >= m_tiles) return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -207,8 +213,9 @@ int launch_v2(const ogmm_gemm& g, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_set = true;
     }
-    dim3 grid((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer);
-    hipLaunchKernelGGL((gemm_f16x3_v2_kernel<MT, NT, WM, WN, POOL>), grid, dim3(T), LDS, stream, g, rows_per_tile, m_tiles, n_tiles);
+    const bool plain = m_tiles % 8 != 0 && m_tiles < 32;
+    dim3 grid((unsigned)((plain ? m_tiles : m_tiles8) * n_tiles), 1, (unsigned)g.batch_outer);
+    hipLaunchKernelGGL((gemm_f16x3_v2_kernel<MT, NT, WM, WN, POOL>), grid, dim3(T), LDS, stream, g, rows_per_tile, plain ? -m_tiles : m_tiles, n_tiles);
     return ogmm::check_launch("ogmm_gemm_nt(f16x3 frag)");
 }
 

@@ -44,14 +44,23 @@ __device__ __forceinline__ void split4w(const f32x4 v, f16x4& hi, f16x4& lo, boo
 }
 
 template <int ABL>
-__global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, const int m_tiles, const int n_tiles) {
+__global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];      // [2 buffers][hi, lo][BM][LD3]
 
+    // XCD-aware map (block b runs on XCD b % 8): all N tiles of an M panel on one XCD, so the panel is fetched into one L2.
+    // With fewer than 8 M panels (weight-gradient GEMMs: M = output channels, the long axis is the split-K batch) that map
+    // would leave XCDs idle -- m_tiles < 0 selects the plain row-major tile order instead.
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int tile_m = (local / n_tiles) * 8 + xcd;
-    const int tile_n = local % n_tiles;
-    if (tile_m >= m_tiles) return;
+    int tile_m, tile_n;
+    if (m_tiles_signed < 0) {
+        tile_m = bid / n_tiles;
+        tile_n = bid % n_tiles;
+    } else {
+        const int xcd = bid & 7, local = bid >> 3;
+        tile_m = (local / n_tiles) * 8 + xcd;
+        tile_n = local % n_tiles;
+        if (tile_m >= m_tiles_signed) return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -245,7 +254,10 @@ static int launch_v4(const ogmm_gemm& g, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v4_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, m_tiles, n_tiles);
+    if (m_tiles % 8 != 0 && m_tiles < 32)
+        hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, -m_tiles, n_tiles);
+    else
+        hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, m_tiles, n_tiles);
     return check_launch("ogmm_gemm_nt(f16x3 v4)");
 }
 

@@ -165,13 +165,26 @@ class _Linear(torch.autograd.Function):
             dx = dall[:, :K1]
             dx2 = dall[:, K1:K1 + x2.shape[1]] if x2 is not None else None
         if ctx.needs_input_grad[2]:
-            if ctx.precision == "f16x3" and W.shape[0] >= 1024 and K1 >= 256 and (x2 is None or x2.shape[1] >= 256):
-                # kernels T3.  Measured at R = 131072 (tools/dw_bench.py, ms engine incl. relayouts vs library): 1024x1024 1.59 vs
-                # 2.74, 1024x512 0.98 vs 1.07, 512x1024 1.34 vs 1.07, 512x512 0.80 vs 0.70 -> the engine takes the 1024-wide layers
-                dW = ops.weight_grad(dy.contiguous(), [x] if x2 is None else [x, x2], ctx.overflow)
-            else:       # narrower layers and the HBM-bound per-edge maps: library GEMM
+            # kernels T3 for every piece with >= 256 input channels when the layer has >= 256 outputs.  Measured at R = 131072
+            # (tools/dw_bench.py, ms engine incl. relayouts vs library): 1024x1024 1.61 vs 2.73, 512x1024 0.95 vs 1.09,
+            # 1024x512 0.98 vs 1.09, 512x512 0.62 vs 0.73, 256x512 0.39 vs 1.12.  Thin pieces (the per-edge maps with <= 128
+            # channels, the 2-channel overlap input) are HBM-bound row sums: library GEMM.
+            pieces = [x] if x2 is None else [x, x2]
+            wide = [ctx.precision == "f16x3" and W.shape[0] >= 256 and p_.shape[1] >= 256 for p_ in pieces]
+            parts = [None] * len(pieces)
+            if any(wide):
+                got = ops.weight_grad(dy.contiguous(), [p_ for p_, w_ in zip(pieces, wide) if w_], ctx.overflow)
+                off = 0
+                for i_, (p_, w_) in enumerate(zip(pieces, wide)):
+                    if w_:
+                        parts[i_] = got[:, off:off + p_.shape[1]]
+                        off += p_.shape[1]
+            if not all(wide):
                 dyt = dy.t()
-                dW = dyt @ x if x2 is None else torch.cat([dyt @ x, dyt @ x2], dim=1)
+                for i_, (p_, w_) in enumerate(zip(pieces, wide)):
+                    if not w_:
+                        parts[i_] = dyt @ p_
+            dW = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = dy.sum(dim=0)
         return dx, dx2, dW, db, None, None, None
