@@ -271,6 +271,13 @@ int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int6
 int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
                      int* overflow, void* stream);
 
+/* ---- T9: weight gradient of the thin layers (per-edge EdgeConv maps, the 6 -> 64 edge layer, the 1 -> 64 positional layers):
+ * part[s][n][k] = sum over the rows of stream s of dY[r][n] X[r][k], exact fp32 on v_mfma_f32_32x32x2_f32 (HBM-bound);
+ * the caller sums the ogmm_weight_grad_thin_streams(n, k) partials (-1: shape not supported, n and k too wide).
+ * Rows of dy / x must be aligned to the kernel's vector loads (4 floats for n > 64, 2 for n > 32; 2 floats for k > 32). */
+int64_t ogmm_weight_grad_thin_streams(int n, int k);
+int ogmm_weight_grad_thin(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t R, int n, int k, float* part, void* stream);
+
 /* ---- T8: the overlap block (models/gmmreg.py:75-80) in training: ogmm_overlap_cross that also saves the row / column softmax
  * statistics (stats [B][4][N] = row max, row sum, column max, column sum), and its backward: given a = dL/dwo_src, b = dL/dwo_tgt
  * (element stride ldg) it writes dS [B][N][N], g_o_src [B][N] (gradient of the logits the row pass reads, accumulated per column)

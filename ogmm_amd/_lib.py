@@ -79,6 +79,8 @@ PROTOTYPES = {
     "ogmm_overlap_cross_train": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_overlap_cross_bwd": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_weight_grad_thin_streams": [c_int, c_int],
+    "ogmm_weight_grad_thin": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p],
     "ogmm_kabsch_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_nearest_point": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_edge_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -107,7 +109,7 @@ def load():
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)      # AttributeError here = missing export
         fn.argtypes = argtypes
-        fn.restype = c_char_p if name == "ogmm_last_error" else (c_int64 if name.endswith("_bytes") else c_int)
+        fn.restype = c_char_p if name == "ogmm_last_error" else (c_int64 if name.endswith(("_bytes", "_streams")) else c_int)
     if lib.ogmm_abi_version() != ABI_VERSION:
         raise OgmmError("libogmm_hip.so ABI %d != binding ABI %d" % (lib.ogmm_abi_version(), ABI_VERSION))
     _lib = lib

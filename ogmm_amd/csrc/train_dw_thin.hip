@@ -1,0 +1,128 @@
+// Weight gradient of the THIN dense layers of the training step:  dW[n][k] = sum_r dY[r][n] X[r][k]  with few channels
+// (per-edge EdgeConv maps: n <= 256, k <= 128 over 2.6 M rows at B = 64; the 6 -> 64 edge layer; the 1 -> 64 positional layers).
+// These are HBM-bound reductions (a few hundred flops per loaded byte at most), so they run in exact fp32 on
+// v_mfma_f32_32x32x2_f32, whose operand layout matches a row-major "contraction over rows" product directly:
+//   A operand: lane l holds A[m = l % 32][kk = l / 32]  ->  dY[row r0 + l/32][some column of the lane l%32]
+//   B operand: lane l holds B[kk = l / 32][n = l % 32]  ->  X [row r0 + l/32][some column of the lane l%32]
+// i.e. one MFMA consumes TWO rows.  A lane loads NV consecutive dY columns (and KV consecutive X columns) of its row with one
+// vector load; component e of that vector feeds MFMA e, so MFMA (e, f) accumulates the outputs n = NV*j + e, k = KV*j' + f
+// (a strided set of 32 x 32 outputs) -- any fixed assignment of output rows to lanes is as good as the contiguous one, the
+// accumulators are un-permuted when they are written.  Per two rows a wave issues 2 vector loads and NV*KV MFMAs.
+// Every stream (workgroup x row split) reduces a contiguous row range and writes its own partial [n][k]; the host sums them.
+#include "ogmm_common.h"
+#include <algorithm>
+
+namespace {
+
+using namespace ogmm;
+using f32x16t = __attribute__((ext_vector_type(16))) float;
+
+template <int V>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, bool ok, int valid, float (&v)[V]) {
+    // `valid` = number of in-range columns starting at p (>= V when the whole vector is inside the matrix)
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.0f;
+    if (!ok || valid <= 0) return;
+    if (valid >= V) {
+        if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else if constexpr (V == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+        else v[0] = p[0];
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) if (e < valid) v[e] = p[e];
+    }
+}
+
+// one wave: output tile of NV*32 rows (n) x KV*32 columns (k), rows [r_lo, r_hi) of the contraction
+template <int NV, int KV>
+__global__ __launch_bounds__(256) void dw_thin_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                      int64_t R, int n, int k, int n_tiles, int k_tiles, int row_splits, int64_t rows_per_stream,
+                                                      float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles = n_tiles * k_tiles;
+    const int tile = wave % tiles, rs = wave / tiles;                  // 4 waves = tiles * row_splits (host guarantees)
+    if (rs >= row_splits) return;
+    const int tn = tile / k_tiles, tk = tile % k_tiles;
+    const int64_t stream = (int64_t)blockIdx.x * row_splits + rs;
+    const int64_t r_lo = stream * rows_per_stream, r_hi = min(R, r_lo + rows_per_stream);
+    const int j = lane & 31, half = lane >> 5;
+    const int n0 = tn * NV * 32 + NV * j, k0 = tk * KV * 32 + KV * j;
+    const float* __restrict__ pa = dy + n0;
+    const float* __restrict__ pb = x + k0;
+    const int a_valid = n - n0, b_valid = k - k0;
+
+    f32x16t acc[NV][KV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = 0; f < KV; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.0f;
+
+    constexpr int U = 4;                                               // row pairs in flight
+    for (int64_t r = r_lo; r < r_hi; r += 2 * U) {
+        float a[U][NV], b[U][KV];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + 2 * u + half;
+            const bool ok = row < r_hi;
+            load_vec<NV>(pa + row * lddy, ok, a_valid, a[u]);
+            load_vec<KV>(pb + row * ldx, ok, b_valid, b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+#pragma unroll
+                for (int f = 0; f < KV; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][f], acc[e][f], 0, 0, 0);
+    }
+    // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* __restrict__ out = part + stream * (int64_t)n * k;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = 0; f < KV; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int nn = tn * NV * 32 + NV * mrow + e, kk = tk * KV * 32 + KV * j + f;
+                if (nn < n && kk < k) out[(int64_t)nn * k + kk] = acc[e][f][r];
+            }
+}
+
+}  // namespace
+
+// Host side: picks (NV, KV) so that NV*32 >= n or the n axis splits into tiles, ditto k; 4 waves = tiles x row splits.
+extern "C" int64_t ogmm_weight_grad_thin_streams(int n, int k) {
+    const int NV = n > 64 ? 4 : (n > 32 ? 2 : 1), KV = k > 32 ? 2 : 1;
+    const int n_tiles = (n + NV * 32 - 1) / (NV * 32), k_tiles = (k + KV * 32 - 1) / (KV * 32);
+    const int tiles = n_tiles * k_tiles;
+    if (tiles > 4) return -1;
+    const int row_splits = 4 / tiles;
+    return (int64_t)1024 * row_splits;                                 // 1024 workgroups
+}
+
+extern "C" int ogmm_weight_grad_thin(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t R, int n, int k, float* part, void* stream) {
+    OGMM_REQUIRE(dy && x && part && R > 0 && n > 0 && k > 0, "ogmm_weight_grad_thin: null pointer or empty input");
+    const int NV = n > 64 ? 4 : (n > 32 ? 2 : 1), KV = k > 32 ? 2 : 1;
+    OGMM_REQUIRE(lddy % NV == 0 && ldx % KV == 0 && (reinterpret_cast<uintptr_t>(dy) % (4 * NV)) == 0 && (reinterpret_cast<uintptr_t>(x) % (4 * KV)) == 0,
+                 "ogmm_weight_grad_thin: rows of dy / x must be aligned to their %d- / %d-float vector loads", NV, KV);
+    const int n_tiles = (n + NV * 32 - 1) / (NV * 32), k_tiles = (k + KV * 32 - 1) / (KV * 32);
+    const int tiles = n_tiles * k_tiles;
+    OGMM_REQUIRE(tiles <= 4, "ogmm_weight_grad_thin: n <= 256 with k <= 64, or n <= 128 with k <= 128, ... (n=%d, k=%d need %d wave tiles > 4)", n, k, tiles);
+    const int row_splits = 4 / tiles;
+    const int64_t streams = (int64_t)1024 * row_splits;
+    int64_t rows_per_stream = (R + streams - 1) / streams;
+    rows_per_stream = (rows_per_stream + 7) / 8 * 8;                   // whole unrolled iterations
+    dim3 grid(1024), block(256);
+    hipStream_t s = as_stream(stream);
+#define OGMM_DW_THIN(NVv, KVv) hipLaunchKernelGGL((dw_thin_kernel<NVv, KVv>), grid, block, 0, s, dy, lddy, x, ldx, R, n, k, n_tiles, k_tiles, row_splits, rows_per_stream, part)
+    if (NV == 4 && KV == 2) OGMM_DW_THIN(4, 2);
+    else if (NV == 4) OGMM_DW_THIN(4, 1);
+    else if (NV == 2 && KV == 2) OGMM_DW_THIN(2, 2);
+    else if (NV == 2) OGMM_DW_THIN(2, 1);
+    else if (KV == 2) OGMM_DW_THIN(1, 2);
+    else OGMM_DW_THIN(1, 1);
+#undef OGMM_DW_THIN
+    return check_launch("ogmm_weight_grad_thin");
+}

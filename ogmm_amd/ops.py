@@ -592,3 +592,20 @@ def overlap_cross_bwd(S, ol, wo, stats, g_wo):
     _lib.call("ogmm_overlap_cross_bwd", _p(S), B, N, _p(ol), _p(ol[B * N:]), 1, _p(wo), _p(wo[B * N:]), 1, _p(stats), _p(g_wo), _p(g_wo[B * N:]), 1,
               _p(dS), _p(g_ol), _p(g_ol[B * N:]), 1, _stream())
     return dS, g_ol
+
+
+def weight_grad_thin_supported(dy, x):
+    n, k = dy.shape[1], x.shape[1]
+    nv, kv = (4 if n > 64 else (2 if n > 32 else 1)), (2 if k > 32 else 1)
+    return (_lib.load().ogmm_weight_grad_thin_streams(n, k) > 0 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % nv == 0
+            and x.stride(0) % kv == 0 and dy.data_ptr() % (4 * nv) == 0 and x.data_ptr() % (4 * kv) == 0)
+
+
+def weight_grad_thin(dy, x):
+    """dW = dY^T X for thin layers in exact fp32 (kernel T9): dy [R, n], x [R, k] -> [n, k]"""
+    R, n = dy.shape
+    k = x.shape[1]
+    streams = _lib.load().ogmm_weight_grad_thin_streams(n, k)
+    part = torch.empty((streams, n, k), dtype=torch.float32, device=dy.device)
+    _lib.call("ogmm_weight_grad_thin", _p(_f32(dy, "dy")), dy.stride(0), _p(_f32(x, "x")), x.stride(0), R, n, k, _p(part), _stream())
+    return part.sum(dim=0)

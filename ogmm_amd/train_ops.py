@@ -106,6 +106,33 @@ class _MaxPoolK(torch.autograd.Function):
         return ops.maxpool_k_bwd(dout.contiguous(), arg, ctx.k), None
 
 
+class _ThinLinear(torch.autograd.Function):
+    """y = x W^T + b for layers too thin for a matrix-core tile in the forward direction (the 6 -> 64 edge layer, the 1 -> 64
+    positional layers): the forward is an HBM-bound outer product (library call), the weight gradient the exact-fp32 thin
+    reduction kernel T9, dX (only the positional hidden layers need it) a library call."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        y = x @ W.t()
+        return y if b is None else y + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx = dW = db = None
+        dyc = dy.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = dyc @ W
+        if ctx.needs_input_grad[1]:
+            xc = x.contiguous()
+            dW = ops.weight_grad_thin(dyc, xc) if ops.weight_grad_thin_supported(dyc, xc) else dyc.t() @ xc
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dyc.sum(dim=0)
+        return dx, dW, db
+
+
 class _Linear(torch.autograd.Function):
     """y = [x | x2] W^T + b.  Forward and dX = dY W on the GEMM engine (fp16x3 split of the CURRENT weights, or exact fp32
     forward + library dX with precision "f32"); dW = dY^T X runs on the engine as a split-K GEMM over transposed operands
@@ -180,10 +207,10 @@ class _Linear(torch.autograd.Function):
                         parts[i_] = got[:, off:off + p_.shape[1]]
                         off += p_.shape[1]
             if not all(wide):
-                dyt = dy.t()
+                dyc = dy.contiguous()
                 for i_, (p_, w_) in enumerate(zip(pieces, wide)):
                     if not w_:
-                        parts[i_] = dyt @ p_
+                        parts[i_] = ops.weight_grad_thin(dyc, p_) if ops.weight_grad_thin_supported(dyc, p_) else dyc.t() @ p_
             dW = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = dy.sum(dim=0)
@@ -332,9 +359,7 @@ class TrainOps:
         (the 6->64 edge layer, the 1->64 positional layers, the Cout=1 heads) are HBM-bound outer products / row dots."""
         K1, Cout = x.shape[1], W.shape[0]
         if K1 < 32 or Cout < 32 or (K1 % 64 and x2 is not None):
-            xin = x if x2 is None else torch.cat([x, x2], dim=1)
-            y = xin @ W.t()
-            return y if b is None else y + b
+            return _ThinLinear.apply(x if x2 is None else torch.cat([x, x2], dim=1), W, b)
         return _Linear.apply(x, x2, W, b, self.precision, self.overflow)
 
     def linear_stats(self, x, W, b, x2=None, groups=1):
