@@ -500,7 +500,7 @@ def weight_grad(dy, xs, overflow=None):
     R, n = dy.shape
     assert dy.stride(1) == 1
     tiles_mn = ((n + 255) // 256) * max((max(x.shape[1] for x in xs) + 255) // 256, 1)
-    S = max(1, min((384 + tiles_mn - 1) // tiles_mn, (R + 255) // 256))
+    S = max(1, min((512 + tiles_mn - 1) // tiles_mn, (R + 255) // 256))        # >= 512 tiles: the large-shape engine's threshold
     chunk = ((R + S - 1) // S + 63) // 64 * 64
     S = (R + chunk - 1) // chunk
     pitch = chunk + 64
