@@ -37,7 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GFLOP_PER_PAIR = 52.82          # algorithmic work of one pair at N=1024, J=16 (FlopCounterMode on the reference)
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}   # MI355X_MICROARCH.md chip table: fp32-matrix / dense f16 MFMA
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md chip table: fp32-matrix / dense f16 MFMA
 CFG = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
 B_PER_GPU, N_POINTS, J = 64, 1024, 16
 
@@ -48,7 +48,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-oracle sample (0 = skip)")
-    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3")
+    ap.add_argument("--precision", choices=["f16x3", "f32", "f16"], default="f16x3",
+                    help="f16 = reduced precision (single binary16 term in the large GEMMs): only meaningful for --workload cfg2, which BASELINE quotes in bf16")
     ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "train"], default="cfg1",
                     help="cfg1 = BASELINE configs[1] (headline); cfg2 = configs[2] shape (N=2048, J=64, B=256); cfg3 = configs[3] shape per GPU "
                          "(room clouds, N=2048, J=64, B=64); train = configs[4]: full training step, N=1024, J=16, 128 pairs per GPU (global 1024 on 8)")
@@ -106,26 +107,29 @@ def main():
     value = pairs / elapsed
     all_gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timeline)
     all_gemm_flop = sum(f for _, _, f, _ in timeline)
-    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v in timeline if v == args.precision]     # un-pooled, N > 64 launches of the engine
+    dom_tag = "f16x3" if args.precision == "f16" else args.precision
+    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v in timeline if v == dom_tag]     # un-pooled, N > 64 launches of the engine
     gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
-    kernel = ("gemm_f16x3_v4_kernel (256x256x64, 3x v_mfma_f32_32x32x16_f16 per block; v2 <2,2,2,2> for small shapes)" if args.precision == "f16x3"
-              else "gemm_nt_kernel<2,2,2,2,false> (v_mfma_f32_32x32x2_f32)")
+    kernel = {"f16x3": "gemm_f16x3_v4_kernel (256x256x64, 3x v_mfma_f32_32x32x16_f16 per block; v2 <2,2,2,2> for small shapes)",
+              "f16": "gemm_f16x3_v4_kernel in single-term mode (1x v_mfma_f32_32x32x16_f16 per block; REDUCED precision)",
+              "f32": "gemm_nt_kernel<2,2,2,2,false> (v_mfma_f32_32x32x2_f32)"}[args.precision]
 
     result = {
         "metric": "pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "engine": args.precision,
+        "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic", "engine": args.precision,
         "config": {"workload": {"cfg1": "BASELINE configs[1]: ModelNet40-shaped partial-overlap+noise pairs, N=1024 points, J=16 mixtures, "
                                         "batch 64 per GPU, GMMReg.forward eval (D=512, k=20, M=128, H=4), closed-form weights",
-                                "cfg2": "BASELINE configs[2] shape: unseen-category-like pairs, N=2048, J=64, batch 256 per GPU (fp32-class arithmetic, not bf16)",
+                                "cfg2": "BASELINE configs[2] shape: unseen-category-like pairs, N=2048, J=64, batch 256 per GPU (" +
+                                        ("single-term binary16 GEMMs: reduced precision, the config is quoted in bf16)" if args.precision == "f16" else "fp32-class arithmetic, not bf16)"),
                                 "cfg3": "BASELINE configs[3] shape per GPU: ICL-NUIM-like room pairs, N=2048, J=64, batch 64 per GPU"}[args.workload],
                    "pairs_per_gpu_step": B_PER_GPU, "n_points": N_POINTS, "n_clusters": J, "parallelism": "pairs sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": None,
                      "kernel": kernel, "launches": len(dom), "avg_launch_us": 1e3 * gemm_ms / max(1, len(dom)),
-                     "issued_frac": (3.0 if args.precision == "f16x3" else 1.0) * achieved / peak,
+                     "issued_frac": (3.0 if args.precision == "f16x3" else 1.0) * achieved / peak,      # (f16: the small shapes still issue 3x)
                      "kernel_share_of_step": gemm_ms / (1e3 * elapsed), "all_gemm_share_of_step": all_gemm_ms / (1e3 * elapsed),
                      "all_gemm_gflop_per_pair": all_gemm_flop / (B_PER_GPU * args.steps) / 1e9,
                      "path_frac": value / world * GFLOP_PER_PAIR / 1e3 / peak},

@@ -78,8 +78,11 @@ int ogmm_gather_rows(const float* feats, int64_t ld, int C, int N, int D, const 
  *   that the caller folds into alpha.  |A| must stay below 65504: larger values are clamped and *overflow
  *   (device int, optional) is set non-zero. */
 enum { OGMM_ACT_NONE = 0, OGMM_ACT_RELU = 1, OGMM_ACT_LEAKY02 = 2, OGMM_ACT_SIGMOID = 3 };
-enum { OGMM_PREC_F32 = 0, OGMM_PREC_F16X3 = 1, OGMM_PREC_F16X3_FRAG = 2 };
-/* OGMM_PREC_F16X3_FRAG: same arithmetic as F16X3, but B_hi/B_lo are given as the fragment-major image
+enum { OGMM_PREC_F32 = 0, OGMM_PREC_F16X3 = 1, OGMM_PREC_F16X3_FRAG = 2, OGMM_PREC_F16_FRAG = 3 };
+/* OGMM_PREC_F16_FRAG (reduced precision, for BASELINE configs[2] which is quoted in bf16): the operands of OGMM_PREC_F16X3_FRAG, but
+ * only the leading binary16 term of A and B is multiplied (11-bit mantissa, fp32 accumulate; 1/3 of the matrix instructions); shapes
+ * outside the large-shape engine run as OGMM_PREC_F16X3_FRAG.
+ * OGMM_PREC_F16X3_FRAG: same arithmetic as F16X3, but B_hi/B_lo are given as the fragment-major image
  *   image[n/32][k/16][lane 0..63][8 halfs], lane = ((k % 16) / 8) * 32 + n % 32, element = k % 8,
  * with n padded to a multiple of 256 and k to a multiple of 64 by zeros (two A pieces: the second piece starts at the
  * k-block K1/16, K1 % 64 == 0); ldb_h = padded K.  Each wave then reads its

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
-PREC_F32, PREC_F16X3, PREC_F16X3_FRAG = 0, 1, 2
+PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
 
 
 class GemmDesc(Structure):

@@ -154,7 +154,7 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(d != nullptr, "ogmm_gemm_nt: null descriptor");
     const ogmm_gemm& g = *d;
     OGMM_REQUIRE(g.A && (g.B || g.precision != OGMM_PREC_F32) && g.M > 0 && g.N > 0 && g.K1 > 0, "ogmm_gemm_nt: A, B, M, N, K1 required");
-    OGMM_REQUIRE(g.precision == OGMM_PREC_F32 || g.precision == OGMM_PREC_F16X3 || g.precision == OGMM_PREC_F16X3_FRAG || (g.precision > 10 && g.precision < 30), "ogmm_gemm_nt: bad precision %d", g.precision);
+    OGMM_REQUIRE(g.precision == OGMM_PREC_F32 || g.precision == OGMM_PREC_F16X3 || g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || (g.precision > 10 && g.precision < 30), "ogmm_gemm_nt: bad precision %d", g.precision);
     OGMM_REQUIRE(g.K2 >= 0 && (g.K2 == 0 || g.A2), "ogmm_gemm_nt: K2 > 0 needs A2");
     OGMM_REQUIRE(g.K1 % 4 == 0 && g.K2 % 4 == 0 && g.lda % 4 == 0 && (g.ldb % 4 == 0 || g.precision != OGMM_PREC_F32) && (g.K2 == 0 || g.lda2 % 4 == 0),
                  "ogmm_gemm_nt: K1, K2, lda, lda2, ldb must be multiples of 4 (got %d %d %lld %lld %lld)", g.K1, g.K2,
@@ -168,13 +168,13 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.C || g.pool_k > 0, "ogmm_gemm_nt: no output");
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
-    const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision >= 18;
+    const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || g.precision >= 18;
     OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale), "ogmm_gemm_nt: InstanceNorm fusion is only available with OGMM_PREC_F16X3_FRAG");
     if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
                      "ogmm_gemm_nt: pooling needs pool_out, ReLU, 4 <= pool_k <= 160, M %% pool_k == 0, no batching");
-    if (g.precision == OGMM_PREC_F16X3_FRAG || g.precision >= 18) return ogmm::gemm_nt_f16x3_frag(g, s);
+    if (frag) return ogmm::gemm_nt_f16x3_frag(g, s);
     if (g.precision != OGMM_PREC_F32) return ogmm::gemm_nt_f16x3(g, s);
     if (g.pool_k > 0) {
         return g.N <= 64 ? launch<5, 1, 1, 2, true>(g, s) : launch<5, 1, 1, 4, true>(g, s);

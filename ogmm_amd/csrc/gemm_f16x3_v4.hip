@@ -144,7 +144,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             bh[j] = BH[bbase[j] + kb];
-            bl[j] = (ABL & 64) ? bh[j] : BL[bbase[j] + kb];          // ablation 64: half the weight traffic (wrong results)
+            bl[j] = (ABL & (64 | 1024)) ? bh[j] : BL[bbase[j] + kb];  // 64: ablation (half the weight traffic); 1024: single-term mode, lo unused
         }
     };
     auto read_a = [&](f16x8 (&ah)[2], f16x8 (&al)[2], int buf, int s, int gI) {
@@ -158,10 +158,12 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
     };
     // group gI = row blocks 2*gI and 2*gI+1: six MFMAs alternating between their two accumulators
     auto mma6 = [&](int gI, const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[NT], const f16x8 (&bl)[NT]) {
+        if (!(ABL & 1024)) {        // 1024 = OGMM_PREC_F16_FRAG: plain binary16 product hi*hi only (reduced precision, 1/3 of the MFMAs)
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[2 * gI + u][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u], bh[0], acc[2 * gI + u][0], 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[2 * gI + u][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bl[0], acc[2 * gI + u][0], 0, 0, 0);
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[2 * gI + u][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bh[0], acc[2 * gI + u][0], 0, 0, 0);
     };
@@ -269,6 +271,7 @@ int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
         case 27: return launch_v4<32 + 8 + 128>(g, s);   // no stores, no A global loads
         case 28: return launch_v4<32 + 512>(g, s);   // A loads at the tile start (older order)
         case 18: return launch_v4<8>(g, s);     // full loop, no epilogue stores
+        case OGMM_PREC_F16_FRAG: return launch_v4<32 + 1024>(g, s);     // single binary16 term
         default: return launch_v4<32>(g, s);     // default: no sched_barrier pinning (measured +3-4 %)
     }
 }

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16X3, PREC_F16X3_FRAG, PREC_F32, GemmDesc  # noqa: F401
+from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16_FRAG, PREC_F16X3, PREC_F16X3_FRAG, PREC_F32, GemmDesc  # noqa: F401
 
 
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
@@ -17,6 +17,7 @@ GEMM_TIMELINE = None
 # engine selection for layers that carry pre-split weights (set by GMMReg.forward from model.precision)
 DEFAULT_SPLIT = True
 DEFAULT_OVERFLOW = None      # device int32[1]: set non-zero by the fp16x3 engine when |activation| > 65504 was clamped
+F16_SINGLE_TERM = False      # model.precision == "f16": the large-shape engine multiplies only the leading binary16 terms (reduced precision)
 
 
 def _stream():
@@ -134,6 +135,8 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.B, d.ldb = (B.data_ptr() if B is not None else None), ldb
     if split is not None:
         d.precision = split.get("variant", PREC_F16X3)
+        if F16_SINGLE_TERM and d.precision == PREC_F16X3_FRAG:
+            d.precision = PREC_F16_FRAG
         d.B_hi, d.B_lo, d.ldb_h = split["W_hi"].data_ptr(), split["W_lo"].data_ptr(), split.get("ldb_h", split["W_hi"].shape[-1])
         d.overflow = overflow.data_ptr() if overflow is not None else None
         alpha = alpha * split["inv_scale"]
