@@ -20,7 +20,7 @@ for R, n, k in ((131072, 1024, 1024), (131072, 512, 1024), (131072, 1024, 512), 
     err = float((got.double() - ref).norm() / ref.norm())
     # components
     tiles_mn = ((n + 255) // 256) * ((k + 255) // 256)
-    S = max(1, min((384 + tiles_mn - 1) // tiles_mn, (R + 255) // 256)); chunk = ((R + S - 1) // S + 63) // 64 * 64; S = (R + chunk - 1) // chunk; pitch = chunk + 64
+    S = max(1, min((512 + tiles_mn - 1) // tiles_mn, (R + 255) // 256)); chunk = ((R + S - 1) // S + 63) // 64 * 64; S = (R + chunk - 1) // chunk; pitch = chunk + 64
     dyt = torch.empty((S, n, pitch), device=dev); n_pad = (k + 255) // 256 * 256
     hi = torch.empty(S * n_pad * pitch, dtype=torch.float16, device=dev); lo = torch.empty_like(hi); part = torch.empty((S, n, k), device=dev)
     split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": ops.PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
