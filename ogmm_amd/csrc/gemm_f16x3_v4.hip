@@ -18,6 +18,7 @@
 // so the only full stop is the single barrier at the end of the tile.  A and B operand formats are those of
 // gemm_f16x3_v2.hip (which remains the engine for small N, small M and the EdgeConv pooling epilogue).
 #include "gemm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -115,6 +116,29 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
             ra_ok |= (ok ? 1u : 0u) << i;
         }
     };
+    // one eighth of load_a (deep mode spreads the tile's A loads over the first two k-steps: eight back-to-back 1 KiB loads per
+    // wave, from all eight waves at once, fill the CU's vector-memory queue and stall MFMA issue behind them)
+    auto load_a_piece = [&](int t, int i) {
+        const bool second = t >= nk1;
+        const float* Ap = second ? A2base : Abase;
+        const int64_t ld = second ? g.lda2 : g.lda;
+        const int kbase = second ? (t - nk1) * BK3 : t * BK3;
+        const int Kp = second ? g.K2 : g.K1;
+        if (i == 0) {
+            ra_ok = 0;
+            if (g.a_scale) {
+                const int kq0 = (tid & 15) * 4;
+                const int kk = (kbase + kq0 < Kp) ? (second ? g.K1 : 0) + kbase + kq0 : 0;
+                asc = *reinterpret_cast<const f32x4*>(g.a_scale + agroup + kk);
+                ash = *reinterpret_cast<const f32x4*>(g.a_shift + agroup + kk);
+            }
+        }
+        const int f = tid + i * T, row = f >> 4, kq = (f & 15) * 4;
+        const int gm = m0 + row;
+        const bool ok = gm < m_end && kbase + kq < Kp;
+        ra[i] = *reinterpret_cast<const f32x4*>(Ap + (int64_t)min(gm, g.M - 1) * ld + (ok ? kbase + kq : 0));
+        ra_ok |= (ok ? 1u : 0u) << i;
+    };
     auto store_a_piece = [&](int buf, int i) {
         _Float16* Ah = smem_h + buf * 2 * PLANE;
         _Float16* Al = Ah + PLANE;
@@ -170,10 +194,13 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
 
     // one k-step: 4 groups of two row blocks; A fragments of the next group (or of step s+1's first group) are read one group ahead
     f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];      // B fragments: even / odd k-steps
+    f16x8 bhC[NT], blC[NT], bhD[NT], blD[NT];      // (deep mode) k-steps 2, 3 of a tile; A, B then hold k-steps 0, 1
     f16x8 ah0[2], al0[2], ah1[2], al1[2];          // A fragments: even / odd groups (two row blocks each)
+    constexpr bool DEEP = (ABL & 2048) != 0;       // B fragments fetched 3 k-steps ahead (one register set per k-step of a tile)
 
     load_a(0);
     load_b(bhA, blA, 0, 0);
+    if (DEEP) { load_b(bhB, blB, 0, 1); load_b(bhC, blC, 0, 2); }
     if (ABL & 7) { load_b(bhB, blB, 0, 1); }
 #pragma unroll
     for (int i = 0; i < A_P; ++i) store_a_piece(0, i);
@@ -188,14 +215,20 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // B fragments of the next k-step (next tile's first step after the last one)
-            if (!(ABL & 2)) {
+            if (DEEP) {
+                // k-step s consumes set s; the set freed by k-step s-1 is refilled with the fragments needed 3 k-steps from now.
+                // Every fragment waited for during this tile was requested BEFORE this tile's A loads (in-order vmcnt): the matrix
+                // pipe never waits for the HBM-latency A loads, which get three k-steps before their split.
+                if (s == 0) load_b(bhD, blD, t, 3);
+                else if (more) { if (s == 1) load_b(bhA, blA, t + 1, 0); else if (s == 2) load_b(bhB, blB, t + 1, 1); else load_b(bhC, blC, t + 1, 2); }
+            } else if (!(ABL & 2)) {
             if (s < 3) { if (s & 1) load_b(bhA, blA, t, s + 1); else load_b(bhB, blB, t, s + 1); }
             else if (more) load_b(bhA, blA, t + 1, 0);
             }
             // The next tile's A loads go out AFTER step 0's B-fragment loads: vmcnt retires in order, so every fragment
             // consumed after this point waits for these (HBM-latency) loads too; issued here the first such consumer is
             // step 2's, two k-steps (~3 us) away, instead of step 1's (measured: the A loads cost 20 % of the loop).
-            if (s == 0 && !(ABL & 512)) {
+            if (s == 0 && !(ABL & 512) && !(ABL & 8192)) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && !(ABL & 4) && !(ABL & 128)) load_a(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -204,12 +237,26 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
             for (int i = 0; i < MT / 2; ++i) {
                 if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0);
                 // prefetch the next group's A fragments (same tile only: the next tile's first group is read after the barrier)
+                if (ABL & 4096) {           // single A-fragment buffer: this group's fragments are read right before its MFMAs (the other
+                    read_a(ah0, al0, buf, s, i);   // wave of the SIMD covers the LDS latency); frees 16 registers for the deep B prefetch
+                } else
                 if (!(ABL & 1)) {
                 if (i < MT / 2 - 1) { if (i & 1) read_a(ah0, al0, buf, s, i + 1); else read_a(ah1, al1, buf, s, i + 1); }
                 else if (s < 3) read_a(ah0, al0, buf, s + 1, 0);
                 }
-                if (more && s >= 2 && !(ABL & 4)) store_a_piece(buf ^ 1, (s - 2) * 4 + i);
+                if ((ABL & 8192) && more && s < 2) load_a_piece(t + 1, s * 4 + i);          // spread A loads: one piece per MFMA group
+                if (DEEP) { if (more && s == 3 && !(ABL & 4)) { store_a_piece(buf ^ 1, 2 * i); store_a_piece(buf ^ 1, 2 * i + 1); } }
+                else if (more && s >= 2 && !(ABL & 4)) store_a_piece(buf ^ 1, (s - 2) * 4 + i);
                 if (!(ABL & 32)) __builtin_amdgcn_sched_barrier(0);
+                if (DEEP && (ABL & 4096)) {
+                    if (s == 0) mma6(i, ah0, al0, bhA, blA); else if (s == 1) mma6(i, ah0, al0, bhB, blB);
+                    else if (s == 2) mma6(i, ah0, al0, bhC, blC); else mma6(i, ah0, al0, bhD, blD);
+                } else if (DEEP) {
+                    if (s == 0)      { if (i & 1) mma6(i, ah1, al1, bhA, blA); else mma6(i, ah0, al0, bhA, blA); }
+                    else if (s == 1) { if (i & 1) mma6(i, ah1, al1, bhB, blB); else mma6(i, ah0, al0, bhB, blB); }
+                    else if (s == 2) { if (i & 1) mma6(i, ah1, al1, bhC, blC); else mma6(i, ah0, al0, bhC, blC); }
+                    else             { if (i & 1) mma6(i, ah1, al1, bhD, blD); else mma6(i, ah0, al0, bhD, blD); }
+                } else
                 if (s & 1) { if (i & 1) mma6(i, ah1, al1, bhB, blB); else mma6(i, ah0, al0, bhB, blB); }
                 else       { if (i & 1) mma6(i, ah1, al1, bhA, blA); else mma6(i, ah0, al0, bhA, blA); }
             }
@@ -271,8 +318,27 @@ int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
         case 27: return launch_v4<32 + 8 + 128>(g, s);   // no stores, no A global loads
         case 28: return launch_v4<32 + 512>(g, s);   // A loads at the tile start (older order)
         case 18: return launch_v4<8>(g, s);     // full loop, no epilogue stores
+        // single-term (1/3 of the MFMAs) ablations: what bounds the loop once the matrix pipe is light
+        case 30: return launch_v4<32 + 1024 + 8>(g, s);              // no stores
+        case 31: return launch_v4<32 + 1024 + 8 + 128>(g, s);        // no stores, no A global loads
+        case 32: return launch_v4<32 + 1024 + 8 + 256>(g, s);        // no stores, no A LDS writes
+        case 33: return launch_v4<32 + 1024 + 8 + 2>(g, s);          // no stores, no B fragment loads
+        case 34: return launch_v4<32 + 1024 + 8 + 1>(g, s);          // no stores, no A fragment LDS reads
+        case 35: return launch_v4<32 + 1024 + 8 + 4>(g, s);          // no stores, no A staging at all (loads, split, LDS writes)
+        case 36: return launch_v4<32 + 1024 + 8 + 4 + 1 + 2>(g, s);  // no stores, MFMA + barrier only
+        case 37: return launch_v4<32 + 2048>(g, s);                  // B fragments 3 k-steps ahead, A split in the last k-step
+        case 38: return launch_v4<32 + 2048 + 8>(g, s);              // same, no stores
+        case 39: return launch_v4<32 + 2048 + 4096>(g, s);           // deep B prefetch + single A-fragment buffer
+        case 24: return launch_v4<32 + 2048 + 4096 + 8192>(g, s);    // + A loads spread over the first two k-steps
+        case 25: return launch_v4<32 + 2048 + 4096 + 8192 + 8>(g, s);   // same, no stores
         case OGMM_PREC_F16_FRAG: return launch_v4<32 + 1024>(g, s);     // single binary16 term
-        default: return launch_v4<32>(g, s);     // default: no sched_barrier pinning (measured +3-4 %)
+        default: {
+            static const char* env = getenv("OGMM_V4_OLD");
+            if (env && env[0] == '1') return launch_v4<32>(g, s);     // previous default (1-step B prefetch, double-buffered A fragments)
+            // B fragments 3 k-steps ahead (no matrix-pipe wait ever falls behind the A loads in the in-order vmcnt queue), one
+            // A-fragment register set (the SIMD's other wave covers the LDS latency), A loads spread over two k-steps: +3 %
+            return launch_v4<32 + 2048 + 4096 + 8192>(g, s);
+        }
     }
 }
 
