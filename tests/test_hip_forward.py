@@ -146,3 +146,29 @@ def test_reduced_precision_f16_mode():
     o = (out["f16"][2] - out["f16x3"][2]).abs().max().item()
     print("PARITY f16(reduced) vs f16x3, 64 pairs: R max=%.2e median=%.2e  t max=%.2e  o max=%.2e" % (r.max(), r.median(), t.max(), o))
     assert 1e-6 < r.max().item() < 5e-2 and r.median().item() < 2e-3 and t.max().item() < 5e-2
+
+
+@pytest.mark.gpu
+def test_largest_supported_cloud_and_input_validation():
+    """N = 4096 (the FPS / kNN kernels keep a whole cloud on chip: their documented ceiling), J = 64, against the CPU oracle; and the
+    argument checks of the forward: wrong dtype, N_src != N_tgt, more neighbours / anchors / clusters than points."""
+    from ogmm_amd._lib import OgmmError
+    B, N, J = 1, 4096, 64
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
+    model = GMMReg(512, J, cfg)
+    synth.fill_state_dict(model.state_dict())
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to("cuda:0").eval()
+    src, tgt, _, _ = synth.make_batch(900, B, N, "room")
+    starts = synth.fps_starts_for(900, B, N)
+    with torch.no_grad():
+        R, t, so, to_, loss = model(src.cuda(), tgt.cuda(), fps_starts=starts)
+        Ro, to, soo, too, losso = O.forward(P, cfg, src, tgt, starts)
+    r, tt = O.rotation_error_rad(R.cpu(), Ro).max().item(), O.translation_error(t.cpu(), to).max().item()
+    print("PARITY f16x3 live N=4096 J=64: R=%.2e t=%.2e o=%.2e" % (r, tt, (so.cpu() - soo).abs().max().item()))
+    assert r < R_TOL and tt < T_TOL and (so.cpu() - soo).abs().max().item() < 1e-5
+    x = torch.zeros(2, 3, 64, device="cuda:0")
+    for bad in ((x.double(), x.double()), (x, torch.zeros(2, 3, 65, device="cuda:0")), (x[:, :, :10], x[:, :, :10]),
+                (torch.zeros(2, 4, 64, device="cuda:0"),) * 2):
+        with pytest.raises(OgmmError):
+            model(*bad)
