@@ -186,6 +186,13 @@ int ogmm_gmm_em(const float* xyz, const float* o /*[C][N]*/, const int32_t* ids0
                 int iters, int sk_iters, float epsilon, float tau,
                 float* gamma /*[C][N][J]*/, float* pi /*[C][J]*/, float* mu /*[C][J][3]*/, void* stream);
 
+/* K15 for shapes whose N x J cost matrix exceeds one CU's LDS: the same loop as a fixed sequence of grid-wide kernels over a cost
+ * matrix kept in `workspace` (ogmm_gmm_em_workspace_bytes, 256-byte aligned), all launched by this one call without host
+ * synchronisation.  Same arguments and results as ogmm_gmm_em. */
+int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J);
+int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
+                      float epsilon, float tau, float* gamma, float* pi, float* mu, void* workspace, void* stream);
+
 /* ---- K16: mu_feat = gamma^T feats / (N pi + 1e-5).  lib/utils.py:289 / :130-140. */
 int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,
                        float* mu_feat /*[C][J][D]*/, void* stream);

@@ -57,6 +57,8 @@ PROTOTYPES = {
     "ogmm_rowdot": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_overlap_cross": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_gmm_em": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogmm_gmm_em_workspace_bytes": [c_int, c_int, c_int],
+    "ogmm_gmm_em_multi": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_gmm_feat_mean": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_match_kabsch": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_kabsch": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],

@@ -1,0 +1,203 @@
+// K15 for shapes whose N x J cost matrix does not fit into one CU's LDS (e.g. N = 2048, J = 64: 512 KB): the same E/M loop
+// (lib/utils.py:269-288 with :69-108 and :130-140) as a fixed sequence of small grid-wide kernels over a cost matrix that lives
+// in a workspace (L2 / Infinity-Cache resident: 64 MB for 128 clouds).  One cloud on one workgroup recomputes every distance
+// in every pass and uses half of the chip (128 workgroups on 256 CUs): 15.7 ms at B = 64, N = 2048, J = 64, the long pole of the
+// forward.  Here every pass spreads over all CUs:
+//   init   : log p, first centres                                         (1 launch)
+//   per outer iteration (10):  cost  ->  [u-pass, v-pass] x sk_iters  ->  gamma  ->  M-step        (2 sk_iters + 3 launches)
+// All launches are issued by ONE call (no host synchronisation; the reference needs ~3000 launches and 200 .item() syncs).
+// The arithmetic of every entry is that of gmm_em_cached_kernel; column reductions differ in summation order only.
+#include "ogmm_common.h"
+
+namespace {
+
+using namespace ogmm;
+
+__device__ __forceinline__ float cdist_mm2(float x, float y, float z, float xn, float mx, float my, float mz, float mn) {
+    float acc = mul_rn(-2.0f * x, mx);
+    acc = __fmaf_rn(-2.0f * y, my, acc);
+    acc = __fmaf_rn(-2.0f * z, mz, acc);
+    acc = add_rn(acc, xn);
+    acc = add_rn(acc, mn);
+    return sqrtf(fmaxf(acc, 0.0f));
+}
+
+struct EmWs {
+    float* cost;     // [C][J][N]  cost, later unnormalised gamma
+    float* u;        // [C][N]
+    float* v;        // [C][J]
+    float* logp;     // [C][N]
+    float* rclip;    // [C][N]
+    float4* mu;      // [C][J]  x, y, z, |mu|^2
+};
+
+// one workgroup per cloud: p = o / max(sum o, 1e-4), log(p + 1e-8); centres = xyz[ids0]
+__global__ __launch_bounds__(256) void em_init_kernel(const float* __restrict__ xyz, const float* __restrict__ o, const int32_t* __restrict__ ids0,
+                                                      int N, int J, EmWs w) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ oc = o + (int64_t)c * N;
+    float part = 0.0f;
+    for (int n = tid; n < N; n += 256) part += oc[n];
+    part = wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    const float osum = fmaxf((red[0] + red[1]) + (red[2] + red[3]), 1e-4f);
+    for (int n = tid; n < N; n += 256) w.logp[(int64_t)c * N + n] = logf(oc[n] / osum + 1e-8f);
+    for (int j = tid; j < J; j += 256) {
+        const float* p = xyz + ((int64_t)c * N + ids0[(int64_t)c * J + j]) * 3;
+        w.mu[(int64_t)c * J + j] = make_float4(p[0], p[1], p[2], sqnorm3(p[0], p[1], p[2]));
+    }
+}
+
+// cost[c][j][n] = cdist(xyz_n, mu_j) / tau;  u = 0, v = 0.   grid (N/256, C)
+__global__ __launch_bounds__(256) void em_cost_kernel(const float* __restrict__ xyz, int N, int J, float inv_tau, EmWs w) {
+    const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) for (int j = threadIdx.x; j < J; j += 256) w.v[(int64_t)c * J + j] = 0.0f;
+    if (n >= N) return;
+    const float* p = xyz + ((int64_t)c * N + n) * 3;
+    const float x = p[0], y = p[1], z = p[2], xn = sqnorm3(x, y, z);
+    w.u[(int64_t)c * N + n] = 0.0f;
+    const float4* __restrict__ mu = w.mu + (int64_t)c * J;
+    float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
+    for (int j = 0; j < J; ++j) {
+        const float4 m = mu[j];
+        Cc[(int64_t)j * N] = cdist_mm2(x, y, z, xn, m.x, m.y, m.z, m.w) * inv_tau;
+    }
+}
+
+// u^{l+1}: one thread per row.  grid (N/256, C)
+__global__ __launch_bounds__(256) void em_u_kernel(int N, int J, float inv_eps, float eps, EmWs w) {
+    extern __shared__ float vs[];                      // [J]
+    const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    for (int j = threadIdx.x; j < J; j += 256) vs[j] = w.v[(int64_t)c * J + j];
+    __syncthreads();
+    if (n >= N) return;
+    const float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
+    const float un = w.u[(int64_t)c * N + n];
+    float mx = -__builtin_inff();
+    for (int j = 0; j < J; ++j) mx = fmaxf(mx, ((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps);
+    float se = 0.0f;
+    for (int j = 0; j < J; ++j) se += expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps - mx);
+    w.u[(int64_t)c * N + n] = eps * (w.logp[(int64_t)c * N + n] - (mx + logf(se))) + un;
+}
+
+// v^{l+1}: one workgroup per (cluster j, cloud).  grid (J, C)
+__global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, float eps, float logq, EmWs w) {
+    __shared__ float red[4];
+    const int j = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ Cj = w.cost + ((int64_t)c * J + j) * N;
+    const float* __restrict__ u = w.u + (int64_t)c * N;
+    const float vj = w.v[(int64_t)c * J + j];
+    float mx = -__builtin_inff();
+    for (int n = tid; n < N; n += 256) mx = fmaxf(mx, ((-Cj[n] + u[n]) + vj) * inv_eps);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.0f;
+    for (int n = tid; n < N; n += 256) se += expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
+    se = wave_sum(se);
+    if (lane == 0) red[wave] = se;
+    __syncthreads();
+    if (tid == 0) w.v[(int64_t)c * J + j] = eps * (logq - (mx + logf((red[0] + red[1]) + (red[2] + red[3])))) + vj;
+}
+
+// gamma = exp(K) (nan -> 0, inf -> FLT_MAX) in place; rclip = max(rowsum, 1e-3); the last iteration also writes gamma / rclip.  grid (N/256, C)
+__global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out) {
+    extern __shared__ float vs[];
+    const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    for (int j = threadIdx.x; j < J; j += 256) vs[j] = w.v[(int64_t)c * J + j];
+    __syncthreads();
+    if (n >= N) return;
+    float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
+    const float un = w.u[(int64_t)c * N + n];
+    float rs = 0.0f;
+    for (int j = 0; j < J; ++j) {
+        float g = expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps);
+        g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+        Cc[(int64_t)j * N] = g;
+        rs += g;
+    }
+    const float rc = fmaxf(rs, 1e-3f);
+    w.rclip[(int64_t)c * N + n] = rc;
+    if (gamma_out) {
+        float* __restrict__ grow = gamma_out + ((int64_t)c * N + n) * J;
+        for (int j = 0; j < J; ++j) grow[j] = Cc[(int64_t)j * N] / rc;
+    }
+}
+
+// M-step: pi_j = mean_n gamma, mu_j = gamma^T xyz / (N pi + 1e-5), fp64 column sums.  grid (J, C)
+__global__ __launch_bounds__(256) void em_mstep_kernel(const float* __restrict__ xyz, int N, int J, EmWs w, float* __restrict__ pi_out,
+                                                       float* __restrict__ mu_out) {
+    __shared__ double red[4][4];
+    const int j = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ Gj = w.cost + ((int64_t)c * J + j) * N;
+    const float* __restrict__ rc = w.rclip + (int64_t)c * N;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
+    double sg = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int n = tid; n < N; n += 256) {
+        const float g = Gj[n] / rc[n];
+        sg += g;
+        sx += (double)g * cloud[3 * n]; sy += (double)g * cloud[3 * n + 1]; sz += (double)g * cloud[3 * n + 2];
+    }
+    sg = wave_sum_d(sg); sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
+    if (lane == 0) { red[wave][0] = sg; red[wave][1] = sx; red[wave][2] = sy; red[wave][3] = sz; }
+    __syncthreads();
+    if (tid == 0) {
+        double t[4];
+        for (int i = 0; i < 4; ++i) t[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        const float pj = (float)t[0] / (float)N;
+        const float npi = pj * (float)N + 1e-5f;
+        const float nx = (float)t[1] / npi, ny = (float)t[2] / npi, nz = (float)t[3] / npi;
+        w.mu[(int64_t)c * J + j] = make_float4(nx, ny, nz, sqnorm3(nx, ny, nz));
+        if (pi_out) {
+            pi_out[(int64_t)c * J + j] = pj;
+            float* mo = mu_out + ((int64_t)c * J + j) * 3;
+            mo[0] = nx; mo[1] = ny; mo[2] = nz;
+        }
+    }
+}
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J) {
+    return (int64_t)(align256((size_t)C * J * N * 4) + 3 * align256((size_t)C * N * 4) + align256((size_t)C * J * 4) + align256((size_t)C * J * 16));
+}
+
+extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
+                                 float epsilon, float tau, float* gamma, float* pi, float* mu, void* workspace, void* stream) {
+    using namespace ogmm;
+    OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu && workspace, "ogmm_gmm_em_multi: null pointer");
+    OGMM_REQUIRE(C > 0 && C <= 65535 && N > 0 && J > 0 && J <= N && J <= 65535 && iters > 0 && sk_iters >= 0 && epsilon > 0 && tau > 0,
+                 "ogmm_gmm_em_multi: bad sizes C=%d N=%d J=%d", C, N, J);
+    OGMM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "ogmm_gmm_em_multi: workspace must be 256-byte aligned");
+    char* p = static_cast<char*>(workspace);
+    EmWs w;
+    w.cost = reinterpret_cast<float*>(p);  p += align256((size_t)C * J * N * 4);
+    w.u = reinterpret_cast<float*>(p);     p += align256((size_t)C * N * 4);
+    w.logp = reinterpret_cast<float*>(p);  p += align256((size_t)C * N * 4);
+    w.rclip = reinterpret_cast<float*>(p); p += align256((size_t)C * N * 4);
+    w.v = reinterpret_cast<float*>(p);     p += align256((size_t)C * J * 4);
+    w.mu = reinterpret_cast<float4*>(p);
+    const float inv_eps = (float)(1.0 / (double)epsilon), inv_tau = (float)(1.0 / (double)tau);
+    const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
+    hipStream_t s = as_stream(stream);
+    const dim3 rows((N + 255) / 256, C), cols(J, C), blk(256);
+    const size_t vs = (size_t)J * sizeof(float);
+    hipLaunchKernelGGL(em_init_kernel, dim3(C), blk, 0, s, xyz, o, ids0, N, J, w);
+    for (int it = 0; it < iters; ++it) {
+        const bool last = it + 1 == iters;
+        hipLaunchKernelGGL(em_cost_kernel, rows, blk, 0, s, xyz, N, J, inv_tau, w);
+        for (int sk = 0; sk < sk_iters; ++sk) {
+            hipLaunchKernelGGL(em_u_kernel, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
+            hipLaunchKernelGGL(em_v_kernel, cols, blk, 0, s, N, J, inv_eps, epsilon, logq, w);
+        }
+        hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr);
+        hipLaunchKernelGGL(em_mstep_kernel, cols, blk, 0, s, xyz, N, J, w, last ? pi : (float*)nullptr, mu);
+    }
+    return check_launch("ogmm_gmm_em_multi");
+}

@@ -338,7 +338,7 @@ def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo):
 
 
 # ---------------------------------------------------------------------------------------------- GMM head
-def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0):
+def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, engine=None):
     """-> gamma [C,N,J], pi [C,J], mu [C,J,3]   (lib/utils.py:269-288)."""
     C, N, _ = xyz.shape
     J = ids0.shape[1]
@@ -346,6 +346,14 @@ def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0):
     gamma = torch.empty((C, N, J), dtype=torch.float32, device=xyz.device)
     pi = torch.empty((C, J), dtype=torch.float32, device=xyz.device)
     mu = torch.empty((C, J, 3), dtype=torch.float32, device=xyz.device)
+    if engine is None:       # the on-chip loop while the N x J cost matrix fits one CU's LDS, the grid-wide sequence beyond
+        engine = "chip" if (4 * N + 3 * ((N + 3) // 4 * 4) + 5 * J + 16 + N * J) * 4 <= 128 * 1024 else "multi"
+    if engine == "multi":
+        ws = torch.empty(_lib.load().ogmm_gmm_em_workspace_bytes(C, N, J), dtype=torch.uint8, device=xyz.device)
+        _lib.call("ogmm_gmm_em_multi", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
+                  _p(gamma), _p(pi), _p(mu), _p(ws), _stream())
+        ws.record_stream(torch.cuda.current_stream())
+        return gamma, pi, mu
     _lib.call("ogmm_gmm_em", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
               _p(gamma), _p(pi), _p(mu), _stream())
     return gamma, pi, mu

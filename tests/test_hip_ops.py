@@ -333,8 +333,9 @@ def test_overlap_cross(ops):
 
 
 # ------------------------------------------------------------------------------------------------ GMM head
+@pytest.mark.parametrize("engine", [None, "chip", "multi"])
 @pytest.mark.parametrize("C,N,J", [(4, 1024, 16), (2, 717, 128), (2, 2048, 64), (3, 200, 8)])
-def test_gmm_em_and_feat_mean(ops, C, N, J):
+def test_gmm_em_and_feat_mean(ops, C, N, J, engine):
     torch.manual_seed(N + J)
     xyz = clouds(C, N, seed=31)
     o = torch.sigmoid(torch.randn(C, N))
@@ -344,7 +345,7 @@ def test_gmm_em_and_feat_mean(ops, C, N, J):
     assert set(st) == {10}
     ids_g = ops.fps(dev(xyz), J, None)
     assert torch.equal(ids_g.cpu().long(), ids)
-    g_gamma, g_pi, g_mu = ops.gmm_em(dev(xyz), dev(o), ids_g)
+    g_gamma, g_pi, g_mu = ops.gmm_em(dev(xyz), dev(o), ids_g, engine=engine)      # on-chip loop / grid-wide kernel sequence / automatic choice
     # fp64 run of the same algorithm = the yardstick both fp32 paths are measured against
     gd, pid, mud, _, _ = O.weighted_em(xyz.double(), feats.double(), o.double(), J)
     ref_err = max((pi - pid).abs().max().item(), (mu - mud).abs().max().item())
