@@ -568,6 +568,50 @@ __global__ void kabsch_bwd_kernel(const float* __restrict__ src, const float* __
     }
 }
 
+// Cosine similarities of match_kabsch: the normalised rows go through LDS in chunks of MK_DC channels, channel-major ([d][cluster],
+// pitch J+4), and every thread accumulates a BS x BS block of the J x J matrix (BS >= ceil(J/16)): J*J*D/256 FMAs per thread
+// instead of one 2 KB row pair fetched from L2 per entry and wave (1.8 ms -> 0.35 ms for the whole kernel at J = 64).
+template <int BS>
+__device__ __forceinline__ void cosine_block(const float* __restrict__ Fs, const float* __restrict__ Ft, const float* __restrict__ ns,
+                                             const float* __restrict__ nt, int J, int D, int tid, float* __restrict__ sim, float* __restrict__ xs) {
+    constexpr int MK_DC = 64;
+    const int pitch = J + 4;
+    float* xt = xs + MK_DC * pitch;
+    const int n0 = (tid >> 4) * BS, m0 = (tid & 15) * BS;
+    float acc[BS][BS];
+#pragma unroll
+    for (int a = 0; a < BS; ++a)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) acc[a][c] = 0.0f;
+    for (int d0 = 0; d0 < D; d0 += MK_DC) {
+        __syncthreads();
+        for (int i = tid; i < 2 * J * MK_DC; i += 256) {
+            const int d = i % MK_DC, r = i / MK_DC;              // consecutive threads read consecutive channels of one row
+            const bool src_row = r < J;
+            const int row = src_row ? r : r - J;
+            const float v = d0 + d < D ? (src_row ? Fs : Ft)[(int64_t)row * D + d0 + d] / (src_row ? ns[row] : nt[row]) : 0.0f;
+            (src_row ? xs : xt)[d * pitch + row] = v;
+        }
+        __syncthreads();
+        if (n0 < J && m0 < J) {
+            for (int d = 0; d < MK_DC; ++d) {
+                float a_[BS], b_[BS];
+#pragma unroll
+                for (int a = 0; a < BS; ++a) { a_[a] = n0 + a < J ? xs[d * pitch + n0 + a] : 0.0f; b_[a] = m0 + a < J ? xt[d * pitch + m0 + a] : 0.0f; }
+#pragma unroll
+                for (int a = 0; a < BS; ++a)
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) acc[a][c] = fmaf(a_[a], b_[c], acc[a][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < BS; ++a)
+#pragma unroll
+        for (int c = 0; c < BS; ++c)
+            if (n0 + a < J && m0 + c < J) sim[(n0 + a) * J + m0 + c] = acc[a][c];
+}
+
 // ================================================================================================
 // K17+K18.  One workgroup of 256 threads per pair: cosine similarity J x J (each wave reduces one entry
 // at a time over D with coalesced 16-byte lane loads), softmax(sim / T) over target clusters, soft
@@ -594,48 +638,13 @@ __global__ __launch_bounds__(256) void match_kabsch_kernel(const float* __restri
         if (lane == 0) (r < J ? ns[r] : nt[r - J]) = fmaxf(sqrtf(ss), 1e-12f);
     }
     __syncthreads();
-    // cosine similarities: the normalised rows go through LDS in chunks of MK_DC channels, channel-major ([d][cluster], pitch J+4),
-    // and every thread accumulates a BS x BS block of the J x J matrix (BS = ceil(J/16)): J*J*D/256 FMAs per thread instead of
-    // one 2 KB row pair fetched from L2 per entry and wave (1.8 ms -> 0.1 ms at J = 64)
     {
-        constexpr int MK_DC = 64, MAXBS = 8;
-        const int pitch = J + 4;
-        float* xs = wsum + J;                     // [MK_DC][pitch]
-        float* xt = xs + MK_DC * pitch;           // [MK_DC][pitch]
-        const int BS = (J + 15) / 16;
-        const int n0 = (tid >> 4) * BS, m0 = (tid & 15) * BS;
-        float acc[MAXBS][MAXBS];
-#pragma unroll
-        for (int a = 0; a < MAXBS; ++a)
-#pragma unroll
-            for (int c = 0; c < MAXBS; ++c) acc[a][c] = 0.0f;
-        for (int d0 = 0; d0 < D; d0 += MK_DC) {
-            __syncthreads();
-            for (int i = tid; i < 2 * J * MK_DC; i += 256) {
-                const int d = i % MK_DC, r = i / MK_DC;              // consecutive threads read consecutive channels of one row
-                const bool src_row = r < J;
-                const int row = src_row ? r : r - J;
-                const float v = d0 + d < D ? (src_row ? Fs : Ft)[(int64_t)row * D + d0 + d] / (src_row ? ns[row] : nt[row]) : 0.0f;
-                (src_row ? xs : xt)[d * pitch + row] = v;
-            }
-            __syncthreads();
-            if (n0 < J && m0 < J) {
-                for (int d = 0; d < MK_DC; ++d) {
-                    float a_[MAXBS], b_[MAXBS];
-#pragma unroll
-                    for (int a = 0; a < MAXBS; ++a) { a_[a] = a < BS && n0 + a < J ? xs[d * pitch + n0 + a] : 0.0f; b_[a] = a < BS && m0 + a < J ? xt[d * pitch + m0 + a] : 0.0f; }
-#pragma unroll
-                    for (int a = 0; a < MAXBS; ++a)
-#pragma unroll
-                        for (int c = 0; c < MAXBS; ++c) acc[a][c] = fmaf(a_[a], b_[c], acc[a][c]);
-                }
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < MAXBS; ++a)
-#pragma unroll
-            for (int c = 0; c < MAXBS; ++c)
-                if (a < BS && c < BS && n0 + a < J && m0 + c < J) sim[(n0 + a) * J + m0 + c] = acc[a][c];
+        const int BSr = (J + 15) / 16;
+        float* xs_ = wsum + J;
+        if (BSr <= 1) cosine_block<1>(Fs, Ft, ns, nt, J, D, tid, sim, xs_);
+        else if (BSr <= 2) cosine_block<2>(Fs, Ft, ns, nt, J, D, tid, sim, xs_);
+        else if (BSr <= 4) cosine_block<4>(Fs, Ft, ns, nt, J, D, tid, sim, xs_);
+        else cosine_block<8>(Fs, Ft, ns, nt, J, D, tid, sim, xs_);
     }
     __syncthreads();
     for (int n = wave; n < J; n += 4) {     // softmax over m, one wave per source cluster
