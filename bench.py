@@ -135,6 +135,24 @@ def main():
                      "path_frac": value / world * GFLOP_PER_PAIR / 1e3 / peak},
     }
 
+    if rank == 0 and world == 1:
+        # yard-stick: the vendor library (hipBLASLt through torch.matmul) on the dominant GEMM shape, measured here and now
+        lib = {}
+        for tag, dt in (("fp32", torch.float32), ("f16", torch.float16)):
+            a_ = torch.randn(B_PER_GPU * 2 * N_POINTS, 1024, device=dev, dtype=dt)
+            b_ = torch.randn(1024, 1024, device=dev, dtype=dt)
+            for _ in range(2):
+                a_ @ b_.t()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                a_ @ b_.t()
+            e1.record()
+            torch.cuda.synchronize()
+            lib[tag + "_tflops"] = 2.0 * a_.shape[0] * 1024 * 1024 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            del a_, b_
+        lib["shape"] = "%dx1024x1024" % (B_PER_GPU * 2 * N_POINTS)
+        result["roofline"]["library_gemm_same_box"] = lib
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import ogmm_oracle as O
         n = args.cpu_sample
