@@ -82,7 +82,7 @@ class DeepGMR(nn.Module):
         if self._overflow is None or self._overflow.device != dev:
             self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         L = self._layers()
-        ops.DEFAULT_SPLIT, ops.DEFAULT_OVERFLOW = self.precision == "f16x3", self._overflow
+        ops.DEFAULT_SPLIT, ops.DEFAULT_OVERFLOW, ops.F16_SINGLE_TERM = self.precision == "f16x3", self._overflow, False
         xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()                 # [C,N,3]
         idx = ops.knn(xyz, k)
         R_ = C * N

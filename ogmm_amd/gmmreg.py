@@ -413,6 +413,9 @@ class GMMReg(nn.Module):
         P = dict(self.named_parameters())
         P.update(dict(self.named_buffers()))
         cap = {} if capture else None
+        if self.precision not in ("f16x3", "f32"):
+            raise OgmmError("training runs with precision 'f16x3' or 'f32' (the reduced 'f16' mode is inference only)")
+        ops.F16_SINGLE_TERM = False         # module-level engine switch of the eval path: never inherit it from an earlier reduced-precision forward
         backend = self._train_ops if self._train_ops is not None else train_ops.TrainOps(self.precision, self._overflow)
         out = train_graph.forward_train(backend, P, self.config, self.n_clusters, src, tgt, fps_starts.to(src.device), cap)
         if capture:
