@@ -306,7 +306,7 @@ class GMMReg(nn.Module):
         fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()   # [stage][src clouds | tgt clouds]
 
         xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()         # [C,N,3]
-        swap = torch.cat([torch.arange(B, C), torch.arange(0, B)]).to(device=dev, dtype=torch.int32)
+        swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
         # Latency-bound selection kernels (one workgroup per cloud: FPS chains, the k=5 graph, later the E/M loop) run on a
         # side stream next to the GEMM-bound main stream: they occupy <= C of the 256 CUs.  Every tensor they touch stays
         # referenced until the streams are joined again.
@@ -425,6 +425,44 @@ class GMMReg(nn.Module):
                                                 out[0].detach(), out[1].detach(), 2.0 * self.config.overlap_radius)
             out = (rot, trans) + tuple(out[2:])
         return out
+
+    def capture_graph(self, batch, n_points, device=None):
+        """HIP-graph version of the eval forward for one (batch, n_points) shape: every kernel launch of the forward -- about 140,
+        on two streams -- is recorded once and replayed with a single hipGraphLaunch, which removes the host-side launch cost that
+        dominates small batches (B = 1: the GPU work is < 1 ms).  Returns `run(src, tgt, fps_starts=None) -> the usual 5-tuple`;
+        the outputs are views of the graph's static buffers and are overwritten by the next call."""
+        if self.training:
+            raise OgmmError("capture_graph is for eval mode")
+        dev = torch.device(device) if device is not None else self.emd.conv1.weight.device
+        s_src = torch.zeros((batch, 3, n_points), dtype=torch.float32, device=dev)
+        s_tgt = torch.zeros_like(s_src)
+        s_starts = torch.zeros((6, batch), dtype=torch.long, device=dev)
+        src0, tgt0, _, _ = __import__("ogmm_amd.synth", fromlist=["make_batch"]).make_batch(0, batch, n_points, "partial")
+        s_src.copy_(src0)
+        s_tgt.copy_(tgt0)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(warm), torch.no_grad():          # warm-up on a side stream: lazy one-time setup (function attributes,
+            for _ in range(2):                                  # packed weights, allocator pools) must not happen during capture
+                self.forward(s_src, s_tgt, fps_starts=s_starts)
+        torch.cuda.current_stream(dev).wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            outs = self.forward(s_src, s_tgt, fps_starts=s_starts)
+
+        def run(src, tgt, fps_starts=None):
+            if tuple(src.shape) != (batch, 3, n_points) or tuple(tgt.shape) != (batch, 3, n_points):
+                raise OgmmError("graph captured for [%d,3,%d] inputs, got %s" % (batch, n_points, tuple(src.shape)))
+            if fps_starts is None:
+                fps_starts = torch.stack([torch.randint(0, n_points, (batch,), dtype=torch.long) for _ in range(6)])
+            s_src.copy_(src, non_blocking=True)
+            s_tgt.copy_(tgt, non_blocking=True)
+            s_starts.copy_(fps_starts.reshape(6, batch), non_blocking=True)
+            graph.replay()
+            return outs
+        run.graph = graph
+        return run
 
     def fp16_overflowed(self):
         """True if any fp16x3 GEMM since the last call clamped an activation beyond +-65504 (synchronises)."""

@@ -172,3 +172,24 @@ def test_largest_supported_cloud_and_input_validation():
                 (torch.zeros(2, 4, 64, device="cuda:0"),) * 2):
         with pytest.raises(OgmmError):
             model(*bad)
+
+
+@pytest.mark.gpu
+def test_hip_graph_replay_is_bit_identical():
+    """GMMReg.capture_graph: the ~140 launches of the eval forward (two streams) recorded once and replayed with one hipGraphLaunch."""
+    B, N, J = 3, 512, 16
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035)
+    model = GMMReg(512, J, cfg)
+    synth.fill_state_dict(model.state_dict())
+    model = model.to("cuda:0").eval()
+    run = model.capture_graph(B, N)
+    for first in (10, 50):
+        src, tgt, _, _ = synth.make_batch(first, B, N, "partial")
+        starts = synth.fps_starts_for(first, B, N)
+        with torch.no_grad():
+            eager = [t.clone() for t in model(src.cuda(), tgt.cuda(), fps_starts=starts)]
+            replay = run(src.cuda(), tgt.cuda(), starts.cuda())
+        for a, b in zip(eager, replay):
+            assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        run(torch.zeros(2, 3, N, device="cuda:0"), torch.zeros(2, 3, N, device="cuda:0"))
