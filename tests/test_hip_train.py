@@ -263,3 +263,23 @@ def test_training_step_matches_reference(name, precision):
     for key in (f[len("stat/"):] for f in fx.files if f.startswith("stat/")):
         np.testing.assert_allclose(sd[key].cpu().numpy(), fx["stat/" + key], rtol=1e-5, atol=1e-6, err_msg=key)
     assert not model.fp16_overflowed()
+
+
+@pytest.mark.parametrize("B,N,J,k,M,topk", [(1, 512, 16, 20, 128, 256), (5, 300, 8, 12, 32, 128), (2, 717, 16, 20, 128, 512)])
+def test_trainer_steps_on_ragged_shapes(B, N, J, k, M, topk):
+    """Three optimiser steps on the same batch: single-pair batches (BatchNorm groups of one cloud), row counts that are no multiple of
+    the kernels' tiles, the loss-scale back-off; the loss must go down and every parameter stay finite."""
+    from argparse import Namespace
+    from ogmm_amd.trainer import Trainer
+    cfg = Namespace(gnn_k=k, num_heads=4, km_clusters=M, overlap_radius=0.035)
+    model = GMMReg(512, J, cfg)
+    synth.fill_state_dict(model.state_dict())
+    model = model.to(DEV)
+    tr = Trainer(model, welsch_top_k=topk)
+    batch = [t_.to(DEV) for t_ in synth.make_train_batch(0, B, N)]
+    starts = synth.fps_starts_for(0, B, N)
+    losses_ = [float(tr.step(*batch, fps_starts=starts)["loss"]) for _ in range(4)]
+    assert losses_[-1] < losses_[0], losses_
+    assert tr.skipped_steps <= 2 and tr.loss_scale >= 65536.0 / 4
+    assert all(torch.isfinite(p).all().item() for p in model.parameters())
+    assert all(torch.isfinite(b).all().item() for b in model.buffers())
