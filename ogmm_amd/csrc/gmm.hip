@@ -578,11 +578,12 @@ __device__ __forceinline__ void cosine_block(const float* __restrict__ Fs, const
     const int pitch = J + 4;
     float* xt = xs + MK_DC * pitch;
     const int n0 = (tid >> 4) * BS, m0 = (tid & 15) * BS;
-    float acc[BS][BS];
+    double acc[BS][BS];      // fp64 accumulation: the softmax behind it has temperature 0.05 and the solve is ill-conditioned for
+                             // near-degenerate cluster layouts (the N=717 / J=128 fixture): keep this stage at the fp32 rounding of its result
 #pragma unroll
     for (int a = 0; a < BS; ++a)
 #pragma unroll
-        for (int c = 0; c < BS; ++c) acc[a][c] = 0.0f;
+        for (int c = 0; c < BS; ++c) acc[a][c] = 0.0;
     for (int d0 = 0; d0 < D; d0 += MK_DC) {
         __syncthreads();
         for (int i = tid; i < 2 * J * MK_DC; i += 256) {
@@ -601,7 +602,7 @@ __device__ __forceinline__ void cosine_block(const float* __restrict__ Fs, const
 #pragma unroll
                 for (int a = 0; a < BS; ++a)
 #pragma unroll
-                    for (int c = 0; c < BS; ++c) acc[a][c] = fmaf(a_[a], b_[c], acc[a][c]);
+                    for (int c = 0; c < BS; ++c) acc[a][c] = fma((double)a_[a], (double)b_[c], acc[a][c]);
             }
         }
     }
@@ -609,7 +610,7 @@ __device__ __forceinline__ void cosine_block(const float* __restrict__ Fs, const
     for (int a = 0; a < BS; ++a)
 #pragma unroll
         for (int c = 0; c < BS; ++c)
-            if (n0 + a < J && m0 + c < J) sim[(n0 + a) * J + m0 + c] = acc[a][c];
+            if (n0 + a < J && m0 + c < J) sim[(n0 + a) * J + m0 + c] = (float)acc[a][c];
 }
 
 // ================================================================================================
@@ -632,10 +633,10 @@ __global__ __launch_bounds__(256) void match_kabsch_kernel(const float* __restri
     const float* __restrict__ Ft = f_t + (int64_t)b * J * D;
     for (int r = wave; r < 2 * J; r += 4) {
         const float* __restrict__ p = r < J ? Fs + (int64_t)r * D : Ft + (int64_t)(r - J) * D;
-        float ss = 0.0f;
-        for (int d = lane; d < D; d += 64) ss = fmaf(p[d], p[d], ss);
-        ss = wave_sum(ss);
-        if (lane == 0) (r < J ? ns[r] : nt[r - J]) = fmaxf(sqrtf(ss), 1e-12f);
+        double ss = 0.0;
+        for (int d = lane; d < D; d += 64) ss = fma((double)p[d], (double)p[d], ss);
+        ss = wave_sum_d(ss);
+        if (lane == 0) (r < J ? ns[r] : nt[r - J]) = fmaxf((float)sqrt(ss), 1e-12f);
     }
     __syncthreads();
     {

@@ -77,14 +77,15 @@ __global__ __launch_bounds__(256) void em_u_kernel(int N, int J, float inv_eps, 
     const float un = w.u[(int64_t)c * N + n];
     float mx = -__builtin_inff();
     for (int j = 0; j < J; ++j) mx = fmaxf(mx, ((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps);
-    float se = 0.0f;
-    for (int j = 0; j < J; ++j) se += expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps - mx);
-    w.u[(int64_t)c * N + n] = eps * (w.logp[(int64_t)c * N + n] - (mx + logf(se))) + un;
+    double se = 0.0;          // sums of exponentials in fp64: the E/M is ill-conditioned for J close to N (5e-6 on mu at N=717, J=128)
+    for (int j = 0; j < J; ++j) se += (double)expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps - mx);
+    w.u[(int64_t)c * N + n] = eps * (w.logp[(int64_t)c * N + n] - (mx + logf((float)se))) + un;
 }
 
 // v^{l+1}: one workgroup per (cluster j, cloud).  grid (J, C)
 __global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, float eps, float logq, EmWs w) {
     __shared__ float red[4];
+    __shared__ double redd[4];
     const int j = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ Cj = w.cost + ((int64_t)c * J + j) * N;
     const float* __restrict__ u = w.u + (int64_t)c * N;
@@ -96,12 +97,12 @@ __global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, 
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
-    float se = 0.0f;
-    for (int n = tid; n < N; n += 256) se += expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
-    se = wave_sum(se);
-    if (lane == 0) red[wave] = se;
+    double se = 0.0;
+    for (int n = tid; n < N; n += 256) se += (double)expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
+    se = wave_sum_d(se);
+    if (lane == 0) redd[wave] = se;
     __syncthreads();
-    if (tid == 0) w.v[(int64_t)c * J + j] = eps * (logq - (mx + logf((red[0] + red[1]) + (red[2] + red[3])))) + vj;
+    if (tid == 0) w.v[(int64_t)c * J + j] = eps * (logq - (mx + logf((float)((redd[0] + redd[1]) + (redd[2] + redd[3]))))) + vj;
 }
 
 // gamma = exp(K) (nan -> 0, inf -> FLT_MAX) in place; rclip = max(rowsum, 1e-3); the last iteration also writes gamma / rclip.  grid (N/256, C)
@@ -113,14 +114,14 @@ __global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_e
     if (n >= N) return;
     float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
     const float un = w.u[(int64_t)c * N + n];
-    float rs = 0.0f;
+    double rs = 0.0;
     for (int j = 0; j < J; ++j) {
         float g = expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps);
         g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
         Cc[(int64_t)j * N] = g;
-        rs += g;
+        rs += (double)g;
     }
-    const float rc = fmaxf(rs, 1e-3f);
+    const float rc = fmaxf((float)rs, 1e-3f);
     w.rclip[(int64_t)c * N + n] = rc;
     if (gamma_out) {
         float* __restrict__ grow = gamma_out + ((int64_t)c * N + n) * J;
