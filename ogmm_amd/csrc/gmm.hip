@@ -725,16 +725,28 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restri
     const int32_t* __restrict__ nr = near + (int64_t)c * J;
     const bool a_is_x = wave < 2, b_is_x = (wave & 1) == 0;
     const float* __restrict__ pa = a_is_x ? F + (int64_t)nr[m] * ld : Y + (int64_t)m * D;
+    // the wave's own row, normalised, stays in registers (D <= 64 * INF_R); every other row is then read ONCE: its norm and
+    // its dot product with the own row come out of the same pass (one division per score instead of two per element)
+    constexpr int INF_R = 16;
+    float an[INF_R];
     float na = 0.0f;
-    for (int d = lane; d < D; d += 64) na = fmaf(pa[d], pa[d], na);
+#pragma unroll
+    for (int i = 0; i < INF_R; ++i) { const int d = lane + 64 * i; an[i] = d < D ? pa[d] : 0.0f; na = fmaf(an[i], an[i], na); }
     na = fmaxf(sqrtf(wave_sum(na)), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < INF_R; ++i) an[i] = an[i] / na;
     for (int n = 0; n < J; ++n) {
         const float* __restrict__ pb = b_is_x ? F + (int64_t)nr[n] * ld : Y + (int64_t)n * D;
         float nb = 0.0f, dot = 0.0f;
-        for (int d = lane; d < D; d += 64) { nb = fmaf(pb[d], pb[d], nb); }
+#pragma unroll
+        for (int i = 0; i < INF_R; ++i) {
+            const int d = lane + 64 * i;
+            const float v = d < D ? pb[d] : 0.0f;
+            nb = fmaf(v, v, nb);
+            dot = fmaf(an[i], v, dot);
+        }
         nb = fmaxf(sqrtf(wave_sum(nb)), 1e-12f);
-        for (int d = lane; d < D; d += 64) dot = fmaf(pa[d] / na, pb[d] / nb, dot);
-        dot = wave_sum(dot);
+        dot = wave_sum(dot) / nb;
         if (lane == 0) sc[wave * J + n] = dot * inv_tau;
     }
     __syncthreads();
@@ -822,6 +834,7 @@ extern "C" int ogmm_clu_infonce(const float* xyz, const float* mu, const float* 
                                 int J, int D, float tau, float* row_loss, int32_t* near, void* stream) {
     OGMM_REQUIRE(xyz && mu && feats && mu_feat && row_loss && near && C > 0 && N > 0 && J > 1 && D > 0 && tau > 0,
                  "ogmm_clu_infonce: null pointer or bad sizes (J must be >= 2)");
+    OGMM_REQUIRE(D <= 1024, "ogmm_clu_infonce: at most 1024 feature channels (a row lives in 16 registers per lane), got %d", D);
     hipStream_t s = ogmm::as_stream(stream);
     hipLaunchKernelGGL(nearest_point_kernel, dim3(J, C), dim3(256), 0, s, xyz, mu, N, J, near);
     hipLaunchKernelGGL(infonce_rows_kernel, dim3(J, C), dim3(256), 4 * (size_t)J * sizeof(float), s, feats, ld, mu_feat, near, N, J, D,
