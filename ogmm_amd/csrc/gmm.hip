@@ -300,22 +300,23 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
 // K16.  mu_feat[c][j][d] = sum_n gamma[c][n][j] * feats[c][n][d] / (N pi[c][j] + 1e-5)
 // block = (cloud, 64-channel slab, 16-cluster slab): 64 channels x 4 row lanes, 16 accumulators each.
 // ================================================================================================
+template <int JS>      // clusters per block: 16, or 64 (feats are then read once instead of J/16 times: 0.87 -> 0.3 ms at J = 64)
 __global__ __launch_bounds__(256) void gmm_feat_mean_kernel(const float* __restrict__ gamma, const float* __restrict__ pi,
                                                             const float* __restrict__ feats, int64_t ld, int N, int J, int D,
                                                             float* __restrict__ mu_feat) {
-    __shared__ float gs[64][17];
+    __shared__ float gs[64][JS + 1];
     __shared__ float red[4][16][64];
     const int c = blockIdx.z, ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int d = blockIdx.x * 64 + ch, j0 = blockIdx.y * 16;
+    const int d = blockIdx.x * 64 + ch, j0 = blockIdx.y * JS;
     const float* __restrict__ F = feats + (int64_t)c * N * ld;
     const float* __restrict__ G = gamma + (int64_t)c * N * J;
-    float acc[16];
+    float acc[JS];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < JS; ++j) acc[j] = 0.0f;
     for (int n0 = 0; n0 < N; n0 += 64) {
         __syncthreads();
-        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-            const int r = i >> 4, j = i & 15;
+        for (int i = threadIdx.x; i < 64 * JS; i += 256) {
+            const int r = i / JS, j = i % JS;
             gs[r][j] = (n0 + r < N && j0 + j < J) ? G[(int64_t)(n0 + r) * J + j0 + j] : 0.0f;
         }
         __syncthreads();
@@ -323,19 +324,23 @@ __global__ __launch_bounds__(256) void gmm_feat_mean_kernel(const float* __restr
             if (n0 + r >= N) break;
             const float f = d < D ? F[(int64_t)(n0 + r) * ld + d] : 0.0f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = fmaf(gs[r][j], f, acc[j]);
+            for (int j = 0; j < JS; ++j) acc[j] = fmaf(gs[r][j], f, acc[j]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) red[rl][j][ch] = acc[j];
-    __syncthreads();
-    if (rl == 0 && d < D) {
+    for (int jb = 0; jb < JS; jb += 16) {          // cross-row-lane reduction, 16 clusters at a time
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j0 + j >= J) break;
-            const float s = (red[0][j][ch] + red[1][j][ch]) + (red[2][j][ch] + red[3][j][ch]);
-            const float npi = pi[(int64_t)c * J + j0 + j] * (float)N + 1e-5f;
-            mu_feat[((int64_t)c * J + j0 + j) * D + d] = s / npi;
+        for (int j = 0; j < 16; ++j) red[rl][j][ch] = acc[jb + j];
+        __syncthreads();
+        if (rl == 0 && d < D) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j0 + jb + j >= J) break;
+                const float sum = (red[0][j][ch] + red[1][j][ch]) + (red[2][j][ch] + red[3][j][ch]);
+                const float npi = pi[(int64_t)c * J + j0 + jb + j] * (float)N + 1e-5f;
+                mu_feat[((int64_t)c * J + j0 + jb + j) * D + d] = sum / npi;
+            }
         }
     }
 }
@@ -803,8 +808,12 @@ extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0
 extern "C" int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,
                                   float* mu_feat, void* stream) {
     OGMM_REQUIRE(gamma && pi && feats && mu_feat && C > 0 && N > 0 && J > 0 && D > 0 && ld >= D, "ogmm_gmm_feat_mean: null pointer or bad sizes");
-    hipLaunchKernelGGL(gmm_feat_mean_kernel, dim3((D + 63) / 64, (J + 15) / 16, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats,
-                       ld, N, J, D, mu_feat);
+    if (J > 16)
+        hipLaunchKernelGGL(gmm_feat_mean_kernel<64>, dim3((D + 63) / 64, (J + 63) / 64, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats,
+                           ld, N, J, D, mu_feat);
+    else
+        hipLaunchKernelGGL(gmm_feat_mean_kernel<16>, dim3((D + 63) / 64, 1, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats,
+                           ld, N, J, D, mu_feat);
     return ogmm::check_launch("ogmm_gmm_feat_mean");
 }
 
