@@ -165,6 +165,9 @@ class _Linear(torch.autograd.Function):
                         split=precision == "f16x3", overflow=overflow, col_stats=stats, group_rows=stats_rows if stats is not None else 0)
         ctx.save_for_backward(x, x2, W)
         ctx.has_bias, ctx.precision, ctx.overflow = b is not None, precision, overflow
+        # a bias in front of a normalisation has an exactly-zero gradient (the normalisation's backward output sums to zero over
+        # every column of a group); the reference's autograd returns rounding noise of order 1e-8 there.  Skip the column sums.
+        ctx.bias_grad_is_zero = bool(stats_rows)
         if stats_rows:
             if stats is None:
                 stats = ops.colstats(y, stats_rows)
@@ -213,7 +216,7 @@ class _Linear(torch.autograd.Function):
                         parts[i_] = ops.weight_grad_thin(dyc, p_) if ops.weight_grad_thin_supported(dyc, p_) else dyc.t() @ p_
             dW = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            db = dy.sum(dim=0)
+            db = torch.zeros(dy.shape[1], dtype=dy.dtype, device=dy.device) if ctx.bias_grad_is_zero else dy.sum(dim=0)
         return dx, dx2, dW, db, None, None, None
 
 
