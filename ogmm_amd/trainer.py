@@ -104,10 +104,8 @@ class Trainer:
         else:
             allreduce_gradients(self.model, self.dist, self.world)
             if self.loss_scale != 1.0:
-                inv = 1.0 / self.loss_scale
-                for p in self.model.parameters():
-                    if p.grad is not None:
-                        p.grad.mul_(inv)
+                grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+                torch._foreach_mul_(grads, 1.0 / self.loss_scale)          # one multi-tensor launch instead of 150 small ones
             self.optimizer.step()
         broadcast_buffers(self.model, self.dist, self.world)
         with torch.no_grad():
