@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void em_cost_kernel(const float* __restrict__ 
     }
 }
 
-// u^{l+1}: one thread per row.  grid (N/256, C)
+// u^{l+1}: one thread per row, the row's J exponents held in registers between the max and the exp-sum pass.  grid (N/256, C)
+template <int JMAX>
 __global__ __launch_bounds__(256) void em_u_kernel(int N, int J, float inv_eps, float eps, EmWs w) {
     extern __shared__ float vs[];                      // [J]
     const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
@@ -75,10 +76,16 @@ __global__ __launch_bounds__(256) void em_u_kernel(int N, int J, float inv_eps, 
     if (n >= N) return;
     const float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
     const float un = w.u[(int64_t)c * N + n];
+    float x[JMAX];
     float mx = -__builtin_inff();
-    for (int j = 0; j < J; ++j) mx = fmaxf(mx, ((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps);
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        x[j] = j < J ? ((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps : -__builtin_inff();
+        mx = fmaxf(mx, x[j]);
+    }
     double se = 0.0;          // sums of exponentials in fp64: the E/M is ill-conditioned for J close to N (5e-6 on mu at N=717, J=128)
-    for (int j = 0; j < J; ++j) se += (double)expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps - mx);
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) se += j < J ? (double)expf(x[j] - mx) : 0.0;
     w.u[(int64_t)c * N + n] = eps * (w.logp[(int64_t)c * N + n] - (mx + logf((float)se))) + un;
 }
 
@@ -90,15 +97,25 @@ __global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, 
     const float* __restrict__ Cj = w.cost + ((int64_t)c * J + j) * N;
     const float* __restrict__ u = w.u + (int64_t)c * N;
     const float vj = w.v[(int64_t)c * J + j];
+    constexpr int VR = 16;                     // exponents of up to 16 rows per thread stay in registers (N <= 4096), the rest is recomputed
+    float x[VR];
     float mx = -__builtin_inff();
-    for (int n = tid; n < N; n += 256) mx = fmaxf(mx, ((-Cj[n] + u[n]) + vj) * inv_eps);
+#pragma unroll
+    for (int i = 0; i < VR; ++i) {
+        const int n = tid + i * 256;
+        x[i] = n < N ? ((-Cj[n] + u[n]) + vj) * inv_eps : -__builtin_inff();
+        mx = fmaxf(mx, x[i]);
+    }
+    for (int n = tid + VR * 256; n < N; n += 256) mx = fmaxf(mx, ((-Cj[n] + u[n]) + vj) * inv_eps);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     double se = 0.0;
-    for (int n = tid; n < N; n += 256) se += (double)expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
+#pragma unroll
+    for (int i = 0; i < VR; ++i) se += tid + i * 256 < N ? (double)expf(x[i] - mx) : 0.0;
+    for (int n = tid + VR * 256; n < N; n += 256) se += (double)expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
     se = wave_sum_d(se);
     if (lane == 0) redd[wave] = se;
     __syncthreads();
@@ -173,6 +190,7 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
                                  float epsilon, float tau, float* gamma, float* pi, float* mu, void* workspace, void* stream) {
     using namespace ogmm;
     OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu && workspace, "ogmm_gmm_em_multi: null pointer");
+    OGMM_REQUIRE(J <= 128, "ogmm_gmm_em_multi: at most 128 clusters (a row of exponents lives in registers), got %d", J);
     OGMM_REQUIRE(C > 0 && C <= 65535 && N > 0 && J > 0 && J <= N && J <= 65535 && iters > 0 && sk_iters >= 0 && epsilon > 0 && tau > 0,
                  "ogmm_gmm_em_multi: bad sizes C=%d N=%d J=%d", C, N, J);
     OGMM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "ogmm_gmm_em_multi: workspace must be 256-byte aligned");
@@ -194,7 +212,9 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(em_cost_kernel, rows, blk, 0, s, xyz, N, J, inv_tau, w);
         for (int sk = 0; sk < sk_iters; ++sk) {
-            hipLaunchKernelGGL(em_u_kernel, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
+            if (J <= 16) hipLaunchKernelGGL(em_u_kernel<16>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
+            else if (J <= 64) hipLaunchKernelGGL(em_u_kernel<64>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
+            else hipLaunchKernelGGL(em_u_kernel<128>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
             hipLaunchKernelGGL(em_v_kernel, cols, blk, 0, s, N, J, inv_eps, epsilon, logq, w);
         }
         hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr);

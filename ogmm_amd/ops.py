@@ -347,7 +347,8 @@ def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, engine=No
     pi = torch.empty((C, J), dtype=torch.float32, device=xyz.device)
     mu = torch.empty((C, J, 3), dtype=torch.float32, device=xyz.device)
     if engine is None:       # the on-chip loop while the N x J cost matrix fits one CU's LDS, the grid-wide sequence beyond
-        engine = "chip" if (4 * N + 3 * ((N + 3) // 4 * 4) + 5 * J + 16 + N * J) * 4 <= 128 * 1024 else "multi"
+        fits = (4 * N + 3 * ((N + 3) // 4 * 4) + 5 * J + 16 + N * J) * 4 <= 128 * 1024
+        engine = "chip" if fits or J > 128 else "multi"          # (the grid-wide kernels keep a row of J <= 128 exponents in registers)
     if engine == "multi":
         ws = torch.empty(_lib.load().ogmm_gmm_em_workspace_bytes(C, N, J), dtype=torch.uint8, device=xyz.device)
         _lib.call("ogmm_gmm_em_multi", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
