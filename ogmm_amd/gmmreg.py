@@ -319,10 +319,11 @@ class GMMReg(nn.Module):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
             ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
             idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
+            hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
             sel_done = torch.cuda.Event()
             sel_done.record(side)
         xyz.record_stream(side)
-        for t_ in (ids_a, ids_j, idx5):
+        for t_ in (ids_a, ids_j, idx5, hd, ha):
             t_.record_stream(main)
         idx = ops.knn(xyz, k)
 
@@ -342,7 +343,6 @@ class GMMReg(nn.Module):
 
         # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)
         main.wait_event(sel_done)
-        hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])
         x0 = torch.empty((R, D), dtype=torch.float32, device=dev)
         ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2])
         ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:])
