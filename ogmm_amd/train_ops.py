@@ -1,10 +1,12 @@
 """Operations of the training graph (ogmm_amd/train_graph.py), each differentiable where the reference is.
 
 `TrainOps` is the product implementation: discrete selections and the E/M loop run on the HIP kernels of
-libogmm_hip.so (no gradient flows through them in the reference either); dense layers run forward on the GEMM engine;
-normalisation, pooling, attention and the overlap block have hand-written forward AND backward kernels wrapped in
-`torch.autograd.Function`; backward GEMMs (dX = dY W, dW = dY^T X) are plain library GEMMs (torch.matmul -> hipBLASLt).
-CPU tensors are rejected by the kernels' wrappers: there is no CPU path here.  The plain-PyTorch statement of the same
+libogmm_hip.so (no gradient flows through them in the reference either); dense layers run forward, dX = dY W and (wide
+layers) dW = dY^T X on the GEMM engine, thin-layer dW on an exact-fp32 MFMA reduction kernel; normalisation (+ pooling), the
+overlap block, the rigid solve, L2 normalisation and the cluster means have hand-written forward AND backward kernels wrapped
+in `torch.autograd.Function`.  Still library calls: the attention backward, dfn = dS fn of the overlap block, thin-layer
+forwards (batched / plain hipBLASLt GEMMs through torch.matmul).  CPU tensors are rejected by the kernels' wrappers: there is
+no CPU path here.  The plain-PyTorch statement of the same
 operations that the tests use as the numerical reference lives in tests/train_ref.py.
 """
 import torch
