@@ -230,6 +230,14 @@ int ogmm_min_sqdist(const float* a /*[B][Na][3]*/, const float* b /*[B][Nb][3]*/
  * baseline's `gmm_register` (baseline/deepgmr.py:28-34), fp64 Jacobi in registers like K18. */
 int ogmm_rotation_from_cov(const float* M, int B, float* R, void* stream);
 
+/* The same refinement for small batches (one workgroup per pair leaves most of the chip idle below ~256 pairs): every iteration is
+ * two grid-wide launches (several workgroups per pair reduce the correspondence sums, one lane per pair updates the motion), all
+ * enqueued by this call, finished pairs skipped through a flag in `workspace` (ogmm_icp_workspace_bytes, 16-byte aligned). */
+int64_t ogmm_icp_workspace_bytes(int B, int N);
+int ogmm_icp_point_to_point_ws(const float* src, const float* tgt, int B, int N, int Nt, const float* R0, const float* t0,
+                               float max_corr_dist, int max_iter, double rel_fitness, double rel_rmse,
+                               float* R, float* t, float* fitness, float* rmse, int* iters, void* workspace, void* stream);
+
 /* =====================================================================================================
  * Training mode (`model.train()`): forward kernels that differ from eval, and the backward kernels.
  * The reference has no hand-written backward: autograd differentiates the model files; each entry cites the

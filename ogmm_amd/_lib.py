@@ -67,6 +67,9 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_min_sqdist": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_rotation_from_cov": [c_void_p, c_int, c_void_p, c_void_p],
+    "ogmm_icp_workspace_bytes": [c_int, c_int],
+    "ogmm_icp_point_to_point_ws": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_double, c_double,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     # training mode
     "ogmm_colstats": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p],
     "ogmm_affine_act": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],

@@ -403,7 +403,7 @@ def clu_infonce(xyz, mu, feats, mu_feat, C, N, tau=0.1):
     return row_loss, near
 
 
-def icp_point_to_point(src, tgt, R0, t0, max_corr_dist, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, want_stats=False):
+def icp_point_to_point(src, tgt, R0, t0, max_corr_dist, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, want_stats=False, engine=None):
     """src [B,N,3], tgt [B,Nt,3], R0 [B,3,3], t0 [B,3] -> R [B,3,3], t [B,3] (, fitness, rmse float32 [B], iters int32 [B])
     (lib/o3dutils.py:172-214)."""
     src, tgt = _f32(src, "src").contiguous(), _f32(tgt, "tgt").contiguous()
@@ -414,9 +414,16 @@ def icp_point_to_point(src, tgt, R0, t0, max_corr_dist, max_iter=30, rel_fitness
     fit = torch.empty(B, dtype=torch.float32, device=src.device) if want_stats else None
     rmse = torch.empty(B, dtype=torch.float32, device=src.device) if want_stats else None
     iters = torch.empty(B, dtype=torch.int32, device=src.device) if want_stats else None
-    _lib.call("ogmm_icp_point_to_point", _p(src), _p(tgt), B, N, Nt, _p(None if R0 is None else _f32(R0, "R0").contiguous()),
-              _p(None if t0 is None else _f32(t0, "t0").contiguous()), float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse),
-              _p(R), _p(t), _p(fit), _p(rmse), _p(iters), _stream())
+    args = (_p(src), _p(tgt), B, N, Nt, _p(None if R0 is None else _f32(R0, "R0").contiguous()),
+            _p(None if t0 is None else _f32(t0, "t0").contiguous()), float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse),
+            _p(R), _p(t), _p(fit), _p(rmse), _p(iters))
+    if engine is None:          # one workgroup per pair once there are enough pairs to fill the chip, the grid-wide sequence below that
+        engine = "chip" if B >= 256 else "multi"
+    if engine == "multi":
+        ws = torch.empty(_lib.load().ogmm_icp_workspace_bytes(B, N), dtype=torch.uint8, device=src.device)
+        _lib.call("ogmm_icp_point_to_point_ws", *args, _p(ws), _stream())
+    else:
+        _lib.call("ogmm_icp_point_to_point", *args, _stream())
     return (R, t, fit, rmse, iters) if want_stats else (R, t)
 
 

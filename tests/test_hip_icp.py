@@ -12,14 +12,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("engine", ["chip", "multi"])
 @pytest.mark.parametrize("kind,n,radius", [("clean", 400, 0.07), ("partial", 717, 0.07), ("partial", 1024, 0.075), ("room", 600, 0.1)])
-def test_matches_oracle(kind, n, radius):
+def test_matches_oracle(kind, n, radius, engine):
     B = 4
     src, tgt, R, t = synth.make_batch(40, B, n, kind)
     T0 = np.stack([_perturbed(R[i].double().numpy(), t[i].double().numpy(), 0.04, 0.01, i) for i in range(B)])
     R0, t0 = torch.from_numpy(T0[:, :3, :3]).float(), torch.from_numpy(T0[:, :3, 3]).float()
     xs, xt = src.transpose(1, 2).contiguous().to(DEV), tgt.transpose(1, 2).contiguous().to(DEV)
-    Rg, tg, fit, rmse, iters = ops.icp_point_to_point(xs, xt, R0.to(DEV), t0.to(DEV), radius, want_stats=True)
+    Rg, tg, fit, rmse, iters = ops.icp_point_to_point(xs, xt, R0.to(DEV), t0.to(DEV), radius, want_stats=True, engine=engine)   # one workgroup per pair / grid-wide sequence
     for i in range(B):
         Ti = np.eye(4)
         Ti[:3, :3], Ti[:3, 3] = R0[i].double().numpy(), t0[i].double().numpy()        # the float32 initial motion both sides start from
@@ -30,14 +31,15 @@ def test_matches_oracle(kind, n, radius):
         assert np.abs(tg[i].cpu().double().numpy() - To[:3, 3]).max() < 2e-6
 
 
-def test_recovers_ground_truth_and_handles_no_overlap():
+@pytest.mark.parametrize("engine", ["chip", "multi"])
+def test_recovers_ground_truth_and_handles_no_overlap(engine):
     B, n = 3, 512
     src, tgt, R, t = synth.make_batch(7, B, n, "clean")
     T0 = np.stack([_perturbed(R[i].double().numpy(), t[i].double().numpy(), 0.06, 0.02, 10 + i) for i in range(B)])
     R0, t0 = torch.from_numpy(T0[:, :3, :3]).float().to(DEV), torch.from_numpy(T0[:, :3, 3]).float().to(DEV)
     t0[2] += 40.0                                           # pair 2: nothing within the radius -> the initial motion comes back
     xs, xt = src.transpose(1, 2).contiguous().to(DEV), tgt.transpose(1, 2).contiguous().to(DEV)
-    Rg, tg, fit, rmse, iters = ops.icp_point_to_point(xs, xt, R0, t0, 0.07, want_stats=True)
+    Rg, tg, fit, rmse, iters = ops.icp_point_to_point(xs, xt, R0, t0, 0.07, want_stats=True, engine=engine)
     assert metric.rotation_error_rad(Rg[:2].cpu(), R[:2]).max() < 1e-5 and metric.translation_error(tg[:2].cpu(), t[:2]).max() < 1e-5
     assert float(fit[0]) == 1.0 and float(fit[2]) == 0.0 and int(iters[2]) == 1
     assert torch.equal(Rg[2], R0[2]) and torch.equal(tg[2], t0[2])
