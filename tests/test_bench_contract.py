@@ -1,0 +1,33 @@
+"""The committed bench line (profiles/round1_bench_n1.json, written by `python bench.py` on the GPU box) carries every field of the
+driver's contract, and bench.py's command line parses the driver's invocation."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    line = json.load(open(os.path.join(ROOT, "profiles", "round1_bench_n1.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["metric"] == "pairs_per_sec" and line["unit"] == "pairs/s" and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
+    assert abs(line["value"] - 64 * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) < 1e-6 * line["value"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cpu = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["cores"] >= 1
+    assert line["parity"]["R_err_rad_max"] < 1e-5 and line["parity"]["t_err_max"] < 1e-5
+
+
+def test_bench_command_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--precision"):
+        assert flag in out.stdout
