@@ -173,11 +173,29 @@ __global__ __launch_bounds__(256) void overlap_rows_kernel(const float* __restri
     if (m >= N) return;
     const float* __restrict__ row = S + ((int64_t)b * N + m) * N;
     const float* __restrict__ o = o_src + (int64_t)b * N * ldo_in;
+    // the row is read once: up to 64 * OVR values per lane stay in registers between the max and the exp-sum pass
+    constexpr int OVR = 16;
+    float v[OVR];
     float mx = -__builtin_inff();
-    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, row[n]);
+#pragma unroll
+    for (int i = 0; i < OVR; ++i) {
+        const int n = lane + 64 * i;
+        v[i] = n < N ? row[n] : -__builtin_inff();
+        mx = fmaxf(mx, v[i]);
+    }
+    for (int n = lane + 64 * OVR; n < N; n += 64) mx = fmaxf(mx, row[n]);
     mx = wave_max(mx);
     float se = 0.0f, so = 0.0f;
-    for (int n = lane; n < N; n += 64) {
+#pragma unroll
+    for (int i = 0; i < OVR; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) {
+            const float e = expf(v[i] - mx);
+            se += e;
+            so = fmaf(e, o[(int64_t)n * ldo_in], so);
+        }
+    }
+    for (int n = lane + 64 * OVR; n < N; n += 64) {
         const float e = expf(row[n] - mx);
         se += e;
         so = fmaf(e, o[(int64_t)n * ldo_in], so);
@@ -202,19 +220,30 @@ __global__ __launch_bounds__(256) void overlap_cols_kernel(const float* __restri
     const float* __restrict__ o = o_tgt + (int64_t)b * N * ldo_in;
     float mx = -__builtin_inff(), se = 0.0f, so = 0.0f;
     if (n < N) {
-        for (int m = rl; m < N; m += 4) {
-            const float v = Sb[(int64_t)m * N + n];
-            const float om = o[(int64_t)m * ldo_in];
-            if (v > mx) {
-                const float r = expf(mx - v);   // exp(-inf) = 0 on the first element
-                se = se * r + 1.0f;
-                so = so * r + om;
-                mx = v;
-            } else {
-                const float e = expf(v - mx);
-                se += e;
-                so = fmaf(e, om, so);
+        // rows in chunks of 8 per row lane: eight independent loads in flight, one rescale per chunk instead of a data-dependent
+        // branch per element
+        constexpr int CH = 8;
+        for (int m0 = rl * CH; m0 < N; m0 += 4 * CH) {
+            float v[CH], om[CH];
+            float cm = -__builtin_inff();
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int m = m0 + i;
+                v[i] = m < N ? Sb[(int64_t)m * N + n] : -__builtin_inff();
+                om[i] = m < N ? o[(int64_t)m * ldo_in] : 0.0f;
+                cm = fmaxf(cm, v[i]);
             }
+            const float nm = fmaxf(mx, cm);
+            const float r = expf(mx - nm);            // exp(-inf) = 0 for the first chunk
+            se *= r;
+            so *= r;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float e = expf(v[i] - nm);      // exp(-inf) = 0 for rows beyond N
+                se += e;
+                so = fmaf(e, om[i], so);
+            }
+            mx = nm;
         }
     }
     sm[rl][cl] = mx; ss[rl][cl] = se; st[rl][cl] = so;
