@@ -4,13 +4,23 @@
 // The per-edge tensors [C*N*k][64|64|128] (2.7 GB at B=64) never leave the chip: layer l's activated output is written
 // -- already split into binary16 hi/lo planes in A-operand order -- into LDS and consumed by layer l+1.
 //
-// Tile = P = floor(160 / k) points = P*k <= 160 edge rows (5 MFMA row blocks); 8 waves (2 per SIMD).
-//   layer 1: VALU (K = 6), thread = (channel, edge slot)
+// PERSISTENT: one 8-wave workgroup per CU (the planes fill its LDS) walks tiles blockIdx.x, + gridDim.x, ...  Everything
+// that does not depend on the tile stays in registers across tiles -- the fragment-major weight images of layers 2-4
+// (128 VGPRs), the folded BatchNorm scale / shift of the wave's columns, layer 1's weight row -- and the neighbour gather of
+// tile t+1 (two dependent global loads) is in flight while tile t computes.  A one-tile-per-workgroup version of this kernel
+// spent 25 % of its time waiting on those loads at the top of every tile, and 45 % outside the MFMA layers and their epilogues.
+//
+// Tile = P = floor(160 / k) points = P*k <= 160 edge rows (5 MFMA row blocks).
+//   layer 1: VALU (K = 6); a wave owns a point at a time, lane = channel, running max over the point's k edges in a register
 //   layers 2-4: fp16x3 split MFMA (v_mfma_f32_32x32x16_f16, see gemm_f16x3.hip); the (row block, 32-column block) grid of a
-//   layer (5 x 2, 5 x 4, 5 x 8) is dealt over the 8 waves; a wave's weight fragments (one column block of a whole layer)
-//   are fetched from the fragment-major images (L2 resident, 180 KB) a full layer ahead of their use.
-// LDS: region A = h1 planes, later h3 planes (87 KB); region B = h2 planes (46 KB); pool scratch 8 x 256 ints.
+//   layer (5 x 2, 5 x 4, 5 x 8) is dealt over the 8 waves; the pooled maxima are collected per (point, column) with LDS integer
+//   atomicMax (post-ReLU values are >= 0) in one of two scratch buffers, so that writing a layer's pooled map to HBM needs no barrier
+//   of its own.  Five barriers per tile.
+// LDS: region A = h1 planes, later h3 planes (87 KB); region B = h2 planes (46 KB); edge features 4 KB; pool scratch 2 x P x 256 ints
+// (one buffer and two more barriers per tile when two do not fit: k < 13).
 #include "ogmm_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -43,9 +53,12 @@ __device__ __forceinline__ void load_weights(f16x8 (&wb)[KS][2], const void* hi,
 //   in  : A planes (hi at Ain, lo at Ain + ROWS*LDA), K = 16*KS input channels
 //   out : relu(acc * scale + shift) -> pooled max per point into pool_s[point][column] (int atomicMax), and, if Aout != null,
 //         split into the next layer's A planes.
-template <int KS, int NB>
-__device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f16x8 (&wb)[KS][2], int nb, int rb0, float inv_scale,
-                                           const float* __restrict__ scale, const float* __restrict__ shift, _Float16* Aout, int LDO,
+// KC > 0: k is the compile-time constant KC and rb0 == RB0; for a full tile every accumulator register's point (row / KC) is then known
+// when the epilogue is unrolled, and the pooling costs one v_max per element plus an atomic where a lane half crosses into the next
+// point, instead of a multiply / shift / compare / branch per element.
+template <int KS, int NB, int KC = 0, int RB0 = 0, int RW = ROWS>
+__device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f16x8 (&wb)[KS][2], int nb, int rb0, float sc, float sh,
+                                           _Float16* Aout, int LDO,
                                            int* pool_s, int pool_ld, unsigned inv_k16, int rows_valid, int lane) {
     const int lr = lane & 31, lh = lane >> 5;
     f32x16 acc[NB];
@@ -53,26 +66,70 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    const int APL = ROWS * LDA;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        f16x8 ah[NB], al[NB];
+    const int APL = RW * LDA;
+    // A fragments one k-step ahead of their MFMAs; the scheduling barriers keep the compiler from hoisting every step's LDS reads to the
+    // top (the weight images already hold 128 of the 256 registers)
+    f16x8 ah[2][NB], al[2][NB];
+    auto load_a = [&](int s, int buf) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int off = ((rb0 + i) * 32 + lr) * LDA + s * 16 + lh * 8;
-            ah[i] = *reinterpret_cast<const f16x8*>(&Ain[off]);
-            al[i] = *reinterpret_cast<const f16x8*>(&Ain[APL + off]);
+            ah[buf][i] = *reinterpret_cast<const f16x8*>(&Ain[off]);
+            al[buf][i] = *reinterpret_cast<const f16x8*>(&Ain[APL + off]);
         }
+    };
+    load_a(0, 0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wb[s][0], acc[i], 0, 0, 0);
+    for (int s = 0; s < KS; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < KS) load_a(s + 1, cur ^ 1);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wb[s][1], acc[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], wb[s][0], acc[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wb[s][0], acc[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], wb[s][1], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], wb[s][0], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    const int OPL = ROWS * LDO;
+    const int OPL = RW * LDO;
     const int col = nb * 32 + lr;
-    const float sc = scale[col] * inv_scale, sh = shift[col];
+    if (KC > 0 && rows_valid == (ROWS / (KC > 0 ? KC : 1)) * KC) {
+        constexpr int KD = KC > 0 ? KC : 1, FULL = (ROWS / KD) * KD;
+        int g_lo = -1, g_hi = -1;                         // current point of the lower / upper lane half: constants once unrolled
+        float cur = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = (RB0 + i) * 32 + (r & 3) + 8 * (r >> 2);          // row of the lower half; the upper half is 4 further
+                const float v = fmaxf(fmaf(acc[i][r], sc, sh), 0.0f);
+                if (Aout) {
+                    _Float16 a, b;
+                    split_h(v, a, b);
+                    Aout[(rowc + 4 * lh) * LDO + col] = a;
+                    Aout[OPL + (rowc + 4 * lh) * LDO + col] = b;
+                }
+                const int n_lo = rowc < FULL ? rowc / KD : -2, n_hi = rowc + 4 < FULL ? (rowc + 4) / KD : -2;   // -2: padding row
+                const bool new_lo = n_lo != g_lo, new_hi = n_hi != g_hi;
+                if (!new_lo && !new_hi) {
+                    if (n_lo >= 0 || n_hi >= 0) cur = fmaxf(cur, v);              // (both halves inside their current point, or padding)
+                } else {
+                    const bool mine_new = lh ? new_hi : new_lo;
+                    const int prev = lh ? g_hi : g_lo, next = lh ? n_hi : n_lo;
+                    if (mine_new) {
+                        if (prev >= 0) atomicMax(&pool_s[prev * pool_ld + col], __float_as_int(cur));
+                        cur = v;
+                    } else if (next >= 0) {
+                        cur = fmaxf(cur, v);
+                    }
+                }
+                g_lo = n_lo;
+                g_hi = n_hi;
+            }
+        const int last = lh ? g_hi : g_lo;
+        if (last >= 0) atomicMax(&pool_s[last * pool_ld + col], __float_as_int(cur));
+        return;
+    }
     int cur_group = -1;
     float cur_max = 0.0f;
 #pragma unroll
@@ -81,7 +138,7 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
         for (int r = 0; r < 16; ++r) {
             const int row = (rb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float v = fmaxf(fmaf(acc[i][r], sc, sh), 0.0f);
-            if (Aout) {
+            if (Aout && (RW == ROWS || row < RW)) {      // planes shorter than the MFMA row blocks: the excess rows are computed, not kept
                 _Float16 a, b;
                 split_h(v, a, b);
                 Aout[row * LDO + col] = a;
@@ -108,102 +165,126 @@ struct EdgeW {
     const void* h4; const void* l4; const float* s4; const float* t4; float inv4;
 };
 
+template <int KC>
 __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, int N, int k,
-                                                             int64_t total_pts, int P, const EdgeW w, float* __restrict__ xcat, int64_t ldx) {
+                                                             int64_t total_pts, int P, int64_t n_tiles, int two_pools, const EdgeW w,
+                                                             float* __restrict__ xcat, int64_t ldx) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     _Float16* regA = lds;                               // h1 planes [2][160][72]  -> later h3 planes [2][160][136]
     _Float16* regB = lds + 2 * ROWS * LD128;            // h2 planes [2][160][72]
-    int* pool_s = reinterpret_cast<int*>(regB + 2 * ROWS * LD64);      // [P <= 40][256]
+    float* ef = reinterpret_cast<float*>(regB + 2 * ROWS * LD64);      // [160][6] edge features of the tile
+    int* pool0 = reinterpret_cast<int*>(ef + ROWS * 6);                // [P][256]
+    int* pool1 = two_pools ? pool0 + P * 256 : pool0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t p0 = (int64_t)blockIdx.x * P;
-    const int pts = (int)min((int64_t)P, total_pts - p0);
-    const int rows_valid = pts * k;
     const unsigned inv_k16 = (65536u + (unsigned)k - 1u) / (unsigned)k;     // (row * inv_k16) >> 16 == row / k on this range
 
-    // weight fragments travel from L2 while the gather and layer 1 run (they do not depend on the activations)
-    f16x8 wb2[4][2], wb3[4][2], wb4[8][2];
-    load_weights<4>(wb2, w.h2, w.l2, wave & 1, lane);
-    load_weights<4>(wb3, w.h3, w.l3, wave & 3, lane);
-
-    // ---- gather: one thread per edge row fetches (x_j - x_i, x_i) once (two dependent global loads per edge, all 160 in flight
-    // together) into region B, which is free until layer 2 writes h2
-    float* ef = reinterpret_cast<float*>(regB);          // [160][6]
-    for (int i = tid; i < P * 256; i += 512) pool_s[i] = 0;
-    if (tid < ROWS) {
-        const int e = tid;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
-        if (e < rows_valid) {
-            const int64_t p = p0 + e / k;
-            const int64_t j = (p / N) * N + idx[p * k + e % k];
-            f3 = xyz[3 * p]; f4 = xyz[3 * p + 1]; f5 = xyz[3 * p + 2];
-            f0 = xyz[3 * j] - f3; f1 = xyz[3 * j + 1] - f4; f2 = xyz[3 * j + 2] - f5;
-        }
-        ef[e * 6 + 0] = f0; ef[e * 6 + 1] = f1; ef[e * 6 + 2] = f2; ef[e * 6 + 3] = f3; ef[e * 6 + 4] = f4; ef[e * 6 + 5] = f5;
-    }
-    __syncthreads();
-    // ---- layer 1 (VALU): thread = (channel, slot); the slot walks edge rows slot, slot+4, ...
-    {
-        const int ch = lane, slot = wave;
-        float wv[6];
+    // ---- tile-independent state, loaded once
+    f16x8 wb4[8][2];                                     // layer 4's image (64 VGPRs) stays; layers 2 and 3 (32 each) are re-fetched from L2
+    load_weights<8>(wb4, w.h4, w.l4, wave, lane);        // per tile, a whole layer ahead of their use -- all three resident would spill
+    const int lr = lane & 31;
+    const float sc2 = w.s2[(wave & 1) * 32 + lr] * w.inv2, sh2 = w.t2[(wave & 1) * 32 + lr];
+    const float sc3 = w.s3[(wave & 3) * 32 + lr] * w.inv3, sh3 = w.t3[(wave & 3) * 32 + lr];
+    const float sc4 = w.s4[wave * 32 + lr] * w.inv4, sh4 = w.t4[wave * 32 + lr];
+    float wv[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) wv[i] = w.W1[ch * 6 + i];
-        const float s = w.s1[ch], t = w.t1[ch];
-        for (int e = slot; e < ROWS; e += 8) {
-            float v = 0.0f;
-            if (e < rows_valid) {
-                const float ctr = fmaf(wv[5], ef[e * 6 + 5], fmaf(wv[4], ef[e * 6 + 4], wv[3] * ef[e * 6 + 3]));
-                const float acc = fmaf(wv[2], ef[e * 6 + 2], fmaf(wv[1], ef[e * 6 + 1], wv[0] * ef[e * 6 + 0])) + ctr;
-                v = fmaxf(fmaf(acc, s, t), 0.0f);
-                atomicMax(&pool_s[(int)(((unsigned)e * inv_k16) >> 16) * 256 + ch], __float_as_int(v));       // x1 = max over the point's k edges
-            }
-            _Float16 a, b;
-            split_h(v, a, b);
-            regA[e * LD64 + ch] = a;
-            regA[ROWS * LD64 + e * LD64 + ch] = b;
+    for (int i = 0; i < 6; ++i) wv[i] = w.W1[lane * 6 + i];
+    const float s1 = w.s1[lane], t1 = w.t1[lane];
+    for (int i = tid; i < (two_pools ? 2 : 1) * P * 256; i += 512) pool0[i] = 0;
+
+    // ---- the gather of an edge row: thread e < 160 fetches (x_j - x_i, x_i); two dependent loads, issued a tile ahead
+    const int e_pt = tid / k, e_nb = tid % k;            // this thread's (point of the tile, neighbour slot) as an edge row
+    auto edge_index = [&](int64_t tile) -> int64_t {     // global index j of the neighbour, or -1 for a padding row
+        const int64_t p = tile * P + e_pt;
+        if (tid >= ROWS || e_pt >= P || tile >= n_tiles || p >= total_pts) return -1;
+        return (p / N) * N + idx[p * k + e_nb];
+    };
+    float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto edge_fetch = [&](int64_t tile, int64_t j) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) f[i] = 0.0f;
+        if (j >= 0) {
+            const int64_t p = tile * P + e_pt;
+            f[3] = xyz[3 * p]; f[4] = xyz[3 * p + 1]; f[5] = xyz[3 * p + 2];
+            f[0] = xyz[3 * j] - f[3]; f[1] = xyz[3 * j + 1] - f[4]; f[2] = xyz[3 * j + 2] - f[5];
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < pts * 64; i += 512) {
-        const int p = i >> 6, ch = i & 63;
-        xcat[(p0 + p) * ldx + ch] = __int_as_float(pool_s[p * 256 + ch]);
-    }
-    __syncthreads();
-    for (int i = tid; i < P * 256; i += 512) pool_s[i] = 0;
-    __syncthreads();
+    };
+    edge_fetch(blockIdx.x, edge_index(blockIdx.x));
 
-    // ---- layer 2: 64 -> 64, waves 0 and 1 own 32 columns each
-    load_weights<8>(wb4, w.h4, w.l4, wave, lane);       // needed two layers from now
-    // 2 column blocks x 5 row blocks over 8 waves: waves 0-1 take row blocks {0,1}, waves 2-7 one of {2,3,4}
-    if (wave < 2) mfma_layer<4, 2>(regA, LD64, wb2, wave & 1, 0, w.inv2, w.s2, w.t2, regB, LD64, pool_s, 256, inv_k16, rows_valid, lane);
-    else mfma_layer<4, 1>(regA, LD64, wb2, wave & 1, 1 + (wave >> 1), w.inv2, w.s2, w.t2, regB, LD64, pool_s, 256, inv_k16, rows_valid, lane);
-    __syncthreads();
-    for (int i = tid; i < pts * 64; i += 512) {
-        const int p = i >> 6, ch = i & 63;
-        xcat[(p0 + p) * ldx + 64 + ch] = __int_as_float(pool_s[p * 256 + ch]);
-    }
-    __syncthreads();
-    for (int i = tid; i < P * 256; i += 512) pool_s[i] = 0;
-    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t p0 = tile * P;
+        const int pts = (int)min((int64_t)P, total_pts - p0);
+        const int rows_valid = pts * k;
+        // opaque copy: otherwise the row -> point map of every accumulator register (tile-invariant) is hoisted out of the tile loop
+        // into ~200 registers and the kernel spills
+        unsigned ik16 = inv_k16;
+        asm volatile("" : "+s"(ik16));
+        int lane_t = lane;                                               // same for the per-register LDS addresses
+        asm volatile("" : "+v"(lane_t));
+        if (tid < ROWS) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ef[tid * 6 + i] = f[i];
+        }
+        const int64_t j_next = edge_index(tile + gridDim.x);            // the index load travels during layer 1
+        f16x8 wb2[4][2], wb3[4][2];
+        load_weights<4>(wb2, w.h2, w.l2, wave & 1, lane);
+        load_weights<4>(wb3, w.h3, w.l3, wave & 3, lane);
+        __syncthreads();                                                 // (1) edge features visible; the previous tile is finished
 
-    // ---- layer 3: 64 -> 128, waves 0-3 own 32 columns each; output planes overwrite region A (h1 is dead)
-    // 4 column blocks x 5 row blocks over 8 waves: waves 0-3 take row blocks {0,1,2}, waves 4-7 {3,4}
-    if (wave < 4) mfma_layer<4, 3>(regB, LD64, wb3, wave & 3, 0, w.inv3, w.s3, w.t3, regA, LD128, pool_s, 256, inv_k16, rows_valid, lane);
-    else mfma_layer<4, 2>(regB, LD64, wb3, wave & 3, 3, w.inv3, w.s3, w.t3, regA, LD128, pool_s, 256, inv_k16, rows_valid, lane);
-    __syncthreads();
-    for (int i = tid; i < pts * 128; i += 512) {
-        const int p = i >> 7, ch = i & 127;
-        xcat[(p0 + p) * ldx + 128 + ch] = __int_as_float(pool_s[p * 256 + ch]);
-    }
-    __syncthreads();
-    for (int i = tid; i < P * 256; i += 512) pool_s[i] = 0;
-    __syncthreads();
+        // ---- layer 1 (VALU): wave -> point, lane -> channel; the centre term is constant over a point's edges
+        for (int pt = wave; pt < pts; pt += 8) {
+            const int e0 = pt * k;
+            const float ctr = fmaf(wv[5], ef[e0 * 6 + 5], fmaf(wv[4], ef[e0 * 6 + 4], wv[3] * ef[e0 * 6 + 3]));
+            float mx = 0.0f;
+            for (int e = e0; e < e0 + k; ++e) {
+                const float acc = fmaf(wv[2], ef[e * 6 + 2], fmaf(wv[1], ef[e * 6 + 1], wv[0] * ef[e * 6 + 0])) + ctr;
+                const float v = fmaxf(fmaf(acc, s1, t1), 0.0f);
+                mx = fmaxf(mx, v);
+                _Float16 a, b;
+                split_h(v, a, b);
+                regA[e * LD64 + lane] = a;
+                regA[ROWS * LD64 + e * LD64 + lane] = b;
+            }
+            xcat[(p0 + pt) * ldx + lane] = mx;                           // x1 = max over the point's k edges
+        }
+        edge_fetch(tile + gridDim.x, j_next);                            // next tile's coordinates travel during layers 2-4
+        __syncthreads();                                                 // (2) h1 planes complete
 
-    // ---- layer 4: 128 -> 256, every wave 32 columns; only the pooled output is needed
-    mfma_layer<8, 5>(regA, LD128, wb4, wave, 0, w.inv4, w.s4, w.t4, nullptr, 0, pool_s, 256, inv_k16, rows_valid, lane);
-    __syncthreads();
-    for (int i = tid; i < pts * 256; i += 512) {
-        const int p = i >> 8, ch = i & 255;
-        xcat[(p0 + p) * ldx + 256 + ch] = __int_as_float(pool_s[p * 256 + ch]);
+        // ---- layer 2: 64 -> 64; 2 column blocks x 5 row blocks over 8 waves: waves 0-1 take row blocks {0,1}, waves 2-7 one of {2,3,4}
+        if (wave < 2) mfma_layer<4, 2, KC, 0>(regA, LD64, wb2, wave & 1, 0, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
+        else if (wave < 4) mfma_layer<4, 1, KC, 2>(regA, LD64, wb2, wave & 1, 2, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
+        else if (wave < 6) mfma_layer<4, 1, KC, 3>(regA, LD64, wb2, wave & 1, 3, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
+        else mfma_layer<4, 1, KC, 4>(regA, LD64, wb2, wave & 1, 4, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
+        __syncthreads();                                                 // (3) h2 planes and x2 maxima complete
+        for (int i = tid; i < pts * 64; i += 512) {
+            const int p = i >> 6, ch = i & 63;
+            xcat[(p0 + p) * ldx + 64 + ch] = __int_as_float(pool0[p * 256 + ch]);
+            pool0[p * 256 + ch] = 0;
+        }
+        if (!two_pools) __syncthreads();
+
+        // ---- layer 3: 64 -> 128; 4 column blocks x 5 row blocks: waves 0-3 take row blocks {0,1,2}, waves 4-7 {3,4}; h3 planes
+        // overwrite region A (h1 is dead)
+        if (wave < 4) mfma_layer<4, 3, KC, 0>(regB, LD64, wb3, wave & 3, 0, sc3, sh3, regA, LD128, pool1, 256, ik16, rows_valid, lane_t);
+        else mfma_layer<4, 2, KC, 3>(regB, LD64, wb3, wave & 3, 3, sc3, sh3, regA, LD128, pool1, 256, ik16, rows_valid, lane_t);
+        __syncthreads();                                                 // (4)
+        for (int i = tid; i < pts * 128; i += 512) {
+            const int p = i >> 7, ch = i & 127;
+            xcat[(p0 + p) * ldx + 128 + ch] = __int_as_float(pool1[p * 256 + ch]);
+            pool1[p * 256 + ch] = 0;
+        }
+        if (!two_pools) __syncthreads();
+
+        // ---- layer 4: 128 -> 256, every wave 32 columns x 5 row blocks; only the pooled output is needed
+        // (two passes over the row blocks: 5 accumulator tiles next to the 128 weight registers would spill)
+        mfma_layer<8, 3, KC, 0>(regA, LD128, wb4, wave, 0, sc4, sh4, nullptr, 0, pool0, 256, ik16, rows_valid, lane_t);
+        mfma_layer<8, 2, KC, 3>(regA, LD128, wb4, wave, 3, sc4, sh4, nullptr, 0, pool0, 256, ik16, rows_valid, lane_t);
+        __syncthreads();                                                 // (5)
+        for (int i = tid; i < pts * 256; i += 512) {
+            const int p = i >> 8, ch = i & 255;
+            xcat[(p0 + p) * ldx + 256 + ch] = __int_as_float(pool0[p * 256 + ch]);
+            pool0[p * 256 + ch] = 0;
+        }
+        // pool0 is next touched by layer 2 of the following tile, two barriers from here
     }
 }
 
@@ -216,17 +297,30 @@ extern "C" int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, 
     OGMM_REQUIRE(xyz && idx && W1 && s1 && t1 && h2 && l2 && s2 && t2 && h3 && l3 && s3 && t3 && h4 && l4 && s4 && t4 && xcat,
                  "ogmm_edgeconv_fused: null pointer");
     OGMM_REQUIRE(C > 0 && N > 0 && k >= 4 && k <= 32 && ldx >= 512, "ogmm_edgeconv_fused: bad sizes C=%d N=%d k=%d ldx=%lld", C, N, k, (long long)ldx);
-    const int P = ROWS / k;
     const int64_t total = (int64_t)C * N;
-    const size_t lds = (size_t)(2 * ROWS * LD128 + 2 * ROWS * LD64) * sizeof(_Float16) + (size_t)P * 256 * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edgeconv_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    const int P = ROWS / k;
+    const size_t fixed = (size_t)(2 * ROWS * LD128 + 2 * ROWS * LD64) * sizeof(_Float16) + (size_t)ROWS * 6 * sizeof(float);
+    const size_t pool = (size_t)P * 256 * sizeof(int);
+    const int two_pools = fixed + 2 * pool <= 160 * 1024;
+    const size_t lds = fixed + (two_pools ? 2 : 1) * pool;
     OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_edgeconv_fused: LDS budget exceeded");
+    static int n_cu = 0;
+    if (!n_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edgeconv_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edgeconv_fused_kernel<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     EdgeW w{W1, s1, t1, h2, l2, s2, t2, inv2, h3, l3, s3, t3, inv3, h4, l4, s4, t4, inv4};
-    const unsigned blocks = (unsigned)((total + P - 1) / P);
-    hipLaunchKernelGGL(edgeconv_fused_kernel, dim3(blocks), dim3(512), lds, ogmm::as_stream(stream), xyz, idx, N, k, total, P, w, xcat, ldx);
+    const int64_t n_tiles = (total + P - 1) / P;
+    const unsigned blocks = (unsigned)std::min<int64_t>(n_tiles, n_cu);          // one persistent workgroup per CU
+    if (k == 20)          // the reference's gnn_k: pooling specialised at compile time
+        hipLaunchKernelGGL(edgeconv_fused_kernel<20>, dim3(blocks), dim3(512), lds, ogmm::as_stream(stream), xyz, idx, N, k, total, P, n_tiles, two_pools,
+                           w, xcat, ldx);
+    else
+        hipLaunchKernelGGL(edgeconv_fused_kernel<0>, dim3(blocks), dim3(512), lds, ogmm::as_stream(stream), xyz, idx, N, k, total, P, n_tiles, two_pools,
+                           w, xcat, ldx);
     return ogmm::check_launch("ogmm_edgeconv_fused");
 }

@@ -1,0 +1,27 @@
+"""Where the fused EdgeConv kernel's time goes: the kernel alone at B=64 / N=1024 / k=20 with parts switched off through OGMM_EDGE_ABL
+(bit 0: no pooling, bit 1: no plane writes, bit 2: no MFMAs).  Needs a library built with the ablation switches (not the shipped one)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from argparse import Namespace
+from ogmm_amd import synth, ops
+from ogmm_amd.gmmreg import GMMReg
+dev = "cuda:0"
+cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035)
+m = GMMReg(512, 16, cfg); synth.fill_state_dict(m.state_dict()); m = m.to(dev).eval()
+src, tgt, R, t = synth.make_batch(0, 64, 1024, "partial")
+with torch.no_grad():
+    m(src.to(dev), tgt.to(dev), fps_starts=synth.fps_starts_for(0, 64, 1024))          # packs the weights
+L = m._layers()
+xyz = torch.cat([src, tgt], 0).transpose(1, 2).contiguous().to(dev)
+idx = ops.knn(xyz, 20)
+xcat = torch.empty((xyz.shape[0] * 1024, 512), device=dev)
+emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
+for abl in [0]:
+    os.environ["OGMM_EDGE_ABL"] = str(abl)
+    for _ in range(2): ops.edgeconv_fused(xyz, idx, emd, xcat)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): ops.edgeconv_fused(xyz, idx, emd, xcat)
+    e1.record(); torch.cuda.synchronize()
+    print("abl=%d  %.1f us" % (abl, e0.elapsed_time(e1) / 5 * 1e3))
