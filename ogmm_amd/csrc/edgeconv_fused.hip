@@ -56,7 +56,7 @@ __device__ __forceinline__ void load_weights(f16x8 (&wb)[KS][2], const void* hi,
 // KC > 0: k is the compile-time constant KC and rb0 == RB0; for a full tile every accumulator register's point (row / KC) is then known
 // when the epilogue is unrolled, and the pooling costs one v_max per element plus an atomic where a lane half crosses into the next
 // point, instead of a multiply / shift / compare / branch per element.
-template <int KS, int NB, int KC = 0, int RB0 = 0, int RW = ROWS>
+template <int KS, int NB, int KC = 0, int RB0 = 0>
 __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f16x8 (&wb)[KS][2], int nb, int rb0, float sc, float sh,
                                            _Float16* Aout, int LDO,
                                            int* pool_s, int pool_ld, unsigned inv_k16, int rows_valid, int lane) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
     for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    const int APL = RW * LDA;
+    const int APL = ROWS * LDA;
     // A fragments one k-step ahead of their MFMAs; the scheduling barriers keep the compiler from hoisting every step's LDS reads to the
     // top (the weight images already hold 128 of the 256 registers)
     f16x8 ah[2][NB], al[2][NB];
@@ -91,8 +91,37 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
         for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], wb[s][0], acc[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    const int OPL = RW * LDO;
     const int col = nb * 32 + lr;
+    // ---- activation in place
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = fmaxf(fmaf(acc[i][r], sc, sh), 0.0f);
+    // ---- next layer's A planes.  A lane holds one column of rows (r, r+1); neighbouring lanes trade one of the two (DPP quad swap) so
+    // that the even lane owns row r and the odd lane row r+1 of the column pair, and each writes both halfs with one ds_write_b32 per
+    // plane: half the LDS write instructions of a b16 store per element, which were the bottleneck of this epilogue.
+    if (Aout) {
+        const int OPL = ROWS * LDO;
+        const bool odd = lane & 1;
+        _Float16* __restrict__ dst = Aout + ((rb0 * 32 + 4 * lh + (odd ? 1 : 0)) * LDO + (col & ~1));
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v0 = acc[i][2 * q], v1 = acc[i][2 * q + 1];
+                const float send = odd ? v0 : v1, keep = odd ? v1 : v0;
+                const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                const float left = odd ? recv : keep, right = odd ? keep : recv;          // columns (col & ~1), (col & ~1) + 1
+                _Float16 lh_, ll_, rh_, rl_;
+                split_h(left, lh_, ll_);
+                split_h(right, rh_, rl_);
+                using h2 = __attribute__((ext_vector_type(2))) _Float16;
+                const int off = (i * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2)) * LDO;      // row of register 2q, relative to the lane's base row
+                *reinterpret_cast<h2*>(&dst[off]) = h2{lh_, rh_};
+                *reinterpret_cast<h2*>(&dst[OPL + off]) = h2{ll_, rl_};
+            }
+    }
+    // ---- pooling
     if (KC > 0 && rows_valid == (ROWS / (KC > 0 ? KC : 1)) * KC) {
         constexpr int KD = KC > 0 ? KC : 1, FULL = (ROWS / KD) * KD;
         int g_lo = -1, g_hi = -1;                         // current point of the lower / upper lane half: constants once unrolled
@@ -102,13 +131,7 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rowc = (RB0 + i) * 32 + (r & 3) + 8 * (r >> 2);          // row of the lower half; the upper half is 4 further
-                const float v = fmaxf(fmaf(acc[i][r], sc, sh), 0.0f);
-                if (Aout) {
-                    _Float16 a, b;
-                    split_h(v, a, b);
-                    Aout[(rowc + 4 * lh) * LDO + col] = a;
-                    Aout[OPL + (rowc + 4 * lh) * LDO + col] = b;
-                }
+                const float v = acc[i][r];
                 const int n_lo = rowc < FULL ? rowc / KD : -2, n_hi = rowc + 4 < FULL ? (rowc + 4) / KD : -2;   // -2: padding row
                 const bool new_lo = n_lo != g_lo, new_hi = n_hi != g_hi;
                 if (!new_lo && !new_hi) {
@@ -137,13 +160,7 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (rb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = fmaxf(fmaf(acc[i][r], sc, sh), 0.0f);
-            if (Aout && (RW == ROWS || row < RW)) {      // planes shorter than the MFMA row blocks: the excess rows are computed, not kept
-                _Float16 a, b;
-                split_h(v, a, b);
-                Aout[row * LDO + col] = a;
-                Aout[OPL + row * LDO + col] = b;
-            }
+            const float v = acc[i][r];
             if (row < rows_valid) {
                 const int grp = (int)(((unsigned)row * inv_k16) >> 16);    // row / k for row < 160, 7 <= k <= 32 (no division, no LDS)
                 if (grp != cur_group) {
