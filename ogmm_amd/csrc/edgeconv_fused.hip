@@ -175,6 +175,17 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
     if (cur_group >= 0) atomicMax(&pool_s[cur_group * pool_ld + col], __float_as_int(cur_max));
 }
 
+// A use the compiler cannot see through: makes it place the s_waitcnt for a load HERE.  The kernel's loads are waited for at points
+// where everything older has long arrived; left to itself the compiler waits at first use, after younger conditional stores have been
+// issued, where the only safe count is vmcnt(0) -- the HBM round trip of a store that was issued a moment ago.
+template <typename T>
+__device__ __forceinline__ void touch(const T& x) { asm volatile("" ::"v"(x) : "memory"); }
+template <int KS>
+__device__ __forceinline__ void touch_weights(const f16x8 (&wb)[KS][2]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { touch(wb[s][0]); touch(wb[s][1]); }
+}
+
 struct EdgeW {
     const float* W1; const float* s1; const float* t1;                                   // [64][6], [64], [64]
     const void* h2; const void* l2; const float* s2; const float* t2; float inv2;        // fragment images + folded BN
@@ -189,8 +200,9 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     _Float16* regA = lds;                               // h1 planes [2][160][72]  -> later h3 planes [2][160][136]
     _Float16* regB = lds + 2 * ROWS * LD128;            // h2 planes [2][160][72]
-    float* ef = reinterpret_cast<float*>(regB + 2 * ROWS * LD64);      // [160][6] edge features of the tile
-    int* pool0 = reinterpret_cast<int*>(ef + ROWS * 6);                // [P][256]
+    float4* ef4 = reinterpret_cast<float4*>(regB + 2 * ROWS * LD64);   // [160] (x_j - x_i, 0) per edge row, then [P <= 24] centres x_i
+    float4* ctr4 = ef4 + ROWS;
+    int* pool0 = reinterpret_cast<int*>(ef4 + ROWS + 24);              // [P][256]
     int* pool1 = two_pools ? pool0 + P * 256 : pool0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned inv_k16 = (65536u + (unsigned)k - 1u) / (unsigned)k;     // (row * inv_k16) >> 16 == row / k on this range
@@ -210,22 +222,49 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
 
     // ---- the gather of an edge row: thread e < 160 fetches (x_j - x_i, x_i); two dependent loads, issued a tile ahead
     const int e_pt = tid / k, e_nb = tid % k;            // this thread's (point of the tile, neighbour slot) as an edge row
-    auto edge_index = [&](int64_t tile) -> int64_t {     // global index j of the neighbour, or -1 for a padding row
+    // (both lambdas only ISSUE loads: the loaded values are first used -- index arithmetic, x_j - x_i -- a phase later, so no wait lands
+    // right behind the load)
+    auto edge_index = [&](int64_t tile) -> int {          // neighbour slot's point index within its cloud, or -1 for a padding row
         const int64_t p = tile * P + e_pt;
         if (tid >= ROWS || e_pt >= P || tile >= n_tiles || p >= total_pts) return -1;
-        return (p / N) * N + idx[p * k + e_nb];
+        return idx[p * k + e_nb];
     };
-    float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto edge_fetch = [&](int64_t tile, int64_t j) {
+    float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // raw x_j, x_i of this thread's edge row
+    auto edge_fetch = [&](int64_t tile, int jn) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) f[i] = 0.0f;
-        if (j >= 0) {
+        if (jn >= 0) {
             const int64_t p = tile * P + e_pt;
+            const int64_t j = (p / N) * N + jn;
             f[3] = xyz[3 * p]; f[4] = xyz[3 * p + 1]; f[5] = xyz[3 * p + 2];
-            f[0] = xyz[3 * j] - f[3]; f[1] = xyz[3 * j + 1] - f[4]; f[2] = xyz[3 * j + 2] - f[5];
+            f[0] = xyz[3 * j]; f[1] = xyz[3 * j + 1]; f[2] = xyz[3 * j + 2];
         }
     };
     edge_fetch(blockIdx.x, edge_index(blockIdx.x));
+    touch_weights<8>(wb4);
+    touch(sc2); touch(sh2); touch(sc3); touch(sh3); touch(sc4); touch(sh4); touch(s1); touch(t1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { touch(wv[i]); touch(f[i]); }
+
+    // Pooled maxima of a layer -> xcat, cells re-zeroed.  With k fixed at compile time every thread does this at most once: a loop
+    // with a run-time trip count would hide the number of stores in flight from the compiler's s_waitcnt bookkeeping, and the next
+    // wait on a LOAD (weights, gather) would degrade to vmcnt(0), i.e. sit out the HBM round trip of these stores.
+    constexpr bool ONE_PASS = KC > 0 && (ROWS / (KC > 0 ? KC : 1)) <= 8;
+    auto flush = [&](int* pool, int shift /* log2(columns / 4) */, int base, int pts, int64_t p0) {
+        auto cell_out = [&](int i) {
+            const int p = i >> shift, ch = (i & ((1 << shift) - 1)) * 4;
+            int4* cell = reinterpret_cast<int4*>(&pool[p * 256 + ch]);
+            const int4 v = *cell;
+            *reinterpret_cast<float4*>(&xcat[(p0 + p) * ldx + base + ch]) =
+                make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+            *cell = make_int4(0, 0, 0, 0);
+        };
+        if constexpr (ONE_PASS) {
+            if (tid < (pts << shift)) cell_out(tid);
+        } else {
+            for (int i = tid; i < (pts << shift); i += 512) cell_out(i);
+        }
+    };
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t p0 = tile * P;
@@ -238,30 +277,57 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         int lane_t = lane;                                               // same for the per-register LDS addresses
         asm volatile("" : "+v"(lane_t));
         if (tid < ROWS) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ef[tid * 6 + i] = f[i];
+            ef4[tid] = make_float4(f[0] - f[3], f[1] - f[4], f[2] - f[5], 0.0f);
+            if (e_nb == 0 && e_pt < P) ctr4[e_pt] = make_float4(f[3], f[4], f[5], 0.0f);
         }
-        const int64_t j_next = edge_index(tile + gridDim.x);            // the index load travels during layer 1
+        const int j_next = edge_index(tile + gridDim.x);                // the index load travels during layer 1
         f16x8 wb2[4][2], wb3[4][2];
         load_weights<4>(wb2, w.h2, w.l2, wave & 1, lane);
         load_weights<4>(wb3, w.h3, w.l3, wave & 3, lane);
         __syncthreads();                                                 // (1) edge features visible; the previous tile is finished
 
         // ---- layer 1 (VALU): wave -> point, lane -> channel; the centre term is constant over a point's edges
-        for (int pt = wave; pt < pts; pt += 8) {
-            const int e0 = pt * k;
-            const float ctr = fmaf(wv[5], ef[e0 * 6 + 5], fmaf(wv[4], ef[e0 * 6 + 4], wv[3] * ef[e0 * 6 + 3]));
+        // two edges per step: neighbouring lanes trade one of the two values so that each writes a (column pair) of one row with a
+        // single ds_write_b32 per plane, as in the MFMA layers' epilogue
+        const bool odd = lane & 1;
+        const int kk = KC > 0 ? KC : k;
+        float mx1 = 0.0f;
+        for (int pt = wave; pt < pts; pt += 8) {                        // (a single pass when ONE_PASS: P <= 8)
+            const int e0 = pt * kk;
+            const float4 c = ctr4[pt];
+            const float ctr = fmaf(wv[5], c.z, fmaf(wv[4], c.y, wv[3] * c.x));
             float mx = 0.0f;
-            for (int e = e0; e < e0 + k; ++e) {
-                const float acc = fmaf(wv[2], ef[e * 6 + 2], fmaf(wv[1], ef[e * 6 + 1], wv[0] * ef[e * 6 + 0])) + ctr;
-                const float v = fmaxf(fmaf(acc, s1, t1), 0.0f);
-                mx = fmaxf(mx, v);
-                _Float16 a, b;
-                split_h(v, a, b);
-                regA[e * LD64 + lane] = a;
-                regA[ROWS * LD64 + e * LD64 + lane] = b;
+            _Float16* __restrict__ dst = regA + (e0 + (odd ? 1 : 0)) * LD64 + (lane & ~1);
+#pragma unroll
+            for (int q = 0; q < (KC > 0 ? (KC + 1) / 2 : 16); ++q) {
+                if (KC == 0 && 2 * q >= kk) break;
+                const bool second = 2 * q + 1 < kk;                      // an odd k leaves the last pair half empty
+                const float4 a0 = ef4[e0 + 2 * q], a1 = ef4[e0 + 2 * q + (second ? 1 : 0)];
+                const float v0 = fmaxf(fmaf(fmaf(wv[2], a0.z, fmaf(wv[1], a0.y, wv[0] * a0.x)) + ctr, s1, t1), 0.0f);
+                const float v1 = second ? fmaxf(fmaf(fmaf(wv[2], a1.z, fmaf(wv[1], a1.y, wv[0] * a1.x)) + ctr, s1, t1), 0.0f) : 0.0f;
+                mx = fmaxf(mx, fmaxf(v0, v1));
+                const float send = odd ? v0 : v1, keep = odd ? v1 : v0;
+                const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, true));
+                const float left = odd ? recv : keep, right = odd ? keep : recv;
+                _Float16 lh_, ll_, rh_, rl_;
+                split_h(left, lh_, ll_);
+                split_h(right, rh_, rl_);
+                using h2 = __attribute__((ext_vector_type(2))) _Float16;
+                if (!odd || second) {
+                    *reinterpret_cast<h2*>(&dst[2 * q * LD64]) = h2{lh_, rh_};
+                    *reinterpret_cast<h2*>(&dst[ROWS * LD64 + 2 * q * LD64]) = h2{ll_, rl_};
+                }
+            }
+            if constexpr (ONE_PASS) {
+                mx1 = mx;
+                break;
             }
             xcat[(p0 + pt) * ldx + lane] = mx;                           // x1 = max over the point's k edges
+        }
+        touch_weights<4>(wb2);                                           // fetched at the top of the tile: arrived during layer 1
+        touch_weights<4>(wb3);
+        if constexpr (ONE_PASS) {
+            if (wave < pts) xcat[(p0 + wave) * ldx + lane] = mx1;
         }
         edge_fetch(tile + gridDim.x, j_next);                            // next tile's coordinates travel during layers 2-4
         __syncthreads();                                                 // (2) h1 planes complete
@@ -272,11 +338,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         else if (wave < 6) mfma_layer<4, 1, KC, 3>(regA, LD64, wb2, wave & 1, 3, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
         else mfma_layer<4, 1, KC, 4>(regA, LD64, wb2, wave & 1, 4, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
         __syncthreads();                                                 // (3) h2 planes and x2 maxima complete
-        for (int i = tid; i < pts * 64; i += 512) {
-            const int p = i >> 6, ch = i & 63;
-            xcat[(p0 + p) * ldx + 64 + ch] = __int_as_float(pool0[p * 256 + ch]);
-            pool0[p * 256 + ch] = 0;
-        }
+        flush(pool0, 4, 64, pts, p0);
         if (!two_pools) __syncthreads();
 
         // ---- layer 3: 64 -> 128; 4 column blocks x 5 row blocks: waves 0-3 take row blocks {0,1,2}, waves 4-7 {3,4}; h3 planes
@@ -284,11 +346,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         if (wave < 4) mfma_layer<4, 3, KC, 0>(regB, LD64, wb3, wave & 3, 0, sc3, sh3, regA, LD128, pool1, 256, ik16, rows_valid, lane_t);
         else mfma_layer<4, 2, KC, 3>(regB, LD64, wb3, wave & 3, 3, sc3, sh3, regA, LD128, pool1, 256, ik16, rows_valid, lane_t);
         __syncthreads();                                                 // (4)
-        for (int i = tid; i < pts * 128; i += 512) {
-            const int p = i >> 7, ch = i & 127;
-            xcat[(p0 + p) * ldx + 128 + ch] = __int_as_float(pool1[p * 256 + ch]);
-            pool1[p * 256 + ch] = 0;
-        }
+        flush(pool1, 5, 128, pts, p0);
         if (!two_pools) __syncthreads();
 
         // ---- layer 4: 128 -> 256, every wave 32 columns x 5 row blocks; only the pooled output is needed
@@ -296,11 +354,9 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         mfma_layer<8, 3, KC, 0>(regA, LD128, wb4, wave, 0, sc4, sh4, nullptr, 0, pool0, 256, ik16, rows_valid, lane_t);
         mfma_layer<8, 2, KC, 3>(regA, LD128, wb4, wave, 3, sc4, sh4, nullptr, 0, pool0, 256, ik16, rows_valid, lane_t);
         __syncthreads();                                                 // (5)
-        for (int i = tid; i < pts * 256; i += 512) {
-            const int p = i >> 8, ch = i & 255;
-            xcat[(p0 + p) * ldx + 256 + ch] = __int_as_float(pool0[p * 256 + ch]);
-            pool0[p * 256 + ch] = 0;
-        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) touch(f[i]);                         // next tile's edge features: in flight since layer 1
+        flush(pool0, 6, 256, pts, p0);
         // pool0 is next touched by layer 2 of the following tile, two barriers from here
     }
 }
@@ -313,10 +369,10 @@ extern "C" int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, 
                                    const float* s4, const float* t4, float inv4, float* xcat, int64_t ldx, void* stream) {
     OGMM_REQUIRE(xyz && idx && W1 && s1 && t1 && h2 && l2 && s2 && t2 && h3 && l3 && s3 && t3 && h4 && l4 && s4 && t4 && xcat,
                  "ogmm_edgeconv_fused: null pointer");
-    OGMM_REQUIRE(C > 0 && N > 0 && k >= 4 && k <= 32 && ldx >= 512, "ogmm_edgeconv_fused: bad sizes C=%d N=%d k=%d ldx=%lld", C, N, k, (long long)ldx);
+    OGMM_REQUIRE(C > 0 && N > 0 && k >= 7 && k <= 32 && ldx >= 512 && ldx % 4 == 0 && reinterpret_cast<uintptr_t>(xcat) % 16 == 0, "ogmm_edgeconv_fused: bad sizes C=%d N=%d k=%d ldx=%lld", C, N, k, (long long)ldx);
     const int64_t total = (int64_t)C * N;
     const int P = ROWS / k;
-    const size_t fixed = (size_t)(2 * ROWS * LD128 + 2 * ROWS * LD64) * sizeof(_Float16) + (size_t)ROWS * 6 * sizeof(float);
+    const size_t fixed = (size_t)(2 * ROWS * LD128 + 2 * ROWS * LD64) * sizeof(_Float16) + (size_t)(ROWS + 24) * sizeof(float4);
     const size_t pool = (size_t)P * 256 * sizeof(int);
     const int two_pools = fixed + 2 * pool <= 160 * 1024;
     const size_t lds = fixed + (two_pools ? 2 : 1) * pool;
