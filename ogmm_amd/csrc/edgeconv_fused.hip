@@ -36,6 +36,25 @@ __device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+// split of two values at once: packed conversions (v_cvt_pk_f16_f32) and a packed subtract instead of five scalar ops per value
+__device__ __forceinline__ void split_h2(float a, float b, f16x2& hi, f16x2& lo) {
+    f32x2 x = {__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+    hi = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(hi, f32x2);
+    lo = __builtin_convertvector(r, f16x2);
+}
+
+// lanes 2j and 2j+1 hold (v0, v1) of columns c and c+1: afterwards the even lane has (v0 of c, v0 of c+1), the odd lane (v1 of c, v1 of c+1)
+__device__ __forceinline__ void trade_pair(float v0, float v1, bool odd, float& left, float& right) {
+    const float n0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v0), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    const float n1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v1), 0xB1, 0xf, 0xf, true));
+    left = odd ? n1 : v0;
+    right = odd ? v1 : n0;
+}
+
 // Weight fragments of one 32-column block for a whole layer (KS k-steps): hi/lo, fetched well before they are needed.
 template <int KS>
 __device__ __forceinline__ void load_weights(f16x8 (&wb)[KS][2], const void* hi, const void* lo, int nb, int lane) {
@@ -108,17 +127,13 @@ __device__ __forceinline__ void mfma_layer(const _Float16* Ain, int LDA, const f
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float v0 = acc[i][2 * q], v1 = acc[i][2 * q + 1];
-                const float send = odd ? v0 : v1, keep = odd ? v1 : v0;
-                const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-                const float left = odd ? recv : keep, right = odd ? keep : recv;          // columns (col & ~1), (col & ~1) + 1
-                _Float16 lh_, ll_, rh_, rl_;
-                split_h(left, lh_, ll_);
-                split_h(right, rh_, rl_);
-                using h2 = __attribute__((ext_vector_type(2))) _Float16;
+                float left, right;
+                trade_pair(acc[i][2 * q], acc[i][2 * q + 1], odd, left, right);           // columns (col & ~1), (col & ~1) + 1
+                f16x2 hi2, lo2;
+                split_h2(left, right, hi2, lo2);
                 const int off = (i * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2)) * LDO;      // row of register 2q, relative to the lane's base row
-                *reinterpret_cast<h2*>(&dst[off]) = h2{lh_, rh_};
-                *reinterpret_cast<h2*>(&dst[OPL + off]) = h2{ll_, rl_};
+                *reinterpret_cast<f16x2*>(&dst[off]) = hi2;
+                *reinterpret_cast<f16x2*>(&dst[OPL + off]) = lo2;
             }
     }
     // ---- pooling
@@ -306,16 +321,13 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
                 const float v0 = fmaxf(fmaf(fmaf(wv[2], a0.z, fmaf(wv[1], a0.y, wv[0] * a0.x)) + ctr, s1, t1), 0.0f);
                 const float v1 = second ? fmaxf(fmaf(fmaf(wv[2], a1.z, fmaf(wv[1], a1.y, wv[0] * a1.x)) + ctr, s1, t1), 0.0f) : 0.0f;
                 mx = fmaxf(mx, fmaxf(v0, v1));
-                const float send = odd ? v0 : v1, keep = odd ? v1 : v0;
-                const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, true));
-                const float left = odd ? recv : keep, right = odd ? keep : recv;
-                _Float16 lh_, ll_, rh_, rl_;
-                split_h(left, lh_, ll_);
-                split_h(right, rh_, rl_);
-                using h2 = __attribute__((ext_vector_type(2))) _Float16;
+                float left, right;
+                trade_pair(v0, v1, odd, left, right);
+                f16x2 hi2, lo2;
+                split_h2(left, right, hi2, lo2);
                 if (!odd || second) {
-                    *reinterpret_cast<h2*>(&dst[2 * q * LD64]) = h2{lh_, rh_};
-                    *reinterpret_cast<h2*>(&dst[ROWS * LD64 + 2 * q * LD64]) = h2{ll_, rl_};
+                    *reinterpret_cast<f16x2*>(&dst[2 * q * LD64]) = hi2;
+                    *reinterpret_cast<f16x2*>(&dst[ROWS * LD64 + 2 * q * LD64]) = lo2;
                 }
             }
             if constexpr (ONE_PASS) {
