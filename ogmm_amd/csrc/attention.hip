@@ -16,6 +16,7 @@
 //   4. P is written (split) to a per-wave LDS patch in A-operand order -- the patch re-uses the K planes, hence one
 //      barrier -- and O = P V accumulates in dh/32 tiles, stored head-major.
 #include "ogmm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -238,7 +239,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // tiles of a head) instead of re-splitting and re-transposing 128 KB of K/V per 128 queries; LDS only holds the per-wave
 // P patch (70 KB per workgroup -> two workgroups per CU).
 // ------------------------------------------------------------------------------------------------------------------
-template <int MK>
+// KEYPERM: the 16 keys of a V k-step are taken in the order in which a 32x32 ACCUMULATOR holds them along its rows (lane half lh,
+// element e -> key 4*lh + (e & 3) + 8*(e >> 2)), for the transposed kernel below whose probabilities never leave the registers.
+template <int MK, bool KEYPERM>
 __global__ __launch_bounds__(256) void attention_pack_kernel(const float* __restrict__ k, int64_t ldk, const float* __restrict__ v,
                                                              int64_t ldv, int H, f16x8* __restrict__ kimg, f16x8* __restrict__ vimg) {
     constexpr int M = MK * 32;
@@ -272,7 +275,8 @@ __global__ __launch_bounds__(256) void attention_pack_kernel(const float* __rest
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 _Float16 x, y;
-                split1(vc[(int64_t)(key0 + e) * ldv + d], x, y);
+                const int key = KEYPERM ? kb * 16 + (lane >> 5) * 4 + (e & 3) + 8 * (e >> 2) : key0 + e;
+                split1(vc[(int64_t)key * ldv + d], x, y);
                 hi[e] = x; lo[e] = y;
             }
             vo[gI] = hi;
@@ -427,6 +431,212 @@ __global__ __launch_bounds__(256, 2) void attention_frag_kernel(const float* __r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Third structure: the TRANSPOSED product.  S^T = K Q^T puts keys on the accumulator's rows (registers) and queries on its columns
+// (lanes): a query's whole score row then lives in ONE lane pair (l, l+32), so
+//   * the softmax is 64 in-register max / exp / sum operations and two cross-half exchanges per query, instead of ten shuffles
+//     per accumulator register (the second structure's softmax + P patch cost more VALU / LDS time than its MFMAs);
+//   * the probabilities are already in B-operand order for O^T = V^T P^T: lane = query, k = keys -- in the accumulator's row
+//     order, which is why the V image is packed with KEYPERM -- so P never goes through LDS; it is split to hi/lo in place.
+// With LDS free of P patches, a workgroup of 8 waves (256 queries of one cloud and head) stages the K and V fragment images
+// there once (128 KB at M = 128) and every wave reads its A fragments with conflict-free ds_read_b128: the second structure
+// streamed 128 KB of fragments from L2 per WAVE (2.1 GB per call at B = 64).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int QT2 = 256;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+__device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& lo) {
+    f32x2 x = {__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+    hi = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(hi, f32x2);
+    lo = __builtin_convertvector(r, f16x2);
+}
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+    f16x2 h, l;
+    split_pair(a[0], a[1], h, l); hi[0] = h[0]; hi[1] = h[1]; lo[0] = l[0]; lo[1] = l[1];
+    split_pair(a[2], a[3], h, l); hi[2] = h[0]; hi[3] = h[1]; lo[2] = l[0]; lo[3] = l[1];
+    split_pair(b[0], b[1], h, l); hi[4] = h[0]; hi[5] = h[1]; lo[4] = l[0]; lo[5] = l[1];
+    split_pair(b[2], b[3], h, l); hi[6] = h[0]; hi[7] = h[1]; lo[6] = l[0]; lo[7] = l[1];
+}
+
+template <int MK>
+__global__ __launch_bounds__(512) void attention_t_kernel(const float* __restrict__ q, int64_t ldq, const f16x8* __restrict__ kimg,
+                                                          const f16x8* __restrict__ vimg, int N, int H, float scale,
+                                                          float* __restrict__ out, int64_t ldo) {
+    constexpr int M = MK * 32;
+    constexpr int GROUPS = M * DH / 8;                   // f16x8 groups per plane and operand
+    constexpr int KS = DH / 16;                          // k-steps of S^T (over d)
+    constexpr int VS = M / 16;                           // k-steps of O^T (over keys)
+    constexpr int NV = DH / 32;                          // row blocks of O^T (over d)
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    f16x8* Ks = reinterpret_cast<f16x8*>(lds);           // [2 planes][MK][KS][64 lanes]
+    f16x8* Vs = Ks + 2 * GROUPS;                         // [2 planes][NV][VS][64 lanes]
+    const int h = blockIdx.y, c = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const f16x8* __restrict__ KG = kimg + ((int64_t)c * H + h) * 2 * GROUPS;
+    const f16x8* __restrict__ VG = vimg + ((int64_t)c * H + h) * 2 * GROUPS;
+
+    // ---- stage both images (coalesced 16-byte loads, all in flight together with the Q rows)
+    constexpr int PER = (2 * GROUPS + 511) / 512;        // vectors per thread and image
+    f16x8 kst[PER], vst[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int g = i * 512 + tid;
+        if (2 * GROUPS % 512 == 0 || g < 2 * GROUPS) { kst[i] = KG[g]; vst[i] = VG[g]; }
+    }
+    // Q rows of a tile: lane = query, 8 consecutive d per k-step (B operand of S^T).  The workgroup walks the query tiles
+    // blockIdx.x, + gridDim.x, ... of its (cloud, head); the next tile's rows are fetched before the current tile is computed.
+    const int n_tiles = (N + QT2 - 1) / QT2;
+    f32x4 qa[KS], qb[KS];
+    auto load_q = [&](int tile) {
+        const int row = min(tile * QT2 + wave * 32 + lr, N - 1);
+        const float* __restrict__ qp = q + ((int64_t)c * N + row) * ldq + h * DH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qa[s] = *reinterpret_cast<const f32x4*>(qp + s * 16 + lh * 8);
+            qb[s] = *reinterpret_cast<const f32x4*>(qp + s * 16 + lh * 8 + 4);
+        }
+    };
+    load_q(blockIdx.x);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int g = i * 512 + tid;
+        if (2 * GROUPS % 512 == 0 || g < 2 * GROUPS) { Ks[g] = kst[i]; Vs[g] = vst[i]; }
+    }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int q_row = tile * QT2 + wave * 32 + lr;
+    // opaque per tile: otherwise the (tile-invariant) LDS fragment reads are hoisted out of the loop, into registers that do not exist
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    const f16x8* __restrict__ Kl = Ks + lane_t;
+    const f16x8* __restrict__ Vl = Vs + lane_t;
+    f16x8 qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) split8(qa[s], qb[s], qh[s], ql[s]);
+    if (tile + (int)gridDim.x < n_tiles) load_q(tile + gridDim.x);
+
+    // ---- S^T = K Q^T: row blocks = 32 keys each, A fragments from LDS
+    f32x16 sacc[MK];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f16x8 ah[MK], al[MK];
+#pragma unroll
+        for (int j = 0; j < MK; ++j) {
+            ah[j] = Kl[(j * KS + s) * 64];
+            al[j] = Kl[GROUPS + (j * KS + s) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < MK; ++j) {
+            if (s == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], qh[s], zero, 0, 0, 0);
+            } else {
+                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], qh[s], sacc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], ql[s], sacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], qh[s], sacc[j], 0, 0, 0);
+    }
+
+    // ---- softmax over the keys of this lane's query: registers of this lane and of lane ^ 32
+    const float sl2 = scale * 1.4426950408889634f;       // exp(x * scale - m) = exp2((x - m') * scale * log2 e), scale > 0
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[j][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[j][r] = __builtin_amdgcn_exp2f((sacc[j][r] - m) * sl2);
+            sum += sacc[j][r];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    // ---- O^T = V^T P^T: B fragments of k-step (j, t) are the accumulator registers 8t .. 8t+7 of key block j, split in place
+    f32x16 oacc[NV];
+#pragma unroll
+    for (int ks = 0; ks < VS; ++ks) {
+        const int j = ks >> 1, t = ks & 1;
+        f16x8 ph, pl;
+        {
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = sacc[j][8 * t + e] * inv; b[e] = sacc[j][8 * t + 4 + e] * inv; }
+            split8(a, b, ph, pl);
+        }
+        f16x8 vh[NV], vl[NV];
+#pragma unroll
+        for (int jd = 0; jd < NV; ++jd) {
+            vh[jd] = Vl[(jd * VS + ks) * 64];
+            vl[jd] = Vl[GROUPS + (jd * VS + ks) * 64];
+        }
+#pragma unroll
+        for (int jd = 0; jd < NV; ++jd) {
+            if (ks == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                oacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[jd], ph, zero, 0, 0, 0);
+            } else {
+                oacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[jd], ph, oacc[jd], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jd = 0; jd < NV; ++jd) oacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[jd], pl, oacc[jd], 0, 0, 0);
+#pragma unroll
+        for (int jd = 0; jd < NV; ++jd) oacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[jd], ph, oacc[jd], 0, 0, 0);
+    }
+
+    // ---- store: lane = query, register quads = 4 consecutive d; the two lane halves fill 32 contiguous bytes, the four quads of a
+    // block one 128-byte line (merged in L2)
+    if (q_row < N) {
+        float* __restrict__ op = out + ((int64_t)c * N + q_row) * ldo + h * DH + 4 * lh;
+#pragma unroll
+        for (int jd = 0; jd < NV; ++jd)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v4 = {oacc[jd][4 * g], oacc[jd][4 * g + 1], oacc[jd][4 * g + 2], oacc[jd][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(op + jd * 32 + 8 * g) = v4;
+            }
+    }
+    }
+}
+
+template <int MK>
+int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H,
+                       float scale, float* out, int64_t ldo, void* workspace, hipStream_t s) {
+    constexpr int M = MK * 32;
+    constexpr int GROUPS = M * DH / 8;
+    const size_t lds = (size_t)4 * GROUPS * sizeof(f16x8);
+    f16x8* kimg = reinterpret_cast<f16x8*>(workspace);
+    f16x8* vimg = kimg + (int64_t)C * H * 2 * GROUPS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attention_pack_kernel<MK, true>), dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
+    // query tiles per workgroup: as many as leave at least two workgroups per CU (the K / V images are staged once per workgroup)
+    const int n_tiles = (N + QT2 - 1) / QT2;
+    static const int force_x = [] { const char* e = getenv("OGMM_ATTN_GX"); return e ? atoi(e) : 0; }();
+    int gx = (512 + C * H - 1) / (C * H);
+    if (force_x > 0) gx = force_x;
+    gx = gx < 1 ? 1 : (gx > n_tiles ? n_tiles : gx);
+    hipLaunchKernelGGL(attention_t_kernel<MK>, dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, N, H, scale, out, ldo);
+    return ogmm::check_launch("ogmm_attention(transposed)");
+}
+
 template <int MK>
 int launch_attention_frag(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H,
                           float scale, float* out, int64_t ldo, void* workspace, hipStream_t s) {
@@ -441,7 +651,7 @@ int launch_attention_frag(const float* q, int64_t ldq, const float* k, int64_t l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_frag_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_pack_kernel<MK>, dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
+    hipLaunchKernelGGL((attention_pack_kernel<MK, false>), dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
     hipLaunchKernelGGL(attention_frag_kernel<MK>, dim3((N + QT - 1) / QT, H, C), dim3(256), lds, s, q, ldq, kimg, vimg, N, H, scale, out, ldo);
     return ogmm::check_launch("ogmm_attention(frag)");
 }
@@ -478,9 +688,15 @@ extern "C" int ogmm_attention(const float* q, int64_t ldq, const float* k, int64
     hipStream_t s = ogmm::as_stream(stream);
     if (workspace) {
         OGMM_REQUIRE(ogmm::aligned16(workspace), "ogmm_attention: workspace must be 16-byte aligned");
-        if (M == 32) return launch_attention_frag<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
-        if (M == 64) return launch_attention_frag<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
-        return launch_attention_frag<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+        static const bool old_frag = [] { const char* e = getenv("OGMM_ATTN_FRAG"); return e && e[0] == '1'; }();     // A/B: the second structure
+        if (old_frag) {
+            if (M == 32) return launch_attention_frag<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+            if (M == 64) return launch_attention_frag<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+            return launch_attention_frag<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+        }
+        if (M == 32) return launch_attention_t<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+        if (M == 64) return launch_attention_t<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+        return launch_attention_t<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
     }
     if (M == 32) return launch_attention<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
     if (M == 64) return launch_attention<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
