@@ -6,6 +6,7 @@
 // (lib/se3.py:276).  Here the whole E/M loop of one cloud runs inside one workgroup with the state in
 // LDS/registers, and the rigid solve runs one pair per wavefront without leaving the GPU.
 #include "ogmm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -181,6 +182,11 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
 // touch consecutive words), every Sinkhorn sweep is two passes over it (max, then sum of exp: one exp per entry, no
 // branches), and the unnormalised gamma overwrites it for the M-step.  ~3x fewer instructions per sweep than recomputing
 // sqrt/exp-merge chains; results agree with gmm_em_kernel to rounding.
+// JT > 0: J == JT and N <= 1024 at compile time -- the Sinkhorn sweeps then keep a row's JT (a column's 16 per lane) exponents in
+// registers between the max and the exp-sum pass instead of reading LDS and recomputing them (same operations in the same order: the
+// results are bit-identical to the JT = 0 form).  FAST: the sweeps' exp(x - max) on v_exp_f32 (x - max <= 0, and only terms with
+// x - max near 0 carry weight, where the 2^(x log2 e) form is as accurate as the range-reduced one).
+template <int JT, bool FAST>
 __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __restrict__ xyz, const float* __restrict__ o,
                                                              const int32_t* __restrict__ ids0, int N, int J, int iters, int sk_iters,
                                                              float inv_eps, float eps, float inv_tau, float* __restrict__ gamma,
@@ -230,6 +236,43 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
         for (int j = tid; j < J; j += EM_T) v[j] = 0.0f;
         __syncthreads();
         for (int sk = 0; sk < sk_iters; ++sk) {
+            auto em_exp = [](float x) { return FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x); };
+            if constexpr (JT > 0) {
+                if (tid < N) {                                            // u^{l+1}: one row per thread (N <= EM_T)
+                    const int n = tid;
+                    const float un = u[n];
+                    float t[JT];
+                    float mx = -__builtin_inff();
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) { t[j] = ((-Cs[j * N + n] + un) + v[j]) * inv_eps; mx = fmaxf(mx, t[j]); }
+                    float se = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) se += em_exp(t[j] - mx);
+                    u[n] = eps * (logp[n] - (mx + logf(se))) + un;
+                }
+                __syncthreads();
+                for (int j = wave; j < JT; j += NW) {                     // v^{l+1}: columns on waves, 16 rows per lane
+                    const float vj = v[j];
+                    const float* __restrict__ Cj = Cs + j * N;
+                    float t[16];
+                    float mx = -__builtin_inff();
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int n = lane + 64 * i;
+                        t[i] = n < N ? ((-Cj[n] + u[n]) + vj) * inv_eps : -__builtin_inff();
+                        mx = fmaxf(mx, t[i]);
+                    }
+                    mx = wave_max(mx);
+                    float se = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (lane + 64 * i < N) se += em_exp(t[i] - mx);
+                    se = wave_sum(se);
+                    if (lane == 0) v[j] = eps * (logq - (mx + logf(se))) + vj;
+                }
+                __syncthreads();
+                continue;
+            }
             for (int n = tid; n < N; n += EM_T) {                     // u^{l+1}: rows on threads
                 const float un = u[n];
                 float mx = -__builtin_inff();
@@ -793,11 +836,21 @@ extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0
     if (lds_cached <= 128 * 1024) {       // cost matrix resident in LDS
         static bool attr2 = false;
         if (!attr2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr2 = true;
         }
-        hipLaunchKernelGGL(gmm_em_cached_kernel, dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters, sk_iters,
-                           inv_eps, epsilon, inv_tau, gamma, pi, mu);
+        static const int em_mode = [] { const char* e = getenv("OGMM_EM_MODE"); return e ? atoi(e) : 2; }();      // 0 generic, 1 registers (bit-identical to 0), 2 + v_exp_f32 (default)
+        if (J == 16 && N <= EM_T && em_mode == 2)
+            hipLaunchKernelGGL((gmm_em_cached_kernel<16, true>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu);
+        else if (J == 16 && N <= EM_T && em_mode == 1)
+            hipLaunchKernelGGL((gmm_em_cached_kernel<16, false>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu);
+        else
+            hipLaunchKernelGGL((gmm_em_cached_kernel<0, false>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu);
         return ogmm::check_launch("ogmm_gmm_em(cached)");
     }
     hipLaunchKernelGGL(gmm_em_kernel, dim3(C), dim3(EM_T), lds, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters, sk_iters, inv_eps,

@@ -1,0 +1,17 @@
+"""E/M clustering kernel alone (B=64: 128 clouds, N=1024, J=16): on-chip and grid-wide engines."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ogmm_amd import ops
+torch.manual_seed(0)
+C, N, J = 128, 1024, 16
+xyz = torch.randn(C, N, 3, device="cuda") * 0.5
+o = torch.rand(C, N, device="cuda")
+ids = ops.fps(xyz, J, None)
+for eng in (None, "multi"):
+    for _ in range(2): ops.gmm_em(xyz, o, ids, engine=eng)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): ops.gmm_em(xyz, o, ids, engine=eng)
+    e1.record(); torch.cuda.synchronize()
+    print("engine=%s  %.1f us" % (eng, e0.elapsed_time(e1) / 5 * 1e3))
