@@ -59,14 +59,30 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
             ik[0] = first ? j : ik[0];
         }
     };
+    // Candidates in chunks of 32.  Pass 1 only tests each distance against the list's current worst entry and records a bit; pass 2
+    // drains the bits: every lane takes its lowest marked candidate (so a lane's insertions stay in index order), recomputes the
+    // distance (same operations, same value) and runs the insertion ladder.  The ladder (~6 selects per list slot) is executed by
+    // the whole wave whenever ANY lane inserts; per candidate that is almost always the case (64 lanes x ~k ln(N/k) / N insertions
+    // each), per drain round it happens max-over-lanes(marks) times per chunk: ~4x fewer ladder passes at N = 1024, k = 20.
     int j = 0;
-    for (; j + 4 <= N; j += 4) {          // 4 candidates per trip: their LDS reads are in flight together
-        const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
-        const float d0 = knn_dist(pq, p0), d1 = knn_dist(pq, p1), d2 = knn_dist(pq, p2), d3 = knn_dist(pq, p3);
-        insert(d0, j);
-        insert(d1, j + 1);
-        insert(d2, j + 2);
-        insert(d3, j + 3);
+    for (; j + 32 <= N; j += 32) {
+        const float worst = dk[KL - 1];
+        unsigned mask = 0u;
+#pragma unroll
+        for (int t = 0; t < 32; t += 4) {
+            const float4 p0 = pts[j + t], p1 = pts[j + t + 1], p2 = pts[j + t + 2], p3 = pts[j + t + 3];
+            mask |= (knn_dist(pq, p0) < worst ? 1u : 0u) << t;
+            mask |= (knn_dist(pq, p1) < worst ? 1u : 0u) << (t + 1);
+            mask |= (knn_dist(pq, p2) < worst ? 1u : 0u) << (t + 2);
+            mask |= (knn_dist(pq, p3) < worst ? 1u : 0u) << (t + 3);
+        }
+        while (__any(mask != 0u)) {
+            const bool mine = mask != 0u;
+            const int b = mine ? __ffs(mask) - 1 : 0;
+            const float d = mine ? knn_dist(pq, pts[j + b]) : __builtin_inff();
+            insert(d, j + b);
+            mask &= mask - 1u;
+        }
     }
     for (; j < N; ++j) insert(knn_dist(pq, pts[j]), j);
     float d_last = 0.0f, d_next = -1.0f;
