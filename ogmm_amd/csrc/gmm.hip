@@ -858,12 +858,83 @@ extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0
     return ogmm::check_launch("ogmm_gmm_em");
 }
 
+namespace {
+// J <= 16: two channels per thread (float2 loads: 512 B per wave and row), a row's 16 weights read from LDS as four ds_read_b128,
+// eight rows' loads in flight per thread.  Rows are dealt to the 4 row lanes exactly as in gmm_feat_mean_kernel<16> (r = lane, +4, ...)
+// and summed in the same order, so the result is bit-identical; the older kernel issued 16 scalar LDS reads per loaded dword and ran at
+// a third of the HBM rate.
+__global__ __launch_bounds__(256) void gmm_feat_mean16_kernel(const float* __restrict__ gamma, const float* __restrict__ pi,
+                                                              const float* __restrict__ feats, int64_t ld, int N, int J, int D,
+                                                              float* __restrict__ mu_feat) {
+    __shared__ __attribute__((aligned(16))) float gs[128][16];
+    __shared__ float red[3][16][128];
+    const int c = blockIdx.z, cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int d = blockIdx.x * 128 + 2 * cl;
+    const bool ok = d + 1 < D;                            // D even (checked on the host)
+    const float* __restrict__ F = feats + (int64_t)c * N * ld + (ok ? d : 0);
+    const float* __restrict__ G = gamma + (int64_t)c * N * J;
+    float a0[16], a1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a0[j] = 0.0f; a1[j] = 0.0f; }
+    for (int n0 = 0; n0 < N; n0 += 128) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 128 * 16; i += 256) {
+            const int r = i >> 4, j = i & 15;
+            gs[r][j] = (n0 + r < N && j < J) ? G[(int64_t)(n0 + r) * J + j] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r0 = 0; r0 < 128; r0 += 32) {           // 8 rows of this row lane per trip
+            float2 f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                // unconditional loads (rows past the end are clamped: their weights in gs are zero), so that all eight are in flight
+                const int r = min(n0 + r0 + rl + 4 * u, N - 1);
+                f[u] = *reinterpret_cast<const float2*>(F + (int64_t)r * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4* g4 = reinterpret_cast<const float4*>(gs[r0 + rl + 4 * u]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 g = g4[q];
+                    a0[4 * q] = fmaf(g.x, f[u].x, a0[4 * q]);         a1[4 * q] = fmaf(g.x, f[u].y, a1[4 * q]);
+                    a0[4 * q + 1] = fmaf(g.y, f[u].x, a0[4 * q + 1]); a1[4 * q + 1] = fmaf(g.y, f[u].y, a1[4 * q + 1]);
+                    a0[4 * q + 2] = fmaf(g.z, f[u].x, a0[4 * q + 2]); a1[4 * q + 2] = fmaf(g.z, f[u].y, a1[4 * q + 2]);
+                    a0[4 * q + 3] = fmaf(g.w, f[u].x, a0[4 * q + 3]); a1[4 * q + 3] = fmaf(g.w, f[u].y, a1[4 * q + 3]);
+                }
+            }
+        }
+    }
+    // (red[0] + red[1]) + (red[2] + red[3]) as in the older kernel; row lane 0 keeps its own partial in registers
+    __syncthreads();
+    if (rl > 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { red[rl - 1][j][2 * cl] = a0[j]; red[rl - 1][j][2 * cl + 1] = a1[j]; }
+    }
+    __syncthreads();
+    if (rl == 0 && ok) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j >= J) break;
+            const float npi = pi[(int64_t)c * J + j] * (float)N + 1e-5f;
+            const float s0 = (a0[j] + red[0][j][2 * cl]) + (red[1][j][2 * cl] + red[2][j][2 * cl]);
+            const float s1 = (a1[j] + red[0][j][2 * cl + 1]) + (red[1][j][2 * cl + 1] + red[2][j][2 * cl + 1]);
+            *reinterpret_cast<float2*>(&mu_feat[((int64_t)c * J + j) * D + d]) = make_float2(s0 / npi, s1 / npi);
+        }
+    }
+}
+}  // namespace
+
 extern "C" int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,
                                   float* mu_feat, void* stream) {
     OGMM_REQUIRE(gamma && pi && feats && mu_feat && C > 0 && N > 0 && J > 0 && D > 0 && ld >= D, "ogmm_gmm_feat_mean: null pointer or bad sizes");
     if (J > 16)
         hipLaunchKernelGGL(gmm_feat_mean_kernel<64>, dim3((D + 63) / 64, (J + 63) / 64, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats,
                            ld, N, J, D, mu_feat);
+    else if (D % 2 == 0 && ld % 2 == 0 && reinterpret_cast<uintptr_t>(feats) % 8 == 0 && reinterpret_cast<uintptr_t>(mu_feat) % 8 == 0)
+        hipLaunchKernelGGL(gmm_feat_mean16_kernel, dim3((D + 127) / 128, 1, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats, ld, N, J, D,
+                           mu_feat);
     else
         hipLaunchKernelGGL(gmm_feat_mean_kernel<16>, dim3((D + 63) / 64, 1, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats,
                            ld, N, J, D, mu_feat);
