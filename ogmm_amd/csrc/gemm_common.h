@@ -1,5 +1,6 @@
 // Shared pieces of the GEMM engines (exact-fp32 and fp16x3-split): activation, tile->workgroup map, fused epilogue.
 #pragma once
+#include <type_traits>
 #include "ogmm_common.h"
 
 namespace ogmm_gemm_detail {
@@ -138,6 +139,60 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
     const float* __restrict__ Rm = g.Res;
     const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 tot1 = zero4, tot2 = zero4;        // column statistics of this wave's MT*32 rows (InstanceNorm fusion)
+    // Fast path: the workgroup's whole tile is inside the matrix and scale / shift are per column.  A lane's four columns are the same
+    // in every pass (idx % F4_PER_ROW == lane % F4_PER_ROW), so scale / shift are fetched once, and every load and store below is
+    // unconditional.  That matters beyond the instruction count: with loads or stores under per-lane conditions the compiler cannot
+    // count the operations in flight, so each pass's wait for its (optional) loads becomes s_waitcnt vmcnt(0) -- which also waits for
+    // the PREVIOUS pass's store to be acknowledged.  The general form below therefore issues one store per HBM round trip per wave
+    // (the "store burst" of DESIGN.md: 14 % of a 131072x1024x1024 launch with the matrix cores idle).
+    const bool tile_inside = m0 + WM * MT * 32 <= m_end && n0 + WN * NT * 32 <= g.N;
+    if (tile_inside && !g.row_affine && 64 % F4_PER_ROW == 0 && g.act != OGMM_ACT_SIGMOID) {
+        const int c4 = (lane % F4_PER_ROW) * 4, rl0 = lane / F4_PER_ROW;
+        constexpr int RSTEP = 64 / F4_PER_ROW;             // patch rows covered per pass
+        const int col = n0 + wn * NT * 32 + c4;
+        const f32x4 sc = g.scale ? *reinterpret_cast<const f32x4*>(g.scale + col) : one4;
+        const f32x4 sh = g.shift ? *reinterpret_cast<const f32x4*>(g.shift + col) : zero4;
+        const bool stats = g.col_stats != nullptr;
+        // none / ReLU / LeakyReLU(0.2) without a branch: max(v, lo), then v > 0 ? v : slope * v
+        const float act_lo = g.act == OGMM_ACT_RELU ? 0.0f : -__builtin_inff(), act_slope = g.act == OGMM_ACT_LEAKY02 ? 0.2f : 1.0f;
+        auto block = [&](auto has_res, int i) {
+            const int row0 = m0 + (wm * MT + i) * 32 + rl0;
+            f32x4 rr[ITER];
+            if constexpr (decltype(has_res)::value) {
+#pragma unroll
+                for (int q = 0; q < ITER; ++q) rr[q] = *reinterpret_cast<const f32x4*>(Rm + (int64_t)(row0 + q * RSTEP) * g.ldr + col);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + j * 32 + lr] = acc[i][j][r];
+#pragma unroll
+            for (int q = 0; q < ITER; ++q) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&patch[(rl0 + q * RSTEP) * LDC + c4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = fmaxf(fmaf(v[e] * alpha, sc[e], sh[e]), act_lo);
+                    v[e] = y > 0.0f ? y : act_slope * y;
+                }
+                if constexpr (decltype(has_res)::value) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[q][e];
+                }
+                *reinterpret_cast<f32x4*>(Cm + (int64_t)(row0 + q * RSTEP) * g.ldc + col) = v;
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { tot1[e] += v[e]; tot2[e] = fmaf(v[e], v[e], tot2[e]); }
+                }
+            }
+        };
+        if (Rm) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) block(std::true_type{}, i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) block(std::false_type{}, i);
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -176,6 +231,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
                 }
             }
         }
+    }
     }
     if (g.col_stats) {
         // lanes that share (lane % F4_PER_ROW) hold the same 4 columns: fold them, then one fp64 atomic per column and statistic
