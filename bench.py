@@ -42,6 +42,26 @@ CFG = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_
 B_PER_GPU, N_POINTS, J = 64, 1024, 16
 
 
+def pmc_traffic_bytes(kernel_substr, path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_counters.txt")):
+    """HBM bytes per launch of `kernel_substr` from the committed PMC summary: FETCH_SIZE (KiB, doubled: the gfx950 correction of
+    MI355X_MICROARCH.md) + WRITE_SIZE (KiB); None when the file or the kernel is absent."""
+    try:
+        fetch = write = None
+        section = None
+        for line in open(path):
+            if line.startswith("## pass:"):
+                section = line.split(":", 1)[1].split()
+            elif kernel_substr in line and section in (["FETCH_SIZE"], ["WRITE_SIZE"]):
+                val = float(line.split()[-1])
+                if section == ["FETCH_SIZE"]:
+                    fetch = val
+                else:
+                    write = val
+        return None if fetch is None or write is None else (2.0 * fetch + write) * 1024.0
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,16 +125,19 @@ def main():
 
     pairs = B_PER_GPU * world * args.steps
     value = pairs / elapsed
-    all_gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timeline)
-    all_gemm_flop = sum(f for _, _, f, _ in timeline)
+    all_gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in timeline)
+    all_gemm_flop = sum(f for _, _, f, _, _ in timeline)
     dom_tag = "f16x3" if args.precision == "f16" else args.precision
-    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v in timeline if v == dom_tag]     # un-pooled, N > 64 launches of the engine
+    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v, _ in timeline if v == dom_tag]
+    gemm_bytes = sum(b for _, _, _, v, b in timeline if v == dom_tag)     # un-pooled, N > 64 launches of the engine
     gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
     kernel = {"f16x3": "gemm_f16x3_v4_kernel (256x256x64, 3x v_mfma_f32_32x32x16_f16 per block; v2 <2,2,2,2> for small shapes)",
               "f16": "gemm_f16x3_v4_kernel in single-term mode (1x v_mfma_f32_32x32x16_f16 per block; REDUCED precision)",
               "f32": "gemm_nt_kernel<2,2,2,2,false> (v_mfma_f32_32x32x2_f32)"}[args.precision]
+
+    traffic = pmc_traffic_bytes("gemm_f16x3_v4_kernel") if args.precision == "f16x3" and args.workload == "cfg1" else None
 
     result = {
         "metric": "pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -127,7 +150,11 @@ def main():
                                 "cfg3": "BASELINE configs[3] shape per GPU: ICL-NUIM-like room pairs, N=2048, J=64, batch 64 per GPU"}[args.workload],
                    "pairs_per_gpu_step": B_PER_GPU, "n_points": N_POINTS, "n_clusters": J, "parallelism": "pairs sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": None,
+                     "frac": achieved / peak, "traffic": traffic,
+                     "traffic_note": None if traffic is None else "HBM bytes per launch of the dominant kernel (mean over the forward's launches) from the "
+                                     "committed rocprofv3 PMC passes of this command (profiles/round1_pmc_counters.txt): 2 x FETCH_SIZE (gfx950 "
+                                     "correction) + WRITE_SIZE; the algorithmic bytes of the same launches are in `algorithmic_bytes_per_launch`",
+                     "algorithmic_bytes_per_launch": gemm_bytes / max(1, len(dom)),
                      "kernel": kernel, "launches": len(dom), "avg_launch_us": 1e3 * gemm_ms / max(1, len(dom)),
                      "issued_frac": (3.0 if args.precision == "f16x3" else 1.0) * achieved / peak,      # (f16: the small shapes still issue 3x)
                      "kernel_share_of_step": gemm_ms / (1e3 * elapsed), "all_gemm_share_of_step": all_gemm_ms / (1e3 * elapsed),
@@ -213,7 +240,7 @@ def train_main(args):
     timeline, ops.GEMM_TIMELINE = ops.GEMM_TIMELINE, None
     elapsed = odist.max_over_ranks(dist, elapsed, dev)
     value = B * world * args.steps / elapsed
-    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v in timeline if v == args.precision]
+    dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v, _ in timeline if v == args.precision]
     gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]

@@ -172,7 +172,10 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
     if split is not None and split.get("variant", 1) != PREC_F16X3_FRAG and batch == (1, 1) and not pool_k:
         variant += "_rowmajor"
-    GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * batch[0] * batch[1], variant))
+    # flops, then the launch's algorithmic HBM bytes: A (and A2) read once, C written once, residual read once, weights once
+    nb = batch[0] * batch[1]
+    abytes = 4.0 * nb * (M * (K1 + K2) + (M * N if store_c else 0) + (M * N if res is not None else 0)) + 4.0 * N * (K1 + K2) * (nb if batch != (1, 1) else 1)
+    GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * nb, variant, abytes))
 
 
 def instnorm_fusable(layer_split, N):
