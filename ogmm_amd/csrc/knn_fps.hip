@@ -98,13 +98,104 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
         if (p < k) out[p] = (p == 0 && boundary_tie) ? ~ik[0] : ik[p];
 }
 
+// ---- std::nth_element's partition, by the whole workgroup, with the element moves of the sequential loop
+//     for (;;) { while (q[first] < pivot) ++first;  --last;  while (pivot < q[last]) --last;
+//                if (!(first < last)) return first;  swap(q[first], q[last]);  ++first; }
+// Until the pointers cross, `first` only ever looks at elements that have not been moved yet, and so does `last`; hence the t-th swap
+// exchanges the t-th position from the left holding a value >= pivot (L_t) with the t-th position from the right holding a value <=
+// pivot (R_t), for as long as L_t < R_t.  With T such swaps the loop returns the next stop of `first`: L_T, unless it runs into the
+// element swap T-1 put at R_{T-1} first.  Ranks come from two workgroup prefix sums, the swaps are independent.  The serial loop on one
+// thread (LDS round trip per element) made a flagged row cost ~180 us, on the critical path of the forward.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    __syncthreads();                                     // wave_tot may still be read from the previous scan
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = wave_tot[w];
+        if (w < wave) off += t;
+        total += t;
+    }
+    return off + inc - v;
+}
+
+// partition q[first, last) around the value of q[pivot] (pivot outside the range); every thread returns the cut
+__device__ int block_partition_around(ogmm_select::Cand* q, int first, int last, int pivot, int* Lpos, int* Rpos, int* wave_tot) {
+    const int tid = threadIdx.x;
+    const float pv = q[pivot].v;
+    const int len = last - first;
+    const int per = (len + 255) / 256;                   // consecutive positions per thread
+    const int lo = first + tid * per, hi = min(last, lo + per);
+    int cl = 0, cr = 0;
+    for (int x = lo; x < hi; ++x) {
+        const float a = q[x].v;
+        cl += !(a < pv);
+        cr += !(pv < a);
+    }
+    int nL, nR;
+    int rl = block_exclusive_scan(cl, wave_tot, nL);
+    int rr = block_exclusive_scan(cr, wave_tot, nR);
+    for (int x = lo; x < hi; ++x) {
+        const float a = q[x].v;
+        if (!(a < pv)) Lpos[rl++] = x;
+        if (!(pv < a)) Rpos[nR - 1 - (rr++)] = x;          // rank from the right
+    }
+    __syncthreads();
+    // T = number of t with L_t < R_t (monotone in t)
+    const int m = min(nL, nR);
+    int mine = 0;
+    for (int t = tid; t < m; t += 256) mine += Lpos[t] < Rpos[t];
+    int T;
+    (void)block_exclusive_scan(mine, wave_tot, T);
+    const int cut = (T < nL && (T == 0 || Lpos[T] < Rpos[T - 1])) ? Lpos[T] : Rpos[T - 1];
+    for (int t = tid; t < T; t += 256) {
+        const ogmm_select::Cand a = q[Lpos[t]], b = q[Rpos[t]];
+        q[Lpos[t]] = b;
+        q[Rpos[t]] = a;
+    }
+    __syncthreads();
+    return cut;
+}
+
+// std::nth_element(q, q + nth, q + n) as in torch_topk_select.h's introselect, partitions of more than 64 elements by the workgroup
+__device__ void block_introselect(ogmm_select::Cand* q, int nth, int n, int* Lpos, int* Rpos, int* wave_tot, int* ctl) {
+    const int tid = threadIdx.x;
+    int first = 0, last = n;
+    int lg = 0;
+    for (int m = n; m > 1; m >>= 1) ++lg;
+    int depth = 2 * lg;
+    while (last - first > 64 && depth > 0) {
+        --depth;
+        if (tid == 0) ogmm_select::median_to_first(q, first, first + 1, first + (last - first) / 2, last - 1);
+        __syncthreads();
+        const int cut = block_partition_around(q, first + 1, last, first, Lpos, Rpos, wave_tot);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (tid == 0) ogmm_select::introselect_range(q, nth, first, last, depth);
+    __syncthreads();
+    (void)ctl;
+}
+
 // Rows marked by knn_kernel: rebuild the row's N candidates in index order and keep what torch.topk keeps
 // (torch_topk_select.h); the kept set is then written in (distance, index) order.  ~6e-5 of rows take this path.
 __global__ __launch_bounds__(256) void knn_resolve_ties_kernel(const float* __restrict__ xyz, int N, int k, int64_t total_rows,
                                                                int32_t* __restrict__ idx) {
-    extern __shared__ __attribute__((aligned(16))) ogmm_select::Cand cand[];   // [N]
+    extern __shared__ __attribute__((aligned(16))) ogmm_select::Cand cand[];   // [N], then int Lpos[N], Rpos[N]
+    int* Lpos = reinterpret_cast<int*>(cand + N);
+    int* Rpos = Lpos + N;
     __shared__ int flagged[256];
     __shared__ int n_flagged;
+    __shared__ int wave_tot[4];
     const int tid = threadIdx.x;
     if (tid == 0) n_flagged = 0;
     __syncthreads();
@@ -125,8 +216,13 @@ __global__ __launch_bounds__(256) void knn_resolve_ties_kernel(const float* __re
             cand[j].i = j;
         }
         __syncthreads();
+        if ((long long)k * 64 <= N) {              // torch's heap-select branch: one thread
+            if (tid == 0) ogmm_select::heap_select(cand, k, N);
+        } else {
+            block_introselect(cand, k - 1, N, Lpos, Rpos, wave_tot, nullptr);
+        }
+        __syncthreads();
         if (tid == 0) {
-            ogmm_select::torch_topk_smallest_set(cand, N, k);
             for (int a = 1; a < k; ++a) {       // order the kept set by (distance, index)
                 const ogmm_select::Cand v = cand[a];
                 int b = a;
@@ -252,8 +348,8 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     else hipLaunchKernelGGL(knn_kernel<33>, grid, dim3(256), lds, s, xyz, N, k, idx);
     if (int rc = ogmm::check_launch("ogmm_knn")) return rc;
     const int64_t rows = (int64_t)C * N;
-    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)N * sizeof(ogmm_select::Cand), s, xyz,
-                       N, k, rows, idx);
+    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)), s,
+                       xyz, N, k, rows, idx);
     return ogmm::check_launch("ogmm_knn(resolve ties)");
 }
 

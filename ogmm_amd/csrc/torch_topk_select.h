@@ -105,12 +105,8 @@ OGMM_HD inline void insertion_sort(Cand* q, int first, int last) {
     }
 }
 
-// std::nth_element(q, q + nth, q + n)
-OGMM_HD inline void introselect(Cand* q, int nth, int n) {
-    int first = 0, last = n;
-    int lg = 0;
-    for (int m = n; m > 1; m >>= 1) ++lg;
-    int depth = 2 * lg;
+// std::nth_element's loop from a given state (range [first, last), remaining depth budget)
+OGMM_HD inline void introselect_range(Cand* q, int nth, int first, int last, int depth) {
     while (last - first > 3) {
         if (depth == 0) {
             heap_select(q + first, nth + 1 - first, last - first);
@@ -125,6 +121,13 @@ OGMM_HD inline void introselect(Cand* q, int nth, int n) {
         else last = cut;
     }
     insertion_sort(q, first, last);
+}
+
+// std::nth_element(q, q + nth, q + n)
+OGMM_HD inline void introselect(Cand* q, int nth, int n) {
+    int lg = 0;
+    for (int m = n; m > 1; m >>= 1) ++lg;
+    introselect_range(q, nth, 0, n, 2 * lg);
 }
 
 // After the call q[0..k) is the set torch.topk(largest=False) keeps for a row of n candidates given in index order.
