@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 6
+#define OGMM_ABI_VERSION 7
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -175,6 +175,12 @@ int ogmm_rowdot(const float* x, int64_t ldx, int64_t rows, int D, const float* w
  * outputs are written with element stride `ldo` (they are channels 512/513 of the conv2 input). */
 int ogmm_overlap_cross(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in,
                        float* wo_src, float* wo_tgt, int64_t ldo, void* stream);
+/* The same in ONE pass over S (64-row x 1024-column tiles emit partial softmaxes for their rows and columns, a second small kernel
+ * merges them).  stats: NULL, or [B][4][N] = row max, row exp-sum, column max, column exp-sum as ogmm_overlap_cross_train saves them.
+ * workspace: ogmm_overlap_cross_workspace_bytes(B, N) bytes of device memory. */
+int64_t ogmm_overlap_cross_workspace_bytes(int B, int N);
+int ogmm_overlap_cross_ws(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in,
+                          float* wo_src, float* wo_tgt, int64_t ldo, float* stats, void* workspace, void* stream);
 
 /* ---- K15: overlap-weighted Sinkhorn k-means, the whole E/M loop on chip.  lib/utils.py:269-288
  * (wkeans_plus) with :69-108 (sinkhorn, log domain), :130-140 (gmm_params).  Centres start at

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -56,6 +56,8 @@ PROTOTYPES = {
     "ogmm_l2norm_rows": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_rowdot": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_overlap_cross": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p],
+    "ogmm_overlap_cross_workspace_bytes": [c_int, c_int],
+    "ogmm_overlap_cross_ws": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     "ogmm_gmm_em": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_gmm_em_workspace_bytes": [c_int, c_int, c_int],
     "ogmm_gmm_em_multi": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -352,6 +352,164 @@ extern "C" int ogmm_rowdot(const float* x, int64_t ldx, int64_t rows, int D, con
     return ogmm::check_launch("ogmm_rowdot");
 }
 
+namespace {
+using namespace ogmm;
+// ---------------------------------------------------------------- overlap block, both directions in ONE pass over S
+// A workgroup owns a 64-row x 1024-column tile of one pair's similarity matrix; wave w takes rows 16w .. 16w+15, a lane 16 columns
+// (lane + 64 i) of the panel.  Four rows at a time are loaded (64 independent coalesced loads per lane) and used twice: for the row
+// softmax-dot (wave reductions) and for a running (max, exp-sum, weighted exp-sum) per column, rescaled once per 4-row chunk.  Row
+// results of a panel and column results of a row block are partial softmaxes (max, sum, dot); ogmm_overlap_finalize merges them.
+// The two-kernel form read S twice (once of it column-wise) for 165 us at B = 64; S is 268 MB, i.e. ~55 us at the HBM rate.
+constexpr int OVT_ROWS = 64, OVT_COLS = 1024;
+
+__global__ __launch_bounds__(256) void overlap_tile_kernel(const float* __restrict__ S, int N, const float* __restrict__ o_src,
+                                                           const float* __restrict__ o_tgt, int64_t ldo_in, float* __restrict__ rowpart,
+                                                           float* __restrict__ colpart) {
+    __shared__ float cm_s[3][3][OVT_COLS];               // waves 1..3: (max, sum, dot) per column
+    const int rb = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    const int n_rb = gridDim.x, n_p = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ Sb = S + (int64_t)b * N * N;
+    const float* __restrict__ os = o_src + (int64_t)b * N * ldo_in;       // weights of the row direction, indexed by column
+    const float* __restrict__ ot = o_tgt + (int64_t)b * N * ldo_in;       // weights of the column direction, indexed by row
+    // exp(x), x <= 0, on v_exp_f32: the terms that carry weight have x near 0, where 2^(x log2 e) is as accurate as the range-reduced expf
+    auto ex = [](float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); };
+    const int c0 = p * OVT_COLS + lane;
+    float osv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) osv[i] = c0 + 64 * i < N ? os[(int64_t)(c0 + 64 * i) * ldo_in] : 0.0f;
+    float cmx[16], cse[16], cso[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cmx[i] = -__builtin_inff(); cse[i] = 0.0f; cso[i] = 0.0f; }
+    const int m_base = rb * OVT_ROWS + wave * 16;
+    for (int m0 = m_base; m0 < m_base + 16 && m0 < N; m0 += 4) {
+        float v[4][16];
+        float otv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + r;
+            otv[r] = m < N ? ot[(int64_t)m * ldo_in] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[r][i] = (m < N && c0 + 64 * i < N) ? Sb[(int64_t)m * N + c0 + 64 * i] : -__builtin_inff();
+        }
+        // column direction: one rescale per chunk
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float cm = fmaxf(fmaxf(v[0][i], v[1][i]), fmaxf(v[2][i], v[3][i]));
+            const float nm = fmaxf(cmx[i], cm);
+            const float sc = ex(cmx[i] - nm);           // first chunk: exp(-inf) = 0
+            float se = cse[i] * sc, so = cso[i] * sc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = ex(v[r][i] - nm);       // rows past N: exp(-inf) = 0
+                se += e;
+                so = fmaf(e, otv[r], so);
+            }
+            cmx[i] = nm; cse[i] = se; cso[i] = so;
+        }
+        // row direction
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + r;
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, v[r][i]);
+            mx = wave_max(mx);
+            float se = 0.0f, so = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = ex(v[r][i] - mx);
+                se += e;
+                so = fmaf(e, osv[i], so);
+            }
+            se = wave_sum(se);
+            so = wave_sum(so);
+            if (lane == 0 && m < N) {
+                float* rp = rowpart + (((int64_t)b * n_p + p) * N + m) * 3;
+                rp[0] = mx; rp[1] = se; rp[2] = so;
+            }
+        }
+    }
+    // merge the four waves' column partials (waves whose rows are all past N hold (-inf, 0, 0))
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            cm_s[wave - 1][0][lane + 64 * i] = cmx[i];
+            cm_s[wave - 1][1][lane + 64 * i] = cse[i];
+            cm_s[wave - 1][2][lane + 64 * i] = cso[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int cl = lane + 64 * i, col = p * OVT_COLS + cl;
+            float M = cmx[i];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) M = fmaxf(M, cm_s[w][0][cl]);
+            float r0 = expf(cmx[i] - M);
+            float E = cse[i] * r0, T = cso[i] * r0;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float r = expf(cm_s[w][0][cl] - M);
+                E = fmaf(cm_s[w][1][cl], r, E);
+                T = fmaf(cm_s[w][2][cl], r, T);
+            }
+            if (col < N) {
+                float* cp = colpart + (((int64_t)b * n_rb + rb) * N + col) * 3;
+                cp[0] = M; cp[1] = E; cp[2] = T;
+            }
+        }
+    }
+}
+
+// merges the partial softmaxes: rows over the column panels, columns over the row blocks
+__global__ __launch_bounds__(256) void overlap_finalize_kernel(const float* __restrict__ rowpart, const float* __restrict__ colpart, int N, int n_p,
+                                                               int n_rb, float* __restrict__ wo_src, float* __restrict__ wo_tgt, int64_t ldo,
+                                                               float* __restrict__ stats) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * N) return;
+    const bool cols = idx >= N;
+    const int x = cols ? idx - N : idx;
+    const float* part = cols ? colpart + (int64_t)b * n_rb * N * 3 : rowpart + (int64_t)b * n_p * N * 3;
+    const int n = cols ? n_rb : n_p;
+    float M = -__builtin_inff();
+    for (int t = 0; t < n; ++t) M = fmaxf(M, part[((int64_t)t * N + x) * 3]);
+    float E = 0.0f, T = 0.0f;
+    for (int t = 0; t < n; ++t) {
+        const float* q = part + ((int64_t)t * N + x) * 3;
+        const float r = expf(q[0] - M);
+        E = fmaf(q[1], r, E);
+        T = fmaf(q[2], r, T);
+    }
+    (cols ? wo_tgt : wo_src)[((int64_t)b * N + x) * ldo] = T / E;
+    if (stats) {
+        stats[((int64_t)b * 4 + (cols ? 2 : 0)) * N + x] = M;
+        stats[((int64_t)b * 4 + (cols ? 3 : 1)) * N + x] = E;
+    }
+}
+}  // namespace
+
+extern "C" int64_t ogmm_overlap_cross_workspace_bytes(int B, int N) {
+    const int64_t n_p = (N + OVT_COLS - 1) / OVT_COLS, n_rb = (N + OVT_ROWS - 1) / OVT_ROWS;
+    return (int64_t)B * (n_p + n_rb) * N * 3 * (int64_t)sizeof(float);
+}
+
+// One pass over S.  stats may be NULL (eval); workspace: ogmm_overlap_cross_workspace_bytes(B, N) bytes.
+extern "C" int ogmm_overlap_cross_ws(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in, float* wo_src,
+                                     float* wo_tgt, int64_t ldo, float* stats, void* workspace, void* stream) {
+    OGMM_REQUIRE(S && o_src && o_tgt && wo_src && wo_tgt && workspace && B > 0 && N > 0 && ldo_in >= 1 && ldo >= 1,
+                 "ogmm_overlap_cross_ws: null pointer or empty input");
+    const int n_p = (N + OVT_COLS - 1) / OVT_COLS, n_rb = (N + OVT_ROWS - 1) / OVT_ROWS;
+    float* rowpart = reinterpret_cast<float*>(workspace);
+    float* colpart = rowpart + (int64_t)B * n_p * N * 3;
+    hipStream_t s = ogmm::as_stream(stream);
+    hipLaunchKernelGGL(overlap_tile_kernel, dim3(n_rb, n_p, B), dim3(256), 0, s, S, N, o_src, o_tgt, ldo_in, rowpart, colpart);
+    hipLaunchKernelGGL(overlap_finalize_kernel, dim3((2 * N + 255) / 256, B), dim3(256), 0, s, rowpart, colpart, N, n_p, n_rb, wo_src, wo_tgt, ldo, stats);
+    return ogmm::check_launch("ogmm_overlap_cross_ws");
+}
+
 extern "C" int ogmm_overlap_cross(const float* S, int B, int N, const float* o_src, const float* o_tgt, int64_t ldo_in, float* wo_src,
                                   float* wo_tgt, int64_t ldo, void* stream) {
     OGMM_REQUIRE(S && o_src && o_tgt && wo_src && wo_tgt && B > 0 && N > 0 && ldo_in >= 1 && ldo >= 1, "ogmm_overlap_cross: null pointer or empty input");

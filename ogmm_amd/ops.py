@@ -335,9 +335,20 @@ def rowdot(x, w, b, act, out, ldy=1):
     return out
 
 
-def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo):
+def _overlap_ws(B, N, device):
+    ws = torch.empty(_lib.load().ogmm_overlap_cross_workspace_bytes(B, N), dtype=torch.uint8, device=device)
+    ws.record_stream(torch.cuda.current_stream())
+    return ws
+
+
+def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, two_pass=False):
+    """models/gmmreg.py:79-80 on S [B,N,N]; one pass over S (two_pass: the older row kernel + column kernel)."""
     B, N, _ = S.shape
-    _lib.call("ogmm_overlap_cross", _p(_f32(S, "S")), B, N, _p(o_src), _p(o_tgt), ldo_in, _p(wo_src), _p(wo_tgt), ldo, _stream())
+    if two_pass:
+        _lib.call("ogmm_overlap_cross", _p(_f32(S, "S")), B, N, _p(o_src), _p(o_tgt), ldo_in, _p(wo_src), _p(wo_tgt), ldo, _stream())
+        return
+    ws = _overlap_ws(B, N, S.device)
+    _lib.call("ogmm_overlap_cross_ws", _p(_f32(S, "S")), B, N, _p(o_src), _p(o_tgt), ldo_in, _p(wo_src), _p(wo_tgt), ldo, None, _p(ws), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- GMM head
@@ -601,7 +612,8 @@ def overlap_cross_train(S, ol):
     B, N, _ = S.shape
     wo = torch.empty((2 * B * N, 1), dtype=torch.float32, device=S.device)
     stats = torch.empty((B, 4, N), dtype=torch.float32, device=S.device)
-    _lib.call("ogmm_overlap_cross_train", _p(_f32(S, "S")), B, N, _p(_f32(ol, "ol")), _p(ol[B * N:]), 1, _p(wo), _p(wo[B * N:]), 1, _p(stats), _stream())
+    ws = _overlap_ws(B, N, S.device)
+    _lib.call("ogmm_overlap_cross_ws", _p(_f32(S, "S")), B, N, _p(_f32(ol, "ol")), _p(ol[B * N:]), 1, _p(wo), _p(wo[B * N:]), 1, _p(stats), _p(ws), _stream())
     return wo, stats
 
 

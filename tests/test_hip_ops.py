@@ -316,19 +316,20 @@ def test_softmax_instnorm_l2norm_rowdot(ops):
     assert (out.cpu() - torch.sigmoid(y @ w + b)).abs().max().item() < 1e-6
 
 
-def test_overlap_cross(ops):
+@pytest.mark.parametrize("B,N,two_pass", [(2, 300, False), (2, 300, True), (1, 1024, False), (2, 1100, False), (1, 2048, False)])
+def test_overlap_cross(ops, B, N, two_pass):
+    """One-pass tiles + merge (row blocks of 64, column panels of 1024: N = 1100 / 2048 need two panels) and the older two-kernel form."""
     torch.manual_seed(3)
-    B, N = 2, 300
     S = torch.rand(B, N, N) * 2 - 1
     o = torch.randn(2 * B * N, 4)
     out = torch.zeros(2 * B * N, 4, device="cuda")
     od = dev(o)
-    ops.overlap_cross(dev(S), od[:B * N, 1], od[B * N:, 1], 4, out[:B * N, 0], out[B * N:, 0], 4)
+    ops.overlap_cross(dev(S), od[:B * N, 1], od[B * N:, 1], 4, out[:B * N, 0], out[B * N:, 0], 4, two_pass=two_pass)
     o_src, o_tgt = o[:B * N, 1].view(B, 1, N), o[B * N:, 1].view(B, 1, N)
-    wo_s = torch.einsum("bmn,bdn->bdm", torch.softmax(S, -1), o_src).reshape(-1)      # models/gmmreg.py:79
-    wo_t = torch.einsum("bmn,bdm->bdn", torch.softmax(S, 1), o_tgt).reshape(-1)       # models/gmmreg.py:80
-    assert (out[:B * N, 0].cpu() - wo_s).abs().max().item() < 1e-6
-    assert (out[B * N:, 0].cpu() - wo_t).abs().max().item() < 1e-6
+    wo_s = torch.einsum("bmn,bdn->bdm", torch.softmax(S.double(), -1), o_src.double()).reshape(-1)      # models/gmmreg.py:79
+    wo_t = torch.einsum("bmn,bdm->bdn", torch.softmax(S.double(), 1), o_tgt.double()).reshape(-1)       # models/gmmreg.py:80
+    assert (out[:B * N, 0].cpu().double() - wo_s).abs().max().item() < 1e-6
+    assert (out[B * N:, 0].cpu().double() - wo_t).abs().max().item() < 1e-6
     assert float(out[:, 1:].abs().max()) == 0.0
 
 
