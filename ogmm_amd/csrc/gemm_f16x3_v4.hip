@@ -17,6 +17,7 @@
 //     other LDS buffer), whose global loads were issued at the start of the tile
 // so the only full stop is the single barrier at the end of the tile.  A and B operand formats are those of
 // gemm_f16x3_v2.hip (which remains the engine for small N, small M and the EdgeConv pooling epilogue).
+#include <cstdlib>
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -289,7 +290,8 @@ namespace ogmm {
 
 bool gemm_f16x3_large_applicable(const ogmm_gemm& g) {
     const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch_outer;
-    return g.pool_k == 0 && g.N >= 256 && tiles >= 512 && g.ldb_h % 64 == 0 && (g.K2 == 0 || g.K1 % 64 == 0) &&
+    static const long long min_tiles = [] { const char* e = getenv("OGMM_V4_MIN_TILES"); return e ? atoll(e) : 256LL; }();      // one full round of 256 CUs; below that the 128x128 engine fills the chip better
+    return g.pool_k == 0 && g.N >= 256 && tiles >= min_tiles && g.ldb_h % 64 == 0 && (g.K2 == 0 || g.K1 % 64 == 0) &&
            (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h;
 }
 
