@@ -348,8 +348,10 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     else hipLaunchKernelGGL(knn_kernel<33>, grid, dim3(256), lds, s, xyz, N, k, idx);
     if (int rc = ogmm::check_launch("ogmm_knn")) return rc;
     const int64_t rows = (int64_t)C * N;
-    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)), s,
-                       xyz, N, k, rows, idx);
+    // the position lists of the workgroup partition only exist on the nth_element branch: the heap branch (k * 64 <= N) keeps its 8 B per
+    // candidate, so that its workgroups still fit next to a kernel that holds most of a CU's LDS (the persistent EdgeConv kernel)
+    const size_t ties_lds = (size_t)N * (sizeof(ogmm_select::Cand) + ((long long)k * 64 <= N ? 0 : 2 * sizeof(int)));
+    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), ties_lds, s, xyz, N, k, rows, idx);
     return ogmm::check_launch("ogmm_knn(resolve ties)");
 }
 
