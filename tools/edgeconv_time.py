@@ -1,5 +1,5 @@
-"""Where the fused EdgeConv kernel's time goes: the kernel alone at B=64 / N=1024 / k=20 with parts switched off through OGMM_EDGE_ABL
-(bit 0: no pooling, bit 1: no plane writes, bit 2: no MFMAs).  Needs a library built with the ablation switches (not the shipped one)."""
+"""The fused EdgeConv kernel alone at B=64 / N=1024 / k=20.  (The phase-by-phase ablation of DESIGN.md section 4 was done with temporary
+switches in the kernel -- pooling / plane writes / MFMAs / layer 1 / flushes off one at a time -- read through OGMM_EDGE_ABL.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,10 +18,9 @@ idx = ops.knn(xyz, 20)
 xcat = torch.empty((xyz.shape[0] * 1024, 512), device=dev)
 emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
 for abl in [0]:
-    os.environ["OGMM_EDGE_ABL"] = str(abl)
     for _ in range(2): ops.edgeconv_fused(xyz, idx, emd, xcat)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5): ops.edgeconv_fused(xyz, idx, emd, xcat)
     e1.record(); torch.cuda.synchronize()
-    print("abl=%d  %.1f us" % (abl, e0.elapsed_time(e1) / 5 * 1e3))
+    print("edgeconv_fused %.1f us" % (e0.elapsed_time(e1) / 5 * 1e3))
