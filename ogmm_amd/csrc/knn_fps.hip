@@ -189,7 +189,7 @@ __device__ void block_introselect(ogmm_select::Cand* q, int nth, int n, int* Lpo
 // Rows marked by knn_kernel: rebuild the row's N candidates in index order and keep what torch.topk keeps
 // (torch_topk_select.h); the kept set is then written in (distance, index) order.  ~6e-5 of rows take this path.
 __global__ __launch_bounds__(256) void knn_resolve_ties_kernel(const float* __restrict__ xyz, int N, int k, int64_t total_rows,
-                                                               int32_t* __restrict__ idx) {
+                                                               int32_t* __restrict__ idx, int have_lists) {
     extern __shared__ __attribute__((aligned(16))) ogmm_select::Cand cand[];   // [N], then int Lpos[N], Rpos[N]
     int* Lpos = reinterpret_cast<int*>(cand + N);
     int* Rpos = Lpos + N;
@@ -218,8 +218,10 @@ __global__ __launch_bounds__(256) void knn_resolve_ties_kernel(const float* __re
         __syncthreads();
         if ((long long)k * 64 <= N) {              // torch's heap-select branch: one thread
             if (tid == 0) ogmm_select::heap_select(cand, k, N);
-        } else {
+        } else if (have_lists) {
             block_introselect(cand, k - 1, N, Lpos, Rpos, wave_tot, nullptr);
+        } else {                                     // clouds so large that the position lists do not fit next to the candidates
+            if (tid == 0) ogmm_select::introselect(cand, k - 1, N);
         }
         __syncthreads();
         if (tid == 0) {
@@ -343,6 +345,14 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     dim3 grid((N + 255) / 256, C);
     const size_t lds = (size_t)N * sizeof(float4);
     hipStream_t s = ogmm::as_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {          // clouds beyond 4096 points need more than the default 64 KB of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<21>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<33>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_resolve_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        attr_set = true;
+    }
     if (k <= 8) hipLaunchKernelGGL(knn_kernel<9>, grid, dim3(256), lds, s, xyz, N, k, idx);
     else if (k <= 20) hipLaunchKernelGGL(knn_kernel<21>, grid, dim3(256), lds, s, xyz, N, k, idx);
     else hipLaunchKernelGGL(knn_kernel<33>, grid, dim3(256), lds, s, xyz, N, k, idx);
@@ -350,8 +360,9 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     const int64_t rows = (int64_t)C * N;
     // the position lists of the workgroup partition only exist on the nth_element branch: the heap branch (k * 64 <= N) keeps its 8 B per
     // candidate, so that its workgroups still fit next to a kernel that holds most of a CU's LDS (the persistent EdgeConv kernel)
-    const size_t ties_lds = (size_t)N * (sizeof(ogmm_select::Cand) + ((long long)k * 64 <= N ? 0 : 2 * sizeof(int)));
-    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), ties_lds, s, xyz, N, k, rows, idx);
+    const bool lists = (long long)k * 64 > N && (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)) <= 156 * 1024;
+    const size_t ties_lds = (size_t)N * (sizeof(ogmm_select::Cand) + (lists ? 2 * sizeof(int) : 0));
+    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), ties_lds, s, xyz, N, k, rows, idx, lists ? 1 : 0);
     return ogmm::check_launch("ogmm_knn(resolve ties)");
 }
 

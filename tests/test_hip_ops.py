@@ -43,7 +43,7 @@ def test_knn_identical_indices(ops, C, N, k):
     assert torch.equal(got.sort(-1)[0], ref.sort(-1)[0]), "kept sets differ in %d rows" % int((got.sort(-1)[0] != ref.sort(-1)[0]).any(-1).sum())
 
 
-@pytest.mark.parametrize("kind,N,k", [("room", 2048, 20), ("room", 2048, 5), ("room", 1024, 20), ("room", 700, 12)])
+@pytest.mark.parametrize("kind,N,k", [("room", 2048, 20), ("room", 2048, 5), ("room", 1024, 20), ("room", 700, 12), ("room", 1200, 20), ("room", 2000, 32), ("room", 100, 20)])
 def test_knn_boundary_ties_resolved_like_torch(ops, kind, N, k):
     """Axis-aligned room planes produce many exact ties at rank k; both torch code paths (heap select for k*64 <= N,
     introselect otherwise) must be reproduced."""
@@ -66,6 +66,32 @@ def test_knn_duplicate_points_ties(ops):
     ref = O.knn_indices(xyz, 8)
     assert torch.equal(torch.gather(d, 2, got), torch.gather(d, 2, ref))      # same sorted distance values
     assert torch.equal(got.sort(-1)[0], ref.sort(-1)[0])
+
+
+@pytest.mark.parametrize("side,k,shuffle", [(32, 18, False), (32, 18, True), (30, 15, True), (24, 10, True)])
+def test_knn_lattice_ties_introselect_branch(ops, side, k, shuffle):
+    """A square lattice (integer coordinates: every distance exact) puts whole shells of equidistant neighbours across rank k in almost
+    every row, with N < 64 k: torch.topk's std::nth_element branch, which the tie-resolution kernel executes with workgroup-wide
+    partitions.  The kept SET must be torch's, row by row (a different member of a tied shell is a different EdgeConv graph)."""
+    g = torch.Generator().manual_seed(side * 100 + k)
+    ii, jj = torch.meshgrid(torch.arange(side), torch.arange(side), indexing="ij")
+    pts = torch.stack([ii.reshape(-1).float(), jj.reshape(-1).float(), torch.zeros(side * side)], dim=1)
+    clouds_ = []
+    for c in range(2):
+        p = pts[torch.randperm(side * side, generator=g)] if shuffle else pts
+        clouds_.append(p * (0.25 if c else 1.0))                 # exact in fp32 either way
+    xyz = torch.stack(clouds_)
+    N = side * side
+    assert k * 64 > N
+    d = O.sq_dist_expanded(xyz, xyz)
+    dk = d.topk(k + 1, dim=-1, largest=False)[0]
+    n_tied = int((dk[:, :, k - 1] == dk[:, :, k]).sum())
+    assert n_tied > N                                             # most rows tie at rank k
+    ref = O.knn_indices(xyz, k)
+    got = ops.knn(dev(xyz), k).cpu().long()
+    assert torch.equal(torch.gather(d, 2, got), torch.gather(d, 2, ref)), "distance rows differ"
+    differ = (got.sort(-1)[0] != ref.sort(-1)[0]).any(-1)
+    assert not bool(differ.any()), "kept sets differ in %d of %d rows (%d rows tie at rank k)" % (int(differ.sum()), 2 * N, n_tied)
 
 
 # ------------------------------------------------------------------------------------------------ K5 / K6
