@@ -6,6 +6,10 @@
 #include "ogmm_common.h"
 #include "torch_topk_select.h"
 
+#ifndef OGMM_KNN_CHUNK
+#define OGMM_KNN_CHUNK 32
+#endif
+
 namespace {
 
 using namespace ogmm;
@@ -65,11 +69,12 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
     // the whole wave whenever ANY lane inserts; per candidate that is almost always the case (64 lanes x ~k ln(N/k) / N insertions
     // each), per drain round it happens max-over-lanes(marks) times per chunk: ~4x fewer ladder passes at N = 1024, k = 20.
     int j = 0;
-    for (; j + 32 <= N; j += 32) {
+    constexpr int CHK = OGMM_KNN_CHUNK;
+    for (; j + CHK <= N; j += CHK) {
         const float worst = dk[KL - 1];
         unsigned mask = 0u;
 #pragma unroll
-        for (int t = 0; t < 32; t += 4) {
+        for (int t = 0; t < CHK; t += 4) {
             const float4 p0 = pts[j + t], p1 = pts[j + t + 1], p2 = pts[j + t + 2], p3 = pts[j + t + 3];
             mask |= (knn_dist(pq, p0) < worst ? 1u : 0u) << t;
             mask |= (knn_dist(pq, p1) < worst ? 1u : 0u) << (t + 1);
