@@ -401,9 +401,20 @@ class GMMReg(nn.Module):
 
         # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)
         muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)
+        # the clustering loss (nearest point, InfoNCE rows, mean: three small launches) next to the matching / rigid solve (one 64-workgroup
+        # launch): both are latency-bound tails on an otherwise idle chip
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            row_loss, near = ops.clu_infonce(xyz, mu, f2, muf, C, N, 0.1)
+            loss = row_loss.mean()          # 0.5 * (mean over src rows + mean over tgt rows), gmmreg.py:110
+            clu_done = torch.cuda.Event()
+            clu_done.record(side)
+        for t_ in (f2, muf, mu):
+            t_.record_stream(side)
+        for t_ in (row_loss, near, loss):
+            t_.record_stream(main)
         rot, trans = ops.match_kabsch(mu[:B].contiguous(), mu[B:].contiguous(), muf[:B].contiguous(), muf[B:].contiguous(), 0.05)
-        row_loss, near = ops.clu_infonce(xyz, mu, f2, muf, C, N, 0.1)
-        loss = row_loss.mean()          # 0.5 * (mean over src rows + mean over tgt rows), gmmreg.py:110
+        main.wait_event(clu_done)
 
         if capture:
             cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0], o_logit=extra[:, 1],
