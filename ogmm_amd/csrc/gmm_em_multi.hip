@@ -8,6 +8,7 @@
 // All launches are issued by ONE call (no host synchronisation; the reference needs ~3000 launches and 200 .item() syncs).
 // The arithmetic of every entry is that of gmm_em_cached_kernel; column reductions differ in summation order only.
 #include "ogmm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -29,6 +30,8 @@ struct EmWs {
     float* logp;     // [C][N]
     float* rclip;    // [C][N]
     float4* mu;      // [C][J]  x, y, z, |mu|^2
+    float* vbuf;     // [2][C][J]           v of the last two sweeps (fused sweeps)
+    float* pbuf;     // [2][C][chunks][J][2] per-chunk (max, exp-sum) of the pending v-update
 };
 
 // one workgroup per cloud: p = o / max(sum o, 1e-4), log(p + 1e-8); centres = xyz[ids0]
@@ -122,11 +125,110 @@ __global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, 
     if (tid == 0) w.v[(int64_t)c * J + j] = eps * (logq - (mx + logf((float)((redd[0] + redd[1]) + (redd[2] + redd[3]))))) + vj;
 }
 
+// ---- fused sweeps (J <= 64): ONE launch and ONE read of the cost matrix per Sinkhorn sweep instead of two.
+// The v-update needs a column log-sum-exp over ALL rows of the cloud, i.e. a grid-wide dependency; but a row chunk can contribute its
+// (max, exp-sum) per column right after it has updated its own u, and the next launch starts by merging the chunks' partials:
+//   launch k:  v_{k-1} = eps (log q - LSE(partials_{k-1})) + v_{k-2}     (every workgroup, redundantly; workgroup 0 stores it)
+//              u_k     = eps (log p - LSE_j((-C + u_{k-1} + v_{k-1}) / eps)) + u_{k-1}            (thread = row, costs in registers)
+//              partials_k[chunk][j] = (max, sum exp) over the chunk's rows of (-C + u_k + v_{k-1}) / eps
+// The column reduction inside a wave goes through a private 64 x 33 LDS tile (32 columns at a time): lane (column, row half) reads its
+// column's 32 rows.  exp(x - max) on v_exp_f32 as in the on-chip kernel.  N = 2048, J = 64, 128 clouds: 2 x 45 us -> ~20 us per sweep.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+// v of the sweep whose partials are in `part` (or 0 for `first`), into LDS vs[J]; optionally stored to v_out
+__device__ __forceinline__ void em_finish_v(int c, int J, int n_chunks, bool first, float eps, float logq, const float* __restrict__ v_in,
+                                            const float* __restrict__ part, float* __restrict__ v_out, float* vs) {
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        float vcur = 0.0f;
+        if (!first) {
+            const float* __restrict__ pj = part + ((int64_t)c * n_chunks * J + j) * 2;
+            float M = -__builtin_inff();
+            for (int ch = 0; ch < n_chunks; ++ch) M = fmaxf(M, pj[(int64_t)ch * J * 2]);
+            float S = 0.0f;
+            for (int ch = 0; ch < n_chunks; ++ch) S = fmaf(pj[(int64_t)ch * J * 2 + 1], expf(pj[(int64_t)ch * J * 2] - M), S);
+            vcur = eps * (logq - (M + logf(S))) + v_in[(int64_t)c * J + j];
+        }
+        vs[j] = vcur;
+        if (v_out) v_out[(int64_t)c * J + j] = vcur;
+    }
+}
+
+template <int JMAX>
+__global__ __launch_bounds__(256, 4) void em_sweep_kernel(int N, int J, float inv_eps, float eps, float logq, int first, int parity, EmWs w) {
+    __shared__ float vs[JMAX];
+    __shared__ float tile[4][64][33];
+    __shared__ float wp[4][JMAX][2];
+    const int c = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x, C = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = chunk * 256 + tid;
+    const int64_t vsz = (int64_t)C * J, psz = (int64_t)C * n_chunks * J * 2;
+    // launch k (parity = k & 1): reads v_{k-2} from vbuf[k & 1] and partials_{k-1} from pbuf[(k-1) & 1]; writes v_{k-1} to vbuf[(k+1) & 1]
+    // and partials_k to pbuf[k & 1]
+    em_finish_v(c, J, n_chunks, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz,
+                chunk == 0 ? w.vbuf + (parity ^ 1) * vsz : nullptr, vs);
+    __syncthreads();
+    const bool valid = n < N;
+    const float* __restrict__ Cc = w.cost + (int64_t)c * J * N + (valid ? n : 0);
+    float cst[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) cst[j] = j < J ? Cc[(int64_t)j * N] : 0.0f;
+    const float un = valid ? w.u[(int64_t)c * N + n] : 0.0f;
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+        if (j < J) mx = fmaxf(mx, ((-cst[j] + un) + vs[j]) * inv_eps);
+    float se = 0.0f;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+        if (j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
+    const float unew = valid ? eps * (w.logp[(int64_t)c * N + n] - (mx + logf(se))) + un : 0.0f;
+    if (valid) w.u[(int64_t)c * N + n] = unew;
+    // column partials of the pending v-update, 32 columns at a time through this wave's tile
+#pragma unroll
+    for (int h = 0; h < JMAX / 32; ++h) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int j = 32 * h + i;
+            tile[wave][lane][i] = (valid && j < J) ? ((-cst[j] + unew) + vs[j]) * inv_eps : -__builtin_inff();
+        }
+        // (same wave: LDS operations complete in order)
+        const int col = lane & 31, rh = lane >> 5;
+        float cm = -__builtin_inff();
+        float y[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { y[r] = tile[wave][rh * 32 + r][col]; cm = fmaxf(cm, y[r]); }
+        float cs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) cs += fexp(y[r] - cm);            // all -inf (column past J, rows past N): exp(nan) -- masked below
+        if (!(cm > -__builtin_inff())) cs = 0.0f;
+        const float om = __shfl_xor(cm, 32, 64), os = __shfl_xor(cs, 32, 64);
+        const float M = fmaxf(cm, om);
+        const float S = (cm > -__builtin_inff() ? cs * fexp(cm - M) : 0.0f) + (om > -__builtin_inff() ? os * fexp(om - M) : 0.0f);
+        if (lane < 32) { wp[wave][32 * h + col][0] = M; wp[wave][32 * h + col][1] = S; }
+    }
+    __syncthreads();
+    if (tid < J) {
+        float M = fmaxf(fmaxf(wp[0][tid][0], wp[1][tid][0]), fmaxf(wp[2][tid][0], wp[3][tid][0]));
+        float S = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (wp[q][tid][0] > -__builtin_inff()) S = fmaf(wp[q][tid][1], fexp(wp[q][tid][0] - M), S);
+        float* __restrict__ po = w.pbuf + parity * psz + (((int64_t)c * n_chunks + chunk) * J + tid) * 2;
+        po[0] = M; po[1] = S;
+    }
+}
+
 // gamma = exp(K) (nan -> 0, inf -> FLT_MAX) in place; rclip = max(rowsum, 1e-3); the last iteration also writes gamma / rclip.  grid (N/256, C)
-__global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out) {
+__global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out, int fused, int first,
+                                                       int parity, float eps, float logq) {
     extern __shared__ float vs[];
     const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    for (int j = threadIdx.x; j < J; j += 256) vs[j] = w.v[(int64_t)c * J + j];
+    if (fused) {          // after fused sweeps the last v-update is still pending in the partials
+        const int64_t vsz = (int64_t)gridDim.y * J, psz = (int64_t)gridDim.y * gridDim.x * J * 2;
+        em_finish_v(c, J, gridDim.x, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz, nullptr, vs);
+    } else {
+        for (int j = threadIdx.x; j < J; j += 256) vs[j] = w.v[(int64_t)c * J + j];
+    }
     __syncthreads();
     if (n >= N) return;
     float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
@@ -183,7 +285,9 @@ size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 }  // namespace
 
 extern "C" int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J) {
-    return (int64_t)(align256((size_t)C * J * N * 4) + 3 * align256((size_t)C * N * 4) + align256((size_t)C * J * 4) + align256((size_t)C * J * 16));
+    const size_t chunks = (size_t)(N + 255) / 256;
+    return (int64_t)(align256((size_t)C * J * N * 4) + 3 * align256((size_t)C * N * 4) + align256((size_t)C * J * 4) + align256((size_t)C * J * 16) +
+                     align256((size_t)2 * C * J * 4) + align256((size_t)2 * C * chunks * J * 8));
 }
 
 extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
@@ -201,7 +305,9 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     w.logp = reinterpret_cast<float*>(p);  p += align256((size_t)C * N * 4);
     w.rclip = reinterpret_cast<float*>(p); p += align256((size_t)C * N * 4);
     w.v = reinterpret_cast<float*>(p);     p += align256((size_t)C * J * 4);
-    w.mu = reinterpret_cast<float4*>(p);
+    w.mu = reinterpret_cast<float4*>(p);   p += align256((size_t)C * J * 16);
+    w.vbuf = reinterpret_cast<float*>(p);  p += align256((size_t)2 * C * J * 4);
+    w.pbuf = reinterpret_cast<float*>(p);
     const float inv_eps = (float)(1.0 / (double)epsilon), inv_tau = (float)(1.0 / (double)tau);
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
     hipStream_t s = as_stream(stream);
@@ -211,13 +317,25 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     for (int it = 0; it < iters; ++it) {
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(em_cost_kernel, rows, blk, 0, s, xyz, N, J, inv_tau, w);
-        for (int sk = 0; sk < sk_iters; ++sk) {
-            if (J <= 16) hipLaunchKernelGGL(em_u_kernel<16>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
-            else if (J <= 64) hipLaunchKernelGGL(em_u_kernel<64>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
-            else hipLaunchKernelGGL(em_u_kernel<128>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
-            hipLaunchKernelGGL(em_v_kernel, cols, blk, 0, s, N, J, inv_eps, epsilon, logq, w);
+        static const bool two_launch = [] { const char* e = getenv("OGMM_EM_MULTI_UNFUSED"); return e && e[0] == '1'; }();      // A/B: u and v kernels
+        const bool fused = J <= 64 && !two_launch;
+        if (fused) {
+            // launch k = 1 .. sk_iters; the gamma kernel plays launch sk_iters + 1 for the pending v-update
+            for (int k = 1; k <= sk_iters; ++k) {
+                if (J <= 32) hipLaunchKernelGGL(em_sweep_kernel<32>, rows, blk, 0, s, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
+                else hipLaunchKernelGGL(em_sweep_kernel<64>, rows, blk, 0, s, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
+            }
+            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 1, sk_iters == 0 ? 1 : 0,
+                               (sk_iters + 1) & 1, epsilon, logq);
+        } else {
+            for (int sk = 0; sk < sk_iters; ++sk) {
+                if (J <= 16) hipLaunchKernelGGL(em_u_kernel<16>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
+                else if (J <= 64) hipLaunchKernelGGL(em_u_kernel<64>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
+                else hipLaunchKernelGGL(em_u_kernel<128>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
+                hipLaunchKernelGGL(em_v_kernel, cols, blk, 0, s, N, J, inv_eps, epsilon, logq, w);
+            }
+            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 0, 0, 0, epsilon, logq);
         }
-        hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr);
         hipLaunchKernelGGL(em_mstep_kernel, cols, blk, 0, s, xyz, N, J, w, last ? pi : (float*)nullptr, mu);
     }
     return check_launch("ogmm_gmm_em_multi");

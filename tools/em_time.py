@@ -1,10 +1,10 @@
-"""E/M clustering kernel alone (B=64: 128 clouds, N=1024, J=16): on-chip and grid-wide engines."""
+"""E/M clustering alone (default B=64: 128 clouds, N=1024, J=16; or `em_time.py C N J`): on-chip and grid-wide engines."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ogmm_amd import ops
 torch.manual_seed(0)
-C, N, J = 128, 1024, 16
+C, N, J = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (128, 1024, 16)
 xyz = torch.randn(C, N, 3, device="cuda") * 0.5
 o = torch.rand(C, N, device="cuda")
 ids = ops.fps(xyz, J, None)
@@ -14,4 +14,4 @@ for eng in (None, "multi"):
     e0.record()
     for _ in range(5): ops.gmm_em(xyz, o, ids, engine=eng)
     e1.record(); torch.cuda.synchronize()
-    print("engine=%s  %.1f us" % (eng, e0.elapsed_time(e1) / 5 * 1e3))
+    print("C=%d N=%d J=%d engine=%s  %.1f us" % (C, N, J, eng, e0.elapsed_time(e1) / 5 * 1e3))
