@@ -3,7 +3,7 @@
 own, so these outputs are what pins oracle/ogmm_oracle.py and, through it,
 the HIP path.  The reference itself never travels: only inputs + outputs are stored here.
 
-    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py [name ...]      # rewrites tests/golden/<name>.npz (default: all eval fixtures)
 
 Each fixture holds: the inputs (src, tgt), the six pinned FPS start draws (the reference's
 `torch.randint` at lib/utils.py:190 is patched to return them in call order), the five outputs of
@@ -32,6 +32,10 @@ CASES = {
     "partial_b1_n717_j128": (1, 717, 128, "partial", 300, 20, 128),  # the repo's own defaults (cfgs.py:21,34)
     "room_b1_n2048_j64": (1, 2048, 64, "room", 400, 20, 128),        # BASELINE configs[2]/[3] shape
     "partial_b3_n200_j8_k12": (3, 200, 8, "partial", 500, 12, 32),   # ragged: N not a multiple of anything
+    # added with the round's later kernels: N between tile sizes (attention / overlap-block / EdgeConv partial tiles), k != 20 (EdgeConv's
+    # run-time pooling), J = 32 on the grid-wide E/M (fused sweeps), 64 anchors; and room planes (exact kNN ties) at the headline shape
+    "partial_b2_n1500_j32_k16": (2, 1500, 32, "partial", 600, 16, 64),
+    "room_b2_n1024_j16": (2, 1024, 16, "room", 700, 20, 128),
 }
 
 
@@ -62,7 +66,10 @@ def main():
     torch.set_num_threads(8)
     ref_mod = import_reference()
     here = os.path.dirname(os.path.abspath(__file__))
+    only = sys.argv[1:]                                  # names to (re)generate; default: all
     for name, (B, N, J, kind, first, k, M) in CASES.items():
+        if only and name not in only:
+            continue
         cfg = default_config(n_clusters=J, gnn_k=k, km_clusters=M)
         src, tgt, R_gt, t_gt = synth.make_batch(first, B, N, kind)
         starts = synth.fps_starts_for(first, B, N)
