@@ -127,7 +127,7 @@ __device__ __forceinline__ void gemm_epilogue(const ogmm_gemm& g, f32x16 (&acc)[
 // `smem` must provide waves * 32 * (NT*32 + 4) floats and be free (the K loop has passed its last barrier).
 template <int MT, int NT, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0, int m_end,
-                                                   float alpha) {
+                                                   float alpha, bool direct_stores = false) {
     constexpr int LDC = NT * 32 + 4;
     constexpr int F4_PER_ROW = NT * 8;                      // float4 per patch row
     constexpr int ITER = 32 * F4_PER_ROW / 64;
@@ -205,6 +205,32 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
             for (int i = 0; i < MT; ++i) block(has_res, kind, i);
         };
         const int kind = !alpha_pow2 ? 3 : (g.act == OGMM_ACT_RELU ? 1 : (g.act == OGMM_ACT_LEAKY02 ? 2 : 0));
+        if (direct_stores && !Rm && !stats && kind != 3) {
+            // No residual, no statistics: store straight from the accumulator layout (lane = column, a register = a row: 32 lanes write one
+            // 128-byte row segment) -- 128 dword stores per wave and no LDS transposition (16 ds_write + 4 ds_read + 4 wide stores per block).
+            auto direct = [&](auto kind_c) {
+                constexpr int KIND = decltype(kind_c)::value;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int cj = n0 + (wn * NT + j) * 32 + lr;
+                    const float s1 = (g.scale ? g.scale[cj] : 1.0f) * alpha, t1 = g.shift ? g.shift[cj] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        float* __restrict__ cp = Cm + (int64_t)(m0 + (wm * MT + i) * 32 + 4 * lh) * g.ldc + cj;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float y = fmaf(acc[i][j][r], s1, t1);
+                            if constexpr (KIND == 1) y = fmaxf(y, 0.0f);
+                            else if constexpr (KIND == 2) y = y > 0.0f ? y : 0.2f * y;
+                            cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
+                        }
+                    }
+                }
+            };
+            if (kind == 0) direct(std::integral_constant<int, 0>{});
+            else if (kind == 1) direct(std::integral_constant<int, 1>{});
+            else direct(std::integral_constant<int, 2>{});
+        } else
         if (Rm) {
             if (kind == 0) all_blocks(std::true_type{}, std::integral_constant<int, 0>{});
             else if (kind == 1) all_blocks(std::true_type{}, std::integral_constant<int, 1>{});

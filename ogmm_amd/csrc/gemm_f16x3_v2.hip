@@ -247,7 +247,7 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves
         case 22: return launch_v2<4, 2, 1, 4, false>(g, s);    // 128 x 256, 4 waves of 128 x 64: two independent workgroups per CU
         case 18: case 19: case 23: case 24: case 25: case 26: case 27: case 28: case 29:            // large-shape engine and its ablations (tools/gemm_bench.py)
-        case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
+        case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40:
             OGMM_REQUIRE(gemm_f16x3_large_applicable(g), "large-shape engine not applicable"); return gemm_nt_f16x3_v4(g, s);
         default: break;
     }

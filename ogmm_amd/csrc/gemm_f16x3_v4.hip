@@ -46,7 +46,7 @@ __device__ __forceinline__ void split4w(const f32x4 v, f16x4& hi, f16x4& lo, boo
 }
 
 template <int ABL>
-__global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
+__global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles, const int direct_stores) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];      // [2 buffers][hi, lo][BM][LD3]
 
     // XCD-aware map (block b runs on XCD b % 8): all N tiles of an M panel on one XCD, so the panel is fetched into one L2.
@@ -280,7 +280,11 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v4_kernel(const ogmm_gemm g, con
     ogmm_gemm gz = g;                  // per-batch views for the epilogue
     if (gz.C) gz.C += zb * g.sC_o;
     if (gz.Res) gz.Res += zb * g.sR_o;
-    if (wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha);
+    if (ABL & 16384) {      // ablation: every tile writes C[0:256, 0:256] (all instructions of the epilogue, no HBM write traffic)
+        gemm_epilogue_wide<MT, NT, WM, WN>(gz, acc, reinterpret_cast<float*>(smem_h), 0, 0, BM, g.alpha);
+        return;
+    }
+    if (wide_epilogue_ok(g)) gemm_epilogue_wide<MT, NT, WM, WN>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, g.alpha, direct_stores != 0);
     else gemm_epilogue<MT, NT, WM, WN, false>(gz, acc, reinterpret_cast<float*>(smem_h), m0, n0, m_end, 0, 0, g.alpha);
 }
 
@@ -300,15 +304,16 @@ static int launch_v4(const ogmm_gemm& g, hipStream_t s) {
     constexpr size_t LDS = (size_t)2 * 2 * PLANE * sizeof(_Float16);      // 147456 B
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
+    static const int direct = [] { const char* e = getenv("OGMM_V4_DIRECT"); return e ? atoi(e) : 1; }();      // 0: transposed dwordx4 stores also without residual / statistics
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v4_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_set = true;
     }
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, -m_tiles, n_tiles);
+        hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, -m_tiles, n_tiles, direct);
     else
-        hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, m_tiles, n_tiles);
+        hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, m_tiles, n_tiles, direct);
     return check_launch("ogmm_gemm_nt(f16x3 v4)");
 }
 
@@ -333,6 +338,7 @@ int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
         case 39: return launch_v4<32 + 2048 + 4096>(g, s);           // deep B prefetch + single A-fragment buffer
         case 24: return launch_v4<32 + 2048 + 4096 + 8192>(g, s);    // + A loads spread over the first two k-steps
         case 25: return launch_v4<32 + 2048 + 4096 + 8192 + 8>(g, s);   // same, no stores
+        case 40: return launch_v4<32 + 2048 + 4096 + 8192 + 16384>(g, s);   // same, all tiles store to one 256 x 256 patch of C
         case OGMM_PREC_F16_FRAG: return launch_v4<32 + 1024>(g, s);     // single binary16 term
         default: {
             static const char* env = getenv("OGMM_V4_OLD");

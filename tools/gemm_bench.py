@@ -1,6 +1,7 @@
 """GEMM-engine microbenchmark on the forward's shapes (GPU box).  usage: gemm_bench.py [variant codes...]
    0 = exact-fp32 engine, 1 = fp16x3 row-major B (128x128), 2 = fp16x3 default dispatch, 21 = v2 128x128, 22 = v2 128x256 (2 WG/CU),
-   23 = large-shape engine (v4), ablations of it: 26 = MFMA + barrier only, 29 = + A path only, 18 = no output stores, 19 = MFMA only, no stores"""
+   23 = large-shape engine (v4), ablations of it: 26 = MFMA + barrier only, 29 = + A path only, 18 = no output stores, 19 = MFMA only, no stores, 24 = the default pipeline,
+   25 = default without the epilogue, 40 = default with every tile stored to one 256 x 256 patch (epilogue instructions without HBM write traffic)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
