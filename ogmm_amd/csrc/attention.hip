@@ -462,9 +462,12 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
     split_pair(b[2], b[3], h, l); hi[6] = h[0]; hi[7] = h[1]; lo[6] = l[0]; lo[7] = l[1];
 }
 
-template <int MK>
+// FUSED: no packed images -- the workgroup splits its (cloud, head)'s K and V rows itself while staging them (with one workgroup per (cloud, head),
+// as at B = 64, nothing is split twice, and the pack kernel with its workspace round trip disappears: -25 us per call).
+template <int MK, bool FUSED>
 __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restrict__ q, int64_t ldq, const f16x8* __restrict__ kimg,
-                                                          const f16x8* __restrict__ vimg, int N, int H, float scale,
+                                                          const f16x8* __restrict__ vimg, const float* __restrict__ kraw, int64_t ldk,
+                                                          const float* __restrict__ vraw, int64_t ldv, int N, int H, float scale,
                                                           float* __restrict__ out, int64_t ldo) {
     constexpr int M = MK * 32;
     constexpr int GROUPS = M * DH / 8;                   // f16x8 groups per plane and operand
@@ -480,13 +483,37 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
     const f16x8* __restrict__ KG = kimg + ((int64_t)c * H + h) * 2 * GROUPS;
     const f16x8* __restrict__ VG = vimg + ((int64_t)c * H + h) * 2 * GROUPS;
 
-    // ---- stage both images (coalesced 16-byte loads, all in flight together with the Q rows)
-    constexpr int PER = (2 * GROUPS + 511) / 512;        // vectors per thread and image
+    // ---- stage both images (all loads in flight together with the Q rows)
+    constexpr int PER = FUSED ? 1 : (2 * GROUPS + 511) / 512;        // packed: vectors per thread and image
+    constexpr int GP = FUSED ? (GROUPS + 511) / 512 : 1;             // fused: 8-element groups per thread and operand
     f16x8 kst[PER], vst[PER];
+    f32x4 ka[GP], kb[GP];
+    float vv[GP][8];
+    if constexpr (FUSED) {
+        const float* __restrict__ kc = kraw + ((int64_t)c * M) * ldk + h * DH;
+        const float* __restrict__ vc = vraw + ((int64_t)c * M) * ldv + h * DH;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int g = i * 512 + tid;
-        if (2 * GROUPS % 512 == 0 || g < 2 * GROUPS) { kst[i] = KG[g]; vst[i] = VG[g]; }
+        for (int i = 0; i < GP; ++i) {
+            const int g = min(i * 512 + tid, GROUPS - 1), l = g & 63, blk = g >> 6;
+            {   // K image group: key = 32 j + l % 32, d = 16 s + 8 (l / 32) .. + 7
+                const int s_ = blk % KS, j_ = blk / KS;
+                const float* p = kc + (int64_t)(j_ * 32 + (l & 31)) * ldk + s_ * 16 + (l >> 5) * 8;
+                ka[i] = *reinterpret_cast<const f32x4*>(p);
+                kb[i] = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            {   // V image group (accumulator row order of the keys, see attention_pack_kernel<.., true>): d = 32 jd + l % 32
+                const int ks_ = blk % VS, jd_ = blk / VS;
+                const float* p = vc + jd_ * 32 + (l & 31);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[i][e] = p[(int64_t)(ks_ * 16 + (l >> 5) * 4 + (e & 3) + 8 * (e >> 2)) * ldv];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int g = i * 512 + tid;
+            if (2 * GROUPS % 512 == 0 || g < 2 * GROUPS) { kst[i] = KG[g]; vst[i] = VG[g]; }
+        }
     }
     // Q rows of a tile: lane = query, 8 consecutive d per k-step (B operand of S^T).  The workgroup walks the query tiles
     // blockIdx.x, + gridDim.x, ... of its (cloud, head); the next tile's rows are fetched before the current tile is computed.
@@ -502,10 +529,33 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
         }
     };
     load_q(blockIdx.x);
+    if constexpr (FUSED) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int g = i * 512 + tid;
-        if (2 * GROUPS % 512 == 0 || g < 2 * GROUPS) { Ks[g] = kst[i]; Vs[g] = vst[i]; }
+        for (int i = 0; i < GP; ++i) {
+            const int g = i * 512 + tid;
+            if (GROUPS % 512 == 0 || g < GROUPS) {
+                f16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 x, y;
+                    split1(ka[i][e], x, y); hi[e] = x; lo[e] = y;
+                    split1(kb[i][e], x, y); hi[4 + e] = x; lo[4 + e] = y;
+                }
+                Ks[g] = hi; Ks[GROUPS + g] = lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 x, y;
+                    split1(vv[i][e], x, y); hi[e] = x; lo[e] = y;
+                }
+                Vs[g] = hi; Vs[GROUPS + g] = lo;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int g = i * 512 + tid;
+            if (2 * GROUPS % 512 == 0 || g < 2 * GROUPS) { Ks[g] = kst[i]; Vs[g] = vst[i]; }
+        }
     }
     __syncthreads();
 
@@ -623,17 +673,23 @@ int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk,
     f16x8* vimg = kimg + (int64_t)C * H * 2 * GROUPS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_pack_kernel<MK, true>), dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
     // query tiles per workgroup: as many as leave at least two workgroups per CU (the K / V images are staged once per workgroup)
     const int n_tiles = (N + QT2 - 1) / QT2;
     static const int force_x = [] { const char* e = getenv("OGMM_ATTN_GX"); return e ? atoi(e) : 0; }();
+    static const bool packed = [] { const char* e = getenv("OGMM_ATTN_PACKED"); return e && e[0] == '1'; }();      // A/B: separate pack kernel
     int gx = (512 + C * H - 1) / (C * H);
     if (force_x > 0) gx = force_x;
     gx = gx < 1 ? 1 : (gx > n_tiles ? n_tiles : gx);
-    hipLaunchKernelGGL(attention_t_kernel<MK>, dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, N, H, scale, out, ldo);
+    if (packed) {
+        hipLaunchKernelGGL((attention_pack_kernel<MK, true>), dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
+        hipLaunchKernelGGL((attention_t_kernel<MK, false>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
+    } else {
+        hipLaunchKernelGGL((attention_t_kernel<MK, true>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
+    }
     return ogmm::check_launch("ogmm_attention(transposed)");
 }
 
