@@ -142,8 +142,10 @@ int ogmm_pos_hidden(const float* xyz, const int32_t* idx, int idx_ld, int k_pos,
  * q [C*N][ldq], k and v [C*M][ldk|ldv], out [C*N][ldo]; all head-major: head h owns columns [h*dh, (h+1)*dh)
  * (the host packs the projection weights that way, models/attn.py:96 interleaves d*H + h).  dh = 128, M in {32,64,128}.
  * fp16x3 split arithmetic on the matrix cores, fp32 softmax (see ogmm_gemm_nt).
- * workspace (device, ogmm_attention_workspace_bytes(C, M, H, dh) bytes, 16-byte aligned) receives the split fragment-major
- * K / V images shared by all query tiles of a head; with workspace == NULL every workgroup stages K / V itself (slower). */
+ * workspace (device, ogmm_attention_workspace_bytes(C, M, H, dh) bytes, 16-byte aligned): non-NULL selects the transposed kernel (one
+ * workgroup per (cloud, head) walks the query tiles and splits K / V into fragment order while staging them in LDS; the buffer itself is
+ * only written by the OGMM_ATTN_PACKED / OGMM_ATTN_FRAG variants, which pack the K / V images there first).  With workspace == NULL the
+ * first structure runs: every 128-query workgroup stages K / V itself (slower). */
 int64_t ogmm_attention_workspace_bytes(int C, int M, int H, int dh);
 int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
                    int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream);
