@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 7
+#define OGMM_ABI_VERSION 8
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -168,6 +168,9 @@ int ogmm_pack_frag(const float* x, int64_t ld, int64_t rows, int K, void* hi, vo
 
 /* ---- K13 pieces.  models/gmmreg.py:74: F.normalize over channels (eps 1e-12), rows of length D. */
 int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream);
+/* F.normalize(dim = channels) of x [rows][ld] written straight as the split fragment-major B image of ogmm_pack_frag (rows padded to a
+ * multiple of 32 with zeros): the tgt side of the N x N similarity (models/gmmreg.py:74-75) never exists as an fp32 map. */
+int ogmm_l2norm_pack_frag(const float* x, int64_t ld, int64_t rows, int K, void* hi, void* lo, void* stream);
 /* Cout = 1 convolutions (proj.net.3, overlap.net.6): y[m] = act(dot(x[m][:], w) + b). */
 int ogmm_rowdot(const float* x, int64_t ldx, int64_t rows, int D, const float* w, const float* b /*device [1]*/,
                 int act, float* y, int64_t ldy, void* stream);

@@ -121,6 +121,54 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- F.normalize(dim=channels) + split fragment-major B image in one kernel
+// The tgt half of the normalised map is only ever the B operand of the similarity GEMM: a workgroup takes 32 rows, computes their norms
+// (one wave per row, as l2norm_rows_kernel: same sums, same division) and then writes the rows' slice of the hi/lo images directly
+// (pack_frag_kernel's layout; the second read of the rows comes from L2).  Saves writing and re-reading the fp32 map (2 x 134 MB at B = 64).
+__global__ __launch_bounds__(256) void l2norm_pack_frag_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, f16x8p* __restrict__ hi,
+                                                               f16x8p* __restrict__ lo) {
+    __shared__ float nrm_s[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nb = blockIdx.x, row0 = nb * 32;
+    for (int r = wave; r < 32; r += 4) {
+        const int64_t row = row0 + r;
+        float ss = 0.0f;
+        if (row < rows) {
+            const float* __restrict__ p = x + row * ld;
+            for (int d = lane * 4; d < K; d += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(p + d);
+                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
+        const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+        if (lane == 0) nrm_s[r] = nrm;
+    }
+    __syncthreads();
+    const int r = lane & 31;
+    const int64_t row = row0 + r;
+    const float nrm = nrm_s[r];
+    const int KB = K / 16;
+    for (int kb = wave; kb < KB; kb += 4) {
+        const int k0 = kb * 16 + (lane >> 5) * 8;
+        f16x8p h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < rows) {
+            const float4 a = *reinterpret_cast<const float4*>(x + row * ld + k0);
+            const float4 b = *reinterpret_cast<const float4*>(x + row * ld + k0 + 4);
+            const float v[8] = {a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm, b.x / nrm, b.y / nrm, b.z / nrm, b.w / nrm};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xx = __builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+                const _Float16 hh = (_Float16)xx;
+                h[e] = hh;
+                l[e] = (_Float16)(xx - (float)hh);
+            }
+        }
+        const int64_t gI = (nb * KB + kb) * 64 + lane;
+        hi[gI] = h;
+        lo[gI] = l;
+    }
+}
+
 // ---------------------------------------------------------------- F.normalize(dim=channels), one wave per row
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int D,
                                                           float* __restrict__ out, int64_t ldo) {
@@ -335,6 +383,16 @@ extern "C" int ogmm_pack_frag(const float* x, int64_t ld, int64_t rows, int K, v
     hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, ogmm::as_stream(stream), x, ld, rows, K, rows_pad,
                        reinterpret_cast<f16x8p*>(hi), reinterpret_cast<f16x8p*>(lo));
     return ogmm::check_launch("ogmm_pack_frag");
+}
+
+extern "C" int ogmm_l2norm_pack_frag(const float* x, int64_t ld, int64_t rows, int K, void* hi, void* lo, void* stream) {
+    OGMM_REQUIRE(x && hi && lo && rows > 0 && K > 0 && K % 16 == 0 && ld % 4 == 0 && ogmm::aligned16(x) && ogmm::aligned16(hi) && ogmm::aligned16(lo),
+                 "ogmm_l2norm_pack_frag: K %% 16 == 0, ld %% 4 == 0 and 16-byte aligned pointers required");
+    const int64_t blocks = (rows + 31) / 32;
+    OGMM_REQUIRE(blocks <= 2147483647LL, "ogmm_l2norm_pack_frag: too many rows");
+    hipLaunchKernelGGL(l2norm_pack_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, ogmm::as_stream(stream), x, ld, rows, K,
+                       reinterpret_cast<f16x8p*>(hi), reinterpret_cast<f16x8p*>(lo));
+    return ogmm::check_launch("ogmm_l2norm_pack_frag");
 }
 
 extern "C" int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream) {

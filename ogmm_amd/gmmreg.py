@@ -368,12 +368,13 @@ class GMMReg(nn.Module):
         f = self._transformer(L["cattn"], ft, a1, C, N, res=ft)
 
         # ---- overlap scores (gmmreg.py:74-89)
-        fn = ops.l2norm_rows(f)
         S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
         if ops.DEFAULT_SPLIT and D % 64 == 0:
-            tgt_img = ops.pack_frag_batched(fn[B * N:], B, N)              # the tgt side as a split fragment-major B operand
-            ops.gemm_nt(fn, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img, overflow=self._overflow)
+            fn_src = ops.l2norm_rows(f[:B * N])                            # A operand: the src half, normalised
+            tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)        # B operand: the tgt half, normalised and split in one pass
+            ops.gemm_nt(fn_src, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img, overflow=self._overflow)
         else:
+            fn = ops.l2norm_rows(f)
             ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
         ph = ops.conv1x1(f, L["proj"]["0"], ACT_RELU)
         extra = torch.zeros((R, 4), dtype=torch.float32, device=dev)             # conv2 input channels 512 (wo), 513 (o), zero pad

@@ -285,6 +285,20 @@ def pack_frag_batched(x, batch, rows):
     return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K}
 
 
+def l2norm_pack_frag_batched(x, batch, rows):
+    """pack_frag_batched(l2norm_rows(x), batch, rows) in one kernel per image set: the normalised rows exist only as split images."""
+    K = x.shape[1]
+    assert x.stride(1) == 1 and x.shape[0] == batch * rows and K % 64 == 0
+    rp = (rows + 255) // 256 * 256
+    hi = torch.zeros((batch, rp * K), dtype=torch.float16, device=x.device) if rp != rows else torch.empty((batch, rp * K), dtype=torch.float16, device=x.device)
+    lo = torch.zeros_like(hi) if rp != rows else torch.empty_like(hi)
+    for b in range(batch) if rp != rows else ():
+        _lib.call("ogmm_l2norm_pack_frag", _p(x[b * rows:]), x.stride(0), rows, K, _p(hi[b]), _p(lo[b]), _stream())
+    if rp == rows:
+        _lib.call("ogmm_l2norm_pack_frag", _p(x), x.stride(0), batch * rows, K, _p(hi), _p(lo), _stream())
+    return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K}
+
+
 def attention(q, k, v, C, N, M, H, out=None, use_workspace=True):
     """Fused anchor attention (models/attn.py:78-82).  q [C*N, D], k, v [C*M, D] (row-major views, last stride 1), head-major
     channels; returns [C*N, D]."""

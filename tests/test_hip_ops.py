@@ -323,6 +323,17 @@ def test_fused_attention(ops, C, N, M):
     assert (got3 - ref).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("batch,rows", [(3, 256), (2, 300), (1, 1024)])
+def test_l2norm_pack_frag_equals_two_steps(ops, batch, rows):
+    """The fused normalise + split-image kernel against pack_frag_batched(l2norm_rows(x)): bit-identical images (same sums, same division)."""
+    torch.manual_seed(rows)
+    x = dev(torch.randn(batch * rows, 512) * 3.0)
+    two = ops.pack_frag_batched(ops.l2norm_rows(x), batch, rows)
+    one = ops.l2norm_pack_frag_batched(x, batch, rows)
+    assert torch.equal(one["W_hi"], two["W_hi"]) and torch.equal(one["W_lo"], two["W_lo"])
+    assert one["sB"] == two["sB"] and one["ldb_h"] == two["ldb_h"]
+
+
 # ------------------------------------------------------------------------------------------------ row / column kernels
 def test_softmax_instnorm_l2norm_rowdot(ops):
     torch.manual_seed(2)
