@@ -35,6 +35,27 @@ __device__ __forceinline__ void split4_f16(const f32x4 v, f16x4& hi, f16x4& lo, 
     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
+// The same split for fragments that are already in registers (LDS-DMA engine): the asm has no side effects, so it is not `volatile` and
+// the scheduler may move it into the shadow of the matrix instructions.  The overflow test is one v_dot2_f32_f16 per PAIR of values:
+// ovf += hi . hi turns inf / nan iff some |x| > 65504 made hi infinite (56 -> 16 VALU per K step and wave against the max-|x| form).
+__device__ __forceinline__ void split4_f16_pure(const f32x4 v, f16x4& hi, f16x4& lo, float& ovf) {
+    f16x2 h01, h23, l01, l23;
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    hi = f16x4{h01[0], h01[1], h23[0], h23[1]};
+    lo = f16x4{l01[0], l01[1], l23[0], l23[1]};
+    ovf = __builtin_amdgcn_fdot2(h01, h01, ovf, false);
+    ovf = __builtin_amdgcn_fdot2(h23, h23, ovf, false);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case OGMM_ACT_RELU: return fmaxf(v, 0.0f);

@@ -225,6 +225,8 @@ namespace ogmm {
 
 bool gemm_f16x3_large_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s);
+bool gemm_f16x3_v6_applicable(const ogmm_gemm& g);
+int gemm_nt_f16x3_v6(const ogmm_gemm& g, hipStream_t s);
 
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
@@ -249,8 +251,11 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         case 18: case 19: case 23: case 24: case 25: case 26: case 27: case 28: case 29:            // large-shape engine and its ablations (tools/gemm_bench.py)
         case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40:
             OGMM_REQUIRE(gemm_f16x3_large_applicable(g), "large-shape engine not applicable"); return gemm_nt_f16x3_v4(g, s);
+        case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 79: case 80: case 81: case 82: case 83: case 84: case 85: case 86: case 87: case 88: case 89:            // LDS-DMA engine (v6) and its ablations
+            OGMM_REQUIRE(gemm_f16x3_v6_applicable(g), "LDS-DMA engine not applicable"); return gemm_nt_f16x3_v6(g, s);
         default: break;
     }
+    if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v6_applicable(g)) return gemm_nt_f16x3_v6(g, s);
     if (gemm_f16x3_large_applicable(g)) return gemm_nt_f16x3_v4(g, s);
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
     // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)
