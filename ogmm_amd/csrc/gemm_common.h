@@ -56,6 +56,16 @@ __device__ __forceinline__ void split4_f16_pure(const f32x4 v, f16x4& hi, f16x4&
     ovf = __builtin_amdgcn_fdot2(h23, h23, ovf, false);
 }
 
+// One LDS-DMA instruction: 64 lanes x 16 bytes from `sbase + voff` (a wave-uniform 64-bit base in SGPRs plus a per-lane 32-bit byte offset:
+// no address arithmetic on the vector ALU) to LDS bytes [lds_addr + 16 * lane, + 16).  It is inline assembly on purpose: hipcc models the
+// builtin (__builtin_amdgcn_global_load_lds) as an LGKM event that may complete out of order, so with one in flight EVERY wait for a
+// ds_read becomes `s_waitcnt lgkmcnt(0)` -- also for reads issued just before the wait -- and the fragment reads of the next MFMA group can no
+// longer stay in flight behind the current group (measured: +25 % cycles in the K loop).  The compiler does not see this load: the caller
+// counts vmcnt itself (asm `s_waitcnt vmcnt(N)`), owns M0 (no other M0 user in the kernel) and leaves nothing in flight at kernel end.
+__device__ __forceinline__ void lds_dma16(unsigned voff, const void* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case OGMM_ACT_RELU: return fmaxf(v, 0.0f);
@@ -318,6 +328,51 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
             for (int e = 0; e < 4; ++e) {
                 atomicAdd(st + 2 * e, (double)tot1[e]);
                 atomicAdd(st + 2 * e + 1, (double)tot2[e]);
+            }
+        }
+    }
+}
+
+// Epilogue for a wave that owns ONE 32-row block against NB consecutive 32-column blocks (the 8 x 1 wave layout of gemm_f16x3_v8.hip), straight
+// from the accumulator layout (lane = column, register = row: the 32 lanes of a half wave write one 128-byte row segment -- a full line --
+// per store), no LDS.  Requires the slab to be inside the matrix, per-column scale / shift, no pooling.  Column statistics (InstanceNorm
+// fusion): a lane sums its 16 rows, the two half waves are folded with one cross-lane move, one fp64 atomic per column and statistic.
+template <int NB>
+__device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, int col0, float alpha) {
+    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    float* __restrict__ Cm = g.C;
+    const float* __restrict__ Rm = g.Res;
+    const bool stats = g.col_stats != nullptr;
+    const int act = g.act;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = col0 + j * 32 + lr;
+        const float s1 = (g.scale ? g.scale[col] : 1.0f) * alpha, t1 = g.shift ? g.shift[col] : 0.0f;
+        float* __restrict__ cp = Cm + (int64_t)(row0 + 4 * lh) * g.ldc + col;
+        float rr[16];
+        if (Rm) {
+            const float* __restrict__ rp = Rm + (int64_t)(row0 + 4 * lh) * g.ldr + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rr[r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
+        }
+        float sum1 = 0.0f, sum2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float y = fmaf(acc[j][r], s1, t1);
+            if (act == OGMM_ACT_RELU) y = fmaxf(y, 0.0f);
+            else if (act == OGMM_ACT_LEAKY02) y = y > 0.0f ? y : 0.2f * y;
+            else if (act == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+            if (Rm) y += rr[r];
+            cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
+            if (stats) { sum1 += y; sum2 = fmaf(y, y, sum2); }
+        }
+        if (stats) {
+            sum1 += __shfl_xor(sum1, 32, 64);
+            sum2 += __shfl_xor(sum2, 32, 64);
+            if (lh == 0) {
+                double* st = g.col_stats + ((int64_t)(row0 / g.group_rows) * g.N + col) * 2;
+                atomicAdd(st, (double)sum1);
+                atomicAdd(st + 1, (double)sum2);
             }
         }
     }

@@ -71,29 +71,33 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v6_kernel(const ogmm_gemm g, con
     // <- global chunk (l & 7) ^ ((row >> 1) & 7).  Rows beyond M are clamped (their results are never stored).
     const float* __restrict__ A1p = g.A + zb * g.sA_o + (int64_t)((ABL & 128) ? 0 : m0) * g.lda;          // ablation 128: every tile reads row panel 0 (L2-resident A)
     const float* __restrict__ A2p = g.A2 ? g.A2 + zb * g.sA2_o + (int64_t)m0 * g.lda2 : nullptr;
-    int arow[4], ach[2];             // this lane's four rows (one per DMA instruction) and its source chunk for even / odd instructions, in floats
+    // byte offset of this lane's 16 bytes in each of its four pieces, relative to the stage's first element (row panel start + k0); one set per A piece
+    const unsigned lds0 = (unsigned)(size_t)smem6;
+    unsigned aoff[4];
+    auto set_aoff = [&](int ld) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) arow[i] = min(wave * 32 + i * 8 + (lane >> 3), g.M - 1 - m0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ach[i] = ((lane & 7) ^ ((i << 2) | (lane >> 4))) * 4;          // ((row >> 1) & 7) = ((i & 1) << 2) | (lane >> 4)
-    // B: wave w stages column block w: instruction i = (k16 = i >> 1, plane = i & 1)
+        for (int i = 0; i < 4; ++i) {
+            const int r = wave * 32 + i * 8 + (lane >> 3);
+            aoff[i] = (unsigned)(min(r, g.M - 1 - m0) * ld + ((lane & 7) ^ ((r >> 1) & 7)) * 4) * 4u;
+        }
+    };
+    set_aoff((int)g.lda);
+    // B: wave w stages column block w: instruction i = (k16 = i >> 1, plane = i & 1); 1 KiB fragments of the fragment-major image
     const int KB = (int)(g.ldb_h / 16);
     const f16x8* __restrict__ BH = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_hi) + zb * g.sB_o) + ((int64_t)(n0 / 32 + wave) * KB) * 64;
     const f16x8* __restrict__ BL = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(g.B_lo) + zb * g.sB_o) + ((int64_t)(n0 / 32 + wave) * KB) * 64;
+    const unsigned boff = lane * 16;
 
-    // one DMA instruction (1 KiB) of stage t: piece i of this wave's four activation row groups / four weight fragments
+    // one DMA instruction (1 KiB) of stage t: piece i of this wave's four activation row groups / four weight fragments (inline assembly: gemm_common.h)
     auto issue_a_piece = [&](int t, int i) {
-        unsigned char* dst = smem6 + (t % A_STAGES) * A_STAGE + wave * 4096;
         const bool second = t >= nk1;
+        if (i == 0 && t == nk1 && nk2 > 0) set_aoff((int)g.lda2);          // stages are issued in order and piece 0 first: switch to the second A piece once
         const float* Ap = second ? A2p + (t - nk1) * BK6 : A1p + t * BK6;
-        const int ld = second ? (int)g.lda2 : (int)g.lda;
-        __builtin_amdgcn_global_load_lds(Ap + (__mul24(arow[i], ld) + ach[i & 1]), (lds_void*)(dst + i * 1024), 16, 0, 0);
+        lds_dma16(aoff[i], Ap, lds0 + (t % A_STAGES) * A_STAGE + wave * 4096 + i * 1024);
     };
     auto issue_b_piece = [&](int t, int i) {
         const int kb = (t < nk1 ? t * 2 : (g.K1 / 16) + (t - nk1) * 2) * 64;
-        unsigned char* dst = smem6 + B_OFF + (t % B_STAGES) * B_STAGE + wave * 4096;
-        const f16x8* src = ((i & 1) ? BL : BH) + kb + (i >> 1) * 64 + lane;
-        __builtin_amdgcn_global_load_lds(src, (lds_void*)(dst + i * 1024), 16, 0, 0);
+        lds_dma16(boff, ((i & 1) ? BL : BH) + kb + (i >> 1) * 64, lds0 + B_OFF + (t % B_STAGES) * B_STAGE + wave * 4096 + i * 1024);
     };
     auto issue_a = [&](int t) {
 #pragma unroll

@@ -20,7 +20,7 @@ def run(v, A, k1, W, m, n, out, A2=None, k2=0, split=None, **kw):
 if not time_only:
     # (M, N, K1, K2, residual, scale/shift + act, stats)
     cases = [(65536, 256, 512, 0, False, 0, False), (65536, 512, 512, 0, True, 1, False), (70000, 512, 1024, 0, False, 2, False), (65536, 1024, 512, 512, False, 1, False),
-             (65536 + 100, 1024, 512, 32, True, 0, False), (131072, 1024, 1024, 0, False, 1, True), (65536, 256, 64, 0, False, 1, False), (65536, 768, 512, 0, False, 0, False)]
+             (65536 + 100, 1024, 512, 32, True, 0, False), (131072, 1024, 1024, 0, False, 1, True), (65536, 256, 64, 0, False, 1, False), (65536, 768, 512, 0, False, 0, False), (65536, 256, 32, 0, False, 0, False), (65536, 512, 96, 0, True, 1, False), (66000, 256, 64, 32, False, 2, False)]
     worst = 0.0
     for (m, n, k1, k2, has_res, act, stats) in cases:
         A = torch.randn(m, k1, device=dev) * torch.rand(m, 1, device=dev) * 3
@@ -34,7 +34,7 @@ if not time_only:
         shift = torch.randn(n, device=dev) if act else None
         kw = dict(res=res, ldr=(n if has_res else 0), scale=scale, shift=shift, act=act)
         outs = {}
-        for v in (23, 60):
+        for v in (23, 60, 90, 100):
             out = torch.full((m, n), float("nan"), device=dev)
             st = torch.zeros(((m + 1023) // 1024, n, 2), dtype=torch.float64, device=dev) if stats else None
             run(v, A, k1, W, m, n, out, A2=A2, k2=k2, split=sp, col_stats=st, group_rows=(1024 if stats else 0), **kw)
@@ -58,8 +58,15 @@ if not time_only:
         sdiff = 0.0
         if stats:
             sdiff = ((outs[60][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()
-        print("M=%6d N=%4d K=%4d+%3d res=%d act=%d stats=%d : v6 err %.2e  v4 err %.2e (relative to sum|a||w|)  v6==v4 bitwise %s (max diff %.2e)  nan %d  stats rel diff %.1e" %
-              (m, n, k1, k2, has_res, act, stats, e6, e4, same, dmax, nan6, sdiff))
+        same7 = torch.equal(outs[90][0], outs[23][0])
+        nan7 = torch.isnan(outs[90][0]).sum().item()
+        print("M=%6d N=%4d K=%4d+%3d res=%d act=%d stats=%d : v6 err %.2e  v4 err %.2e (relative to sum|a||w|)  v6==v4 bitwise %s (max diff %.2e)  nan %d  stats rel diff %.1e  | v7==v4 bitwise %s (max diff %.2e, nan %d)" %
+              (m, n, k1, k2, has_res, act, stats, e6, e4, same, dmax, nan6, sdiff, same7, (outs[90][0] - outs[23][0]).abs().max().item(), nan7))
+        assert same7, "v7 differs from v4"
+        same8 = torch.equal(outs[100][0], outs[23][0])
+        print("        v8==v4 bitwise %s (max diff %.2e, nan %d)%s" % (same8, (outs[100][0] - outs[23][0]).abs().max().item(), torch.isnan(outs[100][0]).sum().item(),
+              ("  stats rel diff %.1e" % ((outs[100][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()) if stats else ""))
+        assert same8, "v8 differs from v4"
         worst = max(worst, e6)
         assert nan6 == 0 and (same or e6 < max(2e-6, 1.2 * e4)), "v6 result off"
     print("v6 correctness OK, worst relative error %.2e" % worst)
@@ -98,15 +105,16 @@ if "--clock" in sys.argv:          # in-kernel clock probes (variants 80..86): t
     for rnd in range(2):
         for v in variants:
             for _ in range(3): run(v, A, k1, W, m, n, out, split=sp)
-            torch.cuda.synchronize(); L.ogmm_debug_v6_probe(buf)
+            probe = L.ogmm_debug_v8_probe if v >= 100 else (L.ogmm_debug_v7_probe if v >= 90 else L.ogmm_debug_v6_probe)
+            torch.cuda.synchronize(); probe(buf)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10): run(v, A, k1, W, m, n, out, split=sp)
-            e1.record(); torch.cuda.synchronize(); L.ogmm_debug_v6_probe(buf)
+            e1.record(); torch.cuda.synchronize(); probe(buf)
             ms = e0.elapsed_time(e1) / 10
             cyc, wall, wg = buf[0], buf[1], buf[2]
             print("v%-3d %.3f ms/launch  %5.1f TF-alg   per workgroup: %8.0f shader cycles, %6.2f us -> shader clock %.3f GHz   (MFMA pipe needs 98304 cycles per tile: busy %.1f %%)" %
-                  (v, ms, 2.0 * m * n * k1 / ms / 1e9, cyc / max(wg, 1), wall / max(wg, 1) / 100.0, cyc / max(wall, 1) * 0.1, 98304.0 / (cyc / max(wg, 1)) * 100), flush=True)
+                  (v, ms, 2.0 * m * n * k1 / ms / 1e9, cyc / max(wg, 1), wall / max(wg, 1) / 100.0, cyc / max(wall, 1) * 0.1, 98304.0 / max(cyc / max(wg, 1), 1.0) * 100), flush=True)
     sys.exit(0)
 
 M = 131072
