@@ -263,9 +263,8 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
             OGMM_REQUIRE(gemm_f16x3_v8_applicable(g), "LDS-DMA engine (v8) not applicable"); return gemm_nt_f16x3_v8(g, s);
         default: break;
     }
+    // the LDS-DMA engine (8 x 1 waves) wherever it applies; its earlier forms (v6: 4 x 2 waves, v7: two barriers per step) only by their variant codes
     if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v8_applicable(g)) return gemm_nt_f16x3_v8(g, s);
-    if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v7_applicable(g)) return gemm_nt_f16x3_v7(g, s);
-    if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v6_applicable(g)) return gemm_nt_f16x3_v6(g, s);
     if (gemm_f16x3_large_applicable(g)) return gemm_nt_f16x3_v4(g, s);
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
     // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)

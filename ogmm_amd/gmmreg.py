@@ -182,13 +182,23 @@ def pack_weights(sd, D, H):
         L[name] = T
     for name in ("conv1", "conv2", "overlap"):
         cin = sd[name + ".net.0.weight"].shape[1]
-        S = {"0": conv_bn(name + ".net.0", name + ".net.1", True, pad_to=(cin + 3) // 4 * 4),
+        # conv2.net.0 has 514 input channels: [f | wo, o].  The two extra ones travel as a second A piece of 32 columns (30 of them zero, the
+        # weights zero-padded to match): the LDS-DMA GEMM engine walks K in steps of 32, and a 16 MB all-but-two-columns-zero operand is cheaper than
+        # a slower engine for a 1024 x 514 layer.
+        S = {"0": conv_bn(name + ".net.0", name + ".net.1", True, pad_to=(cin if cin % 32 == 0 else cin // 32 * 32 + 32)),
              "3": conv_bn(name + ".net.3", name + ".net.4", True)}
         if sd[name + ".net.6.weight"].shape[0] == 1:
             S["6"] = {"w": sd[name + ".net.6.weight"].reshape(-1).float().contiguous(), "b": sd[name + ".net.6.bias"].float().contiguous()}
         else:
             S["6"] = conv_bias(name + ".net.6")
         L[name] = S
+    # conv2.net.6 (1024 -> 512, no activation) feeds nothing but overlap.net.0 (512 -> 256) (models/gmmreg.py:83-85: `fo` has no other use), so the two
+    # linear maps are one 1024 -> 256 layer: W = W_o0 W_c6, b = W_o0 b_c6 + b_o0, formed in fp64 and rounded once (0.40 of 11.2 GMAC per cloud less;
+    # the result differs from the two-step evaluation by fp32 rounding only, as with the folded merge convolution).
+    w46 = _w2d(sd, "overlap.net.0").double() @ _w2d(sd, "conv2.net.6").double()
+    b46 = _w2d(sd, "overlap.net.0").double() @ sd["conv2.net.6.bias"].double() + sd["overlap.net.0.bias"].double()
+    s46, t46 = _fold_bn(sd, "overlap.net.1", b46)
+    L["conv2_6_overlap_0"] = {"W": w46.float().contiguous(), "scale": s46, "shift": t46}
     L["proj"] = {"0": conv_bn("proj.net.0", "proj.net.1", True),
                  "3": {"w": sd["proj.net.3.weight"].reshape(-1).float().contiguous(), "b": sd["proj.net.3.bias"].float().contiguous()}}
     _add_splits(L)
@@ -214,6 +224,7 @@ class GMMReg(nn.Module):
         #        terms (11-bit mantissa >= bf16's 8, fp32 accumulate); R / t then agree with the reference to ~1e-4, not 1e-5.
         self.precision = getattr(config, "precision", "f16x3")
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
+        self.fold_conv2_overlap = True      # conv2.net.6 and overlap.net.0 (two linear maps in a row) as one 1024 -> 256 layer
         self._overflow = None
         self._side = None
         self._side2 = None
@@ -377,12 +388,17 @@ class GMMReg(nn.Module):
             fn = ops.l2norm_rows(f)
             ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
         ph = ops.conv1x1(f, L["proj"]["0"], ACT_RELU)
-        extra = torch.zeros((R, 4), dtype=torch.float32, device=dev)             # conv2 input channels 512 (wo), 513 (o), zero pad
-        ops.rowdot(ph, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=4)
-        ops.overlap_cross(S, extra[:B * N, 1], extra[B * N:, 1], 4, extra[:B * N, 0], extra[B * N:, 0], 4)
+        XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
+        extra = torch.zeros((R, XW), dtype=torch.float32, device=dev)
+        ops.rowdot(ph, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW)
+        ops.overlap_cross(S, extra[:B * N, 1], extra[B * N:, 1], XW, extra[:B * N, 0], extra[B * N:, 0], XW)
         del S
-        fo = self._stack3(L["conv2"], f, x2=extra)
-        g = ops.conv1x1(fo, L["overlap"]["0"], ACT_RELU)
+        if self.fold_conv2_overlap:
+            h2 = ops.conv1x1(ops.conv1x1(f, L["conv2"]["0"], ACT_RELU, x2=extra), L["conv2"]["3"], ACT_RELU)
+            g = ops.conv1x1(h2, L["conv2_6_overlap_0"], ACT_RELU)            # conv2.net.6 and overlap.net.0 as one layer (pack_weights)
+        else:
+            fo = self._stack3(L["conv2"], f, x2=extra)
+            g = ops.conv1x1(fo, L["overlap"]["0"], ACT_RELU)
         g = ops.conv1x1(g, L["overlap"]["3"], ACT_RELU)
         o = torch.empty((C, N), dtype=torch.float32, device=dev)
         ops.rowdot(g, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1)

@@ -62,7 +62,7 @@ def test_pack_weights_head_permutation_and_bn_fold():
     for (h, d) in ((0, 0), (1, 5), (3, 127)):
         assert torch.equal(L["sattn1"]["q"]["W"][h * 128 + d], wq[d * 4 + h])
         assert torch.equal(L["sattn1"]["merge"]["W"][:, h * 128 + d], sd["sattn1.attn.merge.weight"][:, d * 4 + h, 0])
-    assert L["conv2"]["0"]["W"].shape == (1024, 516) and float(L["conv2"]["0"]["W"][:, 514:].abs().max()) == 0.0
+    assert L["conv2"]["0"]["W"].shape == (1024, 544) and float(L["conv2"]["0"]["W"][:, 514:].abs().max()) == 0.0
     # folded eval-BN == F.batch_norm
     x = torch.randn(7, 256)
     ref = torch.nn.functional.batch_norm(x + sd["proj.net.0.bias"], sd["proj.net.1.running_mean"], sd["proj.net.1.running_var"],
