@@ -231,6 +231,8 @@ bool gemm_f16x3_v7_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v7(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v8_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s);
+bool gemm_f16x3_v9_applicable(const ogmm_gemm& g);
+int gemm_nt_f16x3_v9(const ogmm_gemm& g, hipStream_t s);
 
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
@@ -261,8 +263,11 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
             OGMM_REQUIRE(gemm_f16x3_v7_applicable(g), "LDS-DMA engine (v7) not applicable"); return gemm_nt_f16x3_v7(g, s);
         case 100: case 101: case 102: case 103: case 104: case 105: case 106: case 107: case 108: case 109:            // LDS-DMA engine, 8 x 1 waves (v8)
             OGMM_REQUIRE(gemm_f16x3_v8_applicable(g), "LDS-DMA engine (v8) not applicable"); return gemm_nt_f16x3_v8(g, s);
+        case 110: case 111: case 112: case 113: case 114: case 115: case 116: case 117: case 118: case 119:            // persistent LDS-DMA engine (v9)
+            OGMM_REQUIRE(gemm_f16x3_v9_applicable(g), "persistent LDS-DMA engine (v9) not applicable"); return gemm_nt_f16x3_v9(g, s);
         default: break;
     }
+    if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v9_applicable(g)) return gemm_nt_f16x3_v9(g, s);
     // the LDS-DMA engine (8 x 1 waves) wherever it applies; its earlier forms (v6: 4 x 2 waves, v7: two barriers per step) only by their variant codes
     if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v8_applicable(g)) return gemm_nt_f16x3_v8(g, s);
     if (gemm_f16x3_large_applicable(g)) return gemm_nt_f16x3_v4(g, s);
