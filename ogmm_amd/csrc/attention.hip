@@ -671,11 +671,10 @@ int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk,
     const size_t lds = (size_t)4 * GROUPS * sizeof(f16x8);
     f16x8* kimg = reinterpret_cast<f16x8*>(workspace);
     f16x8* vimg = kimg + (int64_t)C * H * 2 * GROUPS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     // query tiles per workgroup: as many as leave at least two workgroups per CU (the K / V images are staged once per workgroup)
     const int n_tiles = (N + QT2 - 1) / QT2;
@@ -702,10 +701,9 @@ int launch_attention_frag(const float* q, int64_t ldq, const float* k, int64_t l
     const size_t lds = (size_t)4 * (PPL > OPL ? PPL : OPL) * sizeof(_Float16);
     f16x8* kimg = reinterpret_cast<f16x8*>(workspace);
     f16x8* vimg = kimg + (int64_t)C * H * 2 * GROUPS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_frag_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((attention_pack_kernel<MK, false>), dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
     hipLaunchKernelGGL(attention_frag_kernel<MK>, dim3((N + QT - 1) / QT, H, C), dim3(256), lds, s, q, ldq, kimg, vimg, N, H, scale, out, ldo);
@@ -719,10 +717,9 @@ int launch_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, c
     constexpr int KPL = 2 * M * (DH + 8), PPL = 2 * 32 * (M + 8), OPL = 32 * (DH + 4) * 2;
     constexpr int WST = PPL > OPL ? PPL : OPL;
     const size_t lds = (size_t)((KPL > 4 * WST ? KPL : 4 * WST) + 2 * DH * (M + 8)) * sizeof(_Float16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(attention_kernel<MK>, dim3((N + QT - 1) / QT, H, C), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, N, H, scale, out, ldo);
     return ogmm::check_launch("ogmm_attention");

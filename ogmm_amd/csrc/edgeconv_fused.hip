@@ -389,15 +389,17 @@ extern "C" int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, 
     const int two_pools = fixed + 2 * pool <= 160 * 1024;
     const size_t lds = fixed + (two_pools ? 2 : 1) * pool;
     OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_edgeconv_fused: LDS budget exceeded");
-    static int n_cu = 0;
-    if (!n_cu) {
+    static ogmm::PerDeviceOnce once;          // attributes and the CU count are per device
+    static int n_cu_of[64] = {};
+    const int dev = once.device();
+    if (once.first() || dev < 0 || dev >= 64 || !n_cu_of[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edgeconv_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edgeconv_fused_kernel<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
-        n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        if (dev >= 0 && dev < 64) n_cu_of[dev] = n;
     }
+    const int n_cu = (dev >= 0 && dev < 64 && n_cu_of[dev]) ? n_cu_of[dev] : 256;
     EdgeW w{W1, s1, t1, h2, l2, s2, t2, inv2, h3, l3, s3, t3, inv3, h4, l4, s4, t4, inv4};
     const int64_t n_tiles = (total + P - 1) / P;
     const unsigned blocks = (unsigned)std::min<int64_t>(n_tiles, n_cu);          // one persistent workgroup per CU

@@ -378,50 +378,6 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
     }
 }
 
-// Epilogue for the TRANSPOSED accumulator layout: the wave computed its 32 x (NB * 32) slab with the weight fragment as the MFMA's first operand,
-// so a lane holds ROW lr and, per column block, the columns (r & 3) + 8 * (r >> 2) + 4 * lh: four consecutive columns per register quad -> one
-// global_store_dwordx4 per quad (32 per wave instead of 128 dword stores: the dword form is bound by the CU's address unit, ~16 cycles per
-// instruction whatever its width -- measured 10 us per 256 x 256 tile, also with 3/4 of the chip idle).  Per-column constants would vary
-// along the REGISTER index here, so the caller has folded the column scale into the weights and started the accumulators at shift / alpha;
-// what is left is y = act(acc * alpha) (+ residual).  Slab inside the matrix, no statistics.
-template <int NB>
-__device__ __forceinline__ void gemm_epilogue_rowblock_t(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, int col0, float alpha) {
-    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
-    float* __restrict__ cp = g.C + (int64_t)(row0 + lr) * g.ldc + col0 + 4 * lh;
-    const float* __restrict__ rp = g.Res ? g.Res + (int64_t)(row0 + lr) * g.ldr + col0 + 4 * lh : nullptr;
-    auto run = [&](auto kind_c, auto res_c) {
-        constexpr int KIND = decltype(kind_c)::value;
-        constexpr bool RES = decltype(res_c)::value;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            f32x4 rr[4];
-            if (RES) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rr[q] = *reinterpret_cast<const f32x4*>(rp + j * 32 + q * 8);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float y = acc[j][4 * q + e] * alpha;
-                    if (KIND == OGMM_ACT_RELU) y = fmaxf(y, 0.0f);
-                    else if (KIND == OGMM_ACT_LEAKY02) y = y > 0.0f ? y : 0.2f * y;
-                    else if (KIND == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                    if (RES) y += rr[q][e];
-                    v[e] = y;
-                }
-                *reinterpret_cast<f32x4*>(cp + j * 32 + q * 8) = v;
-            }
-        }
-    };
-    auto by_res = [&](auto kind_c) { if (rp) run(kind_c, std::true_type{}); else run(kind_c, std::false_type{}); };
-    if (g.act == OGMM_ACT_RELU) by_res(std::integral_constant<int, OGMM_ACT_RELU>{});
-    else if (g.act == OGMM_ACT_LEAKY02) by_res(std::integral_constant<int, OGMM_ACT_LEAKY02>{});
-    else if (g.act == OGMM_ACT_SIGMOID) by_res(std::integral_constant<int, OGMM_ACT_SIGMOID>{});
-    else by_res(std::integral_constant<int, OGMM_ACT_NONE>{});
-}
-
 __device__ __forceinline__ bool wide_epilogue_ok(const ogmm_gemm& g) {
     return g.pool_k == 0 && g.C != nullptr && (g.N & 3) == 0 && (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
            (g.Res == nullptr || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.Res) & 15) == 0)) &&

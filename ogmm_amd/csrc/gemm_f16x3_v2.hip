@@ -207,11 +207,10 @@ int launch_v2(const ogmm_gemm& g, hipStream_t stream) {
     const int m_tiles = (g.M + rows_per_tile - 1) / rows_per_tile;
     const int n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v2_kernel<MT, NT, WM, WN, POOL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr_set = true;
     }
     const bool plain = m_tiles % 8 != 0 && m_tiles < 32;
     dim3 grid((unsigned)((plain ? m_tiles : m_tiles8) * n_tiles), 1, (unsigned)g.batch_outer);
@@ -227,12 +226,8 @@ bool gemm_f16x3_large_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v6_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v6(const ogmm_gemm& g, hipStream_t s);
-bool gemm_f16x3_v7_applicable(const ogmm_gemm& g);
-int gemm_nt_f16x3_v7(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v8_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s);
-bool gemm_f16x3_v9_applicable(const ogmm_gemm& g);
-int gemm_nt_f16x3_v9(const ogmm_gemm& g, hipStream_t s);
 
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
@@ -259,16 +254,11 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
             OGMM_REQUIRE(gemm_f16x3_large_applicable(g), "large-shape engine not applicable"); return gemm_nt_f16x3_v4(g, s);
         case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 79: case 80: case 81: case 82: case 83: case 84: case 85: case 86: case 87: case 88: case 89:            // LDS-DMA engine (v6) and its ablations
             OGMM_REQUIRE(gemm_f16x3_v6_applicable(g), "LDS-DMA engine not applicable"); return gemm_nt_f16x3_v6(g, s);
-        case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98: case 99:            // LDS-DMA engine with reads carried across the barriers (v7)
-            OGMM_REQUIRE(gemm_f16x3_v7_applicable(g), "LDS-DMA engine (v7) not applicable"); return gemm_nt_f16x3_v7(g, s);
         case 100: case 101: case 102: case 103: case 104: case 105: case 106: case 107: case 108: case 109:            // LDS-DMA engine, 8 x 1 waves (v8)
             OGMM_REQUIRE(gemm_f16x3_v8_applicable(g), "LDS-DMA engine (v8) not applicable"); return gemm_nt_f16x3_v8(g, s);
-        case 110: case 111: case 112: case 113: case 114: case 115: case 116: case 117: case 118: case 119:            // persistent LDS-DMA engine (v9)
-            OGMM_REQUIRE(gemm_f16x3_v9_applicable(g), "persistent LDS-DMA engine (v9) not applicable"); return gemm_nt_f16x3_v9(g, s);
         default: break;
     }
-    if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v9_applicable(g)) return gemm_nt_f16x3_v9(g, s);
-    // the LDS-DMA engine (8 x 1 waves) wherever it applies; its earlier forms (v6: 4 x 2 waves, v7: two barriers per step) only by their variant codes
+    // the LDS-DMA engine (8 x 1 waves) wherever it applies; its first form (v6: 4 x 2 waves, the ablation vehicle of DESIGN.md) only by its variant codes
     if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v8_applicable(g)) return gemm_nt_f16x3_v8(g, s);
     if (gemm_f16x3_large_applicable(g)) return gemm_nt_f16x3_v4(g, s);
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);

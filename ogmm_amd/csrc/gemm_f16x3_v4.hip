@@ -305,10 +305,9 @@ static int launch_v4(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static const int direct = [] { const char* e = getenv("OGMM_V4_DIRECT"); return e ? atoi(e) : 1; }();      // 0: transposed dwordx4 stores also without residual / statistics
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v4_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr_set = true;
     }
     if (m_tiles % 8 != 0 && m_tiles < 32)
         hipLaunchKernelGGL(gemm_f16x3_v4_kernel<ABL>, dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS, s, g, -m_tiles, n_tiles, direct);

@@ -244,7 +244,8 @@ static int launch_v8(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static const int direct = [] { const char* e = getenv("OGMM_V8_DIRECT"); return e ? atoi(e) : 1; }();
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static ogmm::PerDeviceOnce attr_once;          // per template instance and device
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (m_tiles % 8 != 0 && m_tiles < 32)
         hipLaunchKernelGGL(gemm_f16x3_v8_kernel<ABL>, dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES, s, g, -m_tiles, n_tiles, direct);
     else

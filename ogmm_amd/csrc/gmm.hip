@@ -825,10 +825,9 @@ extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0
     const int Npad = (N + 3) / 4 * 4;   // keeps the float4 mu array 16-byte aligned behind 7 per-point floats
     const size_t lds = ((size_t)4 * N + 3 * (size_t)Npad + 4 * (size_t)J + J + 16) * sizeof(float);
     OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_gmm_em: N=%d, J=%d needs %zu B of LDS (> 160 KiB)", N, J, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const float inv_eps = (float)(1.0 / (double)epsilon);   // torch divides by a python scalar as multiply-by-reciprocal
     const float inv_tau = (float)(1.0 / (double)tau);
@@ -947,10 +946,9 @@ extern "C" int ogmm_match_kabsch(const float* mu_s, const float* mu_t, const flo
     OGMM_REQUIRE(J <= 128, "ogmm_match_kabsch: at most 128 clusters per cloud (8 x 8 similarity block per thread), got %d", J);
     const size_t lds = ((size_t)J * J + 6 * (size_t)J + 2 * 64 * (size_t)(J + 4)) * sizeof(float);
     OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_match_kabsch: J=%d too large for LDS", J);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kabsch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(match_kabsch_kernel, dim3(B), dim3(256), lds, ogmm::as_stream(stream), mu_s, mu_t, f_s, f_t, J, D,
                        (float)(1.0 / (double)temperature), R, t, scores);

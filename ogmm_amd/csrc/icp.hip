@@ -293,12 +293,11 @@ extern "C" int ogmm_icp_point_to_point_ws(const float* src, const float* tgt, in
     const int split = icp_split(B, N);
     auto* st = static_cast<ogmm_icp::IcpState*>(workspace);
     double* part = reinterpret_cast<double*>(static_cast<char*>(workspace) + ((size_t)B * sizeof(ogmm_icp::IcpState) + 15) / 16 * 16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(ogmm_icp::icp_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ogmm_icp::MAX_TGT * 3 * sizeof(float)) != hipSuccess)
             return fail("ogmm_icp_point_to_point_ws: cannot raise the dynamic LDS limit");
-        attr_set = true;
     }
     hipStream_t s = as_stream(stream);
     const double md = (double)max_corr_dist;
@@ -320,12 +319,11 @@ extern "C" int ogmm_icp_point_to_point(const float* src, const float* tgt, int B
     OGMM_REQUIRE(src && tgt && R && t && B > 0 && N > 0 && Nt > 0 && max_iter >= 0 && max_corr_dist > 0, "ogmm_icp_point_to_point: null pointer or bad sizes");
     OGMM_REQUIRE(Nt <= ogmm_icp::MAX_TGT, "ogmm_icp_point_to_point: at most %d target points per cloud (LDS cache), got %d", ogmm_icp::MAX_TGT, Nt);
     const size_t lds = (size_t)Nt * 3 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(ogmm_icp::icp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ogmm_icp::MAX_TGT * 3 * sizeof(float)) != hipSuccess)
             return fail("ogmm_icp_point_to_point: cannot raise the dynamic LDS limit");
-        attr_set = true;
     }
     const double md = (double)max_corr_dist;
     hipLaunchKernelGGL(ogmm_icp::icp_kernel, dim3(B), dim3(ogmm_icp::T), lds, as_stream(stream), src, tgt, N, Nt, R0, t0, md * md, max_iter,

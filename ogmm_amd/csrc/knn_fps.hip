@@ -350,13 +350,12 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     dim3 grid((N + 255) / 256, C);
     const size_t lds = (size_t)N * sizeof(float4);
     hipStream_t s = ogmm::as_stream(stream);
-    static bool attr_set = false;
-    if (!attr_set) {          // clouds beyond 4096 points need more than the default 64 KB of dynamic LDS
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) {          // clouds beyond 4096 points need more than the default 64 KB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<21>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<33>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_resolve_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        attr_set = true;
     }
     if (k <= 8) hipLaunchKernelGGL(knn_kernel<9>, grid, dim3(256), lds, s, xyz, N, k, idx);
     else if (k <= 20) hipLaunchKernelGGL(knn_kernel<21>, grid, dim3(256), lds, s, xyz, N, k, idx);

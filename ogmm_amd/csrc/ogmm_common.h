@@ -15,6 +15,20 @@ int check_launch(const char* what);      // hipGetLastError() -> 0 / fail()
 #define OGMM_REQUIRE(cond, ...) do { if (!(cond)) return ::ogmm::fail(__VA_ARGS__); } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// One-time per-DEVICE setup (hipFuncSetAttribute for > 64 KiB of dynamic LDS, cached device properties): function attributes are per device,
+// so a per-process `static bool` would leave a second GPU used by the same process without them.  first() is true once per device ordinal.
+struct PerDeviceOnce {
+    unsigned char seen[64] = {};
+    int device() const { int d = 0; (void)hipGetDevice(&d); return d; }
+    bool first() {
+        const int d = device();
+        if (d < 0 || d >= 64) return true;          // unknown ordinal: do the (cheap, idempotent) setup every time
+        if (seen[d]) return false;
+        seen[d] = 1;
+        return true;
+    }
+};
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- wave-level reductions (64 lanes), result in every lane

@@ -62,6 +62,18 @@ class DeepGMR(nn.Module):
         self._packed = self._packed_key = None
         self._overflow = None
 
+    def invalidate_packed(self):
+        """Drop the packed weights (needed after in-place edits through `.data`, which do not bump the tensors' _version)."""
+        self._packed = self._packed_key = None
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _layers(self):
         sd = self.state_dict()
         key = tuple((t.data_ptr(), t._version) for t in sd.values())

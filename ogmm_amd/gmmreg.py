@@ -230,13 +230,40 @@ class GMMReg(nn.Module):
         self._side2 = None
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 
-    # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved
+    # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved.  (data_ptr, _version) catches optimizer steps,
+    # load_state_dict, .to(); in-place edits through `.data` (EMA swaps, manual copies) do NOT bump _version, so the key also carries a
+    # content fingerprint -- one device-side reduction over all tensors, re-checked every `fingerprint_every` forwards -- and train() / eval() /
+    # load_state_dict() invalidate explicitly.  Call `invalidate_packed()` after editing weights through `.data` when the next forward must see it.
+    fingerprint_every = 16
+
+    def invalidate_packed(self):
+        self._packed = None
+        self._packed_key = None
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    @staticmethod
+    def _fingerprint(tensors):
+        with torch.no_grad():
+            return torch.stack([t.detach().double().sum() + 3.0 * t.detach().double().abs().sum() for t in tensors]).sum()
+
     def _layers(self):
         sd = self.state_dict()
         key = tuple((t.data_ptr(), t._version) for t in sd.values())
-        if self._packed is None or key != self._packed_key:
+        self._fp_calls = getattr(self, "_fp_calls", 0) + 1
+        stale = self._packed is None or key != self._packed_key
+        if not stale and self.fingerprint_every and self._fp_calls % self.fingerprint_every == 0:
+            stale = not torch.equal(self._fingerprint(list(sd.values())), self._packed_fp)          # one host sync every `fingerprint_every` forwards
+        if stale:
             self._packed = pack_weights(sd, self.emb_dims, self.config.num_heads)
             self._packed_key = key
+            self._packed_fp = self._fingerprint(list(sd.values()))
         return self._packed
 
     def _transformer(self, L, x, anchors, C, N, res):

@@ -86,7 +86,7 @@ def gather_rows(feats, ld, C, N, D, ids, cloud_map=None):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM engine
-def split_f16(W, pad_to=8, frag=False, k1=None):
+def split_f16(W, pad_to=8, frag=False, k1=None, sync=True, exp=None):
     """fp32 [N,K] -> dict(W_hi, W_lo binary16, inv_scale): W * 2^e = hi + lo with the power of two chosen so
     that max|W| * 2^e is in [2^11, 2^12) (keeps `lo` a normal binary16 number); inv_scale = 2^-e goes into alpha.
     frag=False: row-major [N, Kpad8] planes (OGMM_PREC_F16X3).  frag=True: the fragment-major image of
@@ -104,24 +104,56 @@ def split_f16(W, pad_to=8, frag=False, k1=None):
         Wp[:N, :k1] = W[:, :k1]
         if k2:
             Wp[:N, k1p:k1p + k2] = W[:, k1:]
-        planes = split_f16(Wp, pad_to=64)
+        planes = split_f16(Wp, pad_to=64, exp=exp)
         Np, Kp = Wp.shape
 
         def image(P):      # [Np, Kp] -> [Np/32][Kp/16][lane = g*32 + r][8]
             return P.view(Np // 32, 32, Kp // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
         return {"W_hi": image(planes["W_hi"]), "W_lo": image(planes["W_lo"]), "inv_scale": planes["inv_scale"],
                 "variant": PREC_F16X3_FRAG, "ldb_h": Kp}
-    amax = float(W.abs().max())
-    e = 0 if amax == 0.0 or not math.isfinite(amax) else 11 - math.floor(math.log2(amax))
-    e = max(-24, min(24, e))
-    Ws = W * (2.0 ** e)
+    # power of two on the DEVICE (no .item(): the training path splits ~60 weights per step): e = 11 - floor(log2(max|W|)), clamped to +-24;
+    # the scale itself stays a device scalar there, and `inv_scale` is a python float only for the pack-once inference path (one sync per pack)
+    if exp is not None:          # caller-supplied exponent (the training path re-uses last steps' one: no device reduction, no host sync)
+        K = W.shape[1]
+        Kp = (K + pad_to - 1) // pad_to * pad_to
+        Ws = W * (2.0 ** exp)
+        if Kp != K:
+            Ws = torch.cat([Ws, Ws.new_zeros(W.shape[0], Kp - K)], dim=1)
+        hi = Ws.half()
+        lo = (Ws - hi.float()).half()
+        return {"W_hi": hi.contiguous(), "W_lo": lo.contiguous(), "inv_scale": 2.0 ** (-exp)}
+    amax = W.abs().max()
+    ok = torch.isfinite(amax) & (amax > 0)
+    e_t = torch.where(ok, 11.0 - torch.floor(torch.log2(torch.where(ok, amax, torch.ones_like(amax)))), torch.zeros_like(amax)).clamp_(-24.0, 24.0)
+    scale_t = torch.exp2(e_t)
+    Ws = W * scale_t
     K = W.shape[1]
     Kp = (K + pad_to - 1) // pad_to * pad_to
     if Kp != K:
         Ws = torch.cat([Ws, Ws.new_zeros(W.shape[0], Kp - K)], dim=1)
     hi = Ws.half()
     lo = (Ws - hi.float()).half()
+    if not sync:
+        return {"W_hi": hi.contiguous(), "W_lo": lo.contiguous(), "inv_scale_t": torch.exp2(-e_t)}
+    e = float(e_t)
     return {"W_hi": hi.contiguous(), "W_lo": lo.contiguous(), "inv_scale": 2.0 ** (-e)}
+
+
+_SPLIT_EXP = {}          # weight storage -> [exponent, uses left]: see split_f16_training
+
+
+def split_f16_training(W, key, refresh=64, **kw):
+    """split_f16 for weights that change a little every step (the trainer's per-step splits): the power-of-two scale is taken from a cache
+    keyed on the parameter and recomputed -- one device reduction + host sync -- only every `refresh` uses.  The cached exponent leaves one
+    binade of headroom (max|W| * 2^e in [2^10, 2^11)), so the weights may double between refreshes before the leading term could overflow."""
+    ent = _SPLIT_EXP.get(key)
+    if ent is None or ent[1] <= 0:
+        import math
+        amax = float(W.detach().abs().max())
+        e = 0 if amax == 0.0 or not math.isfinite(amax) else 10 - math.floor(math.log2(amax))
+        ent = _SPLIT_EXP[key] = [max(-24, min(24, e)), refresh]
+    ent[1] -= 1
+    return split_f16(W, exp=ent[0], **kw)
 
 
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
@@ -442,8 +474,12 @@ def icp_point_to_point(src, tgt, R0, t0, max_corr_dist, max_iter=30, rel_fitness
     fit = torch.empty(B, dtype=torch.float32, device=src.device) if want_stats else None
     rmse = torch.empty(B, dtype=torch.float32, device=src.device) if want_stats else None
     iters = torch.empty(B, dtype=torch.int32, device=src.device) if want_stats else None
-    args = (_p(src), _p(tgt), B, N, Nt, _p(None if R0 is None else _f32(R0, "R0").contiguous()),
-            _p(None if t0 is None else _f32(t0, "t0").contiguous()), float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse),
+    # contiguous copies are bound to names that live until after the launch: a temporary's block would go back to the caching allocator at once
+    # and could be handed to the `ws` / output allocation below, i.e. be overwritten by the kernel that still reads it
+    R0c = None if R0 is None else _f32(R0, "R0").contiguous()
+    t0c = None if t0 is None else _f32(t0, "t0").contiguous()
+    args = (_p(src), _p(tgt), B, N, Nt, _p(R0c),
+            _p(t0c), float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse),
             _p(R), _p(t), _p(fit), _p(rmse), _p(iters))
     if engine is None:          # one workgroup per pair once there are enough pairs to fill the chip, the grid-wide sequence below that
         engine = "chip" if B >= 256 else "multi"
@@ -574,8 +610,9 @@ def kabsch_bwd(src, corr, w, gR, gt):
     src, corr, w = _f32(src, "src").contiguous(), _f32(corr, "corr").contiguous(), _f32(w, "w").reshape(B, J).contiguous()
     g_src, g_corr = torch.empty_like(src), torch.empty_like(corr)
     g_w = torch.empty((B, J), dtype=torch.float32, device=src.device)
-    _lib.call("ogmm_kabsch_bwd", _p(src), _p(corr), _p(w), B, J, _p(None if gR is None else _f32(gR, "gR").contiguous()),
-              _p(None if gt is None else _f32(gt, "gt").contiguous()), _p(g_src), _p(g_corr), _p(g_w), _stream())
+    gRc = None if gR is None else _f32(gR, "gR").contiguous()          # named: must outlive the launch (see icp_point_to_point)
+    gtc = None if gt is None else _f32(gt, "gt").contiguous()
+    _lib.call("ogmm_kabsch_bwd", _p(src), _p(corr), _p(w), B, J, _p(gRc), _p(gtc), _p(g_src), _p(g_corr), _p(g_w), _stream())
     return g_src, g_corr, g_w
 
 
@@ -583,7 +620,8 @@ def nearest_point(xyz, mu):
     C, N, _ = xyz.shape
     J = mu.shape[1]
     near = torch.empty((C, J), dtype=torch.int32, device=xyz.device)
-    _lib.call("ogmm_nearest_point", _p(_f32(xyz, "xyz")), _p(_f32(mu, "mu").contiguous()), C, N, J, _p(near), _stream())
+    xyz, mu = _f32(xyz, "xyz"), _f32(mu, "mu").contiguous()
+    _lib.call("ogmm_nearest_point", _p(xyz), _p(mu), C, N, J, _p(near), _stream())
     return near
 
 
@@ -598,7 +636,8 @@ def pos_features(xyz, idx, centroid):
     C, N, k = idx.shape
     d2 = torch.empty((C * N, 1), dtype=torch.float32, device=xyz.device)
     alpha = torch.empty((C * N * k, 1), dtype=torch.float32, device=xyz.device)
-    _lib.call("ogmm_pos_features", _p(_f32(xyz, "xyz")), _p(_i32(idx, "idx")), C, N, k, _p(_f32(centroid, "centroid").contiguous()), _p(d2), _p(alpha), _stream())
+    xyz, idx, centroid = _f32(xyz, "xyz"), _i32(idx, "idx"), _f32(centroid, "centroid").contiguous()
+    _lib.call("ogmm_pos_features", _p(xyz), _p(idx), C, N, k, _p(centroid), _p(d2), _p(alpha), _stream())
     return d2, alpha
 
 

@@ -156,7 +156,7 @@ class _Linear(torch.autograd.Function):
         if b is not None:
             layer["shift"] = b.detach().contiguous()
         if precision == "f16x3":
-            layer["split"] = ops.split_f16(layer["W"], frag=True, k1=K1)
+            layer["split"] = ops.split_f16_training(layer["W"], ("fwd", W.data_ptr(), tuple(Wd.shape)), frag=True, k1=K1)
         stats = None
         if stats_rows and precision == "f16x3" and stats_rows % 256 == 0 and W.shape[0] % 4 == 0 and stats_rows <= 131072:
             # the normalisation that follows needs sum / sum of squares per (row group, column): the engine's epilogue adds them up
@@ -190,7 +190,7 @@ class _Linear(torch.autograd.Function):
                 Wt = W.detach().t().contiguous()
                 if Wt.shape[0] % 4:
                     Wt = torch.cat([Wt, Wt.new_zeros(4 - Wt.shape[0] % 4, Wt.shape[1])], dim=0)
-                layer = {"W": Wt, "split": ops.split_f16(Wt, frag=True)}
+                layer = {"W": Wt, "split": ops.split_f16_training(Wt, ("bwd", W.data_ptr(), tuple(Wt.shape)), frag=True)}
                 dall = ops.conv1x1(dy.contiguous(), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
             else:
                 dall = dy @ W

@@ -74,6 +74,11 @@ class Trainer:
         if loss_scale is None:
             loss_scale = 65536.0 if getattr(model, "precision", "f32") == "f16x3" else 1.0
         self.loss_scale = float(loss_scale)
+        self.initial_loss_scale = self.loss_scale
+        self.min_loss_scale = 1.0            # floor: halving below 1 cannot help (the scale only protects small gradients)
+        self.growth_interval = 200           # clean steps after which a reduced scale doubles again (as torch's GradScaler)
+        self._clean_steps = 0
+        self.forward_overflows = 0
         self.skipped_steps = 0
 
     def _any_rank(self, flag):
@@ -94,18 +99,31 @@ class Trainer:
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
         out = self.model(src, tgt, fps_starts=fps_starts)
+        # The engine's overflow flag is shared by forward activations and backward gradients.  A FORWARD overflow (|activation| > 65504) is not
+        # something the loss scale can cure: read and clear the flag here, count it, and raise when it persists instead of halving the scale to zero.
+        if self.loss_scale != 1.0 and self._any_rank(self.model.fp16_overflowed()):
+            self.forward_overflows += 1
+            if self.forward_overflows > 8:
+                raise FloatingPointError("fp16x3 engine: forward activations beyond +-65504 in %d steps -- the loss scale cannot fix this; "
+                                         "use model.precision = 'f32' or rescale the inputs" % self.forward_overflows)
         loss, parts = self.local_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap)
+        self._backward_scale = self.loss_scale          # the scale this step's gradients carry (self.loss_scale may grow below)
         (loss * self.loss_scale).backward()
         overflowed = self.loss_scale != 1.0 and self._any_rank(self.model.fp16_overflowed())
         if overflowed:
             self.skipped_steps += 1
-            self.loss_scale *= 0.5
+            self.loss_scale = max(self.min_loss_scale, self.loss_scale * 0.5)
+            self._clean_steps = 0
             self.optimizer.zero_grad(set_to_none=True)
         else:
+            self._clean_steps += 1
+            if self.loss_scale < self.initial_loss_scale and self._clean_steps >= self.growth_interval:
+                self.loss_scale = min(self.initial_loss_scale, self.loss_scale * 2.0)
+                self._clean_steps = 0
             allreduce_gradients(self.model, self.dist, self.world)
-            if self.loss_scale != 1.0:
+            if self._backward_scale != 1.0:
                 grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-                torch._foreach_mul_(grads, 1.0 / self.loss_scale)          # one multi-tensor launch instead of 150 small ones
+                torch._foreach_mul_(grads, 1.0 / self._backward_scale)          # one multi-tensor launch instead of 150 small ones
             self.optimizer.step()
         broadcast_buffers(self.model, self.dist, self.world)
         with torch.no_grad():

@@ -34,7 +34,7 @@ if not time_only:
         shift = torch.randn(n, device=dev) if act else None
         kw = dict(res=res, ldr=(n if has_res else 0), scale=scale, shift=shift, act=act)
         outs = {}
-        for v in (23, 60, 90, 100, 110):
+        for v in (23, 60, 100):
             out = torch.full((m, n), float("nan"), device=dev)
             st = torch.zeros(((m + 1023) // 1024, n, 2), dtype=torch.float64, device=dev) if stats else None
             run(v, A, k1, W, m, n, out, A2=A2, k2=k2, split=sp, col_stats=st, group_rows=(1024 if stats else 0), **kw)
@@ -58,21 +58,12 @@ if not time_only:
         sdiff = 0.0
         if stats:
             sdiff = ((outs[60][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()
-        same7 = torch.equal(outs[90][0], outs[23][0])
-        nan7 = torch.isnan(outs[90][0]).sum().item()
-        print("M=%6d N=%4d K=%4d+%3d res=%d act=%d stats=%d : v6 err %.2e  v4 err %.2e (relative to sum|a||w|)  v6==v4 bitwise %s (max diff %.2e)  nan %d  stats rel diff %.1e  | v7==v4 bitwise %s (max diff %.2e, nan %d)" %
-              (m, n, k1, k2, has_res, act, stats, e6, e4, same, dmax, nan6, sdiff, same7, (outs[90][0] - outs[23][0]).abs().max().item(), nan7))
-        assert same7, "v7 differs from v4"
+        print("M=%6d N=%4d K=%4d+%3d res=%d act=%d stats=%d : v6 err %.2e  v4 err %.2e (relative to sum|a||w|)  v6==v4 bitwise %s (max diff %.2e)  nan %d  stats rel diff %.1e" %
+              (m, n, k1, k2, has_res, act, stats, e6, e4, same, dmax, nan6, sdiff))
         same8 = torch.equal(outs[100][0], outs[23][0])
         print("        v8==v4 bitwise %s (max diff %.2e, nan %d)%s" % (same8, (outs[100][0] - outs[23][0]).abs().max().item(), torch.isnan(outs[100][0]).sum().item(),
               ("  stats rel diff %.1e" % ((outs[100][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()) if stats else ""))
         assert same8, "v8 differs from v4"
-        same9 = torch.equal(outs[110][0], outs[23][0])
-        print("        v9==v4 bitwise %s (max diff %.2e, nan %d)%s" % (same9, (outs[110][0] - outs[23][0]).abs().max().item(), torch.isnan(outs[110][0]).sum().item(),
-              ("  stats rel diff %.1e" % ((outs[110][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()) if stats else ""))
-        d9 = ((outs[110][0][rows].double() - ref).abs() / mag).max().item()
-        print("        v9 err %.2e (v4 err %.2e)" % (d9, e4))
-        assert same9 or d9 < max(2e-6, 1.5 * e4), "v9 differs from v4"
         worst = max(worst, e6)
         assert nan6 == 0 and (same or e6 < max(2e-6, 1.2 * e4)), "v6 result off"
     print("v6 correctness OK, worst relative error %.2e" % worst)
@@ -111,7 +102,7 @@ if "--clock" in sys.argv:          # in-kernel clock probes (variants 80..86): t
     for rnd in range(2):
         for v in variants:
             for _ in range(3): run(v, A, k1, W, m, n, out, split=sp)
-            probe = L.ogmm_debug_v9_probe if v >= 110 else L.ogmm_debug_v8_probe if v >= 100 else (L.ogmm_debug_v7_probe if v >= 90 else L.ogmm_debug_v6_probe)
+            probe = L.ogmm_debug_v8_probe if v >= 100 else L.ogmm_debug_v6_probe
             torch.cuda.synchronize(); probe(buf)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
