@@ -191,13 +191,17 @@ def main():
                 c0 = time.perf_counter()
                 ref = O.forward(params_cpu, CFG, s_cpu, t_cpu, st_cpu)
                 times.append(time.perf_counter() - c0)
-            got = model(src[:n], tgt[:n], fps_starts=st_cpu)
+        # parity on the TIMED path: the first n pairs of the last timed step's outputs (eval-mode pairs are independent and the anchor draws are
+        # pinned per pair id, so pair i of the 64-pair forward is the same computation as the oracle's pair i) -- a separate n-pair forward would
+        # run the small-shape GEMM engines instead of the one this benchmark measures
+        got = [t_[:n] for t_ in out[:4]]
         result["cpu_baseline"] = {"value": n / statistics.median(times[1:]), "unit": "pairs/s", "cores": cores, "kind": "port",
                                   "sample": "first %d pairs of the same batch, CPU oracle forward, median of 2 after 1 warm-up" % n}
         result["parity"] = {"R_err_rad_max": O.rotation_error_rad(got[0].cpu(), ref[0]).max().item(),
                             "t_err_max": O.translation_error(got[1].cpu(), ref[1]).max().item(),
                             "overlap_err_max": max((got[2].cpu() - ref[2]).abs().max().item(), (got[3].cpu() - ref[3]).abs().max().item()),
-                            "pairs_checked": n, "against": "CPU oracle (bit-identical to the reference on its golden fixtures)"}
+                            "pairs_checked": n, "of": "the timed %d-pair forward itself (its first %d pairs)" % (B_PER_GPU, n),
+                            "against": "CPU oracle (bit-identical to the reference on its golden fixtures)"}
     result["fp16_split_overflowed"] = bool(model.fp16_overflowed())      # |activation| > 65504 clamped anywhere in the run?
     if rank == 0:
         print(json.dumps(result))

@@ -1,6 +1,6 @@
 // fp16x3 split GEMM, LDS-DMA structure, 8 (M) x 1 (N) waves: a wave owns 32 rows x all 256 columns of the 256 x 256 tile.
 //
-// Same operand path as gemm_f16x3_v6.hip (both operands by global_load_lds_dwordx4, activations 3 stages x [256][32] fp32 with the XOR chunk
+// Same operand path as gemm_f16x3_v6.hip (both operands by global_load_lds_dwordx4, activations as stages of [256][32] fp32 with the XOR chunk
 // swizzle, weights 2 stages of the fragment-major image, split of A in registers after the fragment read) -- but v6's 4 x 2 wave layout splits
 // every activation TWICE (the two waves that share a row block) and its loop turned out to be bound by instruction issue between the matrix
 // instructions, not by the operand traffic (PMC: SQ_ACTIVE_INST_VALU x3 against the MFMA-only loop, matrix pipe 65 % busy; clock probes:
@@ -25,15 +25,22 @@ constexpr int MT = 1, NT = 8, WM = 8, WN = 1;
 constexpr int BM = MT * 32 * WM, BN = NT * 32 * WN, T = WM * WN * 64;      // 256, 256, 512
 constexpr int A_STAGE = BM * BK8 * 4;                                        // 32768 B
 constexpr int B_STAGE = BN * BK8 * 2 * 2;                                    // 32768 B
-constexpr int A_STAGES = 3, B_STAGES = 2;
+// Two stages per operand (128 KiB): the activations are wave-private here, so the slot of stage t is free as soon as the wave has read its second
+// k16 block (group 1 of step t) and takes stage t+2 in groups 4-7 of the same step -- v6 needs a third stage because other waves may still be reading.
+// (Measured: 2 stages 121 k cycles per tile, 3 stages 123 k; a THIRD WEIGHT stage with the weights requested two steps ahead: 131 k -- slower.)
+// The InstanceNorm-fusing form (AFF) keeps the tile's [scale | shift] table of the A transform in the 32 KiB behind the rings.
+constexpr int A_STAGES = 2, B_STAGES = 2;
+constexpr int AFF_OFF = A_STAGES * A_STAGE + B_STAGES * B_STAGE, AFF_MAX_K = 4096;
 constexpr int B_OFF = A_STAGES * A_STAGE;
-constexpr int LDS_BYTES = A_STAGES * A_STAGE + B_STAGES * B_STAGE;          // 163840 B
+constexpr int LDS_BYTES = A_STAGES * A_STAGE + B_STAGES * B_STAGE;          // 131072 B (+ 32768 B with AFF)
 
 // clock probe (ablation 2048): every workgroup adds its duration in shader cycles (s_memtime) and in 100 MHz wall ticks: the ratio is the
 // shader clock the kernel actually ran at (the chip's power management picks it per workload; rocprofv3 pins it, so counters cannot tell)
 __device__ unsigned long long g_v8_probe[4];
 
-template <int ABL>
+// AFF: A is read as relu?(a * a_scale[group][k] + a_shift[group][k]) (InstanceNorm of the producing layer, models/attn.py:24-25), applied to the raw
+// fragment right after the ds_read, with the constants of the tile's row group staged once in LDS (a half wave reads the same 8 k: broadcast reads).
+template <int ABL, bool AFF>
 __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles, const int direct_stores) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
 
@@ -116,12 +123,29 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
     f32x4 ra[2];
     f16x8 ah[2], al[2];                    // [k16 block]
     f16x8 bh[2][2], bl[2][2];              // [group parity][column block of the pair]
+    f32x4 rsc[2], rsh[2];          // AFF: the 8 scales / shifts of the fragment's k positions
+    const float aff_lo = (AFF && g.a_relu) ? 0.0f : -__builtin_inff();
     auto read_a = [&](int tau, int s) {          // raw fp32 fragment of this wave's rows, k16 block s of stage tau
         const unsigned char* As = smem8 + (tau % A_STAGES) * A_STAGE + a_rd;
         ra[0] = *reinterpret_cast<const f32x4*>(As + (a_c0 ^ (s * 64)));
         ra[1] = *reinterpret_cast<const f32x4*>(As + (a_c1 ^ (s * 64)));
+        if (AFF) {
+            const int Kt = g.K1 + g.K2;
+            const int k0 = (tau < nk1 ? tau * BK8 : g.K1 + (tau - nk1) * BK8) + s * 16 + lh * 8;
+            const float* tab = reinterpret_cast<const float*>(smem8 + AFF_OFF) + k0;
+            rsc[0] = *reinterpret_cast<const f32x4*>(tab);
+            rsc[1] = *reinterpret_cast<const f32x4*>(tab + 4);
+            rsh[0] = *reinterpret_cast<const f32x4*>(tab + Kt);
+            rsh[1] = *reinterpret_cast<const f32x4*>(tab + Kt + 4);
+        }
     };
     auto split_a = [&](int s) {
+        if (AFF) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[h][e] = fmaxf(fmaf(ra[h][e], rsc[h][e], rsh[h][e]), aff_lo);
+        }
         f16x4 h0, l0, h1, l1;
         split4_f16_pure(ra[0], h0, l0, ovf);
         split4_f16_pure(ra[1], h1, l1, ovf);
@@ -142,6 +166,14 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
     issue_b(0);
     issue_a(0);
     if (nk > 1) issue_a(1);
+    if (AFF) {          // the tile's rows belong to one group (group_rows is a multiple of the tile): its K scales, then its K shifts
+        const int Kt = g.K1 + g.K2;
+        const float* __restrict__ sc = g.a_scale + (int64_t)(m0 / g.group_rows) * Kt;
+        const float* __restrict__ sh = g.a_shift + (int64_t)(m0 / g.group_rows) * Kt;
+        float* tab = reinterpret_cast<float*>(smem8 + AFF_OFF);
+        for (int i = tid; i < Kt; i += T) { tab[i] = sc[i]; tab[Kt + i] = sh[i]; }
+        __syncthreads();          // (the compiler's wait for these loads also drains the DMA issued above: it is needed right below anyway)
+    }
     // The activation rows a wave reads are the rows it staged itself: its own vmcnt orders them, no barrier.  A(0) landed (A(1) may be in flight):
     if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -217,7 +249,17 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
     // a wave's 32 x 256 slab: straight from the accumulators when it lies inside the matrix (the common case), else the general per-element form
     const bool inside = m0 + BM <= m_end && n0 + BN <= g.N && !g.row_affine;
     if (inside) {
-        gemm_epilogue_rowblock<NT>(gz, acc, m0 + wave * 32, n0, g.alpha);
+        float* stat_lds = reinterpret_cast<float*>(smem8);          // [8 waves][256 columns][2]: the rings are dead (barrier above)
+        gemm_epilogue_rowblock<NT>(gz, acc, m0 + wave * 32, n0, g.alpha, stat_lds);
+        if (g.col_stats) {
+            __syncthreads();
+            // thread = (statistic, column): add the eight waves' partial sums (fp64), one atomic per column and statistic per tile
+            const int c = tid & 255, which = tid >> 8;
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tot += (double)stat_lds[(w * 256 + c) * 2 + which];
+            atomicAdd(g.col_stats + ((int64_t)(m0 / g.group_rows) * g.N + n0 + c) * 2 + which, tot);
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -235,21 +277,21 @@ bool gemm_f16x3_v8_applicable(const ogmm_gemm& g) {
     const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch_outer;
     static const int enabled = [] { const char* e = getenv("OGMM_V8"); return e ? atoi(e) : 1; }();
     static const long long min_tiles = [] { const char* e = getenv("OGMM_V8_MIN_TILES"); return e ? atoll(e) : 256LL; }();
-    return enabled && g.pool_k == 0 && !g.a_scale && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
+    return enabled && g.pool_k == 0 && (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 
-template <int ABL>
+template <int ABL, bool AFF = false>
 static int launch_v8(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static const int direct = [] { const char* e = getenv("OGMM_V8_DIRECT"); return e ? atoi(e) : 1; }();
     static ogmm::PerDeviceOnce attr_once;          // per template instance and device
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL(gemm_f16x3_v8_kernel<ABL>, dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES, s, g, -m_tiles, n_tiles, direct);
+        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles, direct);
     else
-        hipLaunchKernelGGL(gemm_f16x3_v8_kernel<ABL>, dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES, s, g, m_tiles, n_tiles, direct);
+        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles, direct);
     return check_launch("ogmm_gemm_nt(f16x3 v8)");
 }
 
@@ -271,7 +313,7 @@ int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s) {
         case 102: return launch_v8<2048>(g, s);                 // clock probe
         case 103: return launch_v8<2048 + 8>(g, s);             // clock probe, no stores
         case 104: return launch_v8<2048 + 8 + 1>(g, s);         //   no DMA after the prologue
-        default: return launch_v8<0>(g, s);
+        default: return g.a_scale ? launch_v8<0, true>(g, s) : launch_v8<0>(g, s);
     }
 }
 

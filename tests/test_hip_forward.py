@@ -149,6 +149,31 @@ def test_reduced_precision_f16_mode():
 
 
 @pytest.mark.gpu
+def test_full_batch_matches_oracle_on_sampled_pairs():
+    """BASELINE configs[1] at its full size (64 pairs, N = 1024, J = 16): this is the only shape at which the large-shape GEMM engines (the LDS-DMA
+    engine with its fused column statistics / InstanceNorm-on-A forms) run, so the 64-pair forward itself is checked: pairs 0, 21, 42 and 63 of
+    its output against the CPU oracle run on each of those pairs alone (eval-mode pairs are independent; anchor draws pinned per pair)."""
+    B, N, J = 64, 1024, 16
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
+    model = GMMReg(512, J, cfg)
+    synth.fill_state_dict(model.state_dict())
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to("cuda:0").eval()
+    src, tgt, _, _ = synth.make_batch(0, B, N, "partial")
+    starts = synth.fps_starts_for(0, B, N)
+    with torch.no_grad():
+        R, t, so, to, _ = [x.cpu() for x in model(src.cuda(), tgt.cuda(), fps_starts=starts)]
+        worst = [0.0, 0.0, 0.0]
+        for i in (0, 21, 42, 63):
+            Ro, to_, soo, too, _ = O.forward(P, cfg, src[i:i + 1], tgt[i:i + 1], starts[:, i:i + 1])
+            worst[0] = max(worst[0], O.rotation_error_rad(R[i:i + 1], Ro).max().item())
+            worst[1] = max(worst[1], O.translation_error(t[i:i + 1], to_).max().item())
+            worst[2] = max(worst[2], (so[i:i + 1] - soo).abs().max().item(), (to[i:i + 1] - too).abs().max().item())
+    print("PARITY full batch (64 pairs) vs oracle on pairs 0/21/42/63: R %.2e rad  t %.2e  overlap %.2e" % tuple(worst))
+    assert worst[0] < 1e-5 and worst[1] < 1e-5 and worst[2] < 1e-5          # north_star: (R, t) within 1e-5 of the reference
+
+
+@pytest.mark.gpu
 def test_largest_supported_cloud_and_input_validation():
     """N = 4096 (the FPS / kNN kernels keep a whole cloud on chip: their documented ceiling), J = 64, against the CPU oracle; and the
     argument checks of the forward: wrong dtype, N_src != N_tgt, more neighbours / anchors / clusters than points."""

@@ -64,8 +64,26 @@ if not time_only:
         print("        v8==v4 bitwise %s (max diff %.2e, nan %d)%s" % (same8, (outs[100][0] - outs[23][0]).abs().max().item(), torch.isnan(outs[100][0]).sum().item(),
               ("  stats rel diff %.1e" % ((outs[100][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()) if stats else ""))
         assert same8, "v8 differs from v4"
+        if stats:
+            assert ((outs[100][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item() < 1e-5, "v8 column statistics differ from v4"
         worst = max(worst, e6)
         assert nan6 == 0 and (same or e6 < max(2e-6, 1.2 * e4)), "v6 result off"
+    # fused InstanceNorm on the A side (a_scale / a_shift per (row group, k)): v8 against v4
+    for (m, n, k1, k2, relu) in [(65536, 512, 1024, 0, True), (66560, 256, 512, 512, False)]:
+        A = torch.randn(m, k1, device=dev); A2 = torch.randn(m, k2, device=dev) if k2 else None
+        W = torch.randn(n, k1 + k2, device=dev) * 0.05
+        sp = ops.split_f16(W, frag=True, k1=(k1 if k2 else None))
+        G = m // 1024
+        asc = torch.rand(G, k1 + k2, device=dev) + 0.5; ash = torch.randn(G, k1 + k2, device=dev)
+        res = torch.randn(m, n, device=dev)
+        outs = {}
+        for v in (23, 100):
+            out = torch.full((m, n), float("nan"), device=dev)
+            run(v, A, k1, W, m, n, out, A2=A2, k2=k2, split=sp, a_affine=(asc, ash, relu), group_rows=1024, res=res, ldr=n)
+            torch.cuda.synchronize(); outs[v] = out
+        same = torch.equal(outs[23], outs[100])
+        print("A-side InstanceNorm M=%d N=%d K=%d+%d relu=%d: v8==v4 bitwise %s (max diff %.2e, nan %d)" % (m, n, k1, k2, relu, same, (outs[23] - outs[100]).abs().max().item(), torch.isnan(outs[100]).sum().item()))
+        assert same, "v8 AFF differs from v4"
     print("v6 correctness OK, worst relative error %.2e" % worst)
 
 if "--grid-sweep" in sys.argv:          # the same tile work on 1/4, 1/2 and all of the chip's CUs, one tile per workgroup: is the operand path a per-CU or a chip-wide limit?
@@ -139,3 +157,19 @@ for name, m, n, k1, k2 in shapes:
     for v in variants:
         row += "  v%-2d %6.1f TF (%6.3f ms)" % (v, 2.0 * m * n * (k1 + k2) / best[v] / 1e9, best[v])
     print(row, flush=True)
+# the InstanceNorm-fusing consumer (mlp3: 512 x 1024 with the A transform)
+m, n, k1 = M, 512, 1024
+A = torch.randn(m, k1, device=dev); W = torch.randn(n, k1, device=dev) * 0.03; out = torch.empty(m, n, device=dev); sp = ops.split_f16(W, frag=True)
+asc = torch.rand(m // 1024, k1, device=dev) + 0.5; ash = torch.randn(m // 1024, k1, device=dev)
+row = "%-22s" % "mlp3 + A transform"
+for v in [x for x in variants if x in (23, 100)]:
+    best_v = 1e9
+    for rnd in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run(v, A, k1, W, m, n, out, split=sp, a_affine=(asc, ash, True), group_rows=1024)
+        e1.record(); torch.cuda.synchronize()
+        best_v = min(best_v, e0.elapsed_time(e1) / 5)
+    row += "  v%-2d %6.1f TF (%6.3f ms)" % (v, 2.0 * m * n * k1 / best_v / 1e9, best_v)
+print(row, flush=True)
