@@ -42,7 +42,7 @@ CFG = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_
 B_PER_GPU, N_POINTS, J = 64, 1024, 16
 
 
-def pmc_traffic_bytes(kernel_substr, path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_counters.txt")):
+def pmc_traffic_bytes(kernel_substr, path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_counters.txt")):
     """HBM bytes per launch of `kernel_substr` from the committed PMC summary: FETCH_SIZE (KiB, doubled: the gfx950 correction of
     MI355X_MICROARCH.md) + WRITE_SIZE (KiB); None when the file or the kernel is absent."""
     try:
@@ -133,11 +133,12 @@ def main():
     gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
-    kernel = {"f16x3": "gemm_f16x3_v4_kernel (256x256x64, 3x v_mfma_f32_32x32x16_f16 per block; v2 <2,2,2,2> for small shapes)",
+    kernel = {"f16x3": "gemm_f16x3_v8_kernel (LDS-DMA engine: 256x256x32 tiles, both operands by global_load_lds, 3x v_mfma_f32_32x32x16_f16 per block; "
+                       "gemm_f16x3_v2 <2,2,2,2> for shapes under 256 tiles)",
               "f16": "gemm_f16x3_v4_kernel in single-term mode (1x v_mfma_f32_32x32x16_f16 per block; REDUCED precision)",
               "f32": "gemm_nt_kernel<2,2,2,2,false> (v_mfma_f32_32x32x2_f32)"}[args.precision]
 
-    traffic = pmc_traffic_bytes("gemm_f16x3_v4_kernel") if args.precision == "f16x3" and args.workload == "cfg1" else None
+    traffic = pmc_traffic_bytes("gemm_f16x3_v8_kernel") if args.precision == "f16x3" and args.workload == "cfg1" else None
 
     result = {
         "metric": "pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +153,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": traffic,
                      "traffic_note": None if traffic is None else "HBM bytes per launch of the dominant kernel (mean over the forward's launches) from the "
-                                     "committed rocprofv3 PMC passes of this command (profiles/round1_pmc_counters.txt): 2 x FETCH_SIZE (gfx950 "
+                                     "committed rocprofv3 PMC passes of this command (profiles/round2_pmc_counters.txt): 2 x FETCH_SIZE (gfx950 "
                                      "correction) + WRITE_SIZE; the algorithmic bytes of the same launches are in `algorithmic_bytes_per_launch`",
                      "algorithmic_bytes_per_launch": gemm_bytes / max(1, len(dom)),
                      "kernel": kernel, "launches": len(dom), "avg_launch_us": 1e3 * gemm_ms / max(1, len(dom)),

@@ -192,6 +192,87 @@ def test_gemm_two_pieces_epilogue_residual(ops, engine):
         assert (out.cpu().double() - ref).abs().max().item() < 2e-5
 
 
+# ---- the LDS-DMA engine (gemm_f16x3_v8.hip) only takes shapes of >= 256 tiles of 256 x 256: these run it on purpose
+LARGE = [  # M, N, K1, K2, residual, act, what
+    (65536, 256, 64, 0, False, "none", "one K step pair, exact tiles"),
+    (65536, 256, 32, 0, False, "relu", "a single K step"),
+    (65536 + 77, 512, 128, 32, True, "leaky", "ragged last row tile, second A piece, residual"),
+    (32768, 768, 128, 0, True, "sigmoid", "three column tiles, sigmoid"),
+    (33000, 600, 64, 64, False, "relu", "ragged rows AND ragged columns (per-element epilogue), two pieces"),
+]
+
+
+@pytest.mark.parametrize("M,N,K1,K2,has_res,act,what", LARGE)
+def test_gemm_lds_dma_engine(ops, M, N, K1, K2, has_res, act, what):
+    torch.manual_seed(M + N + K1)
+    A1 = torch.relu(torch.randn(M, K1, device="cuda")) * (torch.rand(M, 1, device="cuda") * 3)
+    A2 = torch.randn(M, K2, device="cuda") if K2 else None
+    W = torch.randn(N, K1 + K2, device="cuda") * 0.05
+    scale, shift = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda")
+    res = torch.randn(M, N, device="cuda") if has_res else None
+    out = torch.full((M, N), float("nan"), device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY02, "sigmoid": ops.ACT_SIGMOID}[act]
+    ops.gemm_nt(A1, K1, K1, None, K1 + K2, M, N, C=out, ldc=N, A2=A2, lda2=K2, K2=K2, scale=scale, shift=shift, act=code, res=res, ldr=N if has_res else 0,
+                split=ops.split_f16(W, frag=True, k1=(K1 if K2 else None)), overflow=flag)
+    rows = torch.cat([torch.arange(0, 300), torch.randint(0, M, (600,)), torch.arange(M - 300, M)]).cuda()
+    Af = (A1[rows] if A2 is None else torch.cat([A1[rows], A2[rows]], 1)).double()
+    acc = Af @ W.double().t()
+    pre = acc * scale.double() + shift.double()
+    ref = {"none": lambda v: v, "relu": torch.relu, "leaky": lambda v: torch.where(v > 0, v, 0.2 * v), "sigmoid": torch.sigmoid}[act](pre)
+    if has_res:
+        ref = ref + res[rows].double()
+    bound = 6e-7 * ((Af.abs() @ W.double().abs().t()) * scale.double() + shift.double().abs() + (res[rows].double().abs() if has_res else 0)) + 1e-7
+    got = out[rows].double()
+    assert not torch.isnan(out).any(), what
+    assert ((got - ref).abs() / bound).max().item() < 1.0, what
+    assert int(flag.item()) == 0
+    # the same shape on the register-staged engines must agree to the last bit (same products in the same order per accumulator)
+    out2 = torch.empty_like(out)
+    sp = ops.split_f16(W, frag=True, k1=(K1 if K2 else None)); sp["variant"] = 21            # 128 x 128 tiles (gemm_f16x3_v2.hip)
+    ops.gemm_nt(A1, K1, K1, None, K1 + K2, M, N, C=out2, ldc=N, A2=A2, lda2=K2, K2=K2, scale=scale, shift=shift, act=code, res=res, ldr=N if has_res else 0, split=sp)
+    assert torch.equal(out, out2), what
+
+
+def test_gemm_lds_dma_engine_statistics_a_transform_batch_overflow(ops):
+    """Column statistics in the epilogue (producer of an InstanceNorm), the normalisation applied to A (its consumer), outer batching with a
+    per-batch weight image, and the binary16 overflow flag -- all on shapes the LDS-DMA engine takes."""
+    torch.manual_seed(5)
+    G, rows, N, K = 64, 1024, 256, 128
+    M = G * rows
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") * 0.05
+    b = torch.randn(N, device="cuda")
+    st = torch.zeros((G, N, 2), dtype=torch.float64, device="cuda")
+    z = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(A, K, K, None, K, M, N, C=z, ldc=N, shift=b, split=ops.split_f16(W, frag=True), col_stats=st, group_rows=rows)
+    zg = z.view(G, rows, N).double()
+    assert (st[:, :, 0] - zg.sum(1)).abs().max().item() < 1e-6 * rows and ((st[:, :, 1] - (zg * zg).sum(1)).abs() / (zg * zg).sum(1)).max().item() < 1e-6
+    sc, sh = ops.instnorm_finalize(st, rows, 1e-5)
+    W2 = torch.randn(N, N, device="cuda") * 0.05
+    res = torch.randn(M, N, device="cuda")
+    y = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(z, N, N, None, N, M, N, C=y, ldc=N, split=ops.split_f16(W2, frag=True), a_affine=(sc, sh, True), group_rows=rows, res=res, ldr=N)
+    zn = torch.relu((zg - zg.mean(1, keepdim=True)) / torch.sqrt(zg.var(1, unbiased=False, keepdim=True) + 1e-5)).view(M, N)
+    ref = zn @ W2.double().t() + res.double()
+    assert (y.double() - ref).abs().max().item() < 2e-5
+    # batched: 4 problems of 16384 x 1024 x 64 with their own weight images (the similarity GEMM's form)
+    Bn, Mb, Nb, Kb = 4, 16384, 1024, 64
+    Ab = torch.randn(Bn, Mb, Kb, device="cuda"); Wb = torch.randn(Bn, Nb, Kb, device="cuda")
+    imgs = [ops.split_f16(Wb[i], frag=True) for i in range(Bn)]
+    img = {"W_hi": torch.stack([im["W_hi"] for im in imgs]).contiguous(), "W_lo": torch.stack([im["W_lo"] for im in imgs]).contiguous(), "inv_scale": imgs[0]["inv_scale"],
+           "variant": imgs[0]["variant"], "ldb_h": imgs[0]["ldb_h"], "sB": imgs[0]["W_hi"].numel()}
+    if all(im["inv_scale"] == imgs[0]["inv_scale"] for im in imgs):
+        Cb = torch.empty(Bn, Mb, Nb, device="cuda")
+        ops.gemm_nt(Ab, Kb, Kb, None, Kb, Mb, Nb, C=Cb, ldc=Nb, batch=(Bn, 1), sA=(Mb * Kb, 0), sC=(Mb * Nb, 0), split=img)
+        refb = torch.einsum("bmk,bnk->bmn", Ab[:, :512].double(), Wb.double())
+        assert (Cb[:, :512].double() - refb).abs().max().item() < 2e-5
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    A[777, 5] = 1e5
+    ops.gemm_nt(A, K, K, None, K, M, N, C=z, ldc=N, split=ops.split_f16(W, frag=True), overflow=flag)
+    assert int(flag.item()) == 1
+
+
 def test_gemm_batched_strided_row_affine(ops):
     torch.manual_seed(1)
     Co, Hh, N, M, dh = 3, 4, 130, 32, 16
