@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 8
+#define OGMM_ABI_VERSION 9
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -77,6 +77,10 @@ int ogmm_gather_rows(const float* feats, int64_t ld, int C, int N, int D, const 
  *   (binary16 [N][ldb_h], ldb_h a multiple of 8, columns beyond K zero) possibly pre-scaled by a power of two
  *   that the caller folds into alpha.  |A| must stay below 65504: larger values are clamped and *overflow
  *   (device int, optional) is set non-zero. */
+/* Engines behind OGMM_PREC_F16X3_FRAG (chosen by shape, same arithmetic and bit-identical results): >= 256 tiles of 256 x 256 with K1, K2
+ * multiples of 32 run on the LDS-DMA engine (gemm_f16x3_v8.hip: both operands by global_load_lds, activations split in registers; the
+ * InstanceNorm forms included, K1 + K2 <= 4096 with a_scale); other large shapes on the register-staged engine (gemm_f16x3_v4.hip); small
+ * ones on 128 x 128 / 256 x 256 tiles (gemm_f16x3_v2.hip). */
 enum { OGMM_ACT_NONE = 0, OGMM_ACT_RELU = 1, OGMM_ACT_LEAKY02 = 2, OGMM_ACT_SIGMOID = 3 };
 enum { OGMM_PREC_F32 = 0, OGMM_PREC_F16X3 = 1, OGMM_PREC_F16X3_FRAG = 2, OGMM_PREC_F16_FRAG = 3 };
 /* OGMM_PREC_F16_FRAG (reduced precision, for BASELINE configs[2] which is quoted in bf16): the operands of OGMM_PREC_F16X3_FRAG, but
@@ -335,6 +339,13 @@ int ogmm_pos_features(const float* xyz, const int32_t* idx, int C, int N, int k,
 
 /* ---- T7: backward of ogmm_l2norm_rows (models/gmmreg.py:74): dx = g/n - x (x.g)/n^3, n = max(|x|, 1e-12). */
 int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t rows, int D, float* dx, int64_t lddx, void* stream);
+
+/* ---- diagnostics (tools/gemm_v6_check.py; not part of the hot path).  The large-shape GEMM engines have ablation builds selected by
+ * `precision` codes 60..86 (gemm_f16x3_v6.hip) and 100..104 (gemm_f16x3_v8.hip) whose workgroups add their duration in shader cycles and in
+ * 100 MHz wall ticks to a device counter: host3 = {cycles, ticks, workgroups} since the last call (read and cleared).  The ratio is the shader
+ * clock the kernel really ran at -- rocprofv3 pins the clock, so its counters cannot tell. */
+int ogmm_debug_v6_probe(unsigned long long* host3);
+int ogmm_debug_v8_probe(unsigned long long* host3);
 
 #ifdef __cplusplus
 }

@@ -234,7 +234,7 @@ class GMMReg(nn.Module):
     # load_state_dict, .to(); in-place edits through `.data` (EMA swaps, manual copies) do NOT bump _version, so the key also carries a
     # content fingerprint -- one device-side reduction over all tensors, re-checked every `fingerprint_every` forwards -- and train() / eval() /
     # load_state_dict() invalidate explicitly.  Call `invalidate_packed()` after editing weights through `.data` when the next forward must see it.
-    fingerprint_every = 16
+    fingerprint_every = 64
 
     def invalidate_packed(self):
         self._packed = None
@@ -250,8 +250,14 @@ class GMMReg(nn.Module):
 
     @staticmethod
     def _fingerprint(tensors):
+        """Two multi-tensor launches (L1 and L2 norms of every parameter / buffer) + a handful of small ones: a per-tensor python loop costs ~700
+        launches (2.5 ms) here, which showed up in the step time."""
         with torch.no_grad():
-            return torch.stack([t.detach().double().sum() + 3.0 * t.detach().double().abs().sum() for t in tensors]).sum()
+            ts = [t.detach() for t in tensors if t.is_floating_point()]
+            n1 = torch.stack(torch._foreach_norm(ts, 1)).double()
+            n2 = torch.stack(torch._foreach_norm(ts, 2)).double()
+            w = torch.arange(1, len(ts) + 1, dtype=torch.float64, device=n1.device)          # position weights: swapping two tensors' contents is seen too
+            return torch.stack([(n1 * w).sum(), (n2 * w).sum()])
 
     def _layers(self):
         sd = self.state_dict()

@@ -71,6 +71,37 @@ def test_pack_weights_head_permutation_and_bn_fold():
     assert torch.allclose(ref, got, atol=2e-6)
 
 
+def test_packed_weight_cache_follows_every_kind_of_edit():
+    """The eval forward runs on folded / split weights cached per model.  The cache must notice optimizer-style in-place edits (tensor
+    _version), edits through `.data` (no _version bump: content fingerprint, explicit invalidate), load_state_dict and train()/eval()."""
+    m = GMMReg(512, 16, CFG).eval()
+    synth.fill_state_dict(m.state_dict())
+    L0 = m._layers()
+    assert m._layers() is L0                                                  # unchanged weights: cached
+    hi0 = L0["proj"]["0"]["split"]["W_hi"].clone()                            # (the fp32 "W" entries may alias the parameters: compare the split images)
+    with torch.no_grad():
+        m.state_dict()["proj.net.0.weight"].mul_(1.5)                          # bumps _version
+    L1 = m._layers()
+    assert L1 is not L0 and not torch.equal(L1["proj"]["0"]["split"]["W_hi"], hi0)
+    m.fingerprint_every = 1
+    p = dict(m.named_parameters())["conv1.net.0.weight"]
+    c1 = L1["conv1"]["0"]["W"].clone()
+    p.data.mul_(2.0)                                                          # invisible to (data_ptr, _version)
+    L2 = m._layers()
+    assert L2 is not L1 and torch.equal(L2["conv1"]["0"]["W"], 2.0 * c1)
+    m.fingerprint_every = 0                                                   # checks off: only the explicit call helps
+    p.data.mul_(0.5)
+    assert m._layers() is L2
+    m.invalidate_packed()
+    L3 = m._layers()
+    assert L3 is not L2 and torch.equal(L3["conv1"]["0"]["W"], c1)
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    assert m._packed is None                                                  # load_state_dict invalidates
+    m._layers(); m.train(); assert m._packed is None
+    m.eval(); m._layers(); assert m._packed is not None
+    assert "conv2_6_overlap_0" in m._layers() and m._layers()["conv2_6_overlap_0"]["W"].shape == (256, 1024)
+
+
 def test_product_path_refuses_cpu_and_train_mode():
     m = GMMReg(512, 16, CFG).eval()
     x = torch.zeros(1, 3, 128)
