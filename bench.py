@@ -110,9 +110,18 @@ def main():
     def barrier():
         odist.barrier(dist)
 
+    dom_tag = "f16x3" if args.precision == "f16" else args.precision
     with torch.no_grad():
         for _ in range(args.warmup):
             out = model(src, tgt, fps_starts=starts)
+        # The dominant kernel's launches are bracketed by HIP events inside the timed region (roofline.achieved).  Only those launches, and with
+        # events made beforehand: creating two events per launch in the loop costs the host more than the launch (measured: 0.3 ms per step).
+        ops.GEMM_TIMELINE, ops.GEMM_TIMELINE_ONLY = [], {dom_tag}
+        out = model(src, tgt, fps_starts=starts)          # one more warm-up forward: counts the bracketed launches
+        per_step = len(ops.GEMM_TIMELINE)
+        ops.recycle_timing_events(ops.GEMM_TIMELINE)
+        ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * per_step * args.steps))
+        torch.cuda.synchronize()
         barrier()
         ops.GEMM_TIMELINE = []
         t0 = time.perf_counter()
@@ -120,14 +129,13 @@ def main():
             out = model(src, tgt, fps_starts=starts)
         barrier()
         elapsed = time.perf_counter() - t0
-        timeline, ops.GEMM_TIMELINE = ops.GEMM_TIMELINE, None
+        timeline, ops.GEMM_TIMELINE, ops.GEMM_TIMELINE_ONLY = ops.GEMM_TIMELINE, None, None
     elapsed = odist.max_over_ranks(dist, elapsed, dev)
 
     pairs = B_PER_GPU * world * args.steps
     value = pairs / elapsed
     all_gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in timeline)
     all_gemm_flop = sum(f for _, _, f, _, _ in timeline)
-    dom_tag = "f16x3" if args.precision == "f16" else args.precision
     dom = [(e0.elapsed_time(e1), f) for e0, e1, f, v, _ in timeline if v == dom_tag]
     gemm_bytes = sum(b for _, _, _, v, b in timeline if v == dom_tag)     # un-pooled, N > 64 launches of the engine
     gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)

@@ -13,6 +13,18 @@ from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16_FRAG, P
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_flops)
 GEMM_TIMELINE = None
+GEMM_TIMELINE_ONLY = None      # optional set of variant tags: only those launches are bracketed by events (bench.py: the dominant engine only)
+_EVENT_POOL = []               # timing events are recycled: creating two torch events per launch costs more host time than the launch itself
+
+
+def _timing_event():
+    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+
+
+def recycle_timing_events(timeline):
+    """hand the events of a consumed GEMM_TIMELINE back to the pool"""
+    for e0, e1, *_ in timeline:
+        _EVENT_POOL.append(e0); _EVENT_POOL.append(e1)
 
 # engine selection for layers that carry pre-split weights (set by GMMReg.forward from model.precision)
 DEFAULT_SPLIT = True
@@ -194,16 +206,18 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
         d.col_stats = col_stats.data_ptr()
     if a_affine is not None:
         d.a_scale, d.a_shift, d.a_relu = a_affine[0].data_ptr(), a_affine[1].data_ptr(), 1 if a_affine[2] else 0
-    if GEMM_TIMELINE is None:
+    variant = None
+    if GEMM_TIMELINE is not None:
+        variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
+        if split is not None and split.get("variant", 1) != PREC_F16X3_FRAG and batch == (1, 1) and not pool_k:
+            variant += "_rowmajor"
+    if GEMM_TIMELINE is None or (GEMM_TIMELINE_ONLY is not None and variant not in GEMM_TIMELINE_ONLY):
         _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = _timing_event(), _timing_event()
     e0.record()
     _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
     e1.record()
-    variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
-    if split is not None and split.get("variant", 1) != PREC_F16X3_FRAG and batch == (1, 1) and not pool_k:
-        variant += "_rowmajor"
     # flops, then the launch's algorithmic HBM bytes: A (and A2) read once, C written once, residual read once, weights once
     nb = batch[0] * batch[1]
     abytes = 4.0 * nb * (M * (K1 + K2) + (M * N if store_c else 0) + (M * N if res is not None else 0)) + 4.0 * N * (K1 + K2) * (nb if batch != (1, 1) else 1)
