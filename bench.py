@@ -46,18 +46,20 @@ def pmc_traffic_bytes(kernel_substr, path=os.path.join(os.path.dirname(os.path.a
     """HBM bytes per launch of `kernel_substr` from the committed PMC summary: FETCH_SIZE (KiB, doubled: the gfx950 correction of
     MI355X_MICROARCH.md) + WRITE_SIZE (KiB); None when the file or the kernel is absent."""
     try:
-        fetch = write = None
+        tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        calls = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
         section = None
         for line in open(path):
             if line.startswith("## pass:"):
                 section = line.split(":", 1)[1].split()
             elif kernel_substr in line and section in (["FETCH_SIZE"], ["WRITE_SIZE"]):
-                val = float(line.split()[-1])
-                if section == ["FETCH_SIZE"]:
-                    fetch = val
-                else:
-                    write = val
-        return None if fetch is None or write is None else (2.0 * fetch + write) * 1024.0
+                tok = line.split()          # <kernel name ...> <launches> <avg us> <counter mean per launch>
+                n, val = float(tok[-3]), float(tok[-1])
+                tot[section[0]] += n * val          # every template instance of the kernel, weighted by its launches
+                calls[section[0]] += n
+        if not calls["FETCH_SIZE"] or not calls["WRITE_SIZE"]:
+            return None
+        return (2.0 * tot["FETCH_SIZE"] / calls["FETCH_SIZE"] + tot["WRITE_SIZE"] / calls["WRITE_SIZE"]) * 1024.0
     except OSError:
         return None
 
