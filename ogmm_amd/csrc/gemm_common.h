@@ -337,11 +337,11 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
 // from the accumulator layout (lane = column, register = row: the 32 lanes of a half wave write one 128-byte row segment -- a full line --
 // per store), no LDS for the values.  Requires the slab to be inside the matrix, per-column scale / shift, no pooling.  Column statistics
 // (InstanceNorm fusion): a lane sums its 16 rows, the two half waves are folded with one cross-lane move, and the wave's NB * 32 partial sums go
-// to `stat_lds` ([wave][NB * 32][2] floats, the caller's K loop is over): the caller adds the eight waves up and issues ONE fp64 atomic per
+// to `stat_lds` ([row block = stat_slot, by default the wave][NB * 32][2] floats, the caller's K loop is over): the caller adds the eight waves up and issues ONE fp64 atomic per
 // column and statistic per tile (per wave it would be 4096 atomics per tile: measured +10 % on the 1024-wide layers that feed a normalisation).
 template <int NB>
-__device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, int col0, float alpha, float* stat_lds) {
-    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, int col0, float alpha, float* stat_lds, int stat_slot = -1) {
+    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5, wave = stat_slot >= 0 ? stat_slot : (int)(threadIdx.x >> 6);
     float* __restrict__ Cm = g.C;
     const float* __restrict__ Rm = g.Res;
     const bool stats = g.col_stats != nullptr;

@@ -277,7 +277,8 @@ bool gemm_f16x3_v8_applicable(const ogmm_gemm& g) {
     const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch_outer;
     static const int enabled = [] { const char* e = getenv("OGMM_V8"); return e ? atoi(e) : 1; }();
     static const long long min_tiles = [] { const char* e = getenv("OGMM_V8_MIN_TILES"); return e ? atoll(e) : 256LL; }();
-    return enabled && g.pool_k == 0 && (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
+    const bool whole_tiles = g.M % BM == 0 && g.N % BN == 0 && !g.row_affine;          // the statistics come out of the row-block epilogue only
+    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 

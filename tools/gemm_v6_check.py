@@ -34,7 +34,7 @@ if not time_only:
         shift = torch.randn(n, device=dev) if act else None
         kw = dict(res=res, ldr=(n if has_res else 0), scale=scale, shift=shift, act=act)
         outs = {}
-        for v in (23, 60, 100):
+        for v in (23, 60, 100, 110):
             out = torch.full((m, n), float("nan"), device=dev)
             st = torch.zeros(((m + 1023) // 1024, n, 2), dtype=torch.float64, device=dev) if stats else None
             run(v, A, k1, W, m, n, out, A2=A2, k2=k2, split=sp, col_stats=st, group_rows=(1024 if stats else 0), **kw)
@@ -64,6 +64,12 @@ if not time_only:
         print("        v8==v4 bitwise %s (max diff %.2e, nan %d)%s" % (same8, (outs[100][0] - outs[23][0]).abs().max().item(), torch.isnan(outs[100][0]).sum().item(),
               ("  stats rel diff %.1e" % ((outs[100][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()) if stats else ""))
         assert same8, "v8 differs from v4"
+        same10 = torch.equal(outs[110][0], outs[23][0])
+        print("        v10==v4 bitwise %s (max diff %.2e, nan %d)%s" % (same10, (outs[110][0] - outs[23][0]).abs().max().item(), torch.isnan(outs[110][0]).sum().item(),
+              ("  stats rel diff %.1e" % ((outs[110][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item()) if stats else ""))
+        assert same10, "v10 differs from v4"
+        if stats:
+            assert ((outs[110][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item() < 1e-5, "v10 column statistics differ from v4"
         if stats:
             assert ((outs[100][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item() < 1e-5, "v8 column statistics differ from v4"
         worst = max(worst, e6)
@@ -77,10 +83,11 @@ if not time_only:
         asc = torch.rand(G, k1 + k2, device=dev) + 0.5; ash = torch.randn(G, k1 + k2, device=dev)
         res = torch.randn(m, n, device=dev)
         outs = {}
-        for v in (23, 100):
+        for v in (23, 100, 110):
             out = torch.full((m, n), float("nan"), device=dev)
             run(v, A, k1, W, m, n, out, A2=A2, k2=k2, split=sp, a_affine=(asc, ash, relu), group_rows=1024, res=res, ldr=n)
             torch.cuda.synchronize(); outs[v] = out
+        assert torch.equal(outs[23], outs[110]), "v10 AFF differs from v4 (max diff %.2e)" % (outs[23] - outs[110]).abs().max().item()
         same = torch.equal(outs[23], outs[100])
         print("A-side InstanceNorm M=%d N=%d K=%d+%d relu=%d: v8==v4 bitwise %s (max diff %.2e, nan %d)" % (m, n, k1, k2, relu, same, (outs[23] - outs[100]).abs().max().item(), torch.isnan(outs[100]).sum().item()))
         assert same, "v8 AFF differs from v4"
@@ -120,7 +127,7 @@ if "--clock" in sys.argv:          # in-kernel clock probes (variants 80..86): t
     for rnd in range(2):
         for v in variants:
             for _ in range(3): run(v, A, k1, W, m, n, out, split=sp)
-            probe = L.ogmm_debug_v8_probe if v >= 100 else L.ogmm_debug_v6_probe
+            probe = L.ogmm_debug_v10_probe if v >= 110 else (L.ogmm_debug_v8_probe if v >= 100 else L.ogmm_debug_v6_probe)
             torch.cuda.synchronize(); probe(buf)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -162,7 +169,7 @@ m, n, k1 = M, 512, 1024
 A = torch.randn(m, k1, device=dev); W = torch.randn(n, k1, device=dev) * 0.03; out = torch.empty(m, n, device=dev); sp = ops.split_f16(W, frag=True)
 asc = torch.rand(m // 1024, k1, device=dev) + 0.5; ash = torch.randn(m // 1024, k1, device=dev)
 row = "%-22s" % "mlp3 + A transform"
-for v in [x for x in variants if x in (23, 100)]:
+for v in [x for x in variants if x in (23, 100, 110)]:
     best_v = 1e9
     for rnd in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
