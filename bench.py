@@ -52,7 +52,7 @@ def pmc_traffic_bytes(kernel_substr, path=os.path.join(os.path.dirname(os.path.a
         for line in open(path):
             if line.startswith("## pass:"):
                 section = line.split(":", 1)[1].split()
-            elif kernel_substr in line and section in (["FETCH_SIZE"], ["WRITE_SIZE"]):
+            elif any(k in line for k in ((kernel_substr,) if isinstance(kernel_substr, str) else kernel_substr)) and section in (["FETCH_SIZE"], ["WRITE_SIZE"]):
                 tok = line.split()          # <kernel name ...> <launches> <avg us> <counter mean per launch>
                 n, val = float(tok[-3]), float(tok[-1])
                 tot[section[0]] += n * val          # every template instance of the kernel, weighted by its launches
@@ -143,12 +143,12 @@ def main():
     gemm_ms, gemm_flop = sum(d for d, _ in dom), sum(f for _, f in dom)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.precision]
-    kernel = {"f16x3": "gemm_f16x3_v8_kernel (LDS-DMA engine: 256x256x32 tiles, both operands by global_load_lds, 3x v_mfma_f32_32x32x16_f16 per block; "
-                       "gemm_f16x3_v2 <2,2,2,2> for shapes under 256 tiles)",
+    kernel = {"f16x3": "gemm_f16x3_v10_kernel / gemm_f16x3_v8_kernel (LDS-DMA engine: 256x256x32 tiles, both operands by global_load_lds, 3x v_mfma_f32_32x32x16_f16 "
+                       "per block; v10 = 4 waves of 64x256 for N >= 512, v8 = 8 waves of 32x256 for N = 256; gemm_f16x3_v2 <2,2,2,2> for shapes under 256 tiles)",
               "f16": "gemm_f16x3_v4_kernel in single-term mode (1x v_mfma_f32_32x32x16_f16 per block; REDUCED precision)",
               "f32": "gemm_nt_kernel<2,2,2,2,false> (v_mfma_f32_32x32x2_f32)"}[args.precision]
 
-    traffic = pmc_traffic_bytes("gemm_f16x3_v8_kernel") if args.precision == "f16x3" and args.workload == "cfg1" else None
+    traffic = pmc_traffic_bytes(("gemm_f16x3_v10_kernel", "gemm_f16x3_v8_kernel")) if args.precision == "f16x3" and args.workload == "cfg1" else None
 
     result = {
         "metric": "pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

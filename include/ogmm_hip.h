@@ -341,7 +341,7 @@ int ogmm_pos_features(const float* xyz, const int32_t* idx, int C, int N, int k,
 int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t rows, int D, float* dx, int64_t lddx, void* stream);
 
 /* ---- diagnostics (tools/gemm_v6_check.py; not part of the hot path).  The large-shape GEMM engines have ablation builds selected by
- * `precision` codes 60..86 (gemm_f16x3_v6.hip), 100..104 (gemm_f16x3_v8.hip) and 110..114 (gemm_f16x3_v10.hip) whose workgroups add their duration in shader cycles and in
+ * `precision` codes 60..86 (gemm_f16x3_v6.hip), 100..104 (gemm_f16x3_v8.hip) and 110..119 (gemm_f16x3_v10.hip) whose workgroups add their duration in shader cycles and in
  * 100 MHz wall ticks to a device counter: host3 = {cycles, ticks, workgroups} since the last call (read and cleared).  The ratio is the shader
  * clock the kernel really ran at -- rocprofv3 pins the clock, so its counters cannot tell. */
 int ogmm_debug_v6_probe(unsigned long long* host3);

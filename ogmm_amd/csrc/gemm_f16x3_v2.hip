@@ -262,8 +262,13 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
             OGMM_REQUIRE(gemm_f16x3_v10_applicable(g), "LDS-DMA engine (v10) not applicable"); return gemm_nt_f16x3_v10(g, s);
         default: break;
     }
-    // the LDS-DMA engine (8 x 1 waves) wherever it applies; its first form (v6: 4 x 2 waves, the ablation vehicle of DESIGN.md) only by its variant codes
-    if (g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v8_applicable(g)) return gemm_nt_f16x3_v8(g, s);
+    // the LDS-DMA engines (v10: 4 waves of 64 x 256; v8: 8 waves of 32 x 256) wherever they apply; its first form (v6: 4 x 2 waves, the ablation vehicle of DESIGN.md) only by its variant codes
+    if (g.precision == OGMM_PREC_F16X3_FRAG) {
+        // four waves of 64 x 256 (v10) from 512 output columns on; at N = 256 its longer prologue / epilogue per tile costs more than its loop gains
+        // (131072 x 256 x 512: 0.109 against 0.105 ms; x 1024 x 1024: 0.645 against 0.673)
+        if (g.N >= 512 && gemm_f16x3_v10_applicable(g)) return gemm_nt_f16x3_v10(g, s);
+        if (gemm_f16x3_v8_applicable(g)) return gemm_nt_f16x3_v8(g, s);
+    }
     if (gemm_f16x3_large_applicable(g)) return gemm_nt_f16x3_v4(g, s);
     if (g.N <= 64) return launch_v2<2, 1, 2, 2, false>(g, s);
     // 256 x 256 tiles (8 waves) once they still give >= 2 workgroups per CU, else 128 x 128 (4 waves)

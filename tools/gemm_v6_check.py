@@ -70,8 +70,6 @@ if not time_only:
         assert same10, "v10 differs from v4"
         if stats:
             assert ((outs[110][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item() < 1e-5, "v10 column statistics differ from v4"
-        if stats:
-            assert ((outs[100][1] - outs[23][1]).abs() / outs[23][1].abs().clamp_min(1e-9)).max().item() < 1e-5, "v8 column statistics differ from v4"
         worst = max(worst, e6)
         assert nan6 == 0 and (same or e6 < max(2e-6, 1.2 * e4)), "v6 result off"
     # fused InstanceNorm on the A side (a_scale / a_shift per (row group, k)): v8 against v4
