@@ -1,0 +1,45 @@
+"""One eval forward (B = 64, N = 1024, J = 16) with every GEMM launch timed: shape, duration, algorithmic TFLOP/s -- to find the launches the engines
+serve badly.  usage (GPU box): python3 tools/gemm_launch_table.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from ogmm_amd import ops, synth
+from ogmm_amd.gmmreg import GMMReg
+
+dev = torch.device("cuda", 0)
+model = GMMReg(512, 16, bench.CFG)
+synth.fill_state_dict(model.state_dict())
+model = model.to(dev).eval()
+src, tgt, _, _ = synth.make_batch(0, 64, 1024, "partial")
+starts = synth.fps_starts_for(0, 64, 1024)
+src, tgt = src.to(dev), tgt.to(dev)
+
+shapes = []
+real = ops.gemm_nt
+def spy(A, lda, K1, B, ldb, M, N, *a, **kw):
+    shapes.append((M, N, K1, kw.get("K2", 0), kw.get("batch", (1, 1)), kw.get("res") is not None, kw.get("col_stats") is not None, kw.get("a_affine") is not None, kw.get("pool_k", 0)))
+    return real(A, lda, K1, B, ldb, M, N, *a, **kw)
+
+with torch.no_grad():
+    for _ in range(3):
+        model(src, tgt, fps_starts=starts)
+    ops.gemm_nt = spy
+    for mod in list(sys.modules.values()):          # modules that did `from .ops import gemm_nt`
+        if getattr(mod, "__name__", "").startswith("ogmm_amd") and getattr(mod, "gemm_nt", None) is real:
+            mod.gemm_nt = spy
+    best = None
+    for rep in range(5):
+        shapes.clear()
+        ops.GEMM_TIMELINE, ops.GEMM_TIMELINE_ONLY = [], None
+        model(src, tgt, fps_starts=starts)
+        torch.cuda.synchronize()
+        tl = [(e0.elapsed_time(e1) * 1e3, f) for e0, e1, f, v, b in ops.GEMM_TIMELINE]
+        ops.GEMM_TIMELINE = None
+        best = tl if best is None else [(min(a[0], b[0]), a[1]) for a, b in zip(best, tl)]
+tot = 0.0
+print("%8s %5s %5s %4s %8s  res stat aff pool   %8s %7s" % ("M", "N", "K1", "K2", "batch", "us", "TF-alg"))
+for (m, n, k1, k2, bt, r, st, af, pk), (us, f) in zip(shapes, best):
+    tot += us
+    print("%8d %5d %5d %4d %8s   %d    %d   %d  %3d   %8.1f %7.1f" % (m, n, k1, k2, "%dx%d" % bt, r, st, af, pk, us, f / us / 1e6))
+print("GEMM launches: %d, total %.1f us (each launch timed alone between two events: includes launch gaps)" % (len(best), tot))
