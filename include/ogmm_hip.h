@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 9
+#define OGMM_ABI_VERSION 10
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -113,9 +113,26 @@ typedef struct ogmm_gemm {
      *     -- the consumer; ogmm_instnorm_finalize turns the statistics into a_scale / a_shift.
      * group_rows must be a multiple of the row tile (256; 128 for small problems). */
     double* col_stats; const float* a_scale; const float* a_shift; int32_t a_relu; int32_t group_rows;
+    /* Overlap-block fusion (models/gmmreg.py:75-80), OGMM_PREC_F16X3_FRAG, batch_outer = pairs, M = N = points (multiples of 256):
+     *   ovl_rowpart != NULL: the product is the similarity S of L2-normalised rows and is NOT stored (C is ignored); per 256 x 256 tile the epilogue
+     *   leaves the partial softmax-dots  rows: sum_j exp(S_ij - 1) {1, o_col[j]}   columns: sum_i exp(S_ij - 1) {1, o_row[i]}   as (1, sum, dot)
+     *   triples in ovl_rowpart [batch][N / 256][M][3] and ovl_colpart [batch][M / 256][N][3]; ogmm_overlap_finalize merges them into
+     *   softmax(S, dim = 2) @ o_col and softmax(S^T, dim = 2) @ o_row.  o_row / o_col are read at [(batch * M + i) * ovl_ld] / [(batch * N + j) * ovl_ld].
+ *   (models/gmmreg.py:79-80 passes src_o as o_col and tgt_o as o_row: its src_wo weights the row softmax with src_o indexed by the COLUMN.)
+     *   row_rscale ([batch][M], may be NULL): S_ij is multiplied by row_rscale[i] first -- the A rows may then be left un-normalised
+     *   (row_rscale = 1 / max(|row|, eps), ogmm_row_rnorm). */
+    const float* ovl_orow; const float* ovl_ocol; int64_t ovl_ld; float* ovl_rowpart; float* ovl_colpart; const float* row_rscale;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
+/* 1 if ogmm_gemm_nt takes the fused overlap block (ovl_rowpart) for B pairs of N points with D channels, else 0 (the caller then runs the
+ * similarity GEMM into S and ogmm_overlap_cross_ws). */
+int ogmm_gemm_overlap_fusable(int B, int N, int D);
+/* second half of the fused overlap block: merges the (1, sum, dot) triples the similarity GEMM left (models/gmmreg.py:79-80):
+ * wo_src[(b N + i) ldo] = softmax(S_b, dim = 1)[i] . o_tgt, wo_tgt[(b N + j) ldo] = softmax(S_b^T, dim = 1)[j] . o_src */
+int ogmm_overlap_finalize(const float* rowpart, const float* colpart, int B, int N, float* wo_src, float* wo_tgt, int64_t ldo, void* stream);
+/* out[row] = 1 / max(|x[row, 0:D]|_2, 1e-12): the divisor of F.normalize as a row scale (ogmm_gemm.row_rscale) */
+int ogmm_row_rnorm(const float* x, int64_t ldx, int64_t rows, int D, float* out, void* stream);
 
 /* ---- K2+K3 layer 1: neighbour gather + cat(x_j - x_i, x_i) + conv 6->64 + BN + ReLU + max over k.
  * lib/utils.py:56-64, models/dgcnn.py:137-139.  h1 [C*N*k][64] (the un-pooled tensor feeds conv2),

@@ -148,6 +148,7 @@ int launch(const ogmm_gemm& g, hipStream_t stream) {
 namespace ogmm {
 int gemm_nt_f16x3(const ogmm_gemm& g, hipStream_t s);
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s);
+bool gemm_f16x3_v10_applicable(const ogmm_gemm& g);
 }
 
 extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
@@ -165,11 +166,11 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.sA_o % 4 == 0 && g.sA_i % 4 == 0 && g.sB_o % 4 == 0 && g.sB_i % 4 == 0 && g.sA2_o % 4 == 0 && g.sA2_i % 4 == 0,
                  "ogmm_gemm_nt: batch strides of A/B must be multiples of 4");
     OGMM_REQUIRE(g.batch_outer >= 1 && g.batch_inner >= 1, "ogmm_gemm_nt: batch counts must be >= 1");
-    OGMM_REQUIRE(g.C || g.pool_k > 0, "ogmm_gemm_nt: no output");
+    OGMM_REQUIRE(g.C || g.pool_k > 0 || g.ovl_rowpart, "ogmm_gemm_nt: no output");
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
     const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || g.precision >= 18;
-    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale), "ogmm_gemm_nt: InstanceNorm fusion is only available with OGMM_PREC_F16X3_FRAG");
+    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart), "ogmm_gemm_nt: InstanceNorm / overlap-block fusion is only available with OGMM_PREC_F16X3_FRAG");
     if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
@@ -180,4 +181,15 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
         return g.N <= 64 ? launch<5, 1, 1, 2, true>(g, s) : launch<5, 1, 1, 4, true>(g, s);
     }
     return g.N <= 64 ? launch<2, 1, 2, 2, false>(g, s) : launch<2, 2, 2, 2, false>(g, s);
+}
+
+// Would ogmm_gemm_nt take the fused overlap block (ogmm_gemm.ovl_rowpart) for B pairs of N points with D channels?  (host-side planning: 1 / 0)
+extern "C" int ogmm_gemm_overlap_fusable(int B, int N, int D) {
+    if (B <= 0 || N <= 0 || D <= 0) return 0;
+    static float dummy[4];
+    ogmm_gemm g = {};
+    g.A = dummy; g.lda = D; g.K1 = D; g.M = N; g.N = N; g.batch_outer = B; g.batch_inner = 1; g.precision = OGMM_PREC_F16X3_FRAG;
+    g.ldb_h = (D + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy;
+    g.ovl_rowpart = dummy; g.ovl_colpart = dummy; g.ovl_orow = dummy; g.ovl_ocol = dummy; g.ovl_ld = 1;
+    return ogmm::gemm_f16x3_v10_applicable(g) ? 1 : 0;
 }

@@ -29,7 +29,21 @@ constexpr int LDS_BYTES = A_STAGES * A_STAGE + B_STAGES * B_STAGE;          // 1
 
 __device__ unsigned long long g_v10_probe[4];
 
-template <int ABL, bool AFF>
+// sum over the 32 lanes of a half wave (lanes that hold the same accumulator rows), result in every lane: quad swaps and row mirrors on the vector
+// ALU's DPP path, one cross-row exchange
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));           // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));           // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));          // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));          // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+// OVL: the GEMM is the batched similarity S = fn_src fn_tgt^T of the overlap block (models/gmmreg.py:75-80) and S is never stored: the epilogue
+// forms e = exp(S - 1) (|S| <= 1 for normalised rows, so no running maximum is needed: softmax(S) = e / sum e) and leaves, per tile, the partial
+// softmax-dots of its 256 rows against o_tgt and of its 256 columns against o_src as (1, sum e, sum e o) triples; ogmm_overlap_finalize merges them.
+template <int ABL, bool AFF, bool OVL>
 __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
 
@@ -277,6 +291,75 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
         if (sum == 1.2345f) g.C[0] = sum;
         return;
     }
+    if constexpr (OVL) {
+        // LDS (floats): o of the tile's rows | o of its columns | row scale | row results [256][2] | column partials [4 waves][256][2]
+        float* s_orow = reinterpret_cast<float*>(smem10);
+        float* s_ocol = s_orow + 256;
+        float* s_rinv = s_orow + 512;
+        float* s_rowres = s_orow + 768;
+        float* s_col = s_orow + 1280;
+        s_orow[tid] = g.ovl_orow[((int64_t)zb * g.M + m0 + tid) * g.ovl_ld];
+        s_ocol[tid] = g.ovl_ocol[((int64_t)zb * g.N + n0 + tid) * g.ovl_ld];
+        s_rinv[tid] = g.row_rscale ? g.row_rscale[(int64_t)zb * g.M + m0 + tid] : 1.0f;
+        __syncthreads();
+        constexpr float L2E = 1.4426950408889634f;
+        float csum[NT], cdot[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { csum[j] = 0.0f; cdot[j] = 0.0f; }
+        auto row_block = [&](f32x16 (&acc)[NT], int rb) {
+            float rs[16], rd[16], orow[16], fac[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wave * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                orow[r] = s_orow[rl];
+                fac[r] = g.alpha * s_rinv[rl] * L2E;
+                rs[r] = 0.0f; rd[r] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float oc = s_ocol[j * 32 + lr];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(acc[j][r], fac[r], -L2E));          // exp(s - 1), s = acc * alpha * row scale
+                    rs[r] += e;
+                    rd[r] = fmaf(e, oc, rd[r]);
+                    csum[j] += e;
+                    cdot[j] = fmaf(e, orow[r], cdot[j]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rs[r] = half_wave_sum(rs[r]); rd[r] = half_wave_sum(rd[r]); }
+            if (lr == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wave * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    s_rowres[rl * 2] = rs[r];
+                    s_rowres[rl * 2 + 1] = rd[r];
+                }
+            }
+        };
+        row_block(acc0, 0);
+        row_block(acc1, 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {          // the two half waves hold the same columns
+            csum[j] += __shfl_xor(csum[j], 32, 64);
+            cdot[j] += __shfl_xor(cdot[j], 32, 64);
+            if (lh == 0) {
+                s_col[(wave * 256 + j * 32 + lr) * 2] = csum[j];
+                s_col[(wave * 256 + j * 32 + lr) * 2 + 1] = cdot[j];
+            }
+        }
+        __syncthreads();
+        const int m_tiles_z = g.M / BM;
+        float* rp = g.ovl_rowpart + ((((int64_t)zb * n_tiles + tile_n) * g.M) + m0 + tid) * 3;
+        rp[0] = 1.0f; rp[1] = s_rowres[tid * 2]; rp[2] = s_rowres[tid * 2 + 1];
+        float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { c1 += s_col[(w * 256 + tid) * 2]; c2 += s_col[(w * 256 + tid) * 2 + 1]; }
+        float* cp = g.ovl_colpart + ((((int64_t)zb * m_tiles_z + tile_m) * g.N) + n0 + tid) * 3;
+        cp[0] = 1.0f; cp[1] = c1; cp[2] = c2;
+        return;
+    }
     ogmm_gemm gz = g;
     if (gz.C) gz.C += zb * g.sC_o;
     if (gz.Res) gz.Res += zb * g.sR_o;
@@ -319,21 +402,22 @@ bool gemm_f16x3_v10_applicable(const ogmm_gemm& g) {
     static const int enabled = [] { const char* e = getenv("OGMM_V10"); return e ? atoi(e) : 1; }();
     static const long long min_tiles = [] { const char* e = getenv("OGMM_V10_MIN_TILES"); return e ? atoll(e) : 256LL; }();
     const bool whole_tiles = g.M % BM == 0 && g.N % BN == 0 && !g.row_affine;
-    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) &&
+    const bool ovl_ok = !g.ovl_rowpart || (whole_tiles && g.ovl_colpart && g.ovl_orow && g.ovl_ocol && g.ovl_ld >= 1 && !g.a_scale && !g.col_stats && !g.Res && g.batch_inner == 1);
+    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok &&
            (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 
-template <int ABL, bool AFF = false>
+template <int ABL, bool AFF = false, bool OVL = false>
 static int launch_v10(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static ogmm::PerDeviceOnce attr_once;          // per template instance and device
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF, OVL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
     else
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
     return check_launch("ogmm_gemm_nt(f16x3 v10)");
 }
 
@@ -360,7 +444,7 @@ int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
         case 117: return launch_v10<2048 + 8 + 2 + 4 + 16>(g, s);    //   DMA + MFMA + barrier only
         case 118: return launch_v10<2048 + 8 + 1 + 2 + 4 + 16>(g, s);    //   MFMA + barrier only
         case 119: return launch_v10<2048 + 8 + 1 + 2>(g, s);     //   fragment reads + MFMA (no DMA, no split)
-        default: return g.a_scale ? launch_v10<0, true>(g, s) : launch_v10<0>(g, s);
+        default: return g.ovl_rowpart ? launch_v10<0, false, true>(g, s) : g.a_scale ? launch_v10<0, true>(g, s) : launch_v10<0>(g, s);
     }
 }
 

@@ -263,6 +263,10 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         default: break;
     }
     // the LDS-DMA engines (v10: 4 waves of 64 x 256; v8: 8 waves of 32 x 256) wherever they apply; its first form (v6: 4 x 2 waves, the ablation vehicle of DESIGN.md) only by its variant codes
+    if (g.ovl_rowpart) {
+        OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v10_applicable(g), "ogmm_gemm_nt: the overlap-block fusion needs the fragment-major fp16x3 engine on whole 256 x 256 tiles (ogmm_gemm_overlap_fusable)");
+        return gemm_nt_f16x3_v10(g, s);
+    }
     if (g.precision == OGMM_PREC_F16X3_FRAG) {
         // four waves of 64 x 256 (v10) from 512 output columns on; at N = 256 its longer prologue / epilogue per tile costs more than its loop gains
         // (131072 x 256 x 512: 0.109 against 0.105 ms; x 1024 x 1024: 0.645 against 0.673)

@@ -190,6 +190,21 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------- 1 / max(|row|, eps): F.normalize's divisor as a row scale (same sums as above), one wave per row
+__global__ __launch_bounds__(256) void row_rnorm_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* __restrict__ p = x + row * ldx;
+    float ss = 0.0f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + d);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    if (lane == 0) out[row] = 1.0f / nrm;
+}
+
 // ---------------------------------------------------------------- Cout = 1 convolution, one wave per row
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int D,
                                                      const float* __restrict__ w, const float* __restrict__ b, int act,
@@ -402,6 +417,12 @@ extern "C" int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D
     return ogmm::check_launch("ogmm_l2norm_rows");
 }
 
+extern "C" int ogmm_row_rnorm(const float* x, int64_t ldx, int64_t rows, int D, float* out, void* stream) {
+    OGMM_REQUIRE(x && out && rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ogmm::aligned16(x), "ogmm_row_rnorm: D, ldx must be multiples of 4 and x 16-byte aligned");
+    hipLaunchKernelGGL(row_rnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ogmm::as_stream(stream), x, ldx, rows, D, out);
+    return ogmm::check_launch("ogmm_row_rnorm");
+}
+
 extern "C" int ogmm_rowdot(const float* x, int64_t ldx, int64_t rows, int D, const float* w, const float* b, int act, float* y,
                            int64_t ldy, void* stream) {
     OGMM_REQUIRE(x && w && y && rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ogmm::aligned16(x) && ogmm::aligned16(w),
@@ -552,6 +573,15 @@ __global__ __launch_bounds__(256) void overlap_finalize_kernel(const float* __re
 extern "C" int64_t ogmm_overlap_cross_workspace_bytes(int B, int N) {
     const int64_t n_p = (N + OVT_COLS - 1) / OVT_COLS, n_rb = (N + OVT_ROWS - 1) / OVT_ROWS;
     return (int64_t)B * (n_p + n_rb) * N * 3 * (int64_t)sizeof(float);
+}
+
+// Second half of the FUSED overlap block: the similarity GEMM's epilogue (ogmm_gemm.ovl_rowpart / ovl_colpart, 256 x 256 tiles) left the
+// (1, sum, dot) triples; this merges the N / 256 partials per row and per column.
+extern "C" int ogmm_overlap_finalize(const float* rowpart, const float* colpart, int B, int N, float* wo_src, float* wo_tgt, int64_t ldo, void* stream) {
+    OGMM_REQUIRE(rowpart && colpart && wo_src && wo_tgt && B > 0 && N > 0 && N % 256 == 0 && ldo >= 1, "ogmm_overlap_finalize: null pointer, or N not a multiple of 256");
+    hipLaunchKernelGGL(overlap_finalize_kernel, dim3((2 * N + 255) / 256, B), dim3(256), 0, ogmm::as_stream(stream), rowpart, colpart, N, N / 256, N / 256, wo_src,
+                       wo_tgt, ldo, (float*)nullptr);
+    return ogmm::check_launch("ogmm_overlap_finalize");
 }
 
 // One pass over S.  stats may be NULL (eval); workspace: ogmm_overlap_cross_workspace_bytes(B, N) bytes.

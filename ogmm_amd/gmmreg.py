@@ -18,6 +18,7 @@ the reference are independent, models/gmmreg.py:52-53) and feature maps are poin
 """
 import math
 
+import os
 import torch
 from torch import nn
 
@@ -225,6 +226,7 @@ class GMMReg(nn.Module):
         self.precision = getattr(config, "precision", "f16x3")
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self.fold_conv2_overlap = True      # conv2.net.6 and overlap.net.0 (two linear maps in a row) as one 1024 -> 256 layer
+        self.fuse_overlap = os.environ.get("OGMM_FUSE_OVERLAP", "1") != "0"            # overlap block's softmax-dots in the similarity GEMM's epilogue where the engine takes it (ops.overlap_fusable)
         self._overflow = None
         self._side = None
         self._side2 = None
@@ -412,20 +414,26 @@ class GMMReg(nn.Module):
         f = self._transformer(L["cattn"], ft, a1, C, N, res=ft)
 
         # ---- overlap scores (gmmreg.py:74-89)
-        S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-        if ops.DEFAULT_SPLIT and D % 64 == 0:
-            fn_src = ops.l2norm_rows(f[:B * N])                            # A operand: the src half, normalised
-            tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)        # B operand: the tgt half, normalised and split in one pass
-            ops.gemm_nt(fn_src, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img, overflow=self._overflow)
-        else:
-            fn = ops.l2norm_rows(f)
-            ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
         ph = ops.conv1x1(f, L["proj"]["0"], ACT_RELU)
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
         extra = torch.zeros((R, XW), dtype=torch.float32, device=dev)
         ops.rowdot(ph, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW)
-        ops.overlap_cross(S, extra[:B * N, 1], extra[B * N:, 1], XW, extra[:B * N, 0], extra[B * N:, 0], XW)
-        del S
+        if self.fuse_overlap and D % 64 == 0 and ops.overlap_fusable(B, N, D):
+            # the N x N similarity never leaves the GEMM's accumulators: its epilogue forms the partial softmax-dots (struct ogmm_gemm.ovl_rowpart)
+            tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)        # B operand: the tgt half, normalised and split in one pass
+            ops.overlap_fused(f[:B * N], tgt_img, B, N, D, extra[:B * N, 1], extra[B * N:, 1], XW, extra[:B * N, 0], extra[B * N:, 0], XW,
+                              overflow=self._overflow)
+        else:
+            S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+            if ops.DEFAULT_SPLIT and D % 64 == 0:
+                fn_src = ops.l2norm_rows(f[:B * N])                            # A operand: the src half, normalised
+                tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)
+                ops.gemm_nt(fn_src, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img, overflow=self._overflow)
+            else:
+                fn = ops.l2norm_rows(f)
+                ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
+            ops.overlap_cross(S, extra[:B * N, 1], extra[B * N:, 1], XW, extra[:B * N, 0], extra[B * N:, 0], XW)
+            del S
         if self.fold_conv2_overlap:
             h2 = ops.conv1x1(ops.conv1x1(f, L["conv2"]["0"], ACT_RELU, x2=extra), L["conv2"]["3"], ACT_RELU)
             g = ops.conv1x1(h2, L["conv2_6_overlap_0"], ACT_RELU)            # conv2.net.6 and overlap.net.0 as one layer (pack_weights)

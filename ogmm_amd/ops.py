@@ -170,7 +170,8 @@ def split_f16_training(W, key, refresh=64, **kw):
 
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
-            pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0):
+            pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0,
+            overlap=None, row_rscale=None):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -206,6 +207,12 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
         d.col_stats = col_stats.data_ptr()
     if a_affine is not None:
         d.a_scale, d.a_shift, d.a_relu = a_affine[0].data_ptr(), a_affine[1].data_ptr(), 1 if a_affine[2] else 0
+    if overlap is not None:          # (o_row, o_col, ld, rowpart, colpart): the fused overlap block, S is not stored (struct ogmm_gemm)
+        d.ovl_orow, d.ovl_ocol, d.ovl_ld = overlap[0].data_ptr(), overlap[1].data_ptr(), overlap[2]
+        d.ovl_rowpart, d.ovl_colpart = overlap[3].data_ptr(), overlap[4].data_ptr()
+        store_c = False
+    if row_rscale is not None:
+        d.row_rscale = row_rscale.data_ptr()
     variant = None
     if GEMM_TIMELINE is not None:
         variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
@@ -399,6 +406,33 @@ def _overlap_ws(B, N, device):
     ws = torch.empty(_lib.load().ogmm_overlap_cross_workspace_bytes(B, N), dtype=torch.uint8, device=device)
     ws.record_stream(torch.cuda.current_stream())
     return ws
+
+
+def overlap_fusable(B, N, D):
+    """True if the similarity GEMM can run the overlap block's softmax-dots in its epilogue (struct ogmm_gemm.ovl_rowpart)."""
+    return bool(DEFAULT_SPLIT) and not F16_SINGLE_TERM and _lib.load().ogmm_gemm_overlap_fusable(B, N, D) == 1
+
+
+def row_rnorm(x):
+    """1 / max(|row|_2, 1e-12) per row of x [rows, D] (row stride = x.stride(0)): F.normalize's divisor as a GEMM row scale."""
+    rows, D = x.shape
+    out = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.call("ogmm_row_rnorm", _p(_f32(x, "x")), x.stride(0), rows, D, _p(out), _stream())
+    return out
+
+
+def overlap_fused(f_src, tgt_img, B, N, D, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, overflow=None):
+    """models/gmmreg.py:75-80 without the similarity matrix: S = normalize(f_src) normalize(f_tgt)^T lives only in the GEMM's accumulators.
+    f_src [B*N, D] un-normalised (its 1/|row| is a row scale), tgt_img = l2norm_pack_frag_batched(f_tgt); o_* / wo_* as overlap_cross."""
+    nt = N // 256
+    rowpart = torch.empty((B, nt, N, 3), dtype=torch.float32, device=f_src.device)
+    colpart = torch.empty((B, nt, N, 3), dtype=torch.float32, device=f_src.device)
+    rinv = row_rnorm(f_src)
+    gemm_nt(f_src, f_src.stride(0), D, None, D, N, N, batch=(B, 1), sA=(N * f_src.stride(0), 0), split=tgt_img, overflow=overflow,
+            overlap=(o_tgt, o_src, ldo_in, rowpart, colpart), row_rscale=rinv)          # the reference weights the ROW softmax with src_o, indexed by column
+    _lib.call("ogmm_overlap_finalize", _p(rowpart), _p(colpart), B, N, _p(wo_src), _p(wo_tgt), ldo, _stream())
+    for t in (rowpart, colpart, rinv):
+        t.record_stream(torch.cuda.current_stream())
 
 
 def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, two_pass=False):

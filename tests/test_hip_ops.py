@@ -451,6 +451,36 @@ def test_overlap_cross(ops, B, N, two_pass):
     assert float(out[:, 1:].abs().max()) == 0.0
 
 
+def test_overlap_block_fused_into_the_similarity_gemm(ops):
+    """models/gmmreg.py:75-80 with S living only in the GEMM's accumulators (struct ogmm_gemm.ovl_rowpart) against fp64 and against the unfused path."""
+    B, N, D = 16, 1024, 512
+    if not ops.overlap_fusable(B, N, D):
+        pytest.skip("the engine does not take the fused form for this shape")
+    torch.manual_seed(11)
+    f = torch.randn(2 * B * N, D) * (torch.rand(2 * B * N, 1) * 4 + 0.1)
+    f[5] = 0.0                                                     # a zero row: F.normalize's eps path
+    o = torch.randn(2 * B * N, 4)
+    fd, od = dev(f), dev(o)
+    out = torch.zeros(2 * B * N, 4, device="cuda")
+    tgt_img = ops.l2norm_pack_frag_batched(fd[B * N:], B, N)
+    ops.overlap_fused(fd[:B * N], tgt_img, B, N, D, od[:B * N, 1], od[B * N:, 1], 4, out[:B * N, 0], out[B * N:, 0], 4)
+    # the unfused path of the forward
+    out2 = torch.zeros(2 * B * N, 4, device="cuda")
+    S = torch.empty(B, N, N, device="cuda")
+    ops.gemm_nt(ops.l2norm_rows(fd[:B * N]), D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img)
+    ops.overlap_cross(S, od[:B * N, 1], od[B * N:, 1], 4, out2[:B * N, 0], out2[B * N:, 0], 4)
+    fn = torch.nn.functional.normalize(f.double(), dim=1)
+    Sd = torch.einsum("bmd,bnd->bmn", fn[:B * N].view(B, N, D), fn[B * N:].view(B, N, D))
+    o_src, o_tgt = o[:B * N, 1].view(B, 1, N).double(), o[B * N:, 1].view(B, 1, N).double()
+    wo_s = torch.einsum("bmn,bdn->bdm", torch.softmax(Sd, -1), o_src).reshape(-1)      # models/gmmreg.py:79
+    wo_t = torch.einsum("bmn,bdm->bdn", torch.softmax(Sd, 1), o_tgt).reshape(-1)       # models/gmmreg.py:80
+    e_fused = max((out[:B * N, 0].cpu().double() - wo_s).abs().max().item(), (out[B * N:, 0].cpu().double() - wo_t).abs().max().item())
+    e_plain = max((out2[:B * N, 0].cpu().double() - wo_s).abs().max().item(), (out2[B * N:, 0].cpu().double() - wo_t).abs().max().item())
+    print("OVERLAP fused vs fp64 %.2e   unfused vs fp64 %.2e" % (e_fused, e_plain))
+    assert e_fused < 2e-6 and e_plain < 2e-6
+    assert float(out[:, 1:].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------ GMM head
 @pytest.mark.parametrize("engine", [None, "chip", "multi"])
 @pytest.mark.parametrize("C,N,J", [(4, 1024, 16), (2, 717, 128), (2, 2048, 64), (3, 200, 8)])
