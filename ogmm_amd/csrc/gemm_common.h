@@ -339,7 +339,9 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
 // (InstanceNorm fusion): a lane sums its 16 rows, the two half waves are folded with one cross-lane move, and the wave's NB * 32 partial sums go
 // to `stat_lds` ([row block = stat_slot, by default the wave][NB * 32][2] floats, the caller's K loop is over): the caller adds the eight waves up and issues ONE fp64 atomic per
 // column and statistic per tile (per wave it would be 4096 atomics per tile: measured +10 % on the 1024-wide layers that feed a normalisation).
-template <int NB>
+// RES_AHEAD (a caller with ~128 registers to spare: the 512-register engine): all NB * 16 residual values of the slab are requested before the first
+// one is used, so that their latency is exposed once per slab instead of once per column block.
+template <int NB, bool RES_AHEAD = false>
 __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, int col0, float alpha, float* stat_lds, int stat_slot = -1) {
     const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5, wave = stat_slot >= 0 ? stat_slot : (int)(threadIdx.x >> 6);
     float* __restrict__ Cm = g.C;
@@ -347,6 +349,15 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
     const bool stats = g.col_stats != nullptr;
     auto run = [&](auto kind_c) {
         constexpr int KIND = decltype(kind_c)::value;
+        float rra[RES_AHEAD ? NB : 1][16];
+        if (RES_AHEAD && Rm) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float* __restrict__ rp = Rm + (int64_t)(row0 + 4 * lh) * g.ldr + col0 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rra[j][r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int col = col0 + j * 32 + lr;
@@ -354,9 +365,14 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
             float* __restrict__ cp = Cm + (int64_t)(row0 + 4 * lh) * g.ldc + col;
             float rr[16];
             if (Rm) {
-                const float* __restrict__ rp = Rm + (int64_t)(row0 + 4 * lh) * g.ldr + col;
+                if (RES_AHEAD) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rr[r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
+                    for (int r = 0; r < 16; ++r) rr[r] = rra[j][r];
+                } else {
+                    const float* __restrict__ rp = Rm + (int64_t)(row0 + 4 * lh) * g.ldr + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
+                }
             }
             float sum1 = 0.0f, sum2 = 0.0f;
 #pragma unroll

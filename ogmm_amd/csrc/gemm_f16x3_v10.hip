@@ -366,8 +366,8 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     const bool inside = m0 + BM <= m_end && n0 + BN <= g.N && !g.row_affine;
     if (inside) {
         float* stat_lds = reinterpret_cast<float*>(smem10);          // [8 row blocks][256 columns][2]: the rings are dead (barrier above)
-        gemm_epilogue_rowblock<NT>(gz, acc0, m0 + wave * 64, n0, g.alpha, stat_lds, wave * 2);
-        gemm_epilogue_rowblock<NT>(gz, acc1, m0 + wave * 64 + 32, n0, g.alpha, stat_lds, wave * 2 + 1);
+        gemm_epilogue_rowblock<NT, true>(gz, acc0, m0 + wave * 64, n0, g.alpha, stat_lds, wave * 2);
+        gemm_epilogue_rowblock<NT, true>(gz, acc1, m0 + wave * 64 + 32, n0, g.alpha, stat_lds, wave * 2 + 1);
         if (g.col_stats) {
             __syncthreads();
             // thread = column: add the eight row blocks' partial sums (fp64), one atomic per column and statistic per tile

@@ -166,15 +166,17 @@ for name, m, n, k1, k2 in shapes:
 m, n, k1 = M, 512, 1024
 A = torch.randn(m, k1, device=dev); W = torch.randn(n, k1, device=dev) * 0.03; out = torch.empty(m, n, device=dev); sp = ops.split_f16(W, frag=True)
 asc = torch.rand(m // 1024, k1, device=dev) + 0.5; ash = torch.randn(m // 1024, k1, device=dev)
-row = "%-22s" % "mlp3 + A transform"
-for v in [x for x in variants if x in (23, 100, 110)]:
-    best_v = 1e9
-    for rnd in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            run(v, A, k1, W, m, n, out, split=sp, a_affine=(asc, ash, True), group_rows=1024)
-        e1.record(); torch.cuda.synchronize()
-        best_v = min(best_v, e0.elapsed_time(e1) / 5)
-    row += "  v%-2d %6.1f TF (%6.3f ms)" % (v, 2.0 * m * n * k1 / best_v / 1e9, best_v)
-print(row, flush=True)
+res = torch.randn(m, n, device=dev)
+for label, kw in (("mlp3 + A transform", {}), ("mlp3 + A tr. + residual", dict(res=res, ldr=n))):
+    row = "%-22s" % label
+    for v in [x for x in variants if x in (23, 100, 110)]:
+        best_v = 1e9
+        for rnd in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                run(v, A, k1, W, m, n, out, split=sp, a_affine=(asc, ash, True), group_rows=1024, **kw)
+            e1.record(); torch.cuda.synchronize()
+            best_v = min(best_v, e0.elapsed_time(e1) / 5)
+        row += "  v%-2d %6.1f TF (%6.3f ms)" % (v, 2.0 * m * n * k1 / best_v / 1e9, best_v)
+    print(row, flush=True)
