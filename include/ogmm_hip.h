@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 10
+#define OGMM_ABI_VERSION 11
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -122,12 +122,18 @@ typedef struct ogmm_gemm {
      *   row_rscale ([batch][M], may be NULL): S_ij is multiplied by row_rscale[i] first -- the A rows may then be left un-normalised
      *   (row_rscale = 1 / max(|row|, eps), ogmm_row_rnorm). */
     const float* ovl_orow; const float* ovl_ocol; int64_t ovl_ld; float* ovl_rowpart; float* ovl_colpart; const float* row_rscale;
+    /* A Cout = 1 convolution fused behind this layer (the heads proj.3 and overlap.6 of models/gmmreg.py:30-47), OGMM_PREC_F16X3_FRAG, N == 256
+     * (one column tile holds whole rows), M a multiple of 256:  rd_out[row * rd_ld] = rd_act(sum_col y[row][col] * rd_w[col] + rd_b[0]) with y the
+     * value this layer would store.  C may then be NULL: the 256-wide map is not written at all.  ogmm_gemm_rowdot_fusable tells. */
+    const float* rd_w; const float* rd_b; int32_t rd_act; float* rd_out; int64_t rd_ld;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
 /* 1 if ogmm_gemm_nt takes the fused overlap block (ovl_rowpart) for B pairs of N points with D channels, else 0 (the caller then runs the
  * similarity GEMM into S and ogmm_overlap_cross_ws). */
 int ogmm_gemm_overlap_fusable(int B, int N, int D);
+/* 1 if ogmm_gemm_nt takes a fused Cout = 1 head (rd_out) behind an M x N layer with K1 + K2 input channels, else 0 */
+int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2);
 /* second half of the fused overlap block: merges the (1, sum, dot) triples the similarity GEMM left (models/gmmreg.py:79-80):
  * wo_src[(b N + i) ldo] = softmax(S_b, dim = 1)[i] . o_tgt, wo_tgt[(b N + j) ldo] = softmax(S_b^T, dim = 1)[j] . o_src */
 int ogmm_overlap_finalize(const float* rowpart, const float* colpart, int B, int N, float* wo_src, float* wo_tgt, int64_t ldo, void* stream);

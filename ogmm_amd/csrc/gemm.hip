@@ -149,6 +149,7 @@ namespace ogmm {
 int gemm_nt_f16x3(const ogmm_gemm& g, hipStream_t s);
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v10_applicable(const ogmm_gemm& g);
+bool gemm_f16x3_v8_applicable(const ogmm_gemm& g);
 }
 
 extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
@@ -166,11 +167,11 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.sA_o % 4 == 0 && g.sA_i % 4 == 0 && g.sB_o % 4 == 0 && g.sB_i % 4 == 0 && g.sA2_o % 4 == 0 && g.sA2_i % 4 == 0,
                  "ogmm_gemm_nt: batch strides of A/B must be multiples of 4");
     OGMM_REQUIRE(g.batch_outer >= 1 && g.batch_inner >= 1, "ogmm_gemm_nt: batch counts must be >= 1");
-    OGMM_REQUIRE(g.C || g.pool_k > 0 || g.ovl_rowpart, "ogmm_gemm_nt: no output");
+    OGMM_REQUIRE(g.C || g.pool_k > 0 || g.ovl_rowpart || g.rd_out, "ogmm_gemm_nt: no output");
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
     const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || g.precision >= 18;
-    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart), "ogmm_gemm_nt: InstanceNorm / overlap-block fusion is only available with OGMM_PREC_F16X3_FRAG");
+    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart && !g.rd_out), "ogmm_gemm_nt: InstanceNorm / overlap-block / Cout = 1 head fusion is only available with OGMM_PREC_F16X3_FRAG");
     if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
@@ -192,4 +193,15 @@ extern "C" int ogmm_gemm_overlap_fusable(int B, int N, int D) {
     g.ldb_h = (D + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy;
     g.ovl_rowpart = dummy; g.ovl_colpart = dummy; g.ovl_orow = dummy; g.ovl_ocol = dummy; g.ovl_ld = 1;
     return ogmm::gemm_f16x3_v10_applicable(g) ? 1 : 0;
+}
+
+// Would ogmm_gemm_nt take a fused Cout = 1 head (ogmm_gemm.rd_out) behind an M x N layer with K1 + K2 input channels?  (1 / 0)
+extern "C" int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2) {
+    if (M <= 0 || N <= 0 || K1 <= 0 || K2 < 0) return 0;
+    static float dummy[4];
+    ogmm_gemm g = {};
+    g.A = dummy; g.lda = K1; g.K1 = K1; g.A2 = K2 ? dummy : nullptr; g.lda2 = K2 ? K2 : 0; g.K2 = K2; g.M = M; g.N = N; g.batch_outer = 1; g.batch_inner = 1;
+    g.precision = OGMM_PREC_F16X3_FRAG; g.ldb_h = (K1 + 63) / 64 * 64 + (K2 + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy;
+    g.rd_out = dummy; g.rd_w = dummy; g.rd_ld = 1;
+    return ogmm::gemm_f16x3_v8_applicable(g) ? 1 : 0;
 }

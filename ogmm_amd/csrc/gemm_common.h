@@ -401,6 +401,69 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
     else run(std::integral_constant<int, OGMM_ACT_NONE>{});
 }
 
+// sum over the 32 lanes of a half wave (lanes that hold the same accumulator rows), result in every lane: quad swaps and row mirrors on the vector
+// ALU's DPP path, one cross-row exchange
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));           // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));           // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));          // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));          // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+// The row-block epilogue with a Cout = 1 convolution behind it (ogmm_gemm.rd_*): the slab holds whole rows (NB * 32 = N columns), so the head's
+// dot product is a sum over the lane's NB values per row plus a half-wave reduction; the map itself is stored only if C is given.
+template <int NB>
+__device__ __forceinline__ void gemm_epilogue_rowblock_rowdot(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, float alpha) {
+    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    float* __restrict__ Cm = g.C;
+    const float* __restrict__ Rm = g.Res;
+    // the per-column constants of all NB blocks first: behind the (optional) stores of a block the compiler could not move the next block's loads up
+    float s1[NB], t1[NB], w[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = j * 32 + lr;
+        s1[j] = (g.scale ? g.scale[col] : 1.0f) * alpha;
+        t1[j] = g.shift ? g.shift[col] : 0.0f;
+        w[j] = g.rd_w[col];
+    }
+    const float b = g.rd_b ? g.rd_b[0] : 0.0f;
+    float rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs[r] = 0.0f;
+    auto run = [&](auto kind_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float y = fmaf(acc[j][r], s1[j], t1[j]);
+                if (KIND == OGMM_ACT_RELU) y = fmaxf(y, 0.0f);
+                else if (KIND == OGMM_ACT_LEAKY02) y = y > 0.0f ? y : 0.2f * y;
+                else if (KIND == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                if (Rm || Cm) {
+                    const int64_t row = row0 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                    if (Rm) y += Rm[row * g.ldr + col];
+                    if (Cm) Cm[row * g.ldc + col] = y;
+                }
+                rs[r] = fmaf(y, w[j], rs[r]);
+            }
+        }
+    };
+    if (g.act == OGMM_ACT_RELU) run(std::integral_constant<int, OGMM_ACT_RELU>{});
+    else if (g.act == OGMM_ACT_LEAKY02) run(std::integral_constant<int, OGMM_ACT_LEAKY02>{});
+    else if (g.act == OGMM_ACT_SIGMOID) run(std::integral_constant<int, OGMM_ACT_SIGMOID>{});
+    else run(std::integral_constant<int, OGMM_ACT_NONE>{});
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs[r] = half_wave_sum(rs[r]);
+    if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g.rd_out[(int64_t)(row0 + 4 * lh + (r & 3) + 8 * (r >> 2)) * g.rd_ld] = apply_act(rs[r] + b, g.rd_act);
+    }
+}
+
 __device__ __forceinline__ bool wide_epilogue_ok(const ogmm_gemm& g) {
     return g.pool_k == 0 && g.C != nullptr && (g.N & 3) == 0 && (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
            (g.Res == nullptr || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.Res) & 15) == 0)) &&

@@ -29,17 +29,6 @@ constexpr int LDS_BYTES = A_STAGES * A_STAGE + B_STAGES * B_STAGE;          // 1
 
 __device__ unsigned long long g_v10_probe[4];
 
-// sum over the 32 lanes of a half wave (lanes that hold the same accumulator rows), result in every lane: quad swaps and row mirrors on the vector
-// ALU's DPP path, one cross-row exchange
-__device__ __forceinline__ float half_wave_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));           // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));           // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));          // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));          // row_mirror
-    v += __shfl_xor(v, 16, 64);
-    return v;
-}
-
 // OVL: the GEMM is the batched similarity S = fn_src fn_tgt^T of the overlap block (models/gmmreg.py:75-80) and S is never stored: the epilogue
 // forms e = exp(S - 1) (|S| <= 1 for normalised rows, so no running maximum is needed: softmax(S) = e / sum e) and leaves, per tile, the partial
 // softmax-dots of its 256 rows against o_tgt and of its 256 columns against o_src as (1, sum e, sum e o) triples; ogmm_overlap_finalize merges them.

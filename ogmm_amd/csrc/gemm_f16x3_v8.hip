@@ -40,7 +40,7 @@ __device__ unsigned long long g_v8_probe[4];
 
 // AFF: A is read as relu?(a * a_scale[group][k] + a_shift[group][k]) (InstanceNorm of the producing layer, models/attn.py:24-25), applied to the raw
 // fragment right after the ds_read, with the constants of the tile's row group staged once in LDS (a half wave reads the same 8 k: broadcast reads).
-template <int ABL, bool AFF>
+template <int ABL, bool AFF, bool HEAD>
 __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles, const int direct_stores) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
 
@@ -248,6 +248,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
     if (gz.Res) gz.Res += zb * g.sR_o;
     // a wave's 32 x 256 slab: straight from the accumulators when it lies inside the matrix (the common case), else the general per-element form
     const bool inside = m0 + BM <= m_end && n0 + BN <= g.N && !g.row_affine;
+    if constexpr (HEAD) {          // a Cout = 1 head behind this layer (N == 256, whole tiles: gemm_f16x3_v8_applicable); its own instantiation --
+        gemm_epilogue_rowblock_rowdot<NT>(gz, acc, m0 + wave * 32, g.alpha);          // as a run-time branch it cost the default kernel 87 spilled registers
+        return;
+    }
     if (inside) {
         float* stat_lds = reinterpret_cast<float*>(smem8);          // [8 waves][256 columns][2]: the rings are dead (barrier above)
         gemm_epilogue_rowblock<NT>(gz, acc, m0 + wave * 32, n0, g.alpha, stat_lds);
@@ -278,21 +282,22 @@ bool gemm_f16x3_v8_applicable(const ogmm_gemm& g) {
     static const int enabled = [] { const char* e = getenv("OGMM_V8"); return e ? atoi(e) : 1; }();
     static const long long min_tiles = [] { const char* e = getenv("OGMM_V8_MIN_TILES"); return e ? atoll(e) : 256LL; }();
     const bool whole_tiles = g.M % BM == 0 && g.N % BN == 0 && !g.row_affine;          // the statistics come out of the row-block epilogue only
-    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
+    const bool rd_ok = !g.rd_out || (!g.a_scale && whole_tiles && g.N == BN && g.rd_w && g.rd_ld >= 1 && !g.col_stats && !g.ovl_rowpart && g.batch_outer * g.batch_inner == 1);
+    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && rd_ok && !g.ovl_rowpart && (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 
-template <int ABL, bool AFF = false>
+template <int ABL, bool AFF = false, bool HEAD = false>
 static int launch_v8(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static const int direct = [] { const char* e = getenv("OGMM_V8_DIRECT"); return e ? atoi(e) : 1; }();
     static ogmm::PerDeviceOnce attr_once;          // per template instance and device
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL, AFF, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles, direct);
+        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF, HEAD>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles, direct);
     else
-        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles, direct);
+        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF, HEAD>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles, direct);
     return check_launch("ogmm_gemm_nt(f16x3 v8)");
 }
 
@@ -314,7 +319,7 @@ int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s) {
         case 102: return launch_v8<2048>(g, s);                 // clock probe
         case 103: return launch_v8<2048 + 8>(g, s);             // clock probe, no stores
         case 104: return launch_v8<2048 + 8 + 1>(g, s);         //   no DMA after the prologue
-        default: return g.a_scale ? launch_v8<0, true>(g, s) : launch_v8<0>(g, s);
+        default: return g.rd_out ? launch_v8<0, false, true>(g, s) : g.a_scale ? launch_v8<0, true>(g, s) : launch_v8<0>(g, s);
     }
 }
 

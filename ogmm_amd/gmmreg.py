@@ -414,10 +414,9 @@ class GMMReg(nn.Module):
         f = self._transformer(L["cattn"], ft, a1, C, N, res=ft)
 
         # ---- overlap scores (gmmreg.py:74-89)
-        ph = ops.conv1x1(f, L["proj"]["0"], ACT_RELU)
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
         extra = torch.zeros((R, XW), dtype=torch.float32, device=dev)
-        ops.rowdot(ph, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW)
+        ops.conv1x1_head(f, L["proj"]["0"], ACT_RELU, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW)      # proj.0 + proj.3
         if self.fuse_overlap and D % 64 == 0 and ops.overlap_fusable(B, N, D):
             # the N x N similarity never leaves the GEMM's accumulators: its epilogue forms the partial softmax-dots (struct ogmm_gemm.ovl_rowpart)
             tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)        # B operand: the tgt half, normalised and split in one pass
@@ -440,9 +439,8 @@ class GMMReg(nn.Module):
         else:
             fo = self._stack3(L["conv2"], f, x2=extra)
             g = ops.conv1x1(fo, L["overlap"]["0"], ACT_RELU)
-        g = ops.conv1x1(g, L["overlap"]["3"], ACT_RELU)
         o = torch.empty((C, N), dtype=torch.float32, device=dev)
-        ops.rowdot(g, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1)
+        ops.conv1x1_head(g, L["overlap"]["3"], ACT_RELU, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1)      # overlap.3 + overlap.6
 
         # ---- GMM E/M (needs only xyz and the overlap scores) on the side stream, next to self-attention 2 (gmmreg.py:92-101)
         side.wait_stream(main)

@@ -3,6 +3,7 @@ device memory and the stream; every function enqueues HIP kernels of libogmm_hip
 stream and returns without synchronising.  All tensors must be CUDA (ROCm) tensors -- there is no CPU path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -13,6 +14,7 @@ from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16_FRAG, P
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_flops)
 GEMM_TIMELINE = None
+FUSE_HEAD = os.environ.get("OGMM_FUSE_HEAD", "1") != "0"      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
 GEMM_TIMELINE_ONLY = None      # optional set of variant tags: only those launches are bracketed by events (bench.py: the dominant engine only)
 _EVENT_POOL = []               # timing events are recycled: creating two torch events per launch costs more host time than the launch itself
 
@@ -171,7 +173,7 @@ def split_f16_training(W, key, refresh=64, **kw):
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
             pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0,
-            overlap=None, row_rscale=None):
+            overlap=None, row_rscale=None, head=None):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -213,6 +215,11 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
         store_c = False
     if row_rscale is not None:
         d.row_rscale = row_rscale.data_ptr()
+    if head is not None:          # (w [N], b [1] or None, act, out, ld): a Cout = 1 convolution behind this layer (struct ogmm_gemm.rd_*)
+        d.rd_w, d.rd_b, d.rd_act = head[0].data_ptr(), (head[1].data_ptr() if head[1] is not None else None), head[2]
+        d.rd_out, d.rd_ld = head[3].data_ptr(), head[4]
+        if C is None:
+            store_c = False
     variant = None
     if GEMM_TIMELINE is not None:
         variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
@@ -245,7 +252,7 @@ def instnorm_finalize(col_stats, rows, eps=1e-5):
     return scale, shift
 
 
-def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0):
+def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0, head=None, store=True):
     """y[rows, Cout] = act((x | x2)[rows, K] @ W^T * scale + shift) + res for a packed layer
     (dict with W [Cout, Kpad], scale, shift -- see gmmreg.pack_*).  x, x2, res, out may be column views
     of wider row-major buffers (last stride 1).  split=True uses the layer's pre-split weights (fp16x3 engine)
@@ -262,12 +269,12 @@ def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, ove
         assert x2.stride(1) == 1 and x2.shape[0] == rows
         K2 = x2.shape[1]
     assert K1 + K2 == Kp, "conv1x1: input channels %d+%d != packed K %d" % (K1, K2, Kp)
-    if out is None:
+    if out is None and store:
         out = torch.empty((rows, Cout), dtype=torch.float32, device=x.device)
-    assert out.stride(1) == 1 and out.shape == (rows, Cout)
+    assert out is None or (out.stride(1) == 1 and out.shape == (rows, Cout))
     if res is not None:
         assert res.stride(1) == 1 and res.shape == (rows, Cout)
-    gemm_nt(x, x.stride(0), K1, W, Kp, rows, Cout, C=out, ldc=out.stride(0),
+    gemm_nt(x, x.stride(0), K1, W, Kp, rows, Cout, C=out, ldc=(out.stride(0) if out is not None else 0), head=head,
             A2=x2, lda2=(x2.stride(0) if x2 is not None else 0), K2=K2,
             scale=layer.get("scale"), shift=layer.get("shift"), act=act,
             res=res, ldr=(res.stride(0) if res is not None else 0),
@@ -393,6 +400,19 @@ def l2norm_rows(x, out=None):
         out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
     _lib.call("ogmm_l2norm_rows", _p(_f32(x, "x")), x.stride(0), x.shape[0], x.shape[1], _p(out), out.stride(0), _stream())
     return out
+
+
+def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None):
+    """out[row * ldy] = head_act(act(conv1x1(x, layer))[row] . w + b): a layer followed by a Cout = 1 convolution (models/gmmreg.py:30-47: proj, overlap).
+    Where the engine takes it (N = 256, whole row tiles) the head runs in the layer's epilogue and the 256-wide map is never written."""
+    rows, K1 = x.shape
+    Cout = layer["W"].shape[0]
+    K2 = x2.shape[1] if x2 is not None else 0
+    sp = layer.get("split") if DEFAULT_SPLIT else None
+    if (FUSE_HEAD and sp is not None and sp.get("variant") == PREC_F16X3_FRAG and not F16_SINGLE_TERM and _lib.load().ogmm_gemm_rowdot_fusable(rows, Cout, K1, K2) == 1):
+        conv1x1(x, layer, act, x2=x2, head=(w, b, head_act, out, ldy), store=False)
+        return
+    rowdot(conv1x1(x, layer, act, x2=x2), w, b, head_act, out, ldy=ldy)
 
 
 def rowdot(x, w, b, act, out, ldy=1):

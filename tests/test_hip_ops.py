@@ -273,6 +273,40 @@ def test_gemm_lds_dma_engine_statistics_a_transform_batch_overflow(ops):
     assert int(flag.item()) == 1
 
 
+@pytest.mark.parametrize("head_act,with_map", [("none", False), ("sigmoid", False), ("sigmoid", True)])
+def test_gemm_with_fused_cout1_head(ops, head_act, with_map):
+    """A 256-channel layer followed by a Cout = 1 convolution (proj.0 + proj.3, overlap.3 + overlap.6 of models/gmmreg.py:30-47): the head runs in the
+    layer's epilogue (struct ogmm_gemm.rd_*), the 256-wide map is written only on request."""
+    M, N, K = 65536, 256, 512
+    if ops._lib.load().ogmm_gemm_rowdot_fusable(M, N, K, 0) != 1:
+        pytest.skip("the engine does not take the fused head for this shape")
+    torch.manual_seed(17)
+    A = torch.relu(torch.randn(M, K, device="cuda")) * (torch.rand(M, 1, device="cuda") * 2)
+    W = torch.randn(N, K, device="cuda") * 0.05
+    scale, shift = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda")
+    w, b = torch.randn(N, device="cuda") * 0.2, torch.randn(1, device="cuda")
+    out = torch.zeros(M, 3, device="cuda")
+    ymap = torch.full((M, N), float("nan"), device="cuda") if with_map else None
+    code = {"none": ops.ACT_NONE, "sigmoid": ops.ACT_SIGMOID}[head_act]
+    ops.gemm_nt(A, K, K, None, K, M, N, C=ymap, ldc=N if with_map else 0, scale=scale, shift=shift, act=ops.ACT_RELU, split=ops.split_f16(W, frag=True),
+                head=(w, b, code, out[:, 1], 3))
+    y = torch.relu(A.double() @ W.double().t() * scale.double() + shift.double())
+    ref = y @ w.double() + b.double()
+    if head_act == "sigmoid":
+        ref = torch.sigmoid(ref)
+    tol = 2e-6 * ((y.abs() @ w.double().abs()) + 1.0) if head_act == "none" else 2e-6
+    assert ((out[:, 1].double() - ref).abs() / tol).max().item() < 1.0
+    assert float(out[:, 0].abs().max()) == 0.0 and float(out[:, 2].abs().max()) == 0.0
+    if with_map:
+        assert (ymap.double() - y).abs().max().item() < 2e-5
+    # and the unfused pair of launches agrees with the fused one to rounding
+    y32 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(A, K, K, None, K, M, N, C=y32, ldc=N, scale=scale, shift=shift, act=ops.ACT_RELU, split=ops.split_f16(W, frag=True))
+    out2 = torch.zeros(M, 3, device="cuda")
+    ops.rowdot(y32, w, b, code, out2[:, 1], ldy=3)
+    assert (out2[:, 1] - out[:, 1]).abs().max().item() < (2e-5 if head_act == "none" else 2e-6)
+
+
 def test_gemm_batched_strided_row_affine(ops):
     torch.manual_seed(1)
     Co, Hh, N, M, dh = 3, 4, 130, 32, 16
