@@ -3,6 +3,7 @@
 // Both selection kernels reproduce the reference's fp32 distance VALUES bit-for-bit (see the oracle
 // header for the probed rounding sequences), because 1-ulp differences flip neighbour sets / FPS chains
 // and every later feature depends on them (SURVEY.md section 7 "hard parts").
+#include <cstdlib>
 #include "ogmm_common.h"
 #include "torch_topk_select.h"
 
@@ -97,6 +98,153 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
         if (p == k) d_next = dk[p];
     }
     const bool boundary_tie = k < N && d_last == d_next;
+    int32_t* out = idx + ((int64_t)c * N + q) * k;
+#pragma unroll
+    for (int p = 0; p < KL - 1; ++p)
+        if (p < k) out[p] = (p == 0 && boundary_tie) ? ~ik[0] : ik[p];
+}
+
+// The same result in two scans (the default while the candidate buffers fit next to the cloud): the insertion ladder above costs ~6 selects per
+// list slot because the indices travel with the distances, and the whole wave runs it max-over-lanes(marks) times per chunk -- ~220 times per
+// query wave at N = 1024, k = 20, 60 % of the kernel's instructions.
+//   scan A keeps only the k+1 smallest DISTANCES, sorted: inserting d is one v_med3_f32 per slot (new d[p] = median(d[p-1], d, d[p]));
+//   scan B knows tau = the k-th smallest distance and appends, in index order, the candidates with d < tau (at most k-1) and the first k
+//          with d == tau to a per-thread list in LDS; only those go through the full ladder -- k to k+few passes per wave instead of ~220.
+// The first k entries are the lexicographically smallest (distance, index) pairs in both forms; the rank-k tie flag comes from scan A.
+// The scans are bound by vector instructions per candidate, so they use the shortest exact forms: -2 dot + |q|^2 as ONE fma (the product by 2 is
+// exact, so fma(-2, dot, |q|^2) rounds like the reference's mul-then-add), no clamp where only the comparison matters (a clamped distance is
+// 1e-12 <= any threshold), and the per-lane bit mask of a chunk is built by v_cmp + v_addc (mask = 2 mask + (d < t)): candidate t of the chunk
+// ends up in bit 31 - t, so the lowest index is the highest bit.
+__device__ __forceinline__ float knn_dist_raw(const float4 pq, const float4 pj) {
+    const float dot = __fmaf_rn(pq.z, pj.z, __fmaf_rn(pq.y, pj.y, mul_rn(pq.x, pj.x)));
+    return add_rn(__fmaf_rn(-2.0f, dot, pq.w), pj.w);
+}
+__device__ __forceinline__ void mark_lt(unsigned& m, float d, float thr) {
+    asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d), "v"(thr) : "vcc");
+}
+__device__ __forceinline__ void mark_le(unsigned& m, float d, float thr) {
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d), "v"(thr) : "vcc");
+}
+
+template <int KL>
+__global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ xyz, int N, int k, int32_t* __restrict__ idx) {
+    static_assert(OGMM_KNN_CHUNK == 32, "the chunk is one 32-bit mask");
+    extern __shared__ __attribute__((aligned(16))) float4 pts[];   // [N], then the candidate lists [2 (KL-1)][256] int16
+    short* __restrict__ buf = reinterpret_cast<short*>(pts + N) + threadIdx.x;          // entry i of this thread at buf[i * 256]
+    const int c = blockIdx.y;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const float x = cloud[3 * j], y = cloud[3 * j + 1], z = cloud[3 * j + 2];
+        pts[j] = make_float4(x, y, z, sqnorm3(x, y, z));
+    }
+    __syncthreads();
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const float4 pq = pts[q];
+    constexpr int CHK = 32;
+    // ---- scan A: the k+1 smallest distances
+    float dk[KL];
+#pragma unroll
+    for (int p = 0; p < KL; ++p) dk[p] = __builtin_inff();
+    auto insert_d = [&](float d) {
+#pragma unroll
+        for (int p = KL - 1; p > 0; --p) dk[p] = __builtin_amdgcn_fmed3f(dk[p - 1], d, dk[p]);
+        dk[0] = fminf(dk[0], d);
+    };
+    // The chunk's 32 candidates are in registers before they are used: the next chunk's broadcast reads (one ds_read_b128 per candidate, the same
+    // address in every lane) are issued while this chunk is processed -- with two waves per SIMD nothing else hides the LDS latency (the compiler's
+    // own schedule kept 2-4 reads in flight and waited for each: 160 -> 146 us came from fewer instructions, the rest is this).
+    float4 ca[16], cb[16];          // the two halves of a chunk, each requested while the other one is processed
+    auto fetch = [&](float4 (&dst)[16], int j0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dst[t] = pts[j0 + t];          // (past the cloud: the candidate lists' bytes, never used as candidates)
+    };
+    int j = 0;
+    fetch(ca, 0);
+    for (; j + CHK <= N; j += CHK) {
+        const float worst = dk[KL - 1];
+        unsigned mask = 0u;
+        fetch(cb, j + 16);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mark_lt(mask, knn_dist_raw(pq, ca[t]), worst);
+        fetch(ca, j + CHK);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mark_lt(mask, knn_dist_raw(pq, cb[t]), worst);
+        while (__any(mask != 0u)) {
+            const bool mine = mask != 0u;
+            const int t = mine ? __clz(mask) : 0;
+            insert_d(mine ? knn_dist(pq, pts[j + t]) : __builtin_inff());
+            mask &= ~(0x80000000u >> t);
+        }
+    }
+    for (; j < N; ++j) insert_d(knn_dist(pq, pts[j]));
+    float tau = 0.0f, d_next = -1.0f;
+#pragma unroll
+    for (int p = 0; p < KL; ++p) {
+        if (p == k - 1) tau = dk[p];
+        if (p == k) d_next = dk[p];
+    }
+    const bool boundary_tie = k < N && tau == d_next;
+    // ---- scan B: the candidates that can be among the first k, in index order (tau >= 1e-12, so the unclamped distance compares like the
+    // clamped one against it, except that everything below the clamp is EQUAL to tau = 1e-12: both cases below use the clamped value)
+    int cnt = 0, ties = 0;
+    auto append = [&](int jj, bool less) {
+        if (less || ties < k) {
+            buf[cnt * 256] = (short)jj;
+            ++cnt;
+            ties += less ? 0 : 1;
+        }
+    };
+    fetch(ca, 0);
+    for (j = 0; j + CHK <= N; j += CHK) {
+        unsigned lt = 0u, le = 0u;
+        fetch(cb, j + 16);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float d = knn_dist(pq, ca[t]);
+            mark_lt(lt, d, tau);
+            mark_le(le, d, tau);
+        }
+        fetch(ca, j + CHK);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float d = knn_dist(pq, cb[t]);
+            mark_lt(lt, d, tau);
+            mark_le(le, d, tau);
+        }
+        while (le != 0u) {          // (per-lane loop: a handful of iterations per chunk, nothing wave-wide inside)
+            const int t = __clz(le);
+            const unsigned bit = 0x80000000u >> t;
+            append(j + t, (lt & bit) != 0u);
+            le &= ~bit;
+        }
+    }
+    for (; j < N; ++j) {
+        const float d = knn_dist(pq, pts[j]);
+        if (d <= tau) append(j, d < tau);
+    }
+    // ---- the full ladder over the short list (strict '<': equal distances keep their index order)
+    float dl[KL];
+    int ik[KL];
+#pragma unroll
+    for (int p = 0; p < KL; ++p) { dl[p] = __builtin_inff(); ik[p] = 0; }
+    for (int i = 0; __any(i < cnt); ++i) {
+        const bool mine = i < cnt;
+        const int jj = mine ? (int)buf[i * 256] : 0;
+        const float d = mine ? knn_dist(pq, pts[jj]) : __builtin_inff();
+        if (d < dl[KL - 1]) {
+#pragma unroll
+            for (int p = KL - 1; p > 0; --p) {
+                const bool shift = d < dl[p - 1];
+                const bool here = !shift && d < dl[p];
+                dl[p] = shift ? dl[p - 1] : (here ? d : dl[p]);
+                ik[p] = shift ? ik[p - 1] : (here ? jj : ik[p]);
+            }
+            const bool first = d < dl[0];
+            dl[0] = first ? d : dl[0];
+            ik[0] = first ? jj : ik[0];
+        }
+    }
     int32_t* out = idx + ((int64_t)c * N + q) * k;
 #pragma unroll
     for (int p = 0; p < KL - 1; ++p)
@@ -357,7 +505,15 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<33>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_resolve_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     }
-    if (k <= 8) hipLaunchKernelGGL(knn_kernel<9>, grid, dim3(256), lds, s, xyz, N, k, idx);
+    // the two-scan form while its candidate lists fit beside the cloud in 64 KiB (several workgroups per CU stay resident); else one scan
+    const int KLsel = k <= 8 ? 9 : (k <= 20 ? 21 : 33);
+    const size_t lds2 = lds + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
+    static const int two_scans = [] { const char* e = getenv("OGMM_KNN_TWO_SCANS"); return e ? atoi(e) : 1; }();
+    // (for k <= 8 the single scan stays: its ladder is short, 85 against 88 us at N = 1024, k = 5; k = 20: 175 -> 140 us)
+    if (two_scans && k > 8 && lds2 <= 64 * 1024) {
+        if (k <= 20) hipLaunchKernelGGL(knn2_kernel<21>, grid, dim3(256), lds2, s, xyz, N, k, idx);
+        else hipLaunchKernelGGL(knn2_kernel<33>, grid, dim3(256), lds2, s, xyz, N, k, idx);
+    } else if (k <= 8) hipLaunchKernelGGL(knn_kernel<9>, grid, dim3(256), lds, s, xyz, N, k, idx);
     else if (k <= 20) hipLaunchKernelGGL(knn_kernel<21>, grid, dim3(256), lds, s, xyz, N, k, idx);
     else hipLaunchKernelGGL(knn_kernel<33>, grid, dim3(256), lds, s, xyz, N, k, idx);
     if (int rc = ogmm::check_launch("ogmm_knn")) return rc;
