@@ -454,6 +454,28 @@ __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& l
     lo = __builtin_convertvector(r, f16x2);
 }
 
+// The same split on the instructions the GEMM engines use (gemm_common.h split4_f16): hi = v_cvt_pk_f16_f32, lo = v_fma_mix{lo,hi}_f16 (x - hi is exact
+// in fp32 and is rounded straight into the packed destination): 12 vector instructions per 8 values against ~30 of hipcc's lowering of split_pair --
+// the softmax and the two splits cost this kernel as much issue time as its MFMAs.  CLAMP: the +-65504 clamp of the packed form (the probabilities
+// are in [0, 1] and need none).
+template <bool CLAMP>
+__device__ __forceinline__ void split8_fast(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
+    if (CLAMP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = __builtin_amdgcn_fmed3f(a[e], -65504.0f, 65504.0f); b[e] = __builtin_amdgcn_fmed3f(b[e], -65504.0f, 65504.0f); }
+    }
+    f16x2 h0, h1, h2, h3, l0, l1, l2, l3;
+    asm("v_cvt_pk_f16_f32 %0, %8, %9\n\tv_cvt_pk_f16_f32 %1, %10, %11\n\tv_cvt_pk_f16_f32 %2, %12, %13\n\tv_cvt_pk_f16_f32 %3, %14, %15\n\t"
+        "v_fma_mixlo_f16 %4, %0, -1.0, %8 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %5, %1, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %6, %2, -1.0, %12 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %7, %3, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %4, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %5, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %6, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %7, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    hi = f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+    lo = f16x8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
+}
+
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
     f16x2 h, l;
     split_pair(a[0], a[1], h, l); hi[0] = h[0]; hi[1] = h[1]; lo[0] = l[0]; lo[1] = l[1];
@@ -568,7 +590,7 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
     const f16x8* __restrict__ Vl = Vs + lane_t;
     f16x8 qh[KS], ql[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) split8(qa[s], qb[s], qh[s], ql[s]);
+    for (int s = 0; s < KS; ++s) split8_fast<true>(qa[s], qb[s], qh[s], ql[s]);
     if (tile + (int)gridDim.x < n_tiles) load_q(tile + gridDim.x);
 
     // ---- S^T = K Q^T: row blocks = 32 keys each, A fragments from LDS
@@ -605,11 +627,12 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
         for (int r = 0; r < 16; ++r) m = fmaxf(m, sacc[j][r]);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.0f;
+    const float mb = -m * sl2;          // exp2(s sl2 - m sl2): one fma per score
 #pragma unroll
     for (int j = 0; j < MK; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sacc[j][r] = __builtin_amdgcn_exp2f((sacc[j][r] - m) * sl2);
+            sacc[j][r] = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], sl2, mb));
             sum += sacc[j][r];
         }
     sum += __shfl_xor(sum, 32, 64);
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
             f32x4 a, b;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] = sacc[j][8 * t + e] * inv; b[e] = sacc[j][8 * t + 4 + e] * inv; }
-            split8(a, b, ph, pl);
+            split8_fast<false>(a, b, ph, pl);
         }
         f16x8 vh[NV], vl[NV];
 #pragma unroll
