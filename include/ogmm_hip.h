@@ -370,7 +370,6 @@ int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ld
 int ogmm_debug_v6_probe(unsigned long long* host3);
 int ogmm_debug_v8_probe(unsigned long long* host3);
 int ogmm_debug_v10_probe(unsigned long long* host3);
-int ogmm_debug_v14_probe(unsigned long long* host3);
 
 #ifdef __cplusplus
 }

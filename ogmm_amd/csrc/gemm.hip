@@ -156,7 +156,7 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(d != nullptr, "ogmm_gemm_nt: null descriptor");
     const ogmm_gemm& g = *d;
     OGMM_REQUIRE(g.A && (g.B || g.precision != OGMM_PREC_F32) && g.M > 0 && g.N > 0 && g.K1 > 0, "ogmm_gemm_nt: A, B, M, N, K1 required");
-    OGMM_REQUIRE(g.precision == OGMM_PREC_F32 || g.precision == OGMM_PREC_F16X3 || g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || (g.precision > 10 && g.precision <= 139), "ogmm_gemm_nt: bad precision %d", g.precision);
+    OGMM_REQUIRE(g.precision == OGMM_PREC_F32 || g.precision == OGMM_PREC_F16X3 || g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || (g.precision > 10 && g.precision <= 129), "ogmm_gemm_nt: bad precision %d", g.precision);
     OGMM_REQUIRE(g.K2 >= 0 && (g.K2 == 0 || g.A2), "ogmm_gemm_nt: K2 > 0 needs A2");
     OGMM_REQUIRE(g.K1 % 4 == 0 && g.K2 % 4 == 0 && g.lda % 4 == 0 && (g.ldb % 4 == 0 || g.precision != OGMM_PREC_F32) && (g.K2 == 0 || g.lda2 % 4 == 0),
                  "ogmm_gemm_nt: K1, K2, lda, lda2, ldb must be multiples of 4 (got %d %d %lld %lld %lld)", g.K1, g.K2,

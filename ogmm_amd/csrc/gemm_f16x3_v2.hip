@@ -230,8 +230,6 @@ bool gemm_f16x3_v8_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v10_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s);
-bool gemm_f16x3_v14_applicable(const ogmm_gemm& g);
-int gemm_nt_f16x3_v14(const ogmm_gemm& g, hipStream_t s);
 
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     OGMM_REQUIRE(g.B_hi && g.B_lo && aligned16(g.B_hi) && aligned16(g.B_lo), "ogmm_gemm_nt(f16x3 frag): needs the fragment-major B image");
@@ -262,8 +260,6 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
             OGMM_REQUIRE(gemm_f16x3_v8_applicable(g), "LDS-DMA engine (v8) not applicable"); return gemm_nt_f16x3_v8(g, s);
         case 110: case 111: case 112: case 113: case 114: case 115: case 116: case 117: case 118: case 119:            // LDS-DMA engine, 4 waves x (64 x 256) (v10)
             OGMM_REQUIRE(gemm_f16x3_v10_applicable(g), "LDS-DMA engine (v10) not applicable"); return gemm_nt_f16x3_v10(g, s);
-        case 130: case 131: case 132: case 133: case 134: case 135: case 136: case 137: case 138: case 139:            // persistent, staggered streams (v14)
-            OGMM_REQUIRE(gemm_f16x3_v14_applicable(g), "engine v14 not applicable"); return gemm_nt_f16x3_v14(g, s);
         default: break;
     }
     // the LDS-DMA engines (v10: 4 waves of 64 x 256; v8: 8 waves of 32 x 256) wherever they apply; its first form (v6: 4 x 2 waves, the ablation vehicle of DESIGN.md) only by its variant codes
