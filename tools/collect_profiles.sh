@@ -18,7 +18,7 @@ timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 
 rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format rocpd -- $BENCH > $out/trace.log 2>&1
 db=$(find $out/trace -name "*.db" | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- $BENCH   (7 forwards: 2 warm-up + 5 timed; the first one also packs the weights)"; python3 tools/rocpd_stats.py $db; } > $out/${tag}_kernel_stats.txt
-{ echo "# one eval step (B=64, N=1024, J=16) as dispatched: start, gap to the previous kernel's end (negative: overlapped with a side stream), duration, grid"; python3 tools/rocpd_timeline.py $db "knn_kernel<21>" | head -70; } > $out/${tag}_step_timeline.txt
+{ echo "# one eval step (B=64, N=1024, J=16) as dispatched: start, gap to the previous kernel's end (negative: overlapped with a side stream), duration, grid"; python3 tools/rocpd_timeline.py $db "knn2_kernel<21>" | head -70; } > $out/${tag}_step_timeline.txt
 
 # 3. PMC passes (separate runs)
 {
@@ -34,16 +34,19 @@ done
 } > $out/${tag}_pmc_counters.txt
 
 # 4. GEMM engine: variants and ablations with the in-kernel clock probes (cycles per tile, shader clock)
-export OGMM_V6_MIN_TILES=1 OGMM_V4_MIN_TILES=1 OGMM_V8_MIN_TILES=1
+export OGMM_V6_MIN_TILES=1 OGMM_V4_MIN_TILES=1 OGMM_V8_MIN_TILES=1 OGMM_V10_MIN_TILES=1
 {
-echo "# tools/gemm_v6_check.py: register-staged engine (v23 = gemm_f16x3_v4), first LDS-DMA form (v60 = gemm_f16x3_v6, 4x2 waves), final form (v100 = gemm_f16x3_v8, 8x1 waves); x1 = without output stores"
-timeout 300 python3 tools/gemm_v6_check.py --time-only 23 60 100 61 101 2>&1 | grep TF
-echo "# clock probes (131072 x 1024 x 1024): v6 ablations 80 full, 81 no stores, 82 no DMA, 86 DMA + MFMA only, 83 MFMA + barrier, 84 MFMA only, 85 MFMA only on zeros; v8: 102 full, 103 no stores, 104 no DMA"
-timeout 200 python3 tools/gemm_v6_check.py --time-only --clock 80 81 82 86 83 84 85 102 103 104 2>&1 | tail -10
-echo "# one tile per workgroup on 64 / 128 / 256 CUs and whole rounds beyond (v8 full, v8 without stores, v6 MFMA + barrier, v6 DMA only)"
-timeout 200 python3 tools/gemm_v6_check.py --time-only --grid-sweep 100 101 63 70 2>&1 | tail -5
+echo "# tools/gemm_v6_check.py: register-staged engine (v23 = gemm_f16x3_v4), LDS-DMA engines: v60 = gemm_f16x3_v6 (4x2 waves), v100 = gemm_f16x3_v8 (8x1 waves), v110 = gemm_f16x3_v10 (4 waves of 64 x 256, the default from N = 512); x1 = without output stores"
+timeout 300 python3 tools/gemm_v6_check.py --time-only 23 60 100 110 101 111 2>&1 | grep TF
+echo "# clock probes (131072 x 1024 x 1024): v6 ablations 80 full, 83 MFMA + barrier, 84 MFMA only, 85 MFMA only on zeros; v8: 102 full, 103 no stores, 104 no DMA; v10: 112 full, 113 no stores, 114 no DMA,"
+echo "#   115 no split arithmetic, 116 no weight-fragment reads, 117 DMA + MFMA + barrier, 118 MFMA + barrier, 119 fragment reads + MFMA"
+timeout 300 python3 tools/gemm_v6_check.py --time-only --clock 80 83 84 85 102 103 104 112 113 114 115 116 117 118 119 2>&1 | tail -15
+echo "# one tile per workgroup on 64 / 128 / 256 CUs and whole rounds beyond (v10 full, v10 without stores, v8 full, v8 without stores)"
+timeout 200 python3 tools/gemm_v6_check.py --time-only --grid-sweep 110 111 100 101 2>&1 | tail -5
+echo "# every GEMM launch of one eval forward (tools/gemm_launch_table.py)"
+timeout 200 python3 tools/gemm_launch_table.py 2>&1 | tail -27
 } > $out/${tag}_gemm_engine.txt
-unset OGMM_V6_MIN_TILES OGMM_V4_MIN_TILES OGMM_V8_MIN_TILES
+unset OGMM_V6_MIN_TILES OGMM_V4_MIN_TILES OGMM_V8_MIN_TILES OGMM_V10_MIN_TILES
 
 # 5. parity lines of the GPU tests
 timeout 900 python3 -m pytest tests/test_hip_forward.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|passed|failed" > $out/${tag}_parity.txt
