@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 11
+#define OGMM_ABI_VERSION 12
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -126,6 +126,10 @@ typedef struct ogmm_gemm {
      * (one column tile holds whole rows), M a multiple of 256:  rd_out[row * rd_ld] = rd_act(sum_col y[row][col] * rd_w[col] + rd_b[0]) with y the
      * value this layer would store.  C may then be NULL: the 256-wide map is not written at all.  ogmm_gemm_rowdot_fusable tells. */
     const float* rd_w; const float* rd_b; int32_t rd_act; float* rd_out; int64_t rd_ld;
+    /* A rows gathered on the fly (lib/utils.py:111-127 index_points in front of a convolution: the anchors of models/gmmreg.py:54, 67-68),
+     * OGMM_PREC_F16X3_FRAG, one A piece: output row m = c * a_gather_S + s reads A row map(c) * a_gather_N + a_gather_ids[map(c)][s] with
+     * map(c) = a_gather_map ? a_gather_map[c] : c; a_gather_rows = rows of A (for the 32-bit offset check).  ogmm_gemm_gather_fusable tells. */
+    const int32_t* a_gather_ids; const int32_t* a_gather_map; int32_t a_gather_S; int32_t a_gather_N; int64_t a_gather_rows;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
@@ -134,6 +138,8 @@ int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
 int ogmm_gemm_overlap_fusable(int B, int N, int D);
 /* 1 if ogmm_gemm_nt takes a fused Cout = 1 head (rd_out) behind an M x N layer with K1 + K2 input channels, else 0 */
 int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2);
+/* 1 if ogmm_gemm_nt takes gathered A rows (a_gather_ids) for an M x N layer with K input channels over `rows` source rows, else 0 */
+int ogmm_gemm_gather_fusable(int M, int N, int K, int64_t rows);
 /* second half of the fused overlap block: merges the (1, sum, dot) triples the similarity GEMM left (models/gmmreg.py:79-80):
  * wo_src[(b N + i) ldo] = softmax(S_b, dim = 1)[i] . o_tgt, wo_tgt[(b N + j) ldo] = softmax(S_b^T, dim = 1)[j] . o_src */
 int ogmm_overlap_finalize(const float* rowpart, const float* colpart, int B, int N, float* wo_src, float* wo_tgt, int64_t ldo, void* stream);

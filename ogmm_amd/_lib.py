@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -34,6 +34,7 @@ class GemmDesc(Structure):
         ("col_stats", c_void_p), ("a_scale", c_void_p), ("a_shift", c_void_p), ("a_relu", c_int32), ("group_rows", c_int32),
         ("ovl_orow", c_void_p), ("ovl_ocol", c_void_p), ("ovl_ld", c_int64), ("ovl_rowpart", c_void_p), ("ovl_colpart", c_void_p), ("row_rscale", c_void_p),
         ("rd_w", c_void_p), ("rd_b", c_void_p), ("rd_act", c_int32), ("rd_out", c_void_p), ("rd_ld", c_int64),
+        ("a_gather_ids", c_void_p), ("a_gather_map", c_void_p), ("a_gather_S", c_int32), ("a_gather_N", c_int32), ("a_gather_rows", c_int64),
     ]
 
 
@@ -47,6 +48,7 @@ PROTOTYPES = {
     "ogmm_gemm_nt": [POINTER(GemmDesc), c_void_p],
     "ogmm_gemm_overlap_fusable": [c_int, c_int, c_int],
     "ogmm_gemm_rowdot_fusable": [c_int, c_int, c_int, c_int],
+    "ogmm_gemm_gather_fusable": [c_int, c_int, c_int, c_int64],
     "ogmm_overlap_finalize": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_row_rnorm": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p],
     "ogmm_edgeconv_first": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],

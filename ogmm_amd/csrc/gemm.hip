@@ -171,7 +171,7 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
     const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || g.precision >= 18;
-    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart && !g.rd_out), "ogmm_gemm_nt: InstanceNorm / overlap-block / Cout = 1 head fusion is only available with OGMM_PREC_F16X3_FRAG");
+    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart && !g.rd_out && !g.a_gather_ids), "ogmm_gemm_nt: InstanceNorm / overlap-block / Cout = 1 head / row gather fusion is only available with OGMM_PREC_F16X3_FRAG");
     if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
@@ -204,4 +204,16 @@ extern "C" int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2) {
     g.precision = OGMM_PREC_F16X3_FRAG; g.ldb_h = (K1 + 63) / 64 * 64 + (K2 + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy;
     g.rd_out = dummy; g.rd_w = dummy; g.rd_ld = 1;
     return ogmm::gemm_f16x3_v8_applicable(g) ? 1 : 0;
+}
+
+// Would ogmm_gemm_nt take gathered A rows (ogmm_gemm.a_gather_ids) for an M x N layer with K input channels over `rows` source rows?  (1 / 0)
+extern "C" int ogmm_gemm_gather_fusable(int M, int N, int K, int64_t rows) {
+    if (M <= 0 || N < 512 || K <= 0 || rows <= 0) return 0;
+    static float dummy[4];
+    static int32_t idummy[4];
+    ogmm_gemm g = {};
+    g.A = dummy; g.lda = K; g.K1 = K; g.M = M; g.N = N; g.batch_outer = 1; g.batch_inner = 1; g.precision = OGMM_PREC_F16X3_FRAG;
+    g.ldb_h = (K + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy; g.C = dummy;
+    g.a_gather_ids = idummy; g.a_gather_S = 1; g.a_gather_N = 1; g.a_gather_rows = rows;
+    return ogmm::gemm_f16x3_v10_applicable(g) ? 1 : 0;
 }

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
 
     // ---- DMA sources.  A: wave w stages rows [64 w, 64 w + 64), instruction i rows 8 i .. 8 i + 7, lane l -> row (l >> 3), LDS chunk (l & 7)
     // <- global chunk (l & 7) ^ ((row >> 1) & 7).  Rows beyond M are clamped (their results are never stored).
-    const float* __restrict__ A1p = g.A + zb * g.sA_o + (int64_t)m0 * g.lda;
+    // A rows gathered on the fly (ogmm_gemm.a_gather_ids): output row m = c S + s reads source row map(c) N + ids[map(c)][s]; the DMA's per-lane row
+    // offsets then come from the index list, relative to A itself instead of the tile's first row
+    const bool gathered = g.a_gather_ids != nullptr;
+    const float* __restrict__ A1p = g.A + zb * g.sA_o + (gathered ? 0 : (int64_t)m0 * g.lda);
     const float* __restrict__ A2p = g.A2 ? g.A2 + zb * g.sA2_o + (int64_t)m0 * g.lda2 : nullptr;
     const unsigned lds0 = (unsigned)(size_t)smem10;
     unsigned aoff[8];
@@ -68,7 +71,13 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = wave * 64 + i * 8 + (lane >> 3);
-            aoff[i] = (unsigned)(min(r, g.M - 1 - m0) * ld + ((lane & 7) ^ ((r >> 1) & 7)) * 4) * 4u;
+            int src_row = min(r, g.M - 1 - m0);
+            if (gathered) {
+                const int mrow = m0 + src_row, c = mrow / g.a_gather_S, sidx = mrow - c * g.a_gather_S;
+                const int sc = g.a_gather_map ? g.a_gather_map[c] : c;
+                src_row = sc * g.a_gather_N + g.a_gather_ids[(int64_t)sc * g.a_gather_S + sidx];
+            }
+            aoff[i] = (unsigned)(src_row * ld + ((lane & 7) ^ ((r >> 1) & 7)) * 4) * 4u;
         }
     };
     set_aoff((int)g.lda);
@@ -391,8 +400,10 @@ bool gemm_f16x3_v10_applicable(const ogmm_gemm& g) {
     static const int enabled = [] { const char* e = getenv("OGMM_V10"); return e ? atoi(e) : 1; }();
     static const long long min_tiles = [] { const char* e = getenv("OGMM_V10_MIN_TILES"); return e ? atoll(e) : 256LL; }();
     const bool whole_tiles = g.M % BM == 0 && g.N % BN == 0 && !g.row_affine;
+    const bool gather_ok = !g.a_gather_ids || (g.K2 == 0 && !g.a_scale && g.batch_outer * g.batch_inner == 1 && g.a_gather_S > 0 && g.a_gather_N > 0 &&
+                                               (int64_t)g.a_gather_rows * g.lda * 4 < (1ll << 32));
     const bool ovl_ok = !g.ovl_rowpart || (whole_tiles && g.ovl_colpart && g.ovl_orow && g.ovl_ocol && g.ovl_ld >= 1 && !g.a_scale && !g.col_stats && !g.Res && g.batch_inner == 1);
-    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok &&
+    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok &&
            (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }

@@ -263,6 +263,10 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         default: break;
     }
     // the LDS-DMA engines (v10: 4 waves of 64 x 256; v8: 8 waves of 32 x 256) wherever they apply; its first form (v6: 4 x 2 waves, the ablation vehicle of DESIGN.md) only by its variant codes
+    if (g.a_gather_ids) {
+        OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && g.N >= 512 && gemm_f16x3_v10_applicable(g), "ogmm_gemm_nt: gathered A rows need the fragment-major fp16x3 engine, N >= 512, one A piece (ogmm_gemm_gather_fusable)");
+        return gemm_nt_f16x3_v10(g, s);
+    }
     if (g.rd_out) {
         OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v8_applicable(g), "ogmm_gemm_nt: a fused Cout = 1 head needs the fragment-major fp16x3 engine, N == 256 and whole row tiles (ogmm_gemm_rowdot_fusable)");
         return gemm_nt_f16x3_v8(g, s);

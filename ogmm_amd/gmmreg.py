@@ -274,14 +274,15 @@ class GMMReg(nn.Module):
             self._packed_fp = self._fingerprint(list(sd.values()))
         return self._packed
 
-    def _transformer(self, L, x, anchors, C, N, res):
-        """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D], anchors [C, M, D]."""
+    def _transformer(self, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None):
+        """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D]; the anchors [C, M, D] are rows
+        anchor_ids [C, M] of anchor_feats [C*N, D] (of the cloud cloud_map[c], if given): lib/utils.py:111-127."""
         D, H = self.emb_dims, self.config.num_heads
-        dh, M = D // H, anchors.shape[1]
+        dh, M = D // H, anchor_ids.shape[1]
         dev = x.device
         q = ops.conv1x1(x, L["q"])
         if ops.attention_supported(M, dh):
-            kv = ops.conv1x1(anchors.view(C * M, D), L["kv"])            # keys | values in one GEMM
+            kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map)      # keys | values in one GEMM, rows gathered by its DMA
             o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H)
             if self.fold_merge:
                 mlp0, msg = L["mlp0_folded"], o                       # merge conv folded into mlp0's weights
@@ -296,6 +297,7 @@ class GMMReg(nn.Module):
             z = ops.conv1x1(x, mlp0, x2=msg)
             ops.instnorm_relu_(z, C, N, BN_EPS)
             return ops.conv1x1(z, L["mlp3"], res=res)
+        anchors = ops.gather_rows(anchor_feats, D, C, N, D, anchor_ids, cloud_map=cloud_map)
         kk = ops.conv1x1(anchors.view(C * M, D), L["k"])
         vT = torch.empty((C, D, M), dtype=torch.float32, device=dev)            # V^T per cloud: rows = head-major channels
         ops.gemm_nt(L["v"]["W"], D, D, anchors, D, D, M, C=vT, ldc=M, shift=L["v"]["shift"], row_affine=True,
@@ -406,12 +408,10 @@ class GMMReg(nn.Module):
         ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:])
 
         # ---- self-attention 1 + conv1 (gmmreg.py:54-57, 62-63)
-        a0 = ops.gather_rows(emb, D, C, N, D, ids_a[0])
-        t1 = self._transformer(L["sattn1"], x0, a0, C, N, res=x0)
+        t1 = self._transformer(L["sattn1"], x0, emb, ids_a[0], C, N, res=x0)
         ft = self._stack3(L["conv1"], t1)
         # ---- cross-attention: keys/values are the OTHER cloud's anchors (gmmreg.py:67-72)
-        a1 = ops.gather_rows(ft, D, C, N, D, ids_a[1], cloud_map=swap)
-        f = self._transformer(L["cattn"], ft, a1, C, N, res=ft)
+        f = self._transformer(L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap)
 
         # ---- overlap scores (gmmreg.py:74-89)
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
@@ -451,8 +451,7 @@ class GMMReg(nn.Module):
         o.record_stream(side)
         for t_ in (gamma, pi, mu):
             t_.record_stream(main)
-        a2 = ops.gather_rows(f, D, C, N, D, ids_a[2])
-        f2 = self._transformer(L["sattn2"], f, a2, C, N, res=f)
+        f2 = self._transformer(L["sattn2"], f, f, ids_a[2], C, N, res=f)
         main.wait_event(em_done)
 
         # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)

@@ -14,6 +14,7 @@ from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16_FRAG, P
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_flops)
 GEMM_TIMELINE = None
+FUSE_GATHER = os.environ.get("OGMM_FUSE_GATHER", "1") != "0"      # anchor rows gathered by the consuming GEMM's operand DMA (conv1x1_gathered)
 FUSE_HEAD = os.environ.get("OGMM_FUSE_HEAD", "1") != "0"      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
 GEMM_TIMELINE_ONLY = None      # optional set of variant tags: only those launches are bracketed by events (bench.py: the dominant engine only)
 _EVENT_POOL = []               # timing events are recycled: creating two torch events per launch costs more host time than the launch itself
@@ -173,7 +174,7 @@ def split_f16_training(W, key, refresh=64, **kw):
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
             pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0,
-            overlap=None, row_rscale=None, head=None):
+            overlap=None, row_rscale=None, head=None, a_gather=None):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -215,6 +216,9 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
         store_c = False
     if row_rscale is not None:
         d.row_rscale = row_rscale.data_ptr()
+    if a_gather is not None:          # (ids int32 [C, S], cloud_map int32 [C] or None, N points per cloud, rows of A): struct ogmm_gemm.a_gather_*
+        d.a_gather_ids, d.a_gather_map = a_gather[0].data_ptr(), (a_gather[1].data_ptr() if a_gather[1] is not None else None)
+        d.a_gather_S, d.a_gather_N, d.a_gather_rows = a_gather[0].shape[1], a_gather[2], a_gather[3]
     if head is not None:          # (w [N], b [1] or None, act, out, ld): a Cout = 1 convolution behind this layer (struct ogmm_gemm.rd_*)
         d.rd_w, d.rd_b, d.rd_act = head[0].data_ptr(), (head[1].data_ptr() if head[1] is not None else None), head[2]
         d.rd_out, d.rd_ld = head[3].data_ptr(), head[4]
@@ -400,6 +404,24 @@ def l2norm_rows(x, out=None):
         out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
     _lib.call("ogmm_l2norm_rows", _p(_f32(x, "x")), x.stride(0), x.shape[0], x.shape[1], _p(out), out.stride(0), _stream())
     return out
+
+
+def conv1x1_gathered(feats, C, N, ids, layer, act=ACT_NONE, cloud_map=None):
+    """conv1x1(gather_rows(feats, ids, cloud_map), layer): a convolution over the anchor rows of every cloud (models/gmmreg.py:54, 67-68).  Where the
+    engine takes it, the rows are gathered by the GEMM's own operand DMA (struct ogmm_gemm.a_gather_*) and the anchor tensor is never written."""
+    feats, ids = _f32(feats, "feats"), _i32(ids, "ids")
+    rows, D = feats.shape
+    S = ids.shape[1]
+    Cout = layer["W"].shape[0]
+    sp = layer.get("split") if DEFAULT_SPLIT else None
+    if (FUSE_GATHER and sp is not None and sp.get("variant") == PREC_F16X3_FRAG and not F16_SINGLE_TERM and feats.stride(1) == 1 and ids.is_contiguous()
+            and _lib.load().ogmm_gemm_gather_fusable(C * S, Cout, D, rows) == 1):
+        out = torch.empty((C * S, Cout), dtype=torch.float32, device=feats.device)
+        cm = _i32(cloud_map, "cloud_map") if cloud_map is not None else None
+        gemm_nt(feats, feats.stride(0), D, layer["W"], D, C * S, Cout, C=out, ldc=Cout, scale=layer.get("scale"), shift=layer.get("shift"), act=act,
+                split=sp, overflow=DEFAULT_OVERFLOW, a_gather=(ids, cm, N, rows))
+        return out
+    return conv1x1(gather_rows(feats, feats.stride(0), C, N, D, ids, cloud_map=cloud_map).view(C * S, D), layer, act)
 
 
 def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None):

@@ -307,6 +307,28 @@ def test_gemm_with_fused_cout1_head(ops, head_act, with_map):
     assert (out2[:, 1] - out[:, 1]).abs().max().item() < (2e-5 if head_act == "none" else 2e-6)
 
 
+@pytest.mark.parametrize("with_map", [False, True])
+def test_gemm_with_gathered_rows(ops, with_map):
+    """index_points in front of a convolution (the anchors' K/V projection, models/gmmreg.py:54, 67-68): the GEMM's operand DMA gathers the rows
+    (struct ogmm_gemm.a_gather_*); bit-identical to gather_rows + the same GEMM."""
+    C, N, S, D, Cout = 128, 1024, 128, 512, 1024
+    if ops._lib.load().ogmm_gemm_gather_fusable(C * S, Cout, D, C * N) != 1:
+        pytest.skip("the engine does not take gathered rows for this shape")
+    torch.manual_seed(23)
+    feats = torch.randn(C * N, D, device="cuda")
+    ids = torch.stack([torch.randperm(N)[:S] for _ in range(C)]).to(torch.int32).cuda()
+    cmap = (torch.arange(C) ^ 1).to(torch.int32).cuda() if with_map else None
+    W = torch.randn(Cout, D, device="cuda") * 0.05
+    layer = {"W": W, "scale": None, "shift": torch.randn(Cout, device="cuda"), "split": ops.split_f16(W, frag=True)}
+    got = ops.conv1x1_gathered(feats, C, N, ids, layer, cloud_map=cmap)
+    a = ops.gather_rows(feats, D, C, N, D, ids, cloud_map=cmap).view(C * S, D)
+    ref = ops.conv1x1(a, layer)
+    assert torch.equal(got, ref)
+    src = (cmap.long() if with_map else torch.arange(C, device="cuda"))
+    rows = (src[:, None] * N + ids.long()[src]).reshape(-1)
+    assert (got[:512].double() - (feats[rows[:512]].double() @ W.double().t() + layer["shift"].double())).abs().max().item() < 2e-5
+
+
 def test_gemm_batched_strided_row_affine(ops):
     torch.manual_seed(1)
     Co, Hh, N, M, dh = 3, 4, 130, 32, 16
