@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 12
+#define OGMM_ABI_VERSION 13
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -229,6 +229,11 @@ int ogmm_overlap_cross_ws(const float* S, int B, int N, const float* o_src, cons
 int ogmm_gmm_em(const float* xyz, const float* o /*[C][N]*/, const int32_t* ids0 /*[C][J]*/, int C, int N, int J,
                 int iters, int sk_iters, float epsilon, float tau,
                 float* gamma /*[C][N][J]*/, float* pi /*[C][J]*/, float* mu /*[C][J][3]*/, void* stream);
+/* The same with a diagnostic: resid [C][iters][sk_iters] (may be NULL) receives every sweep's sum |u - u0| + sum |v - v0| per cloud, the
+ * quantity whose batch mean the reference compares with 1e-2 for its early exit (lib/utils.py:99-102).  NaN where the problem does not run on
+ * the LDS-resident kernel.  GMMReg.sinkhorn_exit_margin() turns it into "would the reference have left early". */
+int ogmm_gmm_em_resid(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters, float epsilon,
+                      float tau, float* gamma, float* pi, float* mu, float* resid, void* stream);
 
 /* K15 for shapes whose N x J cost matrix exceeds one CU's LDS: the same loop as a fixed sequence of grid-wide kernels over a cost
  * matrix kept in `workspace` (ogmm_gmm_em_workspace_bytes, 256-byte aligned), all launched by this one call without host

@@ -190,7 +190,7 @@ template <int JT, bool FAST>
 __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __restrict__ xyz, const float* __restrict__ o,
                                                              const int32_t* __restrict__ ids0, int N, int J, int iters, int sk_iters,
                                                              float inv_eps, float eps, float inv_tau, float* __restrict__ gamma,
-                                                             float* __restrict__ pi_out, float* __restrict__ mu_out) {
+                                                             float* __restrict__ pi_out, float* __restrict__ mu_out, float* __restrict__ resid) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* pts = reinterpret_cast<float4*>(lds);
     const int Npad = (N + 3) / 4 * 4;
@@ -223,6 +223,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
     for (int j = tid; j < J; j += EM_T) mu[j] = pts[ids0[(int64_t)c * J + j]];
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
     __syncthreads();
+    // resid != NULL (diagnostics): sum |u - u0| + sum |v - v0| of every Sinkhorn sweep, the quantity whose batch mean the reference tests against
+    // 1e-2 for its early exit (lib/utils.py:99-102) -- which this kernel does not implement.  red[0] / red[1] alternate as the sweep's accumulator.
+    if (resid && tid < 2) red[tid] = 0.0f;
 
     for (int it = 0; it < iters; ++it) {
         for (int n = tid; n < N; n += EM_T) {
@@ -248,7 +251,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                     float se = 0.0f;
 #pragma unroll
                     for (int j = 0; j < JT; ++j) se += em_exp(t[j] - mx);
-                    u[n] = eps * (logp[n] - (mx + logf(se))) + un;
+                    const float un1 = eps * (logp[n] - (mx + logf(se))) + un;
+                    u[n] = un1;
+                    if (resid) atomicAdd(&red[sk & 1], fabsf(un1 - un));
                 }
                 __syncthreads();
                 for (int j = wave; j < JT; j += NW) {                     // v^{l+1}: columns on waves, 16 rows per lane
@@ -268,9 +273,14 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                     for (int i = 0; i < 16; ++i)
                         if (lane + 64 * i < N) se += em_exp(t[i] - mx);
                     se = wave_sum(se);
-                    if (lane == 0) v[j] = eps * (logq - (mx + logf(se))) + vj;
+                    if (lane == 0) {
+                        const float vj1 = eps * (logq - (mx + logf(se))) + vj;
+                        v[j] = vj1;
+                        if (resid) atomicAdd(&red[sk & 1], fabsf(vj1 - vj));
+                    }
                 }
                 __syncthreads();
+                if (resid && tid == 0) { resid[((int64_t)c * iters + it) * sk_iters + sk] = red[sk & 1]; red[sk & 1] = 0.0f; }
                 continue;
             }
             for (int n = tid; n < N; n += EM_T) {                     // u^{l+1}: rows on threads
@@ -279,7 +289,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                 for (int j = 0; j < J; ++j) mx = fmaxf(mx, ((-Cs[j * N + n] + un) + v[j]) * inv_eps);
                 float se = 0.0f;
                 for (int j = 0; j < J; ++j) se += expf(((-Cs[j * N + n] + un) + v[j]) * inv_eps - mx);
-                u[n] = eps * (logp[n] - (mx + logf(se))) + un;
+                const float un1 = eps * (logp[n] - (mx + logf(se))) + un;
+                u[n] = un1;
+                if (resid) atomicAdd(&red[sk & 1], fabsf(un1 - un));
             }
             __syncthreads();
             for (int j = wave; j < J; j += NW) {                      // v^{l+1}: columns on waves
@@ -291,9 +303,14 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                 float se = 0.0f;
                 for (int n = lane; n < N; n += 64) se += expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
                 se = wave_sum(se);
-                if (lane == 0) v[j] = eps * (logq - (mx + logf(se))) + vj;
+                if (lane == 0) {
+                    const float vj1 = eps * (logq - (mx + logf(se))) + vj;
+                    v[j] = vj1;
+                    if (resid) atomicAdd(&red[sk & 1], fabsf(vj1 - vj));
+                }
             }
             __syncthreads();
+            if (resid && tid == 0) { resid[((int64_t)c * iters + it) * sk_iters + sk] = red[sk & 1]; red[sk & 1] = 0.0f; }
         }
         const bool last = it + 1 == iters;
         for (int n = tid; n < N; n += EM_T) {                         // gamma = exp(K) (in place), row sums
@@ -818,8 +835,18 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restri
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- entry points
+extern "C" int ogmm_gmm_em_resid(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
+                                 float epsilon, float tau, float* gamma, float* pi, float* mu, float* resid, void* stream);
 extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
                            float epsilon, float tau, float* gamma, float* pi, float* mu, void* stream) {
+    return ogmm_gmm_em_resid(xyz, o, ids0, C, N, J, iters, sk_iters, epsilon, tau, gamma, pi, mu, nullptr, stream);
+}
+
+// The same with a diagnostic output: resid [C][iters][sk_iters] (may be NULL) receives every Sinkhorn sweep's sum |u - u0| + sum |v - v0| per cloud
+// (lib/utils.py:99-101; the reference leaves its sweeps early when the batch mean falls below 1e-2, this library never does).  Filled with NaN
+// when the problem does not run on the LDS-resident kernel (cost matrix beyond 128 KiB).
+extern "C" int ogmm_gmm_em_resid(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
+                                 float epsilon, float tau, float* gamma, float* pi, float* mu, float* resid, void* stream) {
     OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu, "ogmm_gmm_em: null pointer");
     OGMM_REQUIRE(C > 0 && N > 0 && J > 0 && J <= N && iters > 0 && sk_iters >= 0 && epsilon > 0 && tau > 0, "ogmm_gmm_em: bad sizes C=%d N=%d J=%d", C, N, J);
     const int Npad = (N + 3) / 4 * 4;   // keeps the float4 mu array 16-byte aligned behind 7 per-point floats
@@ -843,15 +870,16 @@ extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0
         static const int em_mode = [] { const char* e = getenv("OGMM_EM_MODE"); return e ? atoi(e) : 2; }();      // 0 generic, 1 registers (bit-identical to 0), 2 + v_exp_f32 (default)
         if (J == 16 && N <= EM_T && em_mode == 2)
             hipLaunchKernelGGL((gmm_em_cached_kernel<16, true>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
-                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu);
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, resid);
         else if (J == 16 && N <= EM_T && em_mode == 1)
             hipLaunchKernelGGL((gmm_em_cached_kernel<16, false>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
-                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu);
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, resid);
         else
             hipLaunchKernelGGL((gmm_em_cached_kernel<0, false>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
-                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu);
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, resid);
         return ogmm::check_launch("ogmm_gmm_em(cached)");
     }
+    if (resid) (void)hipMemsetAsync(resid, 0xFF, (size_t)C * iters * sk_iters * sizeof(float), ogmm::as_stream(stream));          // NaN: not measured on this path
     hipLaunchKernelGGL(gmm_em_kernel, dim3(C), dim3(EM_T), lds, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters, sk_iters, inv_eps,
                        epsilon, inv_tau, gamma, pi, mu);
     return ogmm::check_launch("ogmm_gmm_em");

@@ -445,7 +445,10 @@ class GMMReg(nn.Module):
         # ---- GMM E/M (needs only xyz and the overlap scores) on the side stream, next to self-attention 2 (gmmreg.py:92-101)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            gamma, pi, mu = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0)
+            # capture=True also records every Sinkhorn sweep's residual (the reference would leave its sweeps early if its batch mean fell below 1e-2,
+            # lib/utils.py:99-102; this path never does): see sinkhorn_exit_margin()
+            em = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, return_resid=capture)
+            gamma, pi, mu = em[:3]
             em_done = torch.cuda.Event()
             em_done.record(side)
         o.record_stream(side)
@@ -473,13 +476,23 @@ class GMMReg(nn.Module):
 
         if capture:
             cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0], o_logit=extra[:, 1],
-                       o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss)
+                       o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss, sinkhorn_resid=em[3])
             self.last_intermediates = cap
         if is_test:
             # models/gmmreg.py:115-117: point-to-point ICP from the network's motion, correspondence radius 2 * overlap_radius
             # (lib/o3dutils.py:176).  The reference hands every pair to open3d on the CPU; here the whole batch stays on the GPU.
             rot, trans = ops.icp_point_to_point(xyz[:B], xyz[B:], rot, trans, 2.0 * cfg.overlap_radius)
         return rot, trans, o[:B], o[B:], loss
+
+    def sinkhorn_exit_margin(self):
+        """After forward(..., capture=True): the smallest batch-mean Sinkhorn residual of the call, per call group (src clouds, tgt clouds) as the
+        reference forms it (lib/utils.py:99-101: mean over the clouds of sum |u - u0| + sum |v - v0|), divided by its exit threshold 1e-2.
+        A value > 1 means the reference would not have left any sweep early either, i.e. this path (which always runs all sweeps) computed what
+        the reference computes; <= 1 flags a checkpoint / input on which the two differ.  NaN: the residual is not measured for this shape."""
+        r = self.last_intermediates["sinkhorn_resid"]          # [2B, iters, sweeps]
+        B = r.shape[0] // 2
+        means = torch.stack([r[:B].mean(0), r[B:].mean(0)])    # [2, iters, sweeps]
+        return float(means.min().item()) / 1e-2
 
     def _forward_train(self, src, tgt, fps_starts, capture, is_test=False):
         """`.train()` mode: batch-statistics BatchNorm with running-stat updates and autograd through every differentiable

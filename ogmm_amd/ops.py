@@ -488,7 +488,7 @@ def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, two_pass=False):
 
 
 # ---------------------------------------------------------------------------------------------- GMM head
-def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, engine=None):
+def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, engine=None, return_resid=False):
     """-> gamma [C,N,J], pi [C,J], mu [C,J,3]   (lib/utils.py:269-288)."""
     C, N, _ = xyz.shape
     J = ids0.shape[1]
@@ -504,7 +504,14 @@ def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, engine=No
         _lib.call("ogmm_gmm_em_multi", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
                   _p(gamma), _p(pi), _p(mu), _p(ws), _stream())
         ws.record_stream(torch.cuda.current_stream())
+        if return_resid:
+            return gamma, pi, mu, torch.full((C, iters, sk_iters), float("nan"), dtype=torch.float32, device=xyz.device)
         return gamma, pi, mu
+    if return_resid:          # + every sweep's sum |u - u0| + sum |v - v0| per cloud [C, iters, sk_iters] (NaN where the kernel does not measure it)
+        resid = torch.empty((C, iters, sk_iters), dtype=torch.float32, device=xyz.device)
+        _lib.call("ogmm_gmm_em_resid", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
+                  _p(gamma), _p(pi), _p(mu), _p(resid), _stream())
+        return gamma, pi, mu, resid
     _lib.call("ogmm_gmm_em", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
               _p(gamma), _p(pi), _p(mu), _stream())
     return gamma, pi, mu

@@ -92,11 +92,12 @@ def gather_rows(pts, ids):
     return torch.gather(pts, 1, ids[:, :, None].expand(-1, -1, pts.shape[-1]))
 
 
-def sinkhorn_log(cost, p, q=None, epsilon=1e-2, thresh=1e-2, max_iter=100):
+def sinkhorn_log(cost, p, q=None, epsilon=1e-2, thresh=1e-2, max_iter=100, resid=None):
     """lib/utils.py:69-108 (`log_boltzmann_kernel` + `sinkhorn`), log-domain Sinkhorn.
     cost [B,N,J], p [B,N]; q=None -> uniform 1/J (the reference `.squeeze()`s it, which only
     changes shapes, not values).  Returns (gamma=exp(K) [B,N,J], iterations actually run).
-    The early exit compares the BATCH-MEAN of sum|du|+sum|dv| with `thresh` (:99-102)."""
+    The early exit compares the BATCH-MEAN of sum|du|+sum|dv| with `thresh` (:99-102); `resid` (optional list) receives
+    every sweep's per-cloud value of that sum [B]."""
     B, N, J = cost.shape
     if q is None:
         q = torch.full((B, J), 1.0 / J, dtype=torch.float).to(cost.dtype)
@@ -113,6 +114,8 @@ def sinkhorn_log(cost, p, q=None, epsilon=1e-2, thresh=1e-2, max_iter=100):
         Kt = ((-cost + u[:, :, None] + v[:, None, :]) / epsilon).transpose(1, 2)
         v = epsilon * (logq - torch.logsumexp(Kt, dim=-1)) + v
         diff = (u - u0).abs().sum(-1) + (v - v0).abs().sum(-1)
+        if resid is not None:
+            resid.append(diff.clone())
         if diff.mean().item() < thresh:
             break
     K = (-cost + u[:, :, None] + v[:, None, :]) / epsilon
@@ -127,10 +130,11 @@ def gmm_moments(gamma, pts):
     return pi, gamma.transpose(1, 2) @ pts / npi[:, :, None]
 
 
-def weighted_em(xyz, feats, o_scores, n_clusters, iters=10, tau=1.0, stats=None):
+def weighted_em(xyz, feats, o_scores, n_clusters, iters=10, tau=1.0, stats=None, resid=None):
     """lib/utils.py:269-291 (`wkeans_plus`): overlap-weighted Sinkhorn k-means ("GMM E/M").
     xyz [B,N,3], feats [B,N,D], o_scores [B,N] -> gamma [B,N,J], pi [B,J], mu_xyz [B,J,3], mu_feat [B,J,D].
-    `stats` (optional list) receives the Sinkhorn iteration count of every E-step."""
+    `stats` (optional list) receives the Sinkhorn iteration count of every E-step, `resid` (optional list) every sweep's
+    per-cloud residual sum|du| + sum|dv| (the early exit's quantity)."""
     ids = fps(xyz, n_clusters, None)
     mu = gather_rows(xyz, ids)
     o_scores = o_scores.detach()                              # lib/utils.py:275: no gradient reaches the overlap scores from here
@@ -139,7 +143,7 @@ def weighted_em(xyz, feats, o_scores, n_clusters, iters=10, tau=1.0, stats=None)
     with torch.no_grad():                                     # lib/utils.py:278
         for _ in range(iters):
             cost = torch.cdist(xyz, mu).clip(min=0.0) / tau
-            g, n_it = sinkhorn_log(cost, o, None, max_iter=10)
+            g, n_it = sinkhorn_log(cost, o, None, max_iter=10, resid=resid)
             if stats is not None:
                 stats.append(n_it)
             g = torch.nan_to_num(g, nan=0.0)

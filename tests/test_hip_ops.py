@@ -538,6 +538,28 @@ def test_overlap_block_fused_into_the_similarity_gemm(ops):
 
 
 # ------------------------------------------------------------------------------------------------ GMM head
+def test_gmm_em_reports_the_sinkhorn_residual(ops):
+    """The reference leaves its Sinkhorn sweeps early when the batch mean of sum|du| + sum|dv| falls below 1e-2 (lib/utils.py:99-102); the kernel
+    always runs all sweeps and can report that quantity per cloud and sweep, so that a parity run on real checkpoints can tell whether the
+    reference would have left early (GMMReg.sinkhorn_exit_margin)."""
+    torch.manual_seed(9)
+    C, N, J = 4, 1024, 16
+    xyz = clouds(C, N, seed=33)
+    o = torch.sigmoid(torch.randn(C, N))
+    res = []
+    O.weighted_em(xyz, torch.zeros(C, N, 4), o, J, resid=res)
+    ref = torch.stack(res).view(10, 10, C).permute(2, 0, 1)                      # [C, iters, sweeps]
+    ids = ops.fps(dev(xyz), J, None)
+    out = ops.gmm_em(dev(xyz), dev(o), ids, return_resid=True)
+    got = out[3].cpu()
+    assert got.shape == (C, 10, 10) and not torch.isnan(got).any()
+    assert ((got - ref).abs() / ref.abs().clamp_min(1e-6)).max().item() < 2e-3, ((got - ref).abs() / ref.abs()).max().item()
+    assert ref.mean(0).min().item() > 1e-2                                       # the oracle ran all 10 sweeps on this input, like the kernel
+    # without the flag nothing changes
+    plain = ops.gmm_em(dev(xyz), dev(o), ids)
+    assert torch.equal(plain[0], out[0]) and torch.equal(plain[2], out[2])
+
+
 @pytest.mark.parametrize("engine", [None, "chip", "multi"])
 @pytest.mark.parametrize("C,N,J", [(4, 1024, 16), (2, 717, 128), (2, 2048, 64), (3, 200, 8)])
 def test_gmm_em_and_feat_mean(ops, C, N, J, engine):
