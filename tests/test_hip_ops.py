@@ -507,9 +507,11 @@ def test_overlap_cross(ops, B, N, two_pass):
     assert float(out[:, 1:].abs().max()) == 0.0
 
 
-def test_overlap_block_fused_into_the_similarity_gemm(ops):
-    """models/gmmreg.py:75-80 with S living only in the GEMM's accumulators (struct ogmm_gemm.ovl_rowpart) against fp64 and against the unfused path."""
-    B, N, D = 16, 1024, 512
+@pytest.mark.parametrize("B,N", [(16, 1024), (4, 2048)])
+def test_overlap_block_fused_into_the_similarity_gemm(ops, B, N):
+    """models/gmmreg.py:75-80 with S living only in the GEMM's accumulators (struct ogmm_gemm.ovl_rowpart) against fp64 and against the unfused path
+    (N = 2048: eight partial softmax-dots per row and column, the shape of BASELINE configs[2] / [3])."""
+    D = 512
     if not ops.overlap_fusable(B, N, D):
         pytest.skip("the engine does not take the fused form for this shape")
     torch.manual_seed(11)
