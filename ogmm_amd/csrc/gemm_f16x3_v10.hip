@@ -99,11 +99,15 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                   lds0 + B_OFF + (t % B_STAGES) * B_STAGE + (2 * wave + (i >> 2)) * 4096 + (i & 3) * 1024);
     };
 
-    f32x16 acc0[NT], acc1[NT];          // row block 0 / 1 of this wave against the eight column blocks
+    // row block 0 / 1 of this wave against the eight column blocks.  With three or more K steps the accumulators are not cleared: the first product
+    // on each of them takes C = 0 (256 v_accvgpr_write per lane and tile less: ~1000 cycles); shorter loops clear them.
+    f32x16 acc0[NT], acc1[NT];
+    if (nk < 3) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.0f; acc1[j][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.0f; acc1[j][r] = 0.0f; }
+    }
 
     // fragment read offsets: A rows (wave*64 + rb*32 + lr), chunk (s*4 + lh*2 + q) ^ ((lr >> 1) & 7); B: all column blocks
     const int a_rd = (wave * 64 + lr) * 128;
@@ -207,8 +211,9 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     //                     pieces of stage t+1 landed, all its reads of stage t are done -- followed by the first fragments of step t+1
     //   groups 0 / 4      m = 4, 5 (6): raw activation fragments of k16 block 1 of this stage / block 0 of the next stage (after the vmcnt wait for them)
     //   groups 1-3 / 5-7  m = 4..7 (AFF: groups 0-3 / 4-7, m = 8..11 and 4..11): their split, two vector instructions per gap
-    auto step = [&](int t, auto has_b_c, auto has_a_c) {
+    auto step = [&](int t, auto has_b_c, auto has_a_c, auto first_c) {
         constexpr bool HAS_B = decltype(has_b_c)::value, HAS_A = decltype(has_a_c)::value;          // stage t+1 / t+2 exist
+        constexpr bool FIRST = decltype(first_c)::value;                                             // the tile's first step: C = 0 for the first products
 #pragma unroll
         for (int grp = 0; grp < 8; ++grp) {
             const int s = grp >> 2, q = grp & 3, p = grp & 1, gl = grp & 3;
@@ -223,8 +228,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                 const int prod = m >> 2, rb = (m >> 1) & 1, c = m & 1;
                 const f16x8 av = prod == 0 ? (rb ? al1 : al0) : (rb ? ah1 : ah0);
                 const f16x8 bv = prod == 1 ? bl[p][c] : bh[p][c];
-                if (rb == 0) acc0[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc0[2 * q + c], 0, 0, 0);
-                else acc1[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc1[2 * q + c], 0, 0, 0);
+                const bool fresh = FIRST && s == 0 && prod == 0;
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (rb == 0) acc0[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, fresh ? zero : acc0[2 * q + c], 0, 0, 0);
+                else acc1[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, fresh ? zero : acc1[2 * q + c], 0, 0, 0);
                 // ---- the gap after MFMA m
                 if (!(ABL & 1) && (m == 0 || m == 3)) {
                     const int pc = 2 * gl + (m == 3);
@@ -262,9 +269,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     };
     {
         int t = 0;
-        for (; t + 2 < nk; ++t) step(t, std::true_type{}, std::true_type{});
-        if (t + 1 < nk) { step(t, std::true_type{}, std::false_type{}); ++t; }
-        step(t, std::false_type{}, std::false_type{});
+        if (nk >= 3) { step(0, std::true_type{}, std::true_type{}, std::true_type{}); t = 1; }
+        for (; t + 2 < nk; ++t) step(t, std::true_type{}, std::true_type{}, std::false_type{});
+        if (t + 1 < nk) { step(t, std::true_type{}, std::false_type{}, std::false_type{}); ++t; }
+        step(t, std::false_type{}, std::false_type{}, std::false_type{});
     }
     if ((ABL & 2048) && threadIdx.x == 0) {
         atomicAdd(&g_v10_probe[0], (unsigned long long)(clock64() - probe_c0));
