@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 13
+#define OGMM_ABI_VERSION 14
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -337,6 +337,16 @@ int ogmm_maxpool_k_bwd(const float* dout, int64_t ldo, const uint8_t* arg, int64
 int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out, void* stream);
 int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
                      int* overflow, void* stream);
+
+/* ---- T9: backward of the anchor attention (models/attn.py:78-82 under autograd): given dout = dL/dO of
+ * O = softmax(Q K^T * scale) V it writes dq [C*N][lddq], dk and dv [C*M][lddk|lddv] (head-major columns like ogmm_attention; every
+ * element of the three outputs is written).  The scores are re-formed per 32-query tile inside the kernel and never reach HBM;
+ * exact fp32 on v_mfma_f32_32x32x2_f32.  Built for M = 128 anchors and dh = 128 (ogmm_attention_bwd_supported); rows of q / dout
+ * 16-byte aligned, rows of k / v 8-byte aligned. */
+int ogmm_attention_bwd_supported(int M, int dh);
+int ogmm_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
+                       int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk,
+                       float* dv, int64_t lddv, void* stream);
 
 /* ---- T9: weight gradient of the thin layers (per-edge EdgeConv maps, the 6 -> 64 edge layer, the 1 -> 64 positional layers):
  * part[s][n][k] = sum over the rows of stream s of dY[r][n] X[r][k], exact fp32 on v_mfma_f32_32x32x2_f32 (HBM-bound);

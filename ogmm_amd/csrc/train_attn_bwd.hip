@@ -1,0 +1,276 @@
+// Backward of the anchor attention  O = softmax(Q K^T * scale) V  (models/attn.py:78-82) for the training step: given dO it
+// returns dQ, dK, dV per (cloud, head) without materialising the [C,H,N,M] scores (the library path re-formed them with five
+// batched fp32 GEMMs, two softmax passes and six layout copies per attention: 4.3 ms at 128 pairs; this kernel: see DESIGN §7).
+//
+// Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32.  Its operand layout (A: lane l holds A[row l%32][k l/32]; B: lane l holds
+// B[k l/32][col l%32]: ONE element per lane and instruction) makes every transposition free -- any matrix can be read as either
+// operand with plain ds_read / register indexing, and an accumulator tile (lane = column, registers = rows 8i + 4(l/32) + r) is
+// directly a B operand of a product that contracts over its rows.  Five products per query tile, 64 MFMAs each:
+//   S^T  = K Q^T              (rows = keys, columns = queries)       A = K rows of the wave (registers), B = Q tile (LDS)
+//   dP^T = V dO^T                                                     A = V rows of the wave (registers), B = dO tile (LDS)
+//   dV  += P^T dO             (contracts over the tile's queries)     A = P^T via a per-wave LDS patch,   B = dO tile (LDS)
+//   dK  += dS^T Q                                                     A = dS^T via a per-wave LDS patch,  B = Q tile (LDS)
+//   dQ   = dS K               (contracts over all keys)               A = dS tile (LDS, all waves),       B = K columns (registers)
+// Workgroup = one (cloud, head), 4 waves, one wave per SIMD; it walks the query tiles of 32 rows.  Wave w owns key block w
+// (32 keys): its rows of K and V, its 32 columns of K (for dQ) and its [32 keys x 128] blocks of dK and dV stay in registers for the
+// whole cloud.  In S^T / dP^T a lane holds one query and 16 of the wave's keys, so the softmax statistics are in-lane sums plus
+// one lane^32 exchange; the four waves' (max, sum, sum e*dP) triples meet in LDS (one barrier), which gives the row maximum,
+// the normaliser and delta = sum_key P dP at once.  Three barriers per tile, ~320 MFMAs (20.5 k matrix-pipe cycles) per wave.
+#include "ogmm_common.h"
+
+namespace {
+
+using namespace ogmm;
+using f32x16b = __attribute__((ext_vector_type(16))) float;
+using f32x4b = __attribute__((ext_vector_type(4))) float;
+using f32x2b = __attribute__((ext_vector_type(2))) float;
+
+constexpr int BDH = 128;                 // head dimension
+constexpr int BM = 128;                  // anchors (keys)
+constexpr int TQ = 32;                   // queries per tile
+constexpr int PT = 130;                  // floats per row of the Q / dO tiles     (8-byte aligned rows, conflict-free b64 column reads)
+constexpr int PX = 132;                  // floats per row of the dS exchange tile (16-byte aligned rows)
+constexpr int PP = 34;                   // floats per row of a wave's transposition patch
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// step s (0..63) of a contraction over 128 indices takes index sel(s, lh) from lane half lh: two consecutive steps use two adjacent
+// indices, so one 8-byte read feeds both
+__device__ __forceinline__ constexpr int sel(int s, int lh) { return 4 * (s >> 1) + 2 * lh + (s & 1); }
+
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
+                                                            const float* __restrict__ v, int64_t ldv, const float* __restrict__ dout,
+                                                            int64_t lddo, int N, int H, float scale, float* __restrict__ dq, int64_t lddq,
+                                                            float* __restrict__ dk, int64_t lddk, float* __restrict__ dv, int64_t lddv) {
+    extern __shared__ __attribute__((aligned(16))) float smem_ab[];
+    float* Qs = smem_ab;                               // [TQ][PT]
+    float* dOs = Qs + TQ * PT;                         // [TQ][PT]
+    float* dSx = dOs + TQ * PT;                        // [TQ][PX]   dS of the tile, all keys
+    float* Xs = dSx + TQ * PX;                         // [4 waves][3][32]  (max, sum, sum e*dP) per query
+    float* patch = Xs + 4 * 3 * 32;                    // [4 waves][2][32][PP]
+
+    const int h = blockIdx.x % H, c = blockIdx.x / H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const float* __restrict__ kc = k + ((int64_t)c * BM) * ldk + h * BDH;
+    const float* __restrict__ vc = v + ((int64_t)c * BM) * ldv + h * BDH;
+    const float* __restrict__ qc = q + ((int64_t)c * N) * ldq + h * BDH;
+    const float* __restrict__ gc = dout + ((int64_t)c * N) * lddo + h * BDH;
+    float* Pp = patch + wave * 2 * 32 * PP;            // [key of the wave][query]
+    float* Sp = Pp + 32 * PP;
+
+    // ---- the wave's constant slices of K and V
+    float krow[64], vrow[64], kcol[64];
+    {
+        const float* __restrict__ kr = kc + (int64_t)(32 * wave + lr) * ldk + 2 * lh;
+        const float* __restrict__ vr = vc + (int64_t)(32 * wave + lr) * ldv + 2 * lh;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const f32x2b a = *reinterpret_cast<const f32x2b*>(kr + 4 * j);
+            const f32x2b b = *reinterpret_cast<const f32x2b*>(vr + 4 * j);
+            krow[2 * j] = a[0]; krow[2 * j + 1] = a[1];
+            vrow[2 * j] = b[0]; vrow[2 * j + 1] = b[1];
+        }
+#pragma unroll
+        for (int s = 0; s < 64; ++s) kcol[s] = kc[(int64_t)sel(s, lh) * ldk + 32 * wave + lr];
+    }
+    f32x16b dvacc[4], dkacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[t][r] = 0.0f; dkacc[t][r] = 0.0f; }
+
+    // ---- tile staging: thread -> 4 float4 of Q and of dO (row f / 32, columns 4 (f % 32) ...)
+    f32x4b qst[4], gst[4];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 256 * u, row = tile * TQ + (f >> 5), c4 = (f & 31) * 4;
+            if (row < N) {
+                qst[u] = *reinterpret_cast<const f32x4b*>(qc + (int64_t)row * ldq + c4);
+                gst[u] = *reinterpret_cast<const f32x4b*>(gc + (int64_t)row * lddo + c4);
+            } else {
+                qst[u] = f32x4b{0.f, 0.f, 0.f, 0.f};
+                gst[u] = f32x4b{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = tid + 256 * u, row = f >> 5, c4 = (f & 31) * 4;
+            f32x2b* qd = reinterpret_cast<f32x2b*>(Qs + row * PT + c4);
+            f32x2b* gd = reinterpret_cast<f32x2b*>(dOs + row * PT + c4);
+            qd[0] = f32x2b{qst[u][0], qst[u][1]}; qd[1] = f32x2b{qst[u][2], qst[u][3]};
+            gd[0] = f32x2b{gst[u][0], gst[u][1]}; gd[1] = f32x2b{gst[u][2], gst[u][3]};
+        }
+    };
+
+    const int n_tiles = (N + TQ - 1) / TQ;
+    const float sl2 = scale * 1.4426950408889634f;
+    load_tile(0);
+    store_tile();
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();                                                   // (A) tile visible; dSx / Xs of the previous tile are free
+        if (tile + 1 < n_tiles) load_tile(tile + 1);
+        // opaque per tile: keeps the tile-invariant LDS addressing from being hoisted into registers that are needed elsewhere
+        int lr_t = lr, lh_t = lh;
+        asm volatile("" : "+v"(lr_t), "+v"(lh_t));
+
+        // ---- S^T and dP^T blocks of this wave's keys
+        f32x16b sacc, pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
+        {
+            const float* __restrict__ qb = Qs + lr_t * PT + 2 * lh_t;
+            const float* __restrict__ gb = dOs + lr_t * PT + 2 * lh_t;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const f32x2b bq = *reinterpret_cast<const f32x2b*>(qb + 4 * j);
+                const f32x2b bg = *reinterpret_cast<const f32x2b*>(gb + 4 * j);
+                sacc = MFMA32(krow[2 * j], bq[0], sacc);
+                pacc = MFMA32(vrow[2 * j], bg[0], pacc);
+                sacc = MFMA32(krow[2 * j + 1], bq[1], sacc);
+                pacc = MFMA32(vrow[2 * j + 1], bg[1], pacc);
+            }
+        }
+
+        // ---- softmax pieces of this wave's keys for the lane's query: local maximum, e = exp2(s - max), sum e, sum e*dP
+        float mw = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] *= sl2; mw = fmaxf(mw, sacc[r]); }
+        mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+        float sw = 0.0f, ew = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - mw);
+            sw += sacc[r];
+            ew = fmaf(sacc[r], pacc[r], ew);
+        }
+        sw += __shfl_xor(sw, 32, 64);
+        ew += __shfl_xor(ew, 32, 64);
+        if (lh_t == 0) {
+            Xs[(wave * 3 + 0) * 32 + lr_t] = mw;
+            Xs[(wave * 3 + 1) * 32 + lr_t] = sw;
+            Xs[(wave * 3 + 2) * 32 + lr_t] = ew;
+        }
+        __syncthreads();                                                   // (X) the four waves' triples
+        float mall = -__builtin_inff();
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) mall = fmaxf(mall, Xs[(w2 * 3 + 0) * 32 + lr_t]);
+        float tot = 0.0f, dlt = 0.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            const float f = __builtin_amdgcn_exp2f(Xs[(w2 * 3 + 0) * 32 + lr_t] - mall);
+            tot = fmaf(Xs[(w2 * 3 + 1) * 32 + lr_t], f, tot);
+            dlt = fmaf(Xs[(w2 * 3 + 2) * 32 + lr_t], f, dlt);
+        }
+        const float inv = 1.0f / tot;
+        dlt *= inv;
+        const float pf = __builtin_amdgcn_exp2f(mw - mall) * inv;
+        // P = e * pf;  dS = P (dP - delta) * scale      (a query row past N has Q = dO = 0: P uniform, dP = delta = 0, dS = 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] *= pf;
+            pacc[r] = sacc[r] * (pacc[r] - dlt) * scale;
+        }
+
+        // ---- dS -> exchange tile [query][key]; P^T, dS^T -> the wave's patches [key][query]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4b*>(dSx + lr_t * PX + 32 * wave + 8 * i + 4 * lh_t) =
+                f32x4b{pacc[4 * i], pacc[4 * i + 1], pacc[4 * i + 2], pacc[4 * i + 3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Pp[(8 * i + 4 * lh_t + r) * PP + lr_t] = sacc[4 * i + r];
+                Sp[(8 * i + 4 * lh_t + r) * PP + lr_t] = pacc[4 * i + r];
+            }
+        }
+        // ---- dV += P^T dO, dK += dS^T Q over the 32 queries of the tile (16 steps of two queries)
+        {
+            const float* __restrict__ pa = Pp + lr_t * PP + 2 * lh_t;
+            const float* __restrict__ sa = Sp + lr_t * PP + 2 * lh_t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x2b ap = *reinterpret_cast<const f32x2b*>(pa + 4 * j);
+                const f32x2b as = *reinterpret_cast<const f32x2b*>(sa + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int qi = 4 * j + e;                               // + 2 lh: the query this lane half contributes
+                    const float* __restrict__ gb = dOs + (qi + 2 * lh_t) * PT + lr_t;
+                    const float* __restrict__ qb = Qs + (qi + 2 * lh_t) * PT + lr_t;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dvacc[t] = MFMA32(ap[e], gb[32 * t], dvacc[t]);
+                        dkacc[t] = MFMA32(as[e], qb[32 * t], dkacc[t]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                   // (B) dS of all keys; every wave is done with Qs / dOs
+
+        // ---- dQ block: 32 queries x the wave's 32 columns, over all 128 keys
+        f32x16b qacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qacc[r] = 0.0f;
+        {
+            const float* __restrict__ sb = dSx + lr_t * PX + 2 * lh_t;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const f32x2b a = *reinterpret_cast<const f32x2b*>(sb + 4 * j);
+                qacc = MFMA32(a[0], kcol[2 * j], qacc);
+                qacc = MFMA32(a[1], kcol[2 * j + 1], qacc);
+            }
+        }
+        if (tile + 1 < n_tiles) store_tile();                              // the next tile's rows (nobody reads Qs / dOs before (A))
+        {
+            float* __restrict__ dqc = dq + ((int64_t)c * N + tile * TQ) * lddq + h * BDH + 32 * wave + lr_t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 8 * i + 4 * lh_t + r;
+                    if (tile * TQ + row < N) dqc[(int64_t)row * lddq] = qacc[4 * i + r];
+                }
+        }
+    }
+
+    // ---- dK, dV blocks of the wave: lane = column d, registers = keys
+    {
+        float* __restrict__ dkc = dk + ((int64_t)c * BM + 32 * wave) * lddk + h * BDH + lr;
+        float* __restrict__ dvc = dv + ((int64_t)c * BM + 32 * wave) * lddv + h * BDH + lr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 8 * i + 4 * lh + r;
+                    dkc[(int64_t)key * lddk + 32 * t] = dkacc[t][4 * i + r];
+                    dvc[(int64_t)key * lddv + 32 * t] = dvacc[t][4 * i + r];
+                }
+    }
+}
+
+constexpr int BWD_LDS_BYTES = (2 * TQ * PT + TQ * PX + 4 * 3 * 32 + 4 * 2 * 32 * PP) * 4;
+PerDeviceOnce g_bwd_once;
+
+}  // namespace
+
+extern "C" int ogmm_attention_bwd_supported(int M, int dh) { return (M == BM && dh == BDH) ? 1 : 0; }
+
+extern "C" int ogmm_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
+                                  int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk,
+                                  int64_t lddk, float* dv, int64_t lddv, void* stream) {
+    OGMM_REQUIRE(q && k && v && dout && dq && dk && dv, "ogmm_attention_bwd: null pointer");
+    OGMM_REQUIRE(C > 0 && N > 0 && H > 0, "ogmm_attention_bwd: empty problem (C=%d N=%d H=%d)", C, N, H);
+    OGMM_REQUIRE(M == BM && dh == BDH, "ogmm_attention_bwd: built for M = %d anchors and dh = %d (got M=%d dh=%d)", BM, BDH, M, dh);
+    OGMM_REQUIRE(ldq % 4 == 0 && lddo % 4 == 0 && ldk % 2 == 0 && ldv % 2 == 0 && aligned16(q) && aligned16(dout) && aligned16(k) && aligned16(v),
+                 "ogmm_attention_bwd: q / dout rows must be 16-byte aligned, k / v rows 8-byte aligned");
+    OGMM_REQUIRE((int64_t)C * H < (int64_t)1 << 31, "ogmm_attention_bwd: C * H exceeds the grid limit");
+    if (g_bwd_once.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES);
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(C * H), dim3(256), BWD_LDS_BYTES, as_stream(stream), q, ldq, k, ldk, v, ldv, dout, lddo, N, H,
+                       scale, dq, lddq, dk, lddk, dv, lddv);
+    return check_launch("ogmm_attention_bwd");
+}

@@ -384,6 +384,25 @@ def attention_supported(M, dh):
     return dh == 128 and M in (32, 64, 128)
 
 
+def attention_bwd_supported(M, dh):
+    return bool(_lib.load().ogmm_attention_bwd_supported(M, dh))
+
+
+def attention_bwd(q, k, v, dout, C, N, M, H):
+    """Backward of attention(): (dq [C*N, D], dk [C*M, D], dv [C*M, D]) from dout = dL/dO; scores re-formed on chip (kernel T9)."""
+    D = q.shape[1]
+    dh = D // H
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and dout.stride(1) == 1
+    assert q.shape[0] == C * N and dout.shape == q.shape and k.shape[0] == C * M and v.shape == k.shape
+    dq = torch.empty((C * N, D), dtype=torch.float32, device=q.device)
+    dk = torch.empty((C * M, D), dtype=torch.float32, device=q.device)
+    dv = torch.empty((C * M, D), dtype=torch.float32, device=q.device)
+    _lib.call("ogmm_attention_bwd", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0),
+              _p(_f32(dout, "dout")), dout.stride(0), C, N, M, H, dh, 1.0 / dh ** .5, _p(dq), dq.stride(0), _p(dk), dk.stride(0),
+              _p(dv), dv.stride(0), _stream())
+    return dq, dk, dv
+
+
 # ---------------------------------------------------------------------------------------------- row / column kernels
 def softmax_rows_(x2d):
     assert x2d.stride(1) == 1

@@ -4,11 +4,13 @@
 libogmm_hip.so (no gradient flows through them in the reference either); dense layers run forward, dX = dY W and (wide
 layers) dW = dY^T X on the GEMM engine, thin-layer dW on an exact-fp32 MFMA reduction kernel; normalisation (+ pooling), the
 overlap block, the rigid solve, L2 normalisation and the cluster means have hand-written forward AND backward kernels wrapped
-in `torch.autograd.Function`.  Still library calls: the attention backward, dfn = dS fn of the overlap block, thin-layer
+in `torch.autograd.Function`.  Still library calls: the attention backward for M != 128 anchors, dfn = dS fn of the overlap block, thin-layer
 forwards (batched / plain hipBLASLt GEMMs through torch.matmul).  CPU tensors are rejected by the kernels' wrappers: there is
 no CPU path here.  The plain-PyTorch statement of the same
 operations that the tests use as the numerical reference lives in tests/train_ref.py.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -264,10 +266,13 @@ def _attention_torch(q, k, v, C, N, M, H):
     return (p @ vh).transpose(1, 2).reshape(C * N, D)
 
 
+FUSED_ATTENTION_BWD = os.environ.get("OGMM_ATTN_BWD", "1") != "0"      # 0: the library path, for A/B timing
+
+
 class _Attention(torch.autograd.Function):
-    """softmax(q k^T / sqrt(dh)) v (models/attn.py:78-82): forward on the fused attention kernel (scores never reach HBM);
-    backward re-forms the scores with batched library GEMMs + softmax and differentiates them (no hand-written backward
-    kernel yet)."""
+    """softmax(q k^T / sqrt(dh)) v (models/attn.py:78-82): forward on the fused attention kernel, backward on ogmm_attention_bwd
+    (kernel T9: the scores are re-formed per query tile on chip in both directions and never reach HBM).  Shapes the backward
+    kernel is not built for (M != 128) re-form the scores with batched library GEMMs + softmax and differentiate those."""
 
     @staticmethod
     def forward(ctx, q, k, v, C, N, M, H):
@@ -278,6 +283,10 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        C, N, M, H = ctx.dims
+        if FUSED_ATTENTION_BWD and ops.attention_bwd_supported(M, ctx.saved_tensors[0].shape[1] // H):
+            q, k, v = ctx.saved_tensors
+            return ops.attention_bwd(q, k, v, g.contiguous(), C, N, M, H) + (None, None, None, None)
         q, k, v = (t_.detach().requires_grad_(True) for t_ in ctx.saved_tensors)
         with torch.enable_grad():
             o = _attention_torch(q, k, v, *ctx.dims)

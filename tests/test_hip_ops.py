@@ -460,6 +460,49 @@ def test_fused_attention(ops, C, N, M):
     assert (got3 - ref).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("C,N", [(2, 1024), (3, 300), (1, 717), (2, 20)])
+def test_attention_backward_kernel(ops, C, N):
+    """Kernel T9 against fp64 autograd of models/attn.py:78-82: dq, dk, dv for whole and ragged query tiles, a large-scale dO (the
+    trainer's 2^16 loss scale), strided q / k / v / dO views; every output element is written (the buffers start as NaN)."""
+    torch.manual_seed(C * 1000 + N)
+    H, dh, M = 4, 128, 128
+    D = H * dh
+    assert ops.attention_bwd_supported(M, dh) and not ops.attention_bwd_supported(32, dh)
+    q, k, v = torch.randn(C * N, D) * 1.5, torch.randn(C * M, D) * 1.5, torch.randn(C * M, D)
+    g = torch.randn(C * N, D) * 300.0
+    qd, kd, vd = (t_.double().requires_grad_(True) for t_ in (q, k, v))
+    prob = torch.softmax(torch.einsum("cnhd,cmhd->chnm", qd.view(C, N, H, dh), kd.view(C, M, H, dh)) / dh ** .5, dim=-1)
+    out = torch.einsum("chnm,cmhd->cnhd", prob, vd.view(C, M, H, dh)).reshape(C * N, D)
+    rq, rk, rv = torch.autograd.grad(out, (qd, kd, vd), g.double())
+    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), dev(g), C, N, M, H)
+    for name, got, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        got = got.cpu().double()
+        assert torch.isfinite(got).all(), name
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-6, (name, err)
+    # strided operands: q | k-padding in one buffer, keys | values produced by one GEMM, dO a column slice
+    kv = dev(torch.cat([k, v], 1))
+    qg = dev(torch.cat([q, g], 1))
+    dq2, dk2, dv2 = ops.attention_bwd(qg[:, :D], kv[:, :D], kv[:, D:], qg[:, D:], C, N, M, H)
+    assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
+
+
+def test_attention_backward_in_autograd(ops, monkeypatch):
+    """train_ops._Attention: the kernel path and the library path (OGMM_ATTN_BWD=0) give the same gradients"""
+    from ogmm_amd import train_ops
+    torch.manual_seed(5)
+    C, N, M, H, D = 2, 256, 128, 4, 512
+    q, k, v, g = (dev(torch.randn(r_, D)) for r_ in (C * N, C * M, C * M, C * N))
+    grads = []
+    for fused in (True, False):
+        monkeypatch.setattr(train_ops, "FUSED_ATTENTION_BWD", fused)
+        a, b, c_ = (t_.clone().requires_grad_(True) for t_ in (q, k, v))
+        o = train_ops.TrainOps().attention(a, b, c_, C, N, M, H)
+        grads.append(torch.autograd.grad(o, (a, b, c_), g))
+    for x, y in zip(*grads):
+        assert (x - y).abs().max().item() <= 2e-5 * y.abs().max().item()
+
+
 @pytest.mark.parametrize("batch,rows", [(3, 256), (2, 300), (1, 1024)])
 def test_l2norm_pack_frag_equals_two_steps(ops, batch, rows):
     """The fused normalise + split-image kernel against pack_frag_batched(l2norm_rows(x)): bit-identical images (same sums, same division)."""

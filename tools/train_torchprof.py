@@ -22,3 +22,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     tr.step(*batch, fps_starts=starts)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
+if len(sys.argv) > 2 and sys.argv[2] == "shapes":
+    # second view: the aten glue by input shape
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof2:
+        tr.step(*batch, fps_starts=starts)
+        torch.cuda.synchronize()
+    rows = [e for e in prof2.key_averages(group_by_input_shape=True) if e.key.startswith("aten::")]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    for e in rows[:60]:
+        print("%-28s x%-4d %9.3f ms  %s" % (e.key, e.count, e.self_device_time_total / 1e3, str(e.input_shapes)[:150]))
