@@ -17,7 +17,16 @@ namespace {
 
 using namespace ogmm;
 
-constexpr int ROW_CHUNK = 512;       // rows of one group handled by one workgroup of the reduction kernels
+constexpr int ROW_CHUNK = 512;       // rows of one group handled by one workgroup of the reduction kernels (smallest value)
+
+// Rows per workgroup of a reduction kernel.  Every workgroup ends with one fp64 atomic per column and statistic on the SAME few
+// addresses of its group: on the 5.2 M-row per-edge maps 512-row chunks meant 5120 atomics per address, and the kernels ran at
+// 0.9-1.7 TB/s waiting for them.  Grow the chunk until ~2048 workgroups are left (still 8 per CU).
+static int pick_row_chunk(int64_t group_rows, int64_t groups, int64_t col_slabs) {
+    int64_t chunk = ROW_CHUNK;
+    while (chunk < 16384 && ((group_rows + chunk - 1) / chunk) * groups * col_slabs > 2048) chunk *= 2;
+    return (int)chunk;
+}
 
 __device__ __forceinline__ float act_grad(float y, int act) {      // derivative of the activation, from its output or its pre-activation (same sign)
     if (act == OGMM_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
@@ -42,16 +51,17 @@ struct Map {
 // ---------------------------------------------------------------- column statistics: stats[g][c] = {sum x, sum x^2}
 template <int CV>
 __global__ __launch_bounds__(256) void colstats_v4_kernel(const float* __restrict__ x, int64_t ldx, int cols, int64_t group_rows,
-                                                          double* __restrict__ stats) {
+                                                          double* __restrict__ stats, int row_chunk) {
     __shared__ double red[4][64][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane % CV, rl = wave * Map<CV>::rows_per_wave + lane / CV;
     const int col = (blockIdx.y * CV + cl) * 4;
     const int g = blockIdx.z;
-    const int64_t r0 = (int64_t)blockIdx.x * ROW_CHUNK, r1 = min(r0 + ROW_CHUNK, group_rows);
+    const int64_t r0 = (int64_t)blockIdx.x * row_chunk, r1 = min(r0 + row_chunk, group_rows);
     const float* __restrict__ base = x + ((int64_t)g * group_rows) * ldx + col;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     if (col < cols)
+#pragma unroll 4
         for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
             const float4 v = *reinterpret_cast<const float4*>(base + r * ldx);
             const double a = v.x, b = v.y, c = v.z, d = v.w;
@@ -165,13 +175,13 @@ template <int CV>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_v4_kernel(const float* __restrict__ x, int64_t ldx, const Routed up,
                                                                  int cols, int64_t group_rows, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
-                                                                 const float* __restrict__ rstd, int act, double* __restrict__ sums) {
+                                                                 const float* __restrict__ rstd, int act, double* __restrict__ sums, int row_chunk) {
     __shared__ double red[4][64][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane % CV, rl = wave * Map<CV>::rows_per_wave + lane / CV;
     const int col = (blockIdx.y * CV + cl) * 4;
     const int g = blockIdx.z;
-    const int64_t r0 = (int64_t)blockIdx.x * ROW_CHUNK, r1 = min(r0 + ROW_CHUNK, group_rows);
+    const int64_t r0 = (int64_t)blockIdx.x * row_chunk, r1 = min(r0 + row_chunk, group_rows);
     const int64_t gr = (int64_t)g * group_rows;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (col < cols) {
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_v4_kernel(const float* __
         const float4 sc = *reinterpret_cast<const float4*>(scale + gc), sh = *reinterpret_cast<const float4*>(shift + gc);
         const float4 m = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc);
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll 2
         for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
             const float4 xv4 = *reinterpret_cast<const float4*>(x + (gr + r) * ldx + col);
             const float4 dv4 = routed_load4(up, gr + r, col);
@@ -246,12 +257,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_v4_kernel(const float* __r
 
 // ---------------------------------------------------------------- scalar fallbacks (cols % 4 != 0 or unaligned rows)
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int64_t ldx, int cols, int64_t group_rows,
-                                                       double* __restrict__ stats) {
+                                                       double* __restrict__ stats, int row_chunk) {
     __shared__ double red[2][4][64];
     const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.y * 64 + ch;
     const int g = blockIdx.z;
-    const int64_t r0 = (int64_t)blockIdx.x * ROW_CHUNK, r1 = min(r0 + ROW_CHUNK, group_rows);
+    const int64_t r0 = (int64_t)blockIdx.x * row_chunk, r1 = min(r0 + row_chunk, group_rows);
     const float* __restrict__ base = x + ((int64_t)g * group_rows) * ldx + col;
     double s = 0.0, ss = 0.0;
     if (col < cols)
@@ -285,12 +296,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, int64_t ldx, const Routed up,
                                                               int cols, int64_t group_rows, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, int act, double* __restrict__ sums) {
+                                                              const float* __restrict__ rstd, int act, double* __restrict__ sums, int row_chunk) {
     __shared__ double red[2][4][64];
     const int ch = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.y * 64 + ch;
     const int g = blockIdx.z;
-    const int64_t r0 = (int64_t)blockIdx.x * ROW_CHUNK, r1 = min(r0 + ROW_CHUNK, group_rows);
+    const int64_t r0 = (int64_t)blockIdx.x * row_chunk, r1 = min(r0 + row_chunk, group_rows);
     const int64_t gr = (int64_t)g * group_rows;
     double s1 = 0.0, s2 = 0.0;
     if (col < cols) {
@@ -397,13 +408,15 @@ int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t g
     const int64_t G = rows / group_rows;
     OGMM_REQUIRE(G <= 65535, "ogmm_colstats: too many groups (%lld)", (long long)G);
     (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * G * cols, as_stream(stream));
-    const unsigned chunks = (unsigned)((group_rows + ROW_CHUNK - 1) / ROW_CHUNK);
     if (vec_ok(x, ldx, cols)) {
         const int cv = lanes_per_row(cols);
-        dim3 grid(chunks, (cols / 4 + cv - 1) / cv, (unsigned)G);
-        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(colstats_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, cols, group_rows, stats));
+        const int slabs = (cols / 4 + cv - 1) / cv, row_chunk = pick_row_chunk(group_rows, G, slabs);
+        dim3 grid((unsigned)((group_rows + row_chunk - 1) / row_chunk), slabs, (unsigned)G);
+        OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(colstats_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, cols, group_rows, stats, row_chunk));
     } else {
-        hipLaunchKernelGGL(colstats_kernel, dim3(chunks, (cols + 63) / 64, (unsigned)G), dim3(256), 0, as_stream(stream), x, ldx, cols, group_rows, stats);
+        const int slabs = (cols + 63) / 64, row_chunk = pick_row_chunk(group_rows, G, slabs);
+        hipLaunchKernelGGL(colstats_kernel, dim3((unsigned)((group_rows + row_chunk - 1) / row_chunk), slabs, (unsigned)G), dim3(256), 0, as_stream(stream), x, ldx,
+                           cols, group_rows, stats, row_chunk);
     }
     return check_launch("ogmm_colstats");
 }
@@ -447,15 +460,16 @@ int ogmm_norm_bwd_reduce(const float* x, int64_t ldx, const float* dy, int64_t l
     const int64_t G = rows / group_rows;
     OGMM_REQUIRE(G <= 65535, "ogmm_norm_bwd_reduce: too many groups");
     (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * G * cols, as_stream(stream));
-    const unsigned chunks = (unsigned)((group_rows + ROW_CHUNK - 1) / ROW_CHUNK);
     if (vec_ok(x, ldx, cols) && routed_vec_ok(up, cols) && aligned16(scale) && aligned16(shift) && aligned16(mean) && aligned16(rstd)) {
         const int cv = lanes_per_row(cols);
-        dim3 grid(chunks, (cols / 4 + cv - 1) / cv, (unsigned)G);
+        const int slabs = (cols / 4 + cv - 1) / cv, row_chunk = pick_row_chunk(group_rows, G, slabs);
+        dim3 grid((unsigned)((group_rows + row_chunk - 1) / row_chunk), slabs, (unsigned)G);
         OGMM_DISPATCH_CV(cv, hipLaunchKernelGGL(norm_bwd_reduce_v4_kernel<CV>, grid, dim3(256), 0, as_stream(stream), x, ldx, up, cols, group_rows,
-                                                scale, shift, mean, rstd, act, sums));
+                                                scale, shift, mean, rstd, act, sums, row_chunk));
     } else {
-        hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(chunks, (cols + 63) / 64, (unsigned)G), dim3(256), 0, as_stream(stream), x, ldx, up, cols,
-                           group_rows, scale, shift, mean, rstd, act, sums);
+        const int slabs = (cols + 63) / 64, row_chunk = pick_row_chunk(group_rows, G, slabs);
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)((group_rows + row_chunk - 1) / row_chunk), slabs, (unsigned)G), dim3(256), 0, as_stream(stream),
+                           x, ldx, up, cols, group_rows, scale, shift, mean, rstd, act, sums, row_chunk);
     }
     return check_launch("ogmm_norm_bwd_reduce");
 }
