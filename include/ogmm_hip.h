@@ -333,12 +333,15 @@ int ogmm_maxpool_k_bwd(const float* dout, int64_t ldo, const uint8_t* arg, int64
  *   ogmm_transpose_pad: out[s][c][rr] = x[s*chunk + rr][c]                       (A = dY^T, fp32; sA_o = cols*pitch floats, lda = pitch)
  *   ogmm_pack_frag_t:   per chunk the OGMM_PREC_F16X3_FRAG image of X^T, [n_pad/32][pitch/16][64 lanes][8 halfs], hi and lo
  *                       planes (ldb_h = pitch, sB_o = n_pad*pitch halfs); *overflow |= 1 if a finite |x| > 65504 was clamped.
+ *                       a_scale != NULL ([rows/group_rows][cols] float, with a_shift): X is taken as relu(x * a_scale + a_shift)
+ *                       (relu iff a_relu) -- the same read as struct ogmm_gemm.a_scale, for layers whose normalised input was
+ *                       consumed by the forward GEMM that way and never written.
  * The S partial products (sC_o = n*k) are summed afterwards. */
 int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out, void* stream);
 int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
-                     int* overflow, void* stream);
+                     int* overflow, const float* a_scale, const float* a_shift, int a_relu, int64_t group_rows, void* stream);
 
-/* ---- T9: backward of the anchor attention (models/attn.py:78-82 under autograd): given dout = dL/dO of
+/* ---- T11: backward of the anchor attention (models/attn.py:78-82 under autograd): given dout = dL/dO of
  * O = softmax(Q K^T * scale) V it writes dq [C*N][lddq], dk and dv [C*M][lddk|lddv] (head-major columns like ogmm_attention; every
  * element of the three outputs is written).  The scores are re-formed per 32-query tile inside the kernel and never reach HBM;
  * exact fp32 on v_mfma_f32_32x32x2_f32.  Built for M = 128 anchors and dh = 128 (ogmm_attention_bwd_supported); rows of q / dout

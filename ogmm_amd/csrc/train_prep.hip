@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 // matrix and in the pitch padding (kb*16 >= chunk).
 __global__ __launch_bounds__(256) void pack_frag_t_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols, int64_t chunk,
                                                           int64_t pitch, int S, int n_pad, f16x8t* __restrict__ hi, f16x8t* __restrict__ lo,
-                                                          int* __restrict__ overflow) {
+                                                          int* __restrict__ overflow, const float* __restrict__ a_scale,
+                                                          const float* __restrict__ a_shift, int a_relu, int64_t group_rows) {
     const int64_t kblocks = pitch / 16;
     const int64_t total = (int64_t)S * (n_pad / 32) * kblocks * 64;
     bool clipped = false;
@@ -63,6 +64,11 @@ __global__ __launch_bounds__(256) void pack_frag_t_kernel(const float* __restric
             for (int j = 0; j < 8; ++j) {
                 const int64_t r = k0 + j;
                 float v = r < rows ? x[r * ldx + n] : 0.0f;
+                if (a_scale && r < rows) {      // the map is the pre-normalisation output: X = relu(x * scale_g + shift_g), as the forward GEMM read it
+                    const int64_t gc = (r / group_rows) * cols + n;
+                    v = fmaf(v, a_scale[gc], a_shift[gc]);
+                    if (a_relu) v = fmaxf(v, 0.0f);
+                }
                 const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
                 clipped |= c != v && v == v;
                 const _Float16 hh = (_Float16)c;
@@ -87,13 +93,14 @@ extern "C" int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int
 }
 
 extern "C" int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
-                                int* overflow, void* stream) {
+                                int* overflow, const float* a_scale, const float* a_shift, int a_relu, int64_t group_rows, void* stream) {
+    OGMM_REQUIRE(!a_scale || (a_shift && group_rows > 0), "ogmm_pack_frag_t: a_scale needs a_shift and group_rows > 0");
     OGMM_REQUIRE(x && hi && lo && rows > 0 && cols > 0 && S > 0 && (int64_t)S * chunk >= rows && chunk % 16 == 0 && pitch % 16 == 0 && pitch >= chunk &&
                  n_pad >= cols && n_pad % 32 == 0 && aligned16(hi) && aligned16(lo),
                  "ogmm_pack_frag_t: chunk, pitch %% 16 == 0, n_pad %% 32 == 0, 16-byte aligned images required");
     const int64_t total = (int64_t)S * (n_pad / 32) * (pitch / 16) * 64;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20);
     hipLaunchKernelGGL(pack_frag_t_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, chunk, pitch, S, n_pad,
-                       reinterpret_cast<f16x8t*>(hi), reinterpret_cast<f16x8t*>(lo), overflow);
+                       reinterpret_cast<f16x8t*>(hi), reinterpret_cast<f16x8t*>(lo), overflow, a_scale, a_shift, a_relu, group_rows);
     return check_launch("ogmm_pack_frag_t");
 }

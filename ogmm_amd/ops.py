@@ -389,7 +389,7 @@ def attention_bwd_supported(M, dh):
 
 
 def attention_bwd(q, k, v, dout, C, N, M, H):
-    """Backward of attention(): (dq [C*N, D], dk [C*M, D], dv [C*M, D]) from dout = dL/dO; scores re-formed on chip (kernel T9)."""
+    """Backward of attention(): (dq [C*N, D], dk [C*M, D], dv [C*M, D]) from dout = dL/dO; scores re-formed on chip (kernel T11)."""
     D = q.shape[1]
     dh = D // H
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and dout.stride(1) == 1
@@ -692,8 +692,9 @@ def maxpool_k_bwd(dout, arg, k):
     return dh
 
 
-def weight_grad(dy, xs, overflow=None):
+def weight_grad(dy, xs, overflow=None, x_affine=None):
     """dW = dY^T [x_0 | x_1 | ...] on the fp16x3 engine: dy [R, n], xs = list of [R, k_i] (last stride 1) -> [n, sum k_i].
+    x_affine (one x only): (scale [G, k], shift [G, k], relu, group_rows) -- x is a pre-normalisation map, X = relu(x * scale + shift).
     dY^T is materialised once (fp32, chunk-major), every x_i becomes per-chunk split fragment images of x_i^T, the contraction
     over r runs as split-K batches of the engine and the partial products are summed (kernels T3 of include/ogmm_hip.h)."""
     R, n = dy.shape
@@ -712,7 +713,10 @@ def weight_grad(dy, xs, overflow=None):
         n_pad = (k + 255) // 256 * 256
         hi = torch.empty(S * n_pad * pitch, dtype=torch.float16, device=dy.device)
         lo = torch.empty_like(hi)
-        _lib.call("ogmm_pack_frag_t", _p(_f32(x, "x")), x.stride(0), R, k, chunk, pitch, S, n_pad, _p(hi), _p(lo), _p(overflow), _stream())
+        aff = x_affine if x_affine is not None else (None, None, False, 0)
+        assert x_affine is None or (len(xs) == 1 and aff[0].shape[-1] == k and aff[0].is_contiguous() and aff[1].is_contiguous())
+        _lib.call("ogmm_pack_frag_t", _p(_f32(x, "x")), x.stride(0), R, k, chunk, pitch, S, n_pad, _p(hi), _p(lo), _p(overflow), _p(aff[0]), _p(aff[1]),
+                  1 if aff[2] else 0, aff[3], _stream())
         part = torch.empty((S, n, k), dtype=torch.float32, device=dy.device)
         split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
         gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow)

@@ -81,17 +81,19 @@ def transformer(ops, P, name, x, anchors, C, N, M, H):
     o = ops.attention(q, kk, vv, C, N, M, H)
     msg = ops.linear(o, _w(P, name + ".attn.merge")[:, perm], _b(P, name + ".attn.merge"))
     z, st = ops.linear_stats(x, _w(P, name + ".mlp.0"), _b(P, name + ".mlp.0"), x2=msg, groups=C)
-    z = ops.instnorm_relu(z, C, N, stats=st)
-    return ops.linear(z, _w(P, name + ".mlp.3"), _b(P, name + ".mlp.3"))
+    return ops.instnorm_relu_linear(z, C, N, st, _w(P, name + ".mlp.3"), _b(P, name + ".mlp.3"))
 
 
 def conv_stack(ops, P, name, x, three, x2=None):
     """models/dgcnn.py:16-38"""
-    h = _conv_bn(ops, P, name + ".net.0", name + ".net.1", x, "relu", x2=x2)
+    def bn(key):
+        return [P[name + key + s_] for s_ in (".weight", ".bias", ".running_mean", ".running_var", ".num_batches_tracked")]
+
+    y, st = ops.linear_stats(x, _w(P, name + ".net.0"), _b(P, name + ".net.0"), x2=x2, groups=GROUPS)
     if not three:
-        return ops.linear(h, _w(P, name + ".net.3"), _b(P, name + ".net.3"))
-    h = _conv_bn(ops, P, name + ".net.3", name + ".net.4", h, "relu")
-    return ops.linear(h, _w(P, name + ".net.6"), _b(P, name + ".net.6"))
+        return ops.batchnorm_relu_linear(y, st, *bn(".net.1"), GROUPS, _w(P, name + ".net.3"), _b(P, name + ".net.3"))
+    y, st = ops.batchnorm_relu_linear(y, st, *bn(".net.1"), GROUPS, _w(P, name + ".net.3"), _b(P, name + ".net.3"), want_stats=True)
+    return ops.batchnorm_relu_linear(y, st, *bn(".net.4"), GROUPS, _w(P, name + ".net.6"), _b(P, name + ".net.6"))
 
 
 def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):

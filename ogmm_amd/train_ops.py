@@ -224,6 +224,62 @@ class _Linear(torch.autograd.Function):
         return dx, dx2, dW, db, None, None, None
 
 
+FUSE_NORM_LINEAR = os.environ.get("OGMM_FUSE_NORM_LINEAR", "1") != "0"      # 0: write the normalised maps (A/B timing)
+
+
+class _NormLinear(torch.autograd.Function):
+    """relu((y - mean_g) rstd_g weight + bias) W^T + b without ever writing the normalised map: the forward GEMM reads y through
+    struct ogmm_gemm.a_scale (relu(y * scale_g + shift_g) while the operand is split), the weight gradient's operand image is built
+    from y the same way (ogmm_pack_frag_t a_scale), and the normalisation's own backward is _NormAct's (it recomputes the activation
+    mask from y).  One fewer 2-byte-per-byte pass over every hidden map, and the map is not kept for the backward either.
+    Conditions (TrainOps._norm_linear_fusable): fp16x3 engine, ReLU, group_rows a multiple of the engine's 256-row tile, a wide layer."""
+
+    @staticmethod
+    def forward(ctx, y, st, nweight, nbias, group_rows, W, b, overflow, stats_rows):
+        y = y.contiguous()
+        mean64 = st[..., 0] / group_rows
+        var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
+        rstd64 = torch.rsqrt(var64 + BN_EPS)
+        scale64 = rstd64 if nweight is None else rstd64 * nweight.detach().double()
+        shift64 = -mean64 * scale64 if nbias is None else nbias.detach().double() - mean64 * scale64
+        scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
+        mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
+        Wd = W.detach().contiguous()
+        layer = {"W": Wd, "split": ops.split_f16_training(Wd, ("fwd", W.data_ptr(), tuple(Wd.shape)), frag=True, k1=Wd.shape[1])}
+        if b is not None:
+            layer["shift"] = b.detach().contiguous()
+        stats = None
+        if stats_rows and stats_rows == group_rows and W.shape[0] % 4 == 0 and stats_rows <= 131072:
+            stats = torch.zeros((y.shape[0] // stats_rows, W.shape[0], 2), dtype=torch.float64, device=y.device)
+        out = ops.conv1x1(y, layer, ops.ACT_NONE, split=True, overflow=overflow, col_stats=stats, a_affine=(scale, shift, True), group_rows=group_rows)
+        ctx.save_for_backward(y, scale, shift, mean, rstd, W)
+        ctx.group_rows, ctx.affine, ctx.has_bias, ctx.overflow = group_rows, nweight is not None, b is not None, overflow
+        ctx.bias_grad_is_zero = bool(stats_rows)          # see _Linear
+        ctx.mark_non_differentiable(mean64, var64)
+        if stats_rows:
+            if stats is None:
+                stats = ops.colstats(out, stats_rows)
+            ctx.mark_non_differentiable(stats)
+            return out, mean64, var64, stats
+        return out, mean64, var64
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _dv, _dst=None):
+        y, scale, shift, mean, rstd, W = ctx.saved_tensors
+        dout = dout.contiguous()
+        Wt = W.detach().t().contiguous()
+        layer = {"W": Wt, "split": ops.split_f16_training(Wt, ("bwd", W.data_ptr(), tuple(Wt.shape)), frag=True)}
+        dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
+        dW = ops.weight_grad(dout, [y], ctx.overflow, x_affine=(scale, shift, True, ctx.group_rows)) if ctx.needs_input_grad[5] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[6]:
+            db = torch.zeros(dout.shape[1], dtype=dout.dtype, device=dout.device) if ctx.bias_grad_is_zero else dout.sum(dim=0)
+        dy, sums = ops.norm_bwd(y, dh, ctx.group_rows, scale, shift, mean, rstd, ops.ACT_RELU)
+        dg = sums[..., 1].sum(dim=0).float() if ctx.affine else None
+        dbeta = sums[..., 0].sum(dim=0).float() if ctx.affine else None
+        return dy, None, dg, dbeta, None, dW, db, None, None
+
+
 class _L2Norm(torch.autograd.Function):
     """F.normalize over channels (models/gmmreg.py:74): ogmm_l2norm_rows / ogmm_l2norm_rows_bwd"""
 
@@ -271,7 +327,7 @@ FUSED_ATTENTION_BWD = os.environ.get("OGMM_ATTN_BWD", "1") != "0"      # 0: the 
 
 class _Attention(torch.autograd.Function):
     """softmax(q k^T / sqrt(dh)) v (models/attn.py:78-82): forward on the fused attention kernel, backward on ogmm_attention_bwd
-    (kernel T9: the scores are re-formed per query tile on chip in both directions and never reach HBM).  Shapes the backward
+    (kernel T11: the scores are re-formed per query tile on chip in both directions and never reach HBM).  Shapes the backward
     kernel is not built for (M != 128) re-form the scores with batched library GEMMs + softmax and differentiate those."""
 
     @staticmethod
@@ -413,6 +469,36 @@ class TrainOps:
                 running_var.mul_(1 - BN_MOMENTUM).add_(unbiased[g].to(running_var.dtype), alpha=BN_MOMENTUM)
             num_batches += groups
         return (h if want_h else None), pooled
+
+    def _norm_linear_fusable(self, y, group_rows, W):
+        K, Cout = y.shape[1], W.shape[0]
+        return (FUSE_NORM_LINEAR and self.precision == "f16x3" and group_rows % 256 == 0 and K % 32 == 0 and 256 <= K <= 4096 and Cout >= 256
+                and Cout % 4 == 0)
+
+    def _update_running(self, running_mean, running_var, num_batches, mean64, var64, n, groups):
+        with torch.no_grad():
+            unbiased = var64 * (n / max(n - 1, 1))
+            for g in range(groups):
+                running_mean.mul_(1 - BN_MOMENTUM).add_(mean64[g].to(running_mean.dtype), alpha=BN_MOMENTUM)
+                running_var.mul_(1 - BN_MOMENTUM).add_(unbiased[g].to(running_var.dtype), alpha=BN_MOMENTUM)
+            num_batches += groups
+
+    def batchnorm_relu_linear(self, y, stats, weight, bias, running_mean, running_var, num_batches, groups, W, b, want_stats=False):
+        """linear(batchnorm_act(y, ..., "relu"), W, b) [-> (out, column sums of out) with want_stats]; where the engine takes it the normalised
+        map is never written (_NormLinear)."""
+        n = y.shape[0] // groups
+        if self._norm_linear_fusable(y, n, W):
+            res = _NormLinear.apply(y, stats, weight, bias, n, W, b, self.overflow, n if want_stats else 0)
+            self._update_running(running_mean, running_var, num_batches, res[1], res[2], n, groups)
+            return (res[0], res[3]) if want_stats else res[0]
+        h = self.batchnorm_act(y, weight, bias, running_mean, running_var, num_batches, groups, "relu", stats=stats)
+        return self.linear_stats(h, W, b, groups=groups) if want_stats else self.linear(h, W, b)
+
+    def instnorm_relu_linear(self, z, C, N, stats, W, b):
+        """linear(instnorm_relu(z), W, b)"""
+        if self._norm_linear_fusable(z, N, W):
+            return _NormLinear.apply(z, stats, None, None, N, W, b, self.overflow, 0)[0]
+        return self.linear(self.instnorm_relu(z, C, N, stats=stats), W, b)
 
     def instnorm_relu(self, z, C, N, stats=None):
         """InstanceNorm1d (no affine, biased variance, eps 1e-5) over the N points of each cloud, then ReLU"""

@@ -462,7 +462,7 @@ def test_fused_attention(ops, C, N, M):
 
 @pytest.mark.parametrize("C,N", [(2, 1024), (3, 300), (1, 717), (2, 20)])
 def test_attention_backward_kernel(ops, C, N):
-    """Kernel T9 against fp64 autograd of models/attn.py:78-82: dq, dk, dv for whole and ragged query tiles, a large-scale dO (the
+    """Kernel T11 against fp64 autograd of models/attn.py:78-82: dq, dk, dv for whole and ragged query tiles, a large-scale dO (the
     trainer's 2^16 loss scale), strided q / k / v / dO views; every output element is written (the buffers start as NaN)."""
     torch.manual_seed(C * 1000 + N)
     H, dh, M = 4, 128, 128

@@ -137,6 +137,49 @@ def test_linear_forward_backward(precision, rows, k1, k2, cout, bias):
         assert _rel(a, r) < tol * 3, (_rel(a, r))
 
 
+@pytest.mark.parametrize("kind,rows,groups,k,cout,want_stats", [("bn", 1024, 2, 256, 512, True), ("bn", 2048, 2, 1024, 256, False),
+                                                               ("in", 1536, 3, 512, 256, False)])
+def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_stats):
+    """_NormLinear (normalised map never written: GEMM a_scale read + ogmm_pack_frag_t a_scale) against the fp64 statement of
+    normalise -> ReLU -> layer: output, column sums, running statistics, and the gradients of y, gamma, beta, W, b."""
+    g = torch.Generator().manual_seed(rows + k)
+    y = (torch.randn(rows, k, generator=g) * 2 + 0.3).to(DEV).requires_grad_(True)
+    gamma = (torch.rand(k, generator=g) + 0.5).to(DEV).requires_grad_(True) if kind == "bn" else None
+    beta = (torch.randn(k, generator=g) * 0.2).to(DEV).requires_grad_(True) if kind == "bn" else None
+    W = (torch.randn(cout, k, generator=g) / k ** .5).to(DEV).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(DEV).requires_grad_(True)
+    dout = torch.randn(rows, cout, generator=g).to(DEV)
+    leaves = [t_ for t_ in (y, gamma, beta, W, b) if t_ is not None]
+    res = {}
+    for tag, o in (("hip", TrainOps("f16x3")), ("ref", RefTrainOps())):
+        for t_ in leaves:
+            t_.grad = None
+        dbl = (lambda t_: None if t_ is None else t_.double()) if tag == "ref" else (lambda t_: t_)
+        rm = torch.zeros(k, device=DEV, dtype=torch.float64 if tag == "ref" else torch.float32)
+        rv = torch.ones_like(rm)
+        nb = torch.zeros((), dtype=torch.long, device=DEV)
+        n = rows // groups
+        assert tag == "ref" or o._norm_linear_fusable(y, n, W)
+        st = None if tag == "ref" else __import__("ogmm_amd.ops", fromlist=["x"]).colstats(y.detach(), n)
+        if kind == "bn":
+            out = o.batchnorm_relu_linear(dbl(y), st, dbl(gamma), dbl(beta), rm, rv, nb, groups, dbl(W), dbl(b), want_stats=want_stats)
+            stats = None
+            if want_stats:
+                out, stats = out
+        else:
+            out, stats = o.instnorm_relu_linear(dbl(y), groups, n, st, dbl(W), dbl(b)), None
+        out.backward(dout.double() if tag == "ref" else dout)
+        res[tag] = [out.detach()] + [t_.grad.clone() for t_ in leaves] + ([rm.clone(), rv.clone()] if kind == "bn" else [])
+        if tag == "hip" and want_stats:
+            ref_st = torch.stack([out.detach().double().view(groups, n, cout).sum(1), (out.detach().double() ** 2).view(groups, n, cout).sum(1)], dim=-1)
+            assert _rel(stats, ref_st) < 1e-6
+    for i_, (a, r) in enumerate(zip(res["hip"], res["ref"])):
+        if want_stats and i_ == len(leaves):
+            assert float(a.abs().max()) == 0.0      # the layer's bias sits in front of the next normalisation: its gradient is exactly zero (see _Linear)
+            continue
+        assert _rel(a, r) < 2e-5, (i_, _rel(a, r))
+
+
 @pytest.mark.parametrize("B,J,reflect", [(5, 16, False), (3, 8, True), (4, 128, False)])
 def test_kabsch_forward_backward(B, J, reflect):
     g = torch.Generator().manual_seed(B * J)
