@@ -130,6 +130,10 @@ typedef struct ogmm_gemm {
      * OGMM_PREC_F16X3_FRAG, one A piece: output row m = c * a_gather_S + s reads A row map(c) * a_gather_N + a_gather_ids[map(c)][s] with
      * map(c) = a_gather_map ? a_gather_map[c] : c; a_gather_rows = rows of A (for the 32-bit offset check).  ogmm_gemm_gather_fusable tells. */
     const int32_t* a_gather_ids; const int32_t* a_gather_map; int32_t a_gather_S; int32_t a_gather_N; int64_t a_gather_rows;
+    /* col_stats spread over several copies: row tile t adds into copy (t & col_stats_slot_mask), col_stats_slot_stride doubles apart (>= groups * N * 2;
+     * the caller zeroes and afterwards sums the mask + 1 copies).  One copy (mask 0) serialises the atomics of every row tile of a group on the same
+     * addresses: fine for <= 512 tiles, 12x slower than a separate pass on the 5.2 M-row per-edge maps of the training step (10240 tiles per group). */
+    int32_t col_stats_slot_mask; int64_t col_stats_slot_stride;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);

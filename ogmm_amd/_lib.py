@@ -35,6 +35,7 @@ class GemmDesc(Structure):
         ("ovl_orow", c_void_p), ("ovl_ocol", c_void_p), ("ovl_ld", c_int64), ("ovl_rowpart", c_void_p), ("ovl_colpart", c_void_p), ("row_rscale", c_void_p),
         ("rd_w", c_void_p), ("rd_b", c_void_p), ("rd_act", c_int32), ("rd_out", c_void_p), ("rd_ld", c_int64),
         ("a_gather_ids", c_void_p), ("a_gather_map", c_void_p), ("a_gather_S", c_int32), ("a_gather_N", c_int32), ("a_gather_rows", c_int64),
+        ("col_stats_slot_mask", c_int32), ("col_stats_slot_stride", c_int64),
     ]
 
 

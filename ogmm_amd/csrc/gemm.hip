@@ -171,6 +171,9 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
     const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || g.precision >= 18;
+    OGMM_REQUIRE(g.col_stats_slot_mask >= 0 && ((g.col_stats_slot_mask + 1) & g.col_stats_slot_mask) == 0 &&
+                 (g.col_stats_slot_mask == 0 || (g.col_stats && g.group_rows > 0 && g.col_stats_slot_stride >= (int64_t)((g.M + g.group_rows - 1) / g.group_rows) * g.N * 2)),
+                 "ogmm_gemm_nt: col_stats_slot_mask must be 2^n - 1 and col_stats_slot_stride must hold one [groups][N][2] copy");
     OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart && !g.rd_out && !g.a_gather_ids), "ogmm_gemm_nt: InstanceNorm / overlap-block / Cout = 1 head / row gather fusion is only available with OGMM_PREC_F16X3_FRAG");
     if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&

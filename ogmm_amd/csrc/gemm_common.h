@@ -323,7 +323,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
         const int col = n0 + wn * NT * 32 + (lane % F4_PER_ROW) * 4;
         const int first_row = m0 + wm * MT * 32;
         if (lane < F4_PER_ROW && col < g.N && first_row < m_end) {
-            double* st = g.col_stats + ((int64_t)(first_row / g.group_rows) * g.N + col) * 2;
+            double* st = g.col_stats + (int64_t)((first_row >> 8) & g.col_stats_slot_mask) * g.col_stats_slot_stride + ((int64_t)(first_row / g.group_rows) * g.N + col) * 2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 atomicAdd(st + 2 * e, (double)tot1[e]);

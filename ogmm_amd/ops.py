@@ -206,8 +206,11 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.act = act
     d.pool_k, d.pool_out, d.ldp, d.store_c = pool_k, (pool_out.data_ptr() if pool_out is not None else None), ldp, 1 if store_c else 0
     d.group_rows = group_rows
-    if col_stats is not None:
+    if col_stats is not None:          # [G, N, 2] or, spread over 2^n copies that the caller sums, [2^n, G, N, 2] (struct ogmm_gemm.col_stats_slot_mask)
         d.col_stats = col_stats.data_ptr()
+        if col_stats.dim() == 4:
+            assert col_stats.is_contiguous() and col_stats.shape[0] & (col_stats.shape[0] - 1) == 0
+            d.col_stats_slot_mask, d.col_stats_slot_stride = col_stats.shape[0] - 1, col_stats.stride(0)
     if a_affine is not None:
         d.a_scale, d.a_shift, d.a_relu = a_affine[0].data_ptr(), a_affine[1].data_ptr(), 1 if a_affine[2] else 0
     if overlap is not None:          # (o_row, o_col, ld, rowpart, colpart): the fused overlap block, S is not stored (struct ogmm_gemm)

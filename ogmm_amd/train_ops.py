@@ -160,11 +160,15 @@ class _Linear(torch.autograd.Function):
         if precision == "f16x3":
             layer["split"] = ops.split_f16_training(layer["W"], ("fwd", W.data_ptr(), tuple(Wd.shape)), frag=True, k1=K1)
         stats = None
-        if stats_rows and precision == "f16x3" and stats_rows % 256 == 0 and W.shape[0] % 4 == 0 and stats_rows <= 131072:
+        if stats_rows and precision == "f16x3" and stats_rows % 256 == 0 and W.shape[0] % 4 == 0 and (stats_rows <= 131072 or W.shape[0] >= 256):
             # the normalisation that follows needs sum / sum of squares per (row group, column): the engine's epilogue adds them up
-            # (one fp64 atomic per tile and column: fine for <= 512 row tiles per group, measured 12x slower than a separate
-            # pass on the 2.6 M-row per-edge maps, whose 5120 tiles per group all hit the same few addresses)
-            stats = torch.zeros((x.shape[0] // stats_rows, W.shape[0], 2), dtype=torch.float64, device=x.device)
+            # (one fp64 atomic per tile and column: fine for <= 512 row tiles per group; on the 2.6 M-row per-edge maps, whose
+            # 10240 tiles per group would all hit the same few addresses -- measured 12x slower than a separate pass -- the tiles
+            # are dealt over 64 copies of the table, summed afterwards.  Only for >= 256 output channels, where the LDS-DMA engines
+            # issue one atomic per tile and column: the 64- and 128-channel maps run on the 128 x 128-tile kernel, whose epilogue
+            # issues them per wave -- 10 M fp64 atomics per map cost it 0.4-0.55 ms, more than the separate pass (0.2-0.55 ms))
+            slots = 1 if stats_rows <= 131072 else 64
+            stats = torch.zeros((slots, x.shape[0] // stats_rows, W.shape[0], 2)[0 if slots > 1 else 1:], dtype=torch.float64, device=x.device)
         y = ops.conv1x1(x.contiguous(), layer, ops.ACT_NONE, x2=None if x2p is None else x2p.contiguous(),
                         split=precision == "f16x3", overflow=overflow, col_stats=stats, group_rows=stats_rows if stats is not None else 0)
         ctx.save_for_backward(x, x2, W)
@@ -175,6 +179,8 @@ class _Linear(torch.autograd.Function):
         if stats_rows:
             if stats is None:
                 stats = ops.colstats(y, stats_rows)
+            elif stats.dim() == 4:
+                stats = stats.sum(dim=0)
             ctx.mark_non_differentiable(stats)
             return y, stats
         return y

@@ -248,6 +248,16 @@ def test_gemm_lds_dma_engine_statistics_a_transform_batch_overflow(ops):
     ops.gemm_nt(A, K, K, None, K, M, N, C=z, ldc=N, shift=b, split=ops.split_f16(W, frag=True), col_stats=st, group_rows=rows)
     zg = z.view(G, rows, N).double()
     assert (st[:, :, 0] - zg.sum(1)).abs().max().item() < 1e-6 * rows and ((st[:, :, 1] - (zg * zg).sum(1)).abs() / (zg * zg).sum(1)).max().item() < 1e-6
+    # the same statistics dealt over 8 copies of the table (struct ogmm_gemm.col_stats_slot_mask), on every engine that has the epilogue
+    for n_cols, variant in ((256, None), (512, None), (128, None), (64, None)):
+        Wn = torch.randn(n_cols, K, device="cuda") * 0.05
+        st1 = torch.zeros((G // 32, n_cols, 2), dtype=torch.float64, device="cuda")
+        st8 = torch.zeros((8, G // 32, n_cols, 2), dtype=torch.float64, device="cuda")
+        zn_ = torch.empty(M, n_cols, device="cuda")
+        for st_ in (st1, st8):
+            ops.gemm_nt(A, K, K, None, K, M, n_cols, C=zn_, ldc=n_cols, split=ops.split_f16(Wn, frag=True), col_stats=st_, group_rows=32 * rows)
+        assert float(st8.abs().min(dim=0).values.max()) > 0                    # every copy took part
+        assert ((st8.sum(0) - st1).abs() / st1.abs().clamp_min(1.0)).max().item() < 1e-9
     sc, sh = ops.instnorm_finalize(st, rows, 1e-5)
     W2 = torch.randn(N, N, device="cuda") * 0.05
     res = torch.randn(M, N, device="cuda")
