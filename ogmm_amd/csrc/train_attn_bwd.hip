@@ -34,6 +34,11 @@ constexpr int PP = 34;                   // floats per row of a wave's transposi
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Workgroup barrier for LDS hand-over only.  __syncthreads() also waits for every outstanding global access (s_waitcnt vmcnt(0)): the dQ
+// stores issued at the end of a tile would be waited for at the top of the next one -- a store's round trip (1-2 us) per 9 us tile.
+// Nothing in this kernel reads back what it stores, so the LDS counter is all a barrier has to wait for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // step s (0..63) of a contraction over 128 indices takes index sel(s, lh) from lane half lh: two consecutive steps use two adjacent
 // indices, so one 8-byte read feeds both
 __device__ __forceinline__ constexpr int sel(int s, int lh) { return 4 * (s >> 1) + 2 * lh + (s & 1); }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     load_tile(0);
     store_tile();
     for (int tile = 0; tile < n_tiles; ++tile) {
-        __syncthreads();                                                   // (A) tile visible; dSx / Xs of the previous tile are free
+        lds_barrier();                                                   // (A) tile visible; dSx / Xs of the previous tile are free
         if (tile + 1 < n_tiles) load_tile(tile + 1);
         // opaque per tile: keeps the tile-invariant LDS addressing from being hoisted into registers that are needed elsewhere
         int lr_t = lr, lh_t = lh;
@@ -124,14 +129,22 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         {
             const float* __restrict__ qb = Qs + lr_t * PT + 2 * lh_t;
             const float* __restrict__ gb = dOs + lr_t * PT + 2 * lh_t;
+            // operands of step j + 2 are requested before the MFMAs of step j are issued (a read right in front of its use leaves
+            // the matrix pipe idle for the LDS latency: one wave per SIMD, nobody else to fill it)
+            f32x2b bq[3], bg[3];
+            bq[0] = *reinterpret_cast<const f32x2b*>(qb); bg[0] = *reinterpret_cast<const f32x2b*>(gb);
+            bq[1] = *reinterpret_cast<const f32x2b*>(qb + 4); bg[1] = *reinterpret_cast<const f32x2b*>(gb + 4);
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-                const f32x2b bq = *reinterpret_cast<const f32x2b*>(qb + 4 * j);
-                const f32x2b bg = *reinterpret_cast<const f32x2b*>(gb + 4 * j);
-                sacc = MFMA32(krow[2 * j], bq[0], sacc);
-                pacc = MFMA32(vrow[2 * j], bg[0], pacc);
-                sacc = MFMA32(krow[2 * j + 1], bq[1], sacc);
-                pacc = MFMA32(vrow[2 * j + 1], bg[1], pacc);
+                if (j + 2 < 32) {
+                    bq[(j + 2) % 3] = *reinterpret_cast<const f32x2b*>(qb + 4 * (j + 2));
+                    bg[(j + 2) % 3] = *reinterpret_cast<const f32x2b*>(gb + 4 * (j + 2));
+                }
+                sacc = MFMA32(krow[2 * j], bq[j % 3][0], sacc);
+                pacc = MFMA32(vrow[2 * j], bg[j % 3][0], pacc);
+                sacc = MFMA32(krow[2 * j + 1], bq[j % 3][1], sacc);
+                pacc = MFMA32(vrow[2 * j + 1], bg[j % 3][1], pacc);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
             Xs[(wave * 3 + 1) * 32 + lr_t] = sw;
             Xs[(wave * 3 + 2) * 32 + lr_t] = ew;
         }
-        __syncthreads();                                                   // (X) the four waves' triples
+        lds_barrier();                                                   // (X) the four waves' triples
         float mall = -__builtin_inff();
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) mall = fmaxf(mall, Xs[(w2 * 3 + 0) * 32 + lr_t]);
@@ -190,24 +203,32 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         {
             const float* __restrict__ pa = Pp + lr_t * PP + 2 * lh_t;
             const float* __restrict__ sa = Sp + lr_t * PP + 2 * lh_t;
+            // step u = 2 j + e takes query 4 j + e (+ 2 lh); its 8 B values are requested one step ahead, the A pairs two steps ahead
+            const float* __restrict__ gb0 = dOs + 2 * lh_t * PT + lr_t;
+            const float* __restrict__ qb0 = Qs + 2 * lh_t * PT + lr_t;
+            f32x2b ap[2], as[2];
+            float bg[2][4], bq[2][4];
+            ap[0] = *reinterpret_cast<const f32x2b*>(pa); as[0] = *reinterpret_cast<const f32x2b*>(sa);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f32x2b ap = *reinterpret_cast<const f32x2b*>(pa + 4 * j);
-                const f32x2b as = *reinterpret_cast<const f32x2b*>(sa + 4 * j);
+            for (int t = 0; t < 4; ++t) { bg[0][t] = gb0[32 * t]; bq[0][t] = qb0[32 * t]; }
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int qi = 4 * j + e;                               // + 2 lh: the query this lane half contributes
-                    const float* __restrict__ gb = dOs + (qi + 2 * lh_t) * PT + lr_t;
-                    const float* __restrict__ qb = Qs + (qi + 2 * lh_t) * PT + lr_t;
+            for (int u = 0; u < 16; ++u) {
+                const int j = u >> 1, e = u & 1;
+                if (u + 1 < 16) {
+                    const int qn = 4 * ((u + 1) >> 1) + ((u + 1) & 1);
+                    if (e == 1) { ap[(j + 1) & 1] = *reinterpret_cast<const f32x2b*>(pa + 4 * (j + 1)); as[(j + 1) & 1] = *reinterpret_cast<const f32x2b*>(sa + 4 * (j + 1)); }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        dvacc[t] = MFMA32(ap[e], gb[32 * t], dvacc[t]);
-                        dkacc[t] = MFMA32(as[e], qb[32 * t], dkacc[t]);
-                    }
+                    for (int t = 0; t < 4; ++t) { bg[(u + 1) & 1][t] = gb0[qn * PT + 32 * t]; bq[(u + 1) & 1][t] = qb0[qn * PT + 32 * t]; }
                 }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dvacc[t] = MFMA32(ap[j & 1][e], bg[u & 1][t], dvacc[t]);
+                    dkacc[t] = MFMA32(as[j & 1][e], bq[u & 1][t], dkacc[t]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();                                                   // (B) dS of all keys; every wave is done with Qs / dOs
+        lds_barrier();                                                   // (B) dS of all keys; every wave is done with Qs / dOs
 
         // ---- dQ block: 32 queries x the wave's 32 columns, over all 128 keys
         f32x16b qacc;
@@ -215,11 +236,15 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) qacc[r] = 0.0f;
         {
             const float* __restrict__ sb = dSx + lr_t * PX + 2 * lh_t;
+            f32x2b a[3];
+            a[0] = *reinterpret_cast<const f32x2b*>(sb);
+            a[1] = *reinterpret_cast<const f32x2b*>(sb + 4);
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-                const f32x2b a = *reinterpret_cast<const f32x2b*>(sb + 4 * j);
-                qacc = MFMA32(a[0], kcol[2 * j], qacc);
-                qacc = MFMA32(a[1], kcol[2 * j + 1], qacc);
+                if (j + 2 < 32) a[(j + 2) % 3] = *reinterpret_cast<const f32x2b*>(sb + 4 * (j + 2));
+                qacc = MFMA32(a[j % 3][0], kcol[2 * j], qacc);
+                qacc = MFMA32(a[j % 3][1], kcol[2 * j + 1], qacc);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (tile + 1 < n_tiles) store_tile();                              // the next tile's rows (nobody reads Qs / dOs before (A))
