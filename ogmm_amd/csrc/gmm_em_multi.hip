@@ -153,9 +153,14 @@ __device__ __forceinline__ void em_finish_v(int c, int J, int n_chunks, bool fir
     }
 }
 
+// The costs themselves are NOT read: thread = row recomputes its J distances from the point and the cloud's centres (LDS) with the
+// arithmetic of em_cost_kernel -- bit-identical values, 10 VALU instructions instead of a 4-byte load per entry.  The cost matrix of
+// 128 clouds (64 MB) came from the Infinity Cache at ~2 TB/s: 31-55 us per sweep, 100 sweeps per forward; recomputed: see DESIGN.
 template <int JMAX>
-__global__ __launch_bounds__(256, 4) void em_sweep_kernel(int N, int J, float inv_eps, float eps, float logq, int first, int parity, EmWs w) {
+__global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restrict__ xyz, float inv_tau, int N, int J, float inv_eps, float eps,
+                                                          float logq, int first, int parity, EmWs w) {
     __shared__ float vs[JMAX];
+    __shared__ float4 mus[JMAX];
     __shared__ float tile[4][64][33];
     __shared__ float wp[4][JMAX][2];
     const int c = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x, C = gridDim.y;
@@ -166,13 +171,18 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(int N, int J, float in
     // and partials_k to pbuf[k & 1]
     em_finish_v(c, J, n_chunks, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz,
                 chunk == 0 ? w.vbuf + (parity ^ 1) * vsz : nullptr, vs);
+    for (int j = tid; j < J; j += 256) mus[j] = w.mu[(int64_t)c * J + j];
     __syncthreads();
     const bool valid = n < N;
-    const float* __restrict__ Cc = w.cost + (int64_t)c * J * N + (valid ? n : 0);
+    const float* __restrict__ pt = xyz + ((int64_t)c * N + (valid ? n : 0)) * 3;
+    const float px = pt[0], py = pt[1], pz = pt[2], pn = sqnorm3(px, py, pz);
     float cst[JMAX];
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) cst[j] = j < J ? Cc[(int64_t)j * N] : 0.0f;
-    const float un = valid ? w.u[(int64_t)c * N + n] : 0.0f;
+    for (int j = 0; j < JMAX; ++j) {
+        const float4 m = mus[j < J ? j : 0];
+        cst[j] = j < J ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
+    }
+    const float un = (valid && !first) ? w.u[(int64_t)c * N + n] : 0.0f;          // u = v = 0 at the start of every outer iteration
     float mx = -__builtin_inff();
 #pragma unroll
     for (int j = 0; j < JMAX; ++j)
@@ -220,9 +230,11 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(int N, int J, float in
 
 // gamma = exp(K) (nan -> 0, inf -> FLT_MAX) in place; rclip = max(rowsum, 1e-3); the last iteration also writes gamma / rclip.  grid (N/256, C)
 __global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out, int fused, int first,
-                                                       int parity, float eps, float logq) {
-    extern __shared__ float vs[];
+                                                       int parity, float eps, float logq, const float* __restrict__ xyz, float inv_tau) {
+    extern __shared__ float vs[];                    // [J], then (fused) the centres [J] float4 from the next 16-byte boundary
+    float4* mus = reinterpret_cast<float4*>(vs + (J + 3) / 4 * 4);
     const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (fused) for (int j = threadIdx.x; j < J; j += 256) mus[j] = w.mu[(int64_t)c * J + j];
     if (fused) {          // after fused sweeps the last v-update is still pending in the partials
         const int64_t vsz = (int64_t)gridDim.y * J, psz = (int64_t)gridDim.y * gridDim.x * J * 2;
         em_finish_v(c, J, gridDim.x, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz, nullptr, vs);
@@ -232,10 +244,16 @@ __global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_e
     __syncthreads();
     if (n >= N) return;
     float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
-    const float un = w.u[(int64_t)c * N + n];
+    const float un = (fused && first) ? 0.0f : w.u[(int64_t)c * N + n];
+    float px = 0.0f, py = 0.0f, pz = 0.0f, pn = 0.0f;
+    if (fused) {          // the fused sweeps never wrote the costs: same arithmetic as em_cost_kernel
+        const float* __restrict__ pt = xyz + ((int64_t)c * N + n) * 3;
+        px = pt[0]; py = pt[1]; pz = pt[2]; pn = sqnorm3(px, py, pz);
+    }
     double rs = 0.0;
     for (int j = 0; j < J; ++j) {
-        float g = expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps);
+        const float cj = fused ? cdist_mm2(px, py, pz, pn, mus[j].x, mus[j].y, mus[j].z, mus[j].w) * inv_tau : Cc[(int64_t)j * N];
+        float g = expf(((-cj + un) + vs[j]) * inv_eps);
         g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
         Cc[(int64_t)j * N] = g;
         rs += (double)g;
@@ -316,17 +334,17 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     hipLaunchKernelGGL(em_init_kernel, dim3(C), blk, 0, s, xyz, o, ids0, N, J, w);
     for (int it = 0; it < iters; ++it) {
         const bool last = it + 1 == iters;
-        hipLaunchKernelGGL(em_cost_kernel, rows, blk, 0, s, xyz, N, J, inv_tau, w);
         static const bool two_launch = [] { const char* e = getenv("OGMM_EM_MULTI_UNFUSED"); return e && e[0] == '1'; }();      // A/B: u and v kernels
         const bool fused = J <= 64 && !two_launch;
+        if (!fused) hipLaunchKernelGGL(em_cost_kernel, rows, blk, 0, s, xyz, N, J, inv_tau, w);          // (the fused sweeps recompute the costs)
         if (fused) {
             // launch k = 1 .. sk_iters; the gamma kernel plays launch sk_iters + 1 for the pending v-update
             for (int k = 1; k <= sk_iters; ++k) {
-                if (J <= 32) hipLaunchKernelGGL(em_sweep_kernel<32>, rows, blk, 0, s, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
-                else hipLaunchKernelGGL(em_sweep_kernel<64>, rows, blk, 0, s, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
+                if (J <= 32) hipLaunchKernelGGL(em_sweep_kernel<32>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
+                else hipLaunchKernelGGL(em_sweep_kernel<64>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
             }
-            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 1, sk_iters == 0 ? 1 : 0,
-                               (sk_iters + 1) & 1, epsilon, logq);
+            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs + 16 + (size_t)J * sizeof(float4), s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 1,
+                               sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, epsilon, logq, xyz, inv_tau);
         } else {
             for (int sk = 0; sk < sk_iters; ++sk) {
                 if (J <= 16) hipLaunchKernelGGL(em_u_kernel<16>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
@@ -334,7 +352,7 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
                 else hipLaunchKernelGGL(em_u_kernel<128>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
                 hipLaunchKernelGGL(em_v_kernel, cols, blk, 0, s, N, J, inv_eps, epsilon, logq, w);
             }
-            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 0, 0, 0, epsilon, logq);
+            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 0, 0, 0, epsilon, logq, xyz, inv_tau);
         }
         hipLaunchKernelGGL(em_mstep_kernel, cols, blk, 0, s, xyz, N, J, w, last ? pi : (float*)nullptr, mu);
     }
