@@ -48,6 +48,14 @@ timeout 200 python3 tools/gemm_launch_table.py 2>&1 | tail -27
 } > $out/${tag}_gemm_engine.txt
 unset OGMM_V6_MIN_TILES OGMM_V4_MIN_TILES OGMM_V8_MIN_TILES OGMM_V10_MIN_TILES
 
+# 4b. the training step (BASELINE configs[4], 128 pairs per GPU): kernel statistics, per-operation breakdown, attention backward alone
+rocprofv3 --kernel-trace --stats -d $out/trace_train -o r --output-format rocpd -- python3 bench.py --workload train --steps 3 --warmup 2 --cpu-sample 0 > $out/trace_train.log 2>&1
+dbt=$(find $out/trace_train -name "*.db" | head -1)
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload train --steps 3 --warmup 2 --cpu-sample 0   (5 training steps of 128 pairs)"; python3 tools/rocpd_stats.py $dbt | head -80; } > $out/${tag}_train_kernel_stats.txt
+{ echo "# tools/train_breakdown.py 128: forward / backward of the autograd functions of one training step (events)"; timeout 300 python3 tools/train_breakdown.py 128 2>&1 | grep -v amdgpu.ids;
+  echo "# tools/attn_bwd_time.py"; timeout 200 python3 tools/attn_bwd_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_train_breakdown.txt
+rm -rf $out/trace_train
+
 # 5. parity lines of the GPU tests
 timeout 900 python3 -m pytest tests/test_hip_forward.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|passed|failed" > $out/${tag}_parity.txt
 rm -rf $out/trace $out/pmc_*          # the rocpd databases exceed what gpurun copies back; the summaries above are what gets committed

@@ -22,14 +22,14 @@ def timed(tag, fn):
         e0.record(); r = fn(*a, **k); e1.record(); events.append((tag, e0, e1)); return r
     return w
 
-for cls in (train_ops._Linear, train_ops._NormAct, train_ops._MaxPoolK):
+for cls in (train_ops._Linear, train_ops._NormAct, train_ops._NormActPool, train_ops._NormLinear, train_ops._Attention, train_ops._MaxPoolK):
     f, b = cls.forward, cls.backward
     def mk(cls, f, b):
         def fw(ctx, *a):
             shp = tuple(a[0].shape)
             return timed("%s.fwd %s" % (cls.__name__, shp), f)(ctx, *a)
         def bw(ctx, *g):
-            shp = tuple(g[0].shape)
+            shp = next((tuple(t_.shape) for t_ in g if t_ is not None), ())
             return timed("%s.bwd %s" % (cls.__name__, shp), b)(ctx, *g)
         cls.forward, cls.backward = staticmethod(fw), staticmethod(bw)
     mk(cls, f, b)
