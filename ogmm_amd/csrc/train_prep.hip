@@ -60,13 +60,22 @@ __global__ __launch_bounds__(256) void pack_frag_t_kernel(const float* __restric
         const int64_t k0 = sb * chunk + kb * 16 + (lane >> 5) * 8;
         f16x8t h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
         if (n < cols && kb * 16 < chunk) {
+            // a_scale: the map is the pre-normalisation output, X = relu(x * scale_g + shift_g) as the forward GEMM read it.  One division per
+            // 8 rows: they lie in one row group or straddle one boundary.
+            float sc0 = 1.0f, sh0 = 0.0f, sc1 = 1.0f, sh1 = 0.0f;
+            int64_t first_of_next = rows;
+            if (a_scale && k0 < rows) {
+                const int64_t g0 = k0 / group_rows;
+                first_of_next = (g0 + 1) * group_rows;
+                sc0 = a_scale[g0 * cols + n]; sh0 = a_shift[g0 * cols + n];
+                if (first_of_next < k0 + 8 && first_of_next < rows) { sc1 = a_scale[(g0 + 1) * cols + n]; sh1 = a_shift[(g0 + 1) * cols + n]; }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int64_t r = k0 + j;
                 float v = r < rows ? x[r * ldx + n] : 0.0f;
-                if (a_scale && r < rows) {      // the map is the pre-normalisation output: X = relu(x * scale_g + shift_g), as the forward GEMM read it
-                    const int64_t gc = (r / group_rows) * cols + n;
-                    v = fmaf(v, a_scale[gc], a_shift[gc]);
+                if (a_scale && r < rows) {
+                    v = r < first_of_next ? fmaf(v, sc0, sh0) : fmaf(v, sc1, sh1);
                     if (a_relu) v = fmaxf(v, 0.0f);
                 }
                 const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
