@@ -334,14 +334,17 @@ int ogmm_maxpool_k_bwd(const float* dout, int64_t ldo, const uint8_t* arg, int64
  * ogmm_gemm_nt, which contracts over the last axis of both operands.  The contraction is cut into S chunks of `chunk` rows
  * (chunk %% 64 == 0, r zero-padded to S*chunk) that run as the batch dimension of ogmm_gemm_nt (split-K); every chunk's
  * operand is stored compactly with row pitch `pitch` = chunk + 64 (a non power of two: HBM channel spread):
- *   ogmm_transpose_pad: out[s][c][rr] = x[s*chunk + rr][c]                       (A = dY^T, fp32; sA_o = cols*pitch floats, lda = pitch)
+ *   ogmm_transpose_pad: out[s][c][rr] = x[s*chunk + rr][c]                       (A = dY^T, fp32; sA_o = cols*pitch floats, lda = pitch);
+ *                       optionally the column sums of x on the way (the bias gradient of the same layer)
  *   ogmm_pack_frag_t:   per chunk the OGMM_PREC_F16X3_FRAG image of X^T, [n_pad/32][pitch/16][64 lanes][8 halfs], hi and lo
  *                       planes (ldb_h = pitch, sB_o = n_pad*pitch halfs); *overflow |= 1 if a finite |x| > 65504 was clamped.
  *                       a_scale != NULL ([rows/group_rows][cols] float, with a_shift): X is taken as relu(x * a_scale + a_shift)
  *                       (relu iff a_relu) -- the same read as struct ogmm_gemm.a_scale, for layers whose normalised input was
  *                       consumed by the forward GEMM that way and never written.
  * The S partial products (sC_o = n*k) are summed afterwards. */
-int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out, void* stream);
+int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out,
+                       double* colsum /*NULL, or [colsum_slots][cols]: column sums of x (zeroed by the call; the caller adds the copies up)*/,
+                       int colsum_slots /*power of two*/, void* stream);
 int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
                      int* overflow, const float* a_scale, const float* a_shift, int a_relu, int64_t group_rows, void* stream);
 

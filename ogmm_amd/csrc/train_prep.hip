@@ -15,26 +15,59 @@ namespace {
 using namespace ogmm;
 using f16x8t = __attribute__((ext_vector_type(8))) _Float16;
 
-// out[s][c][rr] = x[s*chunk + rr][c] (0 beyond `rows`), row pitch `pitch`.  64x64 tiles through LDS, both sides 256-byte lines.
+// out[s][c][rr] = x[s*chunk + rr][c] (0 beyond `rows`), row pitch `pitch`.  64x64 tiles through LDS, float4 on both sides (a 64-row block lies
+// inside one chunk: chunk % 64 == 0).  colsum != NULL: the block also adds its 64-row column sums into colsum[blockIdx.x & slot_mask][c] (fp64
+// atomics) -- the bias gradient db = sum_r dY[r][:] of the same layer, which would otherwise be one more pass over dY.
+template <bool VEC>
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols, int64_t r_pad,
-                                                            int64_t chunk, int64_t pitch, float* __restrict__ out) {
+                                                            int64_t chunk, int64_t pitch, float* __restrict__ out, double* __restrict__ colsum,
+                                                            int slot_mask) {
     __shared__ float tile[64][65];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int64_t r = r0 + i;
-        tile[i][tx] = (r < rows && c0 + tx < cols) ? x[r * ldx + c0 + tx] : 0.0f;
+    {
+        const int q = tid & 15, c4 = q * 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = p * 16 + (tid >> 4);
+            const int64_t r = r0 + row;
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (r < rows) {
+                if (VEC && c0 + c4 + 3 < cols) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + r * ldx + c0 + c4);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c0 + c4 + e < cols) v[e] = x[r * ldx + c0 + c4 + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[row][c4 + e] = v[e];
+        }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i;
-        const int64_t r = r0 + tx;
-        if (c < cols && r < r_pad) {
-            const int64_t sb = r / chunk;
-            out[(sb * cols + c) * pitch + (r - sb * chunk)] = tile[tx][i];
+    if (colsum && tid < 64 && c0 + tid < cols) {
+        float s = 0.0f;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) s += tile[i][tid];
+        atomicAdd(colsum + (int64_t)(blockIdx.x & slot_mask) * cols + c0 + tid, (double)s);
+    }
+    const int64_t sb = r0 / chunk, rr0 = r0 - sb * chunk;
+    if (r0 < r_pad) {
+        const int q = tid & 15, r4 = q * 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = p * 16 + (tid >> 4);
+            if (c0 + c < cols) {
+                float* __restrict__ o = out + (sb * cols + c0 + c) * pitch + rr0 + r4;
+                if (VEC) {
+                    *reinterpret_cast<float4*>(o) = make_float4(tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = tile[r4 + e][c];
+                }
+            }
         }
     }
 }
@@ -93,11 +126,17 @@ __global__ __launch_bounds__(256) void pack_frag_t_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out, void* stream) {
-    OGMM_REQUIRE(x && out && rows > 0 && cols > 0 && chunk > 0 && S > 0 && (int64_t)S * chunk >= rows && pitch >= chunk, "ogmm_transpose_pad: bad shape");
+extern "C" int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, float* out, double* colsum,
+                                  int colsum_slots, void* stream) {
+    OGMM_REQUIRE(x && out && rows > 0 && cols > 0 && chunk > 0 && chunk % 64 == 0 && S > 0 && (int64_t)S * chunk >= rows && pitch >= chunk,
+                 "ogmm_transpose_pad: bad shape (chunk must be a multiple of 64)");
+    OGMM_REQUIRE(!colsum || (colsum_slots >= 1 && (colsum_slots & (colsum_slots - 1)) == 0), "ogmm_transpose_pad: colsum_slots must be a power of two");
     const int64_t r_pad = (int64_t)S * chunk;
     dim3 grid((unsigned)((r_pad + 63) / 64), (cols + 63) / 64);
-    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, as_stream(stream), x, ldx, rows, cols, r_pad, chunk, pitch, out);
+    if (colsum) (void)hipMemsetAsync(colsum, 0, sizeof(double) * (size_t)colsum_slots * cols, as_stream(stream));
+    const bool vec = ldx % 4 == 0 && pitch % 4 == 0 && aligned16(x) && aligned16(out);
+    if (vec) hipLaunchKernelGGL(transpose_pad_kernel<true>, grid, dim3(256), 0, as_stream(stream), x, ldx, rows, cols, r_pad, chunk, pitch, out, colsum, colsum_slots - 1);
+    else hipLaunchKernelGGL(transpose_pad_kernel<false>, grid, dim3(256), 0, as_stream(stream), x, ldx, rows, cols, r_pad, chunk, pitch, out, colsum, colsum_slots - 1);
     return check_launch("ogmm_transpose_pad");
 }
 

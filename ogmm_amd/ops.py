@@ -695,9 +695,10 @@ def maxpool_k_bwd(dout, arg, k):
     return dh
 
 
-def weight_grad(dy, xs, overflow=None, x_affine=None):
+def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False):
     """dW = dY^T [x_0 | x_1 | ...] on the fp16x3 engine: dy [R, n], xs = list of [R, k_i] (last stride 1) -> [n, sum k_i].
     x_affine (one x only): (scale [G, k], shift [G, k], relu, group_rows) -- x is a pre-normalisation map, X = relu(x * scale + shift).
+    colsum=True: -> (dW, db) with db = dy.sum(0) gathered while dY^T is written (fp64 partial sums), no extra pass over dy.
     dY^T is materialised once (fp32, chunk-major), every x_i becomes per-chunk split fragment images of x_i^T, the contraction
     over r runs as split-K batches of the engine and the partial products are summed (kernels T3 of include/ogmm_hip.h)."""
     R, n = dy.shape
@@ -708,7 +709,8 @@ def weight_grad(dy, xs, overflow=None, x_affine=None):
     S = (R + chunk - 1) // chunk
     pitch = chunk + 64
     dyt = torch.empty((S, n, pitch), dtype=torch.float32, device=dy.device)
-    _lib.call("ogmm_transpose_pad", _p(_f32(dy, "dy")), dy.stride(0), R, n, chunk, pitch, S, _p(dyt), _stream())
+    csum = torch.empty((16, n), dtype=torch.float64, device=dy.device) if colsum else None
+    _lib.call("ogmm_transpose_pad", _p(_f32(dy, "dy")), dy.stride(0), R, n, chunk, pitch, S, _p(dyt), _p(csum), 16, _stream())
     outs = []
     for x in xs:
         assert x.stride(1) == 1 and x.shape[0] == R
@@ -724,7 +726,8 @@ def weight_grad(dy, xs, overflow=None, x_affine=None):
         split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
         gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow)
         outs.append(part.sum(dim=0) if S > 1 else part[0])
-    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    dW = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    return (dW, csum.sum(dim=0).float()) if colsum else dW
 
 
 def kabsch_bwd(src, corr, w, gR, gt):

@@ -212,8 +212,11 @@ class _Linear(torch.autograd.Function):
             pieces = [x] if x2 is None else [x, x2]
             wide = [ctx.precision == "f16x3" and W.shape[0] >= 256 and p_.shape[1] >= 256 for p_ in pieces]
             parts = [None] * len(pieces)
+            want_db = ctx.has_bias and ctx.needs_input_grad[3] and not ctx.bias_grad_is_zero
             if any(wide):
-                got = ops.weight_grad(dy.contiguous(), [p_ for p_, w_ in zip(pieces, wide) if w_], ctx.overflow)
+                got = ops.weight_grad(dy.contiguous(), [p_ for p_, w_ in zip(pieces, wide) if w_], ctx.overflow, colsum=want_db)
+                if want_db:
+                    got, db = got
                 off = 0
                 for i_, (p_, w_) in enumerate(zip(pieces, wide)):
                     if w_:
@@ -225,7 +228,7 @@ class _Linear(torch.autograd.Function):
                     if not w_:
                         parts[i_] = ops.weight_grad_thin(dyc, p_) if ops.weight_grad_thin_supported(dyc, p_) else dyc.t() @ p_
             dW = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+        if ctx.has_bias and ctx.needs_input_grad[3] and db is None:
             db = torch.zeros(dy.shape[1], dtype=dy.dtype, device=dy.device) if ctx.bias_grad_is_zero else dy.sum(dim=0)
         return dx, dx2, dW, db, None, None, None
 
@@ -276,9 +279,13 @@ class _NormLinear(torch.autograd.Function):
         Wt = W.detach().t().contiguous()
         layer = {"W": Wt, "split": ops.split_f16_training(Wt, ("bwd", W.data_ptr(), tuple(Wt.shape)), frag=True)}
         dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
-        dW = ops.weight_grad(dout, [y], ctx.overflow, x_affine=(scale, shift, True, ctx.group_rows)) if ctx.needs_input_grad[5] else None
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[6]:
+        dW = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[6] and not ctx.bias_grad_is_zero
+        if ctx.needs_input_grad[5]:
+            dW = ops.weight_grad(dout, [y], ctx.overflow, x_affine=(scale, shift, True, ctx.group_rows), colsum=want_db)
+            if want_db:
+                dW, db = dW
+        if ctx.has_bias and ctx.needs_input_grad[6] and db is None:
             db = torch.zeros(dout.shape[1], dtype=dout.dtype, device=dout.device) if ctx.bias_grad_is_zero else dout.sum(dim=0)
         dy, sums = ops.norm_bwd(y, dh, ctx.group_rows, scale, shift, mean, rstd, ops.ACT_RELU)
         dg = sums[..., 1].sum(dim=0).float() if ctx.affine else None

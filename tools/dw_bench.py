@@ -24,7 +24,7 @@ for R, n, k in ((131072, 1024, 1024), (131072, 512, 1024), (131072, 1024, 512), 
     dyt = torch.empty((S, n, pitch), device=dev); n_pad = (k + 255) // 256 * 256
     hi = torch.empty(S * n_pad * pitch, dtype=torch.float16, device=dev); lo = torch.empty_like(hi); part = torch.empty((S, n, k), device=dev)
     split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": ops.PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
-    t_tr = t(lambda: _lib.call("ogmm_transpose_pad", ops._p(dy), dy.stride(0), R, n, chunk, pitch, S, ops._p(dyt), ops._stream()))
+    t_tr = t(lambda: _lib.call("ogmm_transpose_pad", ops._p(dy), dy.stride(0), R, n, chunk, pitch, S, ops._p(dyt), None, 1, ops._stream()))
     t_pk = t(lambda: _lib.call("ogmm_pack_frag_t", ops._p(x), x.stride(0), R, k, chunk, pitch, S, n_pad, ops._p(hi), ops._p(lo), None, ops._stream()))
     t_mm = t(lambda: ops.gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split))
     t_sum = t(lambda: part.sum(dim=0))
