@@ -348,6 +348,10 @@ int ogmm_transpose_pad(const float* x, int64_t ldx, int64_t rows, int cols, int6
 int ogmm_pack_frag_t(const float* x, int64_t ldx, int64_t rows, int cols, int64_t chunk, int64_t pitch, int S, int n_pad, void* hi, void* lo,
                      int* overflow, const float* a_scale, const float* a_shift, int a_relu, int64_t group_rows, void* stream);
 
+/* ---- T12: out = s_0 + ... + s_{n-1} for n <= 8 row-major [rows][cols] maps with their own row pitches (srcs, lds: HOST arrays of n entries): the
+ * gradient of a feature map with several consumers in one pass instead of autograd's n - 1 pairwise adds. */
+int ogmm_add_n(int n, const float* const* srcs, const int64_t* lds, int64_t rows, int cols, float* out, int64_t ldo, void* stream);
+
 /* ---- T11: backward of the anchor attention (models/attn.py:78-82 under autograd): given dout = dL/dO of
  * O = softmax(Q K^T * scale) V it writes dq [C*N][lddq], dk and dv [C*M][lddk|lddv] (head-major columns like ogmm_attention; every
  * element of the three outputs is written).  The scores are re-formed per 32-query tile inside the kernel and never reach HBM;

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
     "ogmm_attention_workspace_bytes": [c_int, c_int, c_int, c_int],
     "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_void_p],
+    "ogmm_add_n": [c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_attention_bwd_supported": [c_int, c_int],
     "ogmm_attention_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
                            c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p],

@@ -4,6 +4,7 @@
 //   positional inputs |p - centroid|^2 and cos(angle)     models/attn.py:60-70 (inputs of pos.conv_dis.0 / pos.conv_ang1.0)
 //   d/dx of x / max(|x|, 1e-12)                           models/gmmreg.py:74 (F.normalize over channels)
 #include "ogmm_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -89,6 +90,54 @@ extern "C" int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g,
     OGMM_REQUIRE(x && g && dx && rows > 0 && D > 0, "ogmm_l2norm_rows_bwd: null pointer or empty input");
     hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, ldx, g, ldg, rows, D, dx, lddx);
     return check_launch("ogmm_l2norm_rows_bwd");
+}
+
+// ---------------------------------------------------------------- out = s_0 + s_1 + ... + s_{n-1}  (n <= 8 row-major maps, own row pitches)
+// The gradient of a feature map with several consumers (the residual, the Q projection, the MLP's first piece, the anchor gather, ...: up to
+// seven for the cross-attention output of models/gmmreg.py:64-97).  autograd adds them pairwise as they arrive: (n - 1) x (2 reads + 1 write);
+// here n reads + 1 write.  Summation order s_0 + s_1 + ... as autograd's.
+namespace {
+struct AddN { const float* s[8]; int64_t ld[8]; };
+template <bool VEC>
+__global__ __launch_bounds__(256) void add_n_kernel(AddN a, int n, int64_t rows, int cols, float* __restrict__ out, int64_t ldo) {
+    const int per_row = VEC ? cols / 4 : cols;
+    const int64_t total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row) * (VEC ? 4 : 1);
+        if (VEC) {
+            float4 acc = *reinterpret_cast<const float4*>(a.s[0] + r * a.ld[0] + c);
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                if (k < n) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.s[k] + r * a.ld[k] + c);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            *reinterpret_cast<float4*>(out + r * ldo + c) = acc;
+        } else {
+            float acc = a.s[0][r * a.ld[0] + c];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) if (k < n) acc += a.s[k][r * a.ld[k] + c];
+            out[r * ldo + c] = acc;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ogmm_add_n(int n, const float* const* srcs, const int64_t* lds, int64_t rows, int cols, float* out, int64_t ldo, void* stream) {
+    OGMM_REQUIRE(srcs && lds && out && n >= 1 && n <= 8 && rows > 0 && cols > 0, "ogmm_add_n: 1 <= n <= 8 maps, non-empty");
+    AddN a{};
+    bool vec = cols % 4 == 0 && ldo % 4 == 0 && aligned16(out);
+    for (int k = 0; k < n; ++k) {
+        OGMM_REQUIRE(srcs[k], "ogmm_add_n: null map %d", k);
+        a.s[k] = srcs[k]; a.ld[k] = lds[k];
+        vec = vec && lds[k] % 4 == 0 && aligned16(srcs[k]);
+    }
+    const int64_t total = rows * (vec ? cols / 4 : cols);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 16);
+    if (vec) hipLaunchKernelGGL(add_n_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), a, n, rows, cols, out, ldo);
+    else hipLaunchKernelGGL(add_n_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), a, n, rows, cols, out, ldo);
+    return check_launch("ogmm_add_n");
 }
 
 // ---------------------------------------------------------------- nearest squared distance, brute force (evaluation metrics)

@@ -387,6 +387,18 @@ def attention_supported(M, dh):
     return dh == 128 and M in (32, 64, 128)
 
 
+def add_n(maps):
+    """sum of up to 8 [R, C] maps (last stride 1, own row pitches) in one pass (kernel T12)"""
+    n = len(maps)
+    R, Cc = maps[0].shape
+    assert 1 <= n <= 8 and all(m.shape == (R, Cc) and m.stride(1) == 1 and m.dtype == torch.float32 for m in maps)
+    out = torch.empty((R, Cc), dtype=torch.float32, device=maps[0].device)
+    ptrs = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
+    lds = (ctypes.c_int64 * n)(*[m.stride(0) for m in maps])
+    _lib.call("ogmm_add_n", n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p), R, Cc, _p(out), out.stride(0), _stream())
+    return out
+
+
 def attention_bwd_supported(M, dh):
     return bool(_lib.load().ogmm_attention_bwd_supported(M, dh))
 

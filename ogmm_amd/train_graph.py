@@ -68,14 +68,15 @@ def pos_encoding(ops, P, xyz, idx5):
 
 
 def transformer(ops, P, name, x, anchors, C, N, M, H):
-    """models/attn.py:78-111 without the residual.  x [C*N, D], anchors [C*M, D].  The reference splits heads as channel
+    """models/attn.py:78-111 without the residual.  x [C*N, D] or a pair of handles of it (query projection, MLP input: ops.fanout), anchors [C*M, D].  The reference splits heads as channel
     c = d*H + h (models/attn.py:96); the projections are re-ordered head-major (c' = h*dh + d) by permuting weight rows,
     and the merge convolution's input columns the same way, so that a head is a contiguous slice."""
+    xq, x = x if isinstance(x, tuple) else (x, x)
     D = x.shape[1]
     dh = D // H
     cp = torch.arange(D, device=x.device)
     perm = (cp % dh) * H + (cp // dh)
-    q = ops.linear(x, _w(P, name + ".attn.proj.0")[perm], _b(P, name + ".attn.proj.0")[perm])
+    q = ops.linear(xq, _w(P, name + ".attn.proj.0")[perm], _b(P, name + ".attn.proj.0")[perm])
     kk = ops.linear(anchors, _w(P, name + ".attn.proj.1")[perm], _b(P, name + ".attn.proj.1")[perm])
     vv = ops.linear(anchors, _w(P, name + ".attn.proj.2")[perm], _b(P, name + ".attn.proj.2")[perm])
     o = ops.attention(q, kk, vv, C, N, M, H)
@@ -109,21 +110,26 @@ def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):
     ids_j = ops.fps(xyz, J, None)                                                 # [C,J]
     swap = torch.cat([torch.arange(B, C), torch.arange(0, B)]).to(xyz.device)
 
+    # a map with several consumers goes through ops.fanout: one handle per consumer, their gradients are added in one pass
     emb = dgcnn(ops, P, xyz, idx)
-    a0 = ops.gather_points(emb, C, N, ids_a[0])                                   # gmmreg.py:54-57
-    x0 = emb + pos_encoding(ops, P, xyz, idx5)                                    # gmmreg.py:58-61
-    ft = conv_stack(ops, P, "conv1", transformer(ops, P, "sattn1", x0, a0, C, N, M, H) + x0, True)
-    a1 = ops.gather_points(ft, C, N, ids_a[1], cloud_map=swap)                    # the OTHER cloud's anchors (gmmreg.py:67-72)
-    f = transformer(ops, P, "cattn", ft, a1, C, N, M, H) + ft
+    emb_a, emb_x = ops.fanout(emb, 2)
+    a0 = ops.gather_points(emb_a, C, N, ids_a[0])                                 # gmmreg.py:54-57
+    x0 = emb_x + pos_encoding(ops, P, xyz, idx5)                                  # gmmreg.py:58-61
+    x0_q, x0_m, x0_r = ops.fanout(x0, 3)
+    ft = conv_stack(ops, P, "conv1", transformer(ops, P, "sattn1", (x0_q, x0_m), a0, C, N, M, H) + x0_r, True)
+    ft_a, ft_q, ft_m, ft_r = ops.fanout(ft, 4)
+    a1 = ops.gather_points(ft_a, C, N, ids_a[1], cloud_map=swap)                  # the OTHER cloud's anchors (gmmreg.py:67-72)
+    f = transformer(ops, P, "cattn", (ft_q, ft_m), a1, C, N, M, H) + ft_r
+    f_n, f_p, f_c, f_a, f_q, f_m, f_r = ops.fanout(f, 7)
 
-    fn = ops.l2norm_rows(f)                                                       # gmmreg.py:74
-    ol = conv_stack(ops, P, "proj", f, False)                                     # [C*N, 1] overlap logits
+    fn = ops.l2norm_rows(f_n)                                                     # gmmreg.py:74
+    ol = conv_stack(ops, P, "proj", f_p, False)                                   # [C*N, 1] overlap logits
     wo = ops.overlap_cross(fn, ol, B, N)                                          # [C*N, 1]  (gmmreg.py:75-80)
-    fo = conv_stack(ops, P, "conv2", f, True, x2=torch.cat([wo, ol], dim=1))
+    fo = conv_stack(ops, P, "conv2", f_c, True, x2=torch.cat([wo, ol], dim=1))
     o = torch.sigmoid(conv_stack(ops, P, "overlap", fo, True)).view(C, N)         # gmmreg.py:85-89
 
-    a2 = ops.gather_points(f, C, N, ids_a[2])
-    f2 = transformer(ops, P, "sattn2", f, a2, C, N, M, H) + f                     # gmmreg.py:92-97
+    a2 = ops.gather_points(f_a, C, N, ids_a[2])
+    f2 = transformer(ops, P, "sattn2", (f_q, f_m), a2, C, N, M, H) + f_r          # gmmreg.py:92-97
 
     gamma, pi, mu = ops.gmm_em(xyz, o.detach(), ids_j)                            # no gradient (lib/utils.py:275-288)
     muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)                                  # [C,J,D], gradient to f2 only

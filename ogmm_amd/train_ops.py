@@ -293,6 +293,28 @@ class _NormLinear(torch.autograd.Function):
         return dy, None, dg, dbeta, None, dW, db, None, None
 
 
+class _Fanout(torch.autograd.Function):
+    """n handles of one feature map for its n consumers; the backward adds their gradients in ONE pass (ogmm_add_n) instead of autograd's
+    n - 1 pairwise accumulations (each 2 reads + 1 write of the map)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g_ for g_ in grads if g_ is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        gs = [g_ if g_.stride(1) == 1 else g_.contiguous() for g_ in gs]
+        out = ops.add_n(gs[:8])
+        for i in range(8, len(gs), 7):
+            out = ops.add_n([out] + gs[i:i + 7])
+        return out, None
+
+
 class _L2Norm(torch.autograd.Function):
     """F.normalize over channels (models/gmmreg.py:74): ogmm_l2norm_rows / ogmm_l2norm_rows_bwd"""
 
@@ -512,6 +534,10 @@ class TrainOps:
         if self._norm_linear_fusable(z, N, W):
             return _NormLinear.apply(z, stats, None, None, N, W, b, self.overflow, 0)[0]
         return self.linear(self.instnorm_relu(z, C, N, stats=stats), W, b)
+
+    def fanout(self, x, n):
+        """n handles of x, one per consumer (see _Fanout)"""
+        return _Fanout.apply(x, n) if x.requires_grad else (x,) * n
 
     def instnorm_relu(self, z, C, N, stats=None):
         """InstanceNorm1d (no affine, biased variance, eps 1e-5) over the N points of each cloud, then ReLU"""

@@ -180,6 +180,25 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
         assert _rel(a, r) < 2e-5, (i_, _rel(a, r))
 
 
+@pytest.mark.parametrize("rows,cols,n", [(3000, 512, 7), (1111, 6, 3), (64, 1024, 9), (500, 256, 2)])
+def test_fanout_adds_gradients_in_one_pass(rows, cols, n):
+    """_Fanout / ogmm_add_n: n consumers of one map, some through column views of wider buffers; same sum, same order as autograd's"""
+    from ogmm_amd import ops as O
+    g = torch.Generator().manual_seed(rows + n)
+    x = torch.randn(rows, cols, generator=g).to(DEV).requires_grad_(True)
+    wide = [torch.randn(rows, 2 * cols, generator=g).to(DEV) for _ in range(n)]
+    grads = [w_[:, cols:] if i_ % 2 else w_[:, :cols].contiguous() for i_, w_ in enumerate(wide)]
+    handles = TrainOps().fanout(x, n)
+    assert len(handles) == n
+    torch.autograd.backward(list(handles), grads)
+    ref = grads[0].clone()
+    for g_ in grads[1:]:
+        ref = ref + g_
+    assert torch.equal(x.grad, ref)
+    assert torch.equal(O.add_n(grads[:2]), grads[0] + grads[1])
+    assert TrainOps().fanout(x.detach(), 3)[2] is not None
+
+
 @pytest.mark.parametrize("B,J,reflect", [(5, 16, False), (3, 8, True), (4, 128, False)])
 def test_kabsch_forward_backward(B, J, reflect):
     g = torch.Generator().manual_seed(B * J)
