@@ -20,6 +20,14 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+def _rm(t):
+    """t as the kernels take it: a row-major 2-D map with unit column stride and 16-byte aligned rows -- a column slice of a wider buffer
+    (one half of a two-piece layer's input gradient) qualifies and is NOT copied"""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
 _ACT = {"relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY02, "none": ops.ACT_NONE}
 
 
@@ -48,7 +56,7 @@ class _NormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh, _dm, _dv):
         y, scale, shift, mean, rstd = ctx.saved_tensors
-        dy, sums = ops.norm_bwd(y, dh.contiguous(), ctx.group_rows, scale, shift, mean, rstd, ctx.act)
+        dy, sums = ops.norm_bwd(y, _rm(dh), ctx.group_rows, scale, shift, mean, rstd, ctx.act)
         if not ctx.affine:
             return dy, None, None, None, None, None
         return dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float(), None, None, None
@@ -87,7 +95,7 @@ class _NormActPool(torch.autograd.Function):
             dh = None
         if dh is None and dpooled is None:
             return (None,) * 8
-        dy, sums = ops.norm_bwd(y, None if dh is None else dh.contiguous(), ctx.group_rows, scale, shift, mean, rstd, ctx.act,
+        dy, sums = ops.norm_bwd(y, None if dh is None else _rm(dh), ctx.group_rows, scale, shift, mean, rstd, ctx.act,
                                 dpool=None if dpooled is None else dpooled.contiguous(), arg=arg, k=ctx.k)
         if not ctx.affine:
             return (dy,) + (None,) * 7
@@ -169,7 +177,7 @@ class _Linear(torch.autograd.Function):
             # issues them per wave -- 10 M fp64 atomics per map cost it 0.4-0.55 ms, more than the separate pass (0.2-0.55 ms))
             slots = 1 if stats_rows <= 131072 else 64
             stats = torch.zeros((slots, x.shape[0] // stats_rows, W.shape[0], 2)[0 if slots > 1 else 1:], dtype=torch.float64, device=x.device)
-        y = ops.conv1x1(x.contiguous(), layer, ops.ACT_NONE, x2=None if x2p is None else x2p.contiguous(),
+        y = ops.conv1x1(_rm(x), layer, ops.ACT_NONE, x2=None if x2p is None else _rm(x2p),
                         split=precision == "f16x3", overflow=overflow, col_stats=stats, group_rows=stats_rows if stats is not None else 0)
         ctx.save_for_backward(x, x2, W)
         ctx.has_bias, ctx.precision, ctx.overflow = b is not None, precision, overflow
@@ -199,7 +207,7 @@ class _Linear(torch.autograd.Function):
                 if Wt.shape[0] % 4:
                     Wt = torch.cat([Wt, Wt.new_zeros(4 - Wt.shape[0] % 4, Wt.shape[1])], dim=0)
                 layer = {"W": Wt, "split": ops.split_f16_training(Wt, ("bwd", W.data_ptr(), tuple(Wt.shape)), frag=True)}
-                dall = ops.conv1x1(dy.contiguous(), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
+                dall = ops.conv1x1(_rm(dy), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
             else:
                 dall = dy @ W
             dx = dall[:, :K1]
@@ -214,7 +222,7 @@ class _Linear(torch.autograd.Function):
             parts = [None] * len(pieces)
             want_db = ctx.has_bias and ctx.needs_input_grad[3] and not ctx.bias_grad_is_zero
             if any(wide):
-                got = ops.weight_grad(dy.contiguous(), [p_ for p_, w_ in zip(pieces, wide) if w_], ctx.overflow, colsum=want_db)
+                got = ops.weight_grad(_rm(dy), [_rm(p_) for p_, w_ in zip(pieces, wide) if w_], ctx.overflow, colsum=want_db)
                 if want_db:
                     got, db = got
                 off = 0
@@ -275,7 +283,7 @@ class _NormLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dm, _dv, _dst=None):
         y, scale, shift, mean, rstd, W = ctx.saved_tensors
-        dout = dout.contiguous()
+        dout = _rm(dout)
         Wt = W.detach().t().contiguous()
         layer = {"W": Wt, "split": ops.split_f16_training(Wt, ("bwd", W.data_ptr(), tuple(Wt.shape)), frag=True)}
         dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
@@ -308,7 +316,7 @@ class _Fanout(torch.autograd.Function):
             return None, None
         if len(gs) == 1:
             return gs[0], None
-        gs = [g_ if g_.stride(1) == 1 else g_.contiguous() for g_ in gs]
+        gs = [_rm(g_) for g_ in gs]
         out = ops.add_n(gs[:8])
         for i in range(8, len(gs), 7):
             out = ops.add_n([out] + gs[i:i + 7])
@@ -377,7 +385,7 @@ class _Attention(torch.autograd.Function):
         C, N, M, H = ctx.dims
         if FUSED_ATTENTION_BWD and ops.attention_bwd_supported(M, ctx.saved_tensors[0].shape[1] // H):
             q, k, v = ctx.saved_tensors
-            return ops.attention_bwd(q, k, v, g.contiguous(), C, N, M, H) + (None, None, None, None)
+            return ops.attention_bwd(q, k, v, _rm(g), C, N, M, H) + (None, None, None, None)
         q, k, v = (t_.detach().requires_grad_(True) for t_ in ctx.saved_tensors)
         with torch.enable_grad():
             o = _attention_torch(q, k, v, *ctx.dims)
