@@ -821,6 +821,8 @@ def overlap_cross_bwd(S, ol, wo, stats, g_wo):
 
 def weight_grad_thin_supported(dy, x):
     n, k = dy.shape[1], x.shape[1]
+    if n > 256 and k <= 64 and n % 256 == 0:
+        return weight_grad_thin_supported(dy[:, :256], x)
     nv, kv = (4 if n > 64 else (2 if n > 32 else 1)), (2 if k > 32 else 1)
     return (_lib.load().ogmm_weight_grad_thin_streams(n, k) > 0 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % nv == 0
             and x.stride(0) % kv == 0 and dy.data_ptr() % (4 * nv) == 0 and x.data_ptr() % (4 * kv) == 0)
@@ -830,6 +832,8 @@ def weight_grad_thin(dy, x):
     """dW = dY^T X for thin layers in exact fp32 (kernel T9): dy [R, n], x [R, k] -> [n, k]"""
     R, n = dy.shape
     k = x.shape[1]
+    if n > 256 and k <= 64 and n % 256 == 0:          # a wide layer's few-channel input piece (conv2.net.0's two overlap channels): 256 outputs at a time
+        return torch.cat([weight_grad_thin(dy[:, c0:c0 + 256], x) for c0 in range(0, n, 256)], dim=0)
     streams = _lib.load().ogmm_weight_grad_thin_streams(n, k)
     part = torch.empty((streams, n, k), dtype=torch.float32, device=dy.device)
     _lib.call("ogmm_weight_grad_thin", _p(_f32(dy, "dy")), dy.stride(0), _p(_f32(x, "x")), x.stride(0), R, n, k, _p(part), _stream())

@@ -67,7 +67,7 @@ def pos_encoding(ops, P, xyz, idx5):
     return torch.cat([dis, ang], dim=1)
 
 
-def transformer(ops, P, name, x, anchors, C, N, M, H):
+def transformer(ops, P, name, x, anchors, C, N, M, H, res=None):
     """models/attn.py:78-111 without the residual.  x [C*N, D] or a pair of handles of it (query projection, MLP input: ops.fanout), anchors [C*M, D].  The reference splits heads as channel
     c = d*H + h (models/attn.py:96); the projections are re-ordered head-major (c' = h*dh + d) by permuting weight rows,
     and the merge convolution's input columns the same way, so that a head is a contiguous slice."""
@@ -82,7 +82,7 @@ def transformer(ops, P, name, x, anchors, C, N, M, H):
     o = ops.attention(q, kk, vv, C, N, M, H)
     msg = ops.linear(o, _w(P, name + ".attn.merge")[:, perm], _b(P, name + ".attn.merge"))
     z, st = ops.linear_stats(x, _w(P, name + ".mlp.0"), _b(P, name + ".mlp.0"), x2=msg, groups=C)
-    return ops.instnorm_relu_linear(z, C, N, st, _w(P, name + ".mlp.3"), _b(P, name + ".mlp.3"))
+    return ops.instnorm_relu_linear(z, C, N, st, _w(P, name + ".mlp.3"), _b(P, name + ".mlp.3"), res=res)          # res: the caller's "+ x"
 
 
 def conv_stack(ops, P, name, x, three, x2=None):
@@ -116,10 +116,10 @@ def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):
     a0 = ops.gather_points(emb_a, C, N, ids_a[0])                                 # gmmreg.py:54-57
     x0 = emb_x + pos_encoding(ops, P, xyz, idx5)                                  # gmmreg.py:58-61
     x0_q, x0_m, x0_r = ops.fanout(x0, 3)
-    ft = conv_stack(ops, P, "conv1", transformer(ops, P, "sattn1", (x0_q, x0_m), a0, C, N, M, H) + x0_r, True)
+    ft = conv_stack(ops, P, "conv1", transformer(ops, P, "sattn1", (x0_q, x0_m), a0, C, N, M, H, res=x0_r), True)
     ft_a, ft_q, ft_m, ft_r = ops.fanout(ft, 4)
     a1 = ops.gather_points(ft_a, C, N, ids_a[1], cloud_map=swap)                  # the OTHER cloud's anchors (gmmreg.py:67-72)
-    f = transformer(ops, P, "cattn", (ft_q, ft_m), a1, C, N, M, H) + ft_r
+    f = transformer(ops, P, "cattn", (ft_q, ft_m), a1, C, N, M, H, res=ft_r)
     f_n, f_p, f_c, f_a, f_q, f_m, f_r = ops.fanout(f, 7)
 
     fn = ops.l2norm_rows(f_n)                                                     # gmmreg.py:74
@@ -129,7 +129,7 @@ def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):
     o = torch.sigmoid(conv_stack(ops, P, "overlap", fo, True)).view(C, N)         # gmmreg.py:85-89
 
     a2 = ops.gather_points(f_a, C, N, ids_a[2])
-    f2 = transformer(ops, P, "sattn2", (f_q, f_m), a2, C, N, M, H) + f_r          # gmmreg.py:92-97
+    f2 = transformer(ops, P, "sattn2", (f_q, f_m), a2, C, N, M, H, res=f_r)       # gmmreg.py:92-97
 
     gamma, pi, mu = ops.gmm_em(xyz, o.detach(), ids_j)                            # no gradient (lib/utils.py:275-288)
     muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)                                  # [C,J,D], gradient to f2 only

@@ -252,7 +252,7 @@ class _NormLinear(torch.autograd.Function):
     Conditions (TrainOps._norm_linear_fusable): fp16x3 engine, ReLU, group_rows a multiple of the engine's 256-row tile, a wide layer."""
 
     @staticmethod
-    def forward(ctx, y, st, nweight, nbias, group_rows, W, b, overflow, stats_rows):
+    def forward(ctx, y, st, nweight, nbias, group_rows, W, b, overflow, stats_rows, res=None):
         y = y.contiguous()
         mean64 = st[..., 0] / group_rows
         var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
@@ -268,8 +268,11 @@ class _NormLinear(torch.autograd.Function):
         stats = None
         if stats_rows and stats_rows == group_rows and W.shape[0] % 4 == 0 and stats_rows <= 131072:
             stats = torch.zeros((y.shape[0] // stats_rows, W.shape[0], 2), dtype=torch.float64, device=y.device)
-        out = ops.conv1x1(y, layer, ops.ACT_NONE, split=True, overflow=overflow, col_stats=stats, a_affine=(scale, shift, True), group_rows=group_rows)
+        # res: the block's residual (models/gmmreg.py:62, 73, 97: x + transformer(x)) rides in the GEMM's epilogue; its gradient is dout itself
+        out = ops.conv1x1(y, layer, ops.ACT_NONE, split=True, overflow=overflow, col_stats=stats, a_affine=(scale, shift, True), group_rows=group_rows,
+                          res=None if res is None else _rm(res))
         ctx.save_for_backward(y, scale, shift, mean, rstd, W)
+        ctx.has_res = res is not None
         ctx.group_rows, ctx.affine, ctx.has_bias, ctx.overflow = group_rows, nweight is not None, b is not None, overflow
         ctx.bias_grad_is_zero = bool(stats_rows)          # see _Linear
         ctx.mark_non_differentiable(mean64, var64)
@@ -298,7 +301,7 @@ class _NormLinear(torch.autograd.Function):
         dy, sums = ops.norm_bwd(y, dh, ctx.group_rows, scale, shift, mean, rstd, ops.ACT_RELU)
         dg = sums[..., 1].sum(dim=0).float() if ctx.affine else None
         dbeta = sums[..., 0].sum(dim=0).float() if ctx.affine else None
-        return dy, None, dg, dbeta, None, dW, db, None, None
+        return dy, None, dg, dbeta, None, dW, db, None, None, (dout if ctx.has_res else None)
 
 
 class _Fanout(torch.autograd.Function):
@@ -537,11 +540,12 @@ class TrainOps:
         h = self.batchnorm_act(y, weight, bias, running_mean, running_var, num_batches, groups, "relu", stats=stats)
         return self.linear_stats(h, W, b, groups=groups) if want_stats else self.linear(h, W, b)
 
-    def instnorm_relu_linear(self, z, C, N, stats, W, b):
-        """linear(instnorm_relu(z), W, b)"""
+    def instnorm_relu_linear(self, z, C, N, stats, W, b, res=None):
+        """linear(instnorm_relu(z), W, b) [+ res]"""
         if self._norm_linear_fusable(z, N, W):
-            return _NormLinear.apply(z, stats, None, None, N, W, b, self.overflow, 0)[0]
-        return self.linear(self.instnorm_relu(z, C, N, stats=stats), W, b)
+            return _NormLinear.apply(z, stats, None, None, N, W, b, self.overflow, 0, res)[0]
+        out = self.linear(self.instnorm_relu(z, C, N, stats=stats), W, b)
+        return out if res is None else out + res
 
     def fanout(self, x, n):
         """n handles of x, one per consumer (see _Fanout)"""

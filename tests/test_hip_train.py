@@ -149,7 +149,8 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
     W = (torch.randn(cout, k, generator=g) / k ** .5).to(DEV).requires_grad_(True)
     b = torch.randn(cout, generator=g).to(DEV).requires_grad_(True)
     dout = torch.randn(rows, cout, generator=g).to(DEV)
-    leaves = [t_ for t_ in (y, gamma, beta, W, b) if t_ is not None]
+    res_t = torch.randn(rows, cout, generator=g).to(DEV).requires_grad_(True) if kind == "in" else None      # the block's residual rides in the epilogue
+    leaves = [t_ for t_ in (y, gamma, beta, W, b, res_t) if t_ is not None]
     res = {}
     for tag, o in (("hip", TrainOps("f16x3")), ("ref", RefTrainOps())):
         for t_ in leaves:
@@ -167,14 +168,14 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
             if want_stats:
                 out, stats = out
         else:
-            out, stats = o.instnorm_relu_linear(dbl(y), groups, n, st, dbl(W), dbl(b)), None
+            out, stats = o.instnorm_relu_linear(dbl(y), groups, n, st, dbl(W), dbl(b), res=dbl(res_t)), None
         out.backward(dout.double() if tag == "ref" else dout)
         res[tag] = [out.detach()] + [t_.grad.clone() for t_ in leaves] + ([rm.clone(), rv.clone()] if kind == "bn" else [])
         if tag == "hip" and want_stats:
             ref_st = torch.stack([out.detach().double().view(groups, n, cout).sum(1), (out.detach().double() ** 2).view(groups, n, cout).sum(1)], dim=-1)
             assert _rel(stats, ref_st) < 1e-6
     for i_, (a, r) in enumerate(zip(res["hip"], res["ref"])):
-        if want_stats and i_ == len(leaves):
+        if want_stats and i_ == len(leaves):          # (kind "bn": b is the last leaf)
             assert float(a.abs().max()) == 0.0      # the layer's bias sits in front of the next normalisation: its gradient is exactly zero (see _Linear)
             continue
         assert _rel(a, r) < 2e-5, (i_, _rel(a, r))
