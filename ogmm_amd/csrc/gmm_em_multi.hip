@@ -32,6 +32,8 @@ struct EmWs {
     float4* mu;      // [C][J]  x, y, z, |mu|^2
     float* vbuf;     // [2][C][J]           v of the last two sweeps (fused sweeps)
     float* pbuf;     // [2][C][chunks][J][2] per-chunk (max, exp-sum) of the pending v-update
+    double* mpart;   // [C][chunks][J][4]   per-chunk M-step sums (resident kernel)
+    int* sync;       // [0] ticket counter, [1] error flag, [2 + c] arrivals at cloud c's barrier (resident kernel)
 };
 
 // one workgroup per cloud: p = o / max(sum o, 1e-4), log(p + 1e-8); centres = xyz[ids0]
@@ -228,6 +230,212 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restric
     }
 }
 
+// ---- resident form (J <= 64): the WHOLE E/M loop in one launch.  A cloud is worked on by its n_chunks workgroups of 256 rows, which stay
+// on the chip for all outer iterations and meet at a per-cloud barrier in global memory after every sweep (column partials) and every M-step
+// (partial sums): 110 barriers of 2-3 us instead of 120 launches whose drain + dispatch costs ~8 us each, and the 64 distances of a row
+// are computed once per outer iteration (registers) instead of once per sweep -- a third of a sweep's vector instructions.
+//   * Who works on what is decided by a ticket taken at workgroup start: ticket t -> cloud t / n_chunks, chunk t % n_chunks.  Tickets are
+//     handed out in order to workgroups that are running, so the lowest unfinished cloud always has all its chunks resident and makes
+//     progress whatever else shares the chip (the GEMM stream next to it, grids larger than the chip): no co-residency assumption.
+//   * Data that crosses workgroups (column partials, M-step partial sums) is written and read with agent-scope atomic accesses (sc1:
+//     coherent across the XCDs' L2s without fences); the barrier is: stores acknowledged (s_waitcnt vmcnt(0) inside __syncthreads) ->
+//     one relaxed atomic add per workgroup -> poll until all chunks have arrived.  A poll limit turns a lost workgroup into an error flag
+//     (ws.sync[1]) instead of a hang.
+// Arithmetic per entry is that of the launch sequence; the M-step sums the chunks' fp64 partials in chunk order.
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// stores of exchanged data are atomic EXCHANGES whose old value is returned: the return travels back from the point where agent-scope atomics are
+// performed, so "s_waitcnt vmcnt(0)" means the value is there (a plain sc1 store is acknowledged earlier: measured, 4-5 of 100 clouds read stale partials)
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    const float old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(old));
+}
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    const double old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(old));
+}
+
+__device__ __forceinline__ void cloud_barrier(int* arrivals, int target, int* err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int polls = 0;
+        while (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++polls > (1 << 26)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+
+template <int JMAX>
+__global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __restrict__ xyz, int C, int N, int J, int n_chunks, int iters, int sk_iters,
+                                                              float inv_tau, float inv_eps, float eps, float logq, EmWs w,
+                                                              float* __restrict__ gamma_out, float* __restrict__ pi_out, float* __restrict__ mu_out) {
+    __shared__ float vs[JMAX];
+    __shared__ float4 mus[JMAX];
+    __shared__ float tile[4][64][33];
+    __shared__ float wp[4][JMAX][2];
+    __shared__ float pxyz[4][64][3];
+    __shared__ int s_ticket;
+    double (*wd)[JMAX][4] = reinterpret_cast<double (*)[JMAX][4]>(&tile[0][0][0]);      // [4][JMAX][4], over the tiles once every wave is done with them (keeps the kernel at 40 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ticket = atomicAdd(w.sync, 1);
+    __syncthreads();
+    const int c = s_ticket / n_chunks, chunk = s_ticket % n_chunks;
+    if (c >= C) return;
+    int* arrivals = w.sync + 2 + c;
+    int epoch = 0;
+    const int n = chunk * 256 + tid;
+    const bool valid = n < N;
+    const float* __restrict__ pt = xyz + ((int64_t)c * N + (valid ? n : 0)) * 3;
+    const float px = pt[0], py = pt[1], pz = pt[2], pn = sqnorm3(px, py, pz);
+    const float logp = valid ? w.logp[(int64_t)c * N + n] : 0.0f;
+    pxyz[wave][lane][0] = px; pxyz[wave][lane][1] = py; pxyz[wave][lane][2] = pz;
+    for (int j = tid; j < J; j += 256) mus[j] = w.mu[(int64_t)c * J + j];          // em_init_kernel's centres (an earlier launch)
+    const int64_t psz = (int64_t)C * n_chunks * J * 2;
+    const int col = lane & 31, rh = lane >> 5;
+
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                                           // mus complete
+        float cst[JMAX];
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const float4 m = mus[j < J ? j : 0];
+            cst[j] = j < J ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
+        }
+        float un = 0.0f;
+        for (int j = tid; j < J; j += 256) vs[j] = 0.0f;
+        // sweep k = 1 .. sk_iters, then the gamma pass as sweep sk_iters + 1: each starts by finishing the pending v-update from the previous
+        // sweep's column partials (buffer parity (k - 1) & 1)
+        for (int k = 1; k <= sk_iters + 1; ++k) {
+            if (k > 1) {
+                const float* __restrict__ part = w.pbuf + ((k - 1) & 1) * psz;
+                for (int j = tid; j < J; j += 256) {
+                    const float* __restrict__ pj = part + ((int64_t)c * n_chunks * J + j) * 2;
+                    float M = -__builtin_inff();
+                    for (int ch = 0; ch < n_chunks; ++ch) M = fmaxf(M, ld_agent(pj + (int64_t)ch * J * 2));
+                    float S = 0.0f;
+                    for (int ch = 0; ch < n_chunks; ++ch) S = fmaf(ld_agent(pj + (int64_t)ch * J * 2 + 1), expf(ld_agent(pj + (int64_t)ch * J * 2) - M), S);
+                    vs[j] = eps * (logq - (M + logf(S))) + vs[j];
+                }
+            }
+            __syncthreads();
+            if (k == sk_iters + 1) break;
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                if (j < J) mx = fmaxf(mx, ((-cst[j] + un) + vs[j]) * inv_eps);
+            float se = 0.0f;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                if (j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
+            const float unew = valid ? eps * (logp - (mx + logf(se))) + un : 0.0f;
+            un = unew;
+#pragma unroll
+            for (int h = 0; h < JMAX / 32; ++h) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int j = 32 * h + i;
+                    tile[wave][lane][i] = (valid && j < J) ? ((-cst[j] + unew) + vs[j]) * inv_eps : -__builtin_inff();
+                }
+                float cm = -__builtin_inff();
+                float y[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) { y[r] = tile[wave][rh * 32 + r][col]; cm = fmaxf(cm, y[r]); }
+                float cs = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) cs += fexp(y[r] - cm);
+                if (!(cm > -__builtin_inff())) cs = 0.0f;
+                const float om = __shfl_xor(cm, 32, 64), os = __shfl_xor(cs, 32, 64);
+                const float M = fmaxf(cm, om);
+                const float S = (cm > -__builtin_inff() ? cs * fexp(cm - M) : 0.0f) + (om > -__builtin_inff() ? os * fexp(om - M) : 0.0f);
+                if (lane < 32) { wp[wave][32 * h + col][0] = M; wp[wave][32 * h + col][1] = S; }
+            }
+            __syncthreads();
+            if (tid < J) {
+                float M = fmaxf(fmaxf(wp[0][tid][0], wp[1][tid][0]), fmaxf(wp[2][tid][0], wp[3][tid][0]));
+                float S = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (wp[q][tid][0] > -__builtin_inff()) S = fmaf(wp[q][tid][1], fexp(wp[q][tid][0] - M), S);
+                float* __restrict__ po = w.pbuf + (k & 1) * psz + (((int64_t)c * n_chunks + chunk) * J + tid) * 2;
+                st_agent(po, M); st_agent(po + 1, S);
+            }
+            cloud_barrier(arrivals, (++epoch) * n_chunks, w.sync + 1);
+        }
+        // ---- gamma (exp(K), nan -> 0, inf -> FLT_MAX), row clip, and the chunk's M-step sums per column in fp64
+        double rs = 0.0;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+            if (j < J) {
+                float g = expf(((-cst[j] + un) + vs[j]) * inv_eps);
+                g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+                rs += (double)g;
+            }
+        const float rc = fmaxf((float)rs, 1e-3f);
+        const bool last = it + 1 == iters;
+        float* __restrict__ grow = gamma_out + ((int64_t)c * N + (valid ? n : 0)) * J;
+        double msum[JMAX / 32][4];
+#pragma unroll
+        for (int h = 0; h < JMAX / 32; ++h) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int j = 32 * h + i;
+                float g = 0.0f;
+                if (valid && j < J) {
+                    g = expf(((-cst[j] + un) + vs[j]) * inv_eps);
+                    g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+                    g = g / rc;
+                    if (last) grow[j] = g;
+                }
+                tile[wave][lane][i] = g;
+            }
+            double sg = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const float g = tile[wave][rh * 32 + r][col];
+                sg += g;
+                sx += (double)g * pxyz[wave][rh * 32 + r][0]; sy += (double)g * pxyz[wave][rh * 32 + r][1]; sz += (double)g * pxyz[wave][rh * 32 + r][2];
+            }
+            sg += __shfl_xor(sg, 32, 64); sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64); sz += __shfl_xor(sz, 32, 64);
+            msum[h][0] = sg; msum[h][1] = sx; msum[h][2] = sy; msum[h][3] = sz;
+        }
+        __syncthreads();                                                           // every wave is done with its tile: the sums go on top
+        if (lane < 32) {
+#pragma unroll
+            for (int h = 0; h < JMAX / 32; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wd[wave][32 * h + col][i] = msum[h][i];
+        }
+        __syncthreads();
+        if (tid < J) {
+            double* __restrict__ mo = w.mpart + (((int64_t)c * n_chunks + chunk) * J + tid) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_agent(mo + i, (wd[0][tid][i] + wd[1][tid][i]) + (wd[2][tid][i] + wd[3][tid][i]));
+        }
+        cloud_barrier(arrivals, (++epoch) * n_chunks, w.sync + 1);
+        if (tid < J) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                const double* __restrict__ mi = w.mpart + (((int64_t)c * n_chunks + ch) * J + tid) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] += ld_agent(mi + i);
+            }
+            const float pj = (float)t[0] / (float)N;
+            const float npi = pj * (float)N + 1e-5f;
+            const float nx = (float)t[1] / npi, ny = (float)t[2] / npi, nz = (float)t[3] / npi;
+            mus[tid] = make_float4(nx, ny, nz, sqnorm3(nx, ny, nz));
+            if (last && chunk == 0) {
+                pi_out[(int64_t)c * J + tid] = pj;
+                float* mo = mu_out + ((int64_t)c * J + tid) * 3;
+                mo[0] = nx; mo[1] = ny; mo[2] = nz;
+            }
+        }
+        // (the next M-step's partials are written only after 1 + sk_iters more barriers: nobody still reads this iteration's)
+    }
+}
+
 // gamma = exp(K) (nan -> 0, inf -> FLT_MAX) in place; rclip = max(rowsum, 1e-3); the last iteration also writes gamma / rclip.  grid (N/256, C)
 __global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out, int fused, int first,
                                                        int parity, float eps, float logq, const float* __restrict__ xyz, float inv_tau) {
@@ -305,7 +513,8 @@ size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 extern "C" int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J) {
     const size_t chunks = (size_t)(N + 255) / 256;
     return (int64_t)(align256((size_t)C * J * N * 4) + 3 * align256((size_t)C * N * 4) + align256((size_t)C * J * 4) + align256((size_t)C * J * 16) +
-                     align256((size_t)2 * C * J * 4) + align256((size_t)2 * C * chunks * J * 8));
+                     align256((size_t)2 * C * J * 4) + align256((size_t)2 * C * chunks * J * 8) + align256((size_t)C * chunks * J * 32) +
+                     align256((size_t)(C + 2) * 4));
 }
 
 extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
@@ -324,14 +533,30 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     w.rclip = reinterpret_cast<float*>(p); p += align256((size_t)C * N * 4);
     w.v = reinterpret_cast<float*>(p);     p += align256((size_t)C * J * 4);
     w.mu = reinterpret_cast<float4*>(p);   p += align256((size_t)C * J * 16);
+    const size_t n_chunks_ws = (size_t)(N + 255) / 256;
     w.vbuf = reinterpret_cast<float*>(p);  p += align256((size_t)2 * C * J * 4);
-    w.pbuf = reinterpret_cast<float*>(p);
+    w.pbuf = reinterpret_cast<float*>(p);  p += align256((size_t)2 * C * n_chunks_ws * J * 8);
+    w.mpart = reinterpret_cast<double*>(p); p += align256((size_t)C * n_chunks_ws * J * 32);
+    w.sync = reinterpret_cast<int*>(p);
     const float inv_eps = (float)(1.0 / (double)epsilon), inv_tau = (float)(1.0 / (double)tau);
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
     hipStream_t s = as_stream(stream);
     const dim3 rows((N + 255) / 256, C), cols(J, C), blk(256);
     const size_t vs = (size_t)J * sizeof(float);
     hipLaunchKernelGGL(em_init_kernel, dim3(C), blk, 0, s, xyz, o, ids0, N, J, w);
+    // Measured (N = 2048, J = 64; resident / launch sequence): 6 clouds 1.59 / 2.68 ms, 96 clouds 3.0 / 3.9 (3 workgroups per CU, all resident),
+    // 128 clouds 4.0 / 3.94 (4 per CU, 33 spills) or 5.2 (3 per CU: a third of the clouds wait for a second round).  A full chip is bound by the
+    // sweeps' vector instructions either way, so the resident form serves the grids that leave CUs idle: the small batches, where the chain of
+    // 120 launches is pure latency.  OGMM_EM_RESIDENT=0 / =1 force the launch sequence / the resident kernel.
+    const char* res_env = getenv("OGMM_EM_RESIDENT");                      // (read per call: the tests switch it)
+    const int resident = res_env ? (res_env[0] == '0' ? 0 : 2) : 1;
+    if (J <= 64 && (resident == 2 || (resident == 1 && (int64_t)C * (int64_t)n_chunks_ws <= 384))) {
+        (void)hipMemsetAsync(w.sync, 0, (size_t)(C + 2) * 4, s);
+        const dim3 grid((unsigned)(C * n_chunks_ws));
+        if (J <= 32) hipLaunchKernelGGL(em_resident_kernel<32>, grid, blk, 0, s, xyz, C, N, J, (int)n_chunks_ws, iters, sk_iters, inv_tau, inv_eps, epsilon, logq, w, gamma, pi, mu);
+        else hipLaunchKernelGGL(em_resident_kernel<64>, grid, blk, 0, s, xyz, C, N, J, (int)n_chunks_ws, iters, sk_iters, inv_tau, inv_eps, epsilon, logq, w, gamma, pi, mu);
+        return check_launch("ogmm_gmm_em_multi");
+    }
     for (int it = 0; it < iters; ++it) {
         const bool last = it + 1 == iters;
         static const bool two_launch = [] { const char* e = getenv("OGMM_EM_MULTI_UNFUSED"); return e && e[0] == '1'; }();      // A/B: u and v kernels

@@ -593,6 +593,24 @@ def test_overlap_block_fused_into_the_similarity_gemm(ops, B, N):
 
 
 # ------------------------------------------------------------------------------------------------ GMM head
+@pytest.mark.parametrize("C,N,J", [(3, 2048, 64), (2, 717, 64), (5, 300, 20), (40, 1500, 32)])
+def test_gmm_em_resident_kernel_equals_the_launch_sequence(ops, monkeypatch, C, N, J):
+    """The resident E/M kernel (one launch, per-cloud barriers in global memory, tickets) against the sequence of grid-wide launches: same
+    arithmetic per entry, so gamma, pi, mu agree to the last bit -- also when the grid exceeds what is resident at once (40 clouds x 6 chunks
+    with three workgroups per CU still fits; the forced mode below runs it regardless of the size gate)."""
+    torch.manual_seed(C * 100 + J)
+    xyz = dev(torch.randn(C, N, 3) * 0.5)
+    o = dev(torch.rand(C, N))
+    ids = ops.fps(xyz, J, None)
+    monkeypatch.setenv("OGMM_EM_RESIDENT", "0")
+    ref = ops.gmm_em(xyz, o, ids, engine="multi")
+    monkeypatch.setenv("OGMM_EM_RESIDENT", "1")
+    for _ in range(3):
+        got = ops.gmm_em(xyz, o, ids, engine="multi")
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+
+
 def test_gmm_em_reports_the_sinkhorn_residual(ops):
     """The reference leaves its Sinkhorn sweeps early when the batch mean of sum|du| + sum|dv| falls below 1e-2 (lib/utils.py:99-102); the kernel
     always runs all sweeps and can report that quantity per cloud and sweep, so that a parity run on real checkpoints can tell whether the
