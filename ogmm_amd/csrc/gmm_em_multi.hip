@@ -158,7 +158,8 @@ __device__ __forceinline__ void em_finish_v(int c, int J, int n_chunks, bool fir
 // The costs themselves are NOT read: thread = row recomputes its J distances from the point and the cloud's centres (LDS) with the
 // arithmetic of em_cost_kernel -- bit-identical values, 10 VALU instructions instead of a 4-byte load per entry.  The cost matrix of
 // 128 clouds (64 MB) came from the Infinity Cache at ~2 TB/s: 31-55 us per sweep, 100 sweeps per forward; recomputed: see DESIGN.
-template <int JMAX>
+// FULL: J == JMAX, every `j < J` test is compile-time true (a quarter of the kernel's instructions were those tests and their selects)
+template <int JMAX, bool FULL>
 __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restrict__ xyz, float inv_tau, int N, int J, float inv_eps, float eps,
                                                           float logq, int first, int parity, EmWs w) {
     __shared__ float vs[JMAX];
@@ -181,18 +182,18 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restric
     float cst[JMAX];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
-        const float4 m = mus[j < J ? j : 0];
-        cst[j] = j < J ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
+        const float4 m = mus[(FULL || j < J) ? j : 0];
+        cst[j] = (FULL || j < J) ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
     }
     const float un = (valid && !first) ? w.u[(int64_t)c * N + n] : 0.0f;          // u = v = 0 at the start of every outer iteration
     float mx = -__builtin_inff();
 #pragma unroll
     for (int j = 0; j < JMAX; ++j)
-        if (j < J) mx = fmaxf(mx, ((-cst[j] + un) + vs[j]) * inv_eps);
+        if (FULL || j < J) mx = fmaxf(mx, ((-cst[j] + un) + vs[j]) * inv_eps);
     float se = 0.0f;
 #pragma unroll
     for (int j = 0; j < JMAX; ++j)
-        if (j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
+        if (FULL || j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
     const float unew = valid ? eps * (w.logp[(int64_t)c * N + n] - (mx + logf(se))) + un : 0.0f;
     if (valid) w.u[(int64_t)c * N + n] = unew;
     // column partials of the pending v-update, 32 columns at a time through this wave's tile
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int j = 32 * h + i;
-            tile[wave][lane][i] = (valid && j < J) ? ((-cst[j] + unew) + vs[j]) * inv_eps : -__builtin_inff();
+            tile[wave][lane][i] = (valid && (FULL || j < J)) ? ((-cst[j] + unew) + vs[j]) * inv_eps : -__builtin_inff();
         }
         // (same wave: LDS operations complete in order)
         const int col = lane & 31, rh = lane >> 5;
@@ -268,7 +269,7 @@ __device__ __forceinline__ void cloud_barrier(int* arrivals, int target, int* er
     __syncthreads();
 }
 
-template <int JMAX>
+template <int JMAX, bool FULL>
 __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __restrict__ xyz, int C, int N, int J, int n_chunks, int iters, int sk_iters,
                                                               float inv_tau, float inv_eps, float eps, float logq, EmWs w,
                                                               float* __restrict__ gamma_out, float* __restrict__ pi_out, float* __restrict__ mu_out) {
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
         float cst[JMAX];
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) {
-            const float4 m = mus[j < J ? j : 0];
-            cst[j] = j < J ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
+            const float4 m = mus[(FULL || j < J) ? j : 0];
+            cst[j] = (FULL || j < J) ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
         }
         float un = 0.0f;
         for (int j = tid; j < J; j += 256) vs[j] = 0.0f;
@@ -325,11 +326,11 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
             float mx = -__builtin_inff();
 #pragma unroll
             for (int j = 0; j < JMAX; ++j)
-                if (j < J) mx = fmaxf(mx, ((-cst[j] + un) + vs[j]) * inv_eps);
+                if (FULL || j < J) mx = fmaxf(mx, ((-cst[j] + un) + vs[j]) * inv_eps);
             float se = 0.0f;
 #pragma unroll
             for (int j = 0; j < JMAX; ++j)
-                if (j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
+                if (FULL || j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
             const float unew = valid ? eps * (logp - (mx + logf(se))) + un : 0.0f;
             un = unew;
 #pragma unroll
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const int j = 32 * h + i;
-                    tile[wave][lane][i] = (valid && j < J) ? ((-cst[j] + unew) + vs[j]) * inv_eps : -__builtin_inff();
+                    tile[wave][lane][i] = (valid && (FULL || j < J)) ? ((-cst[j] + unew) + vs[j]) * inv_eps : -__builtin_inff();
                 }
                 float cm = -__builtin_inff();
                 float y[32];
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
         double rs = 0.0;
 #pragma unroll
         for (int j = 0; j < JMAX; ++j)
-            if (j < J) {
+            if (FULL || j < J) {
                 float g = expf(((-cst[j] + un) + vs[j]) * inv_eps);
                 g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
                 rs += (double)g;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
             for (int i = 0; i < 32; ++i) {
                 const int j = 32 * h + i;
                 float g = 0.0f;
-                if (valid && j < J) {
+                if (valid && (FULL || j < J)) {
                     g = expf(((-cst[j] + un) + vs[j]) * inv_eps);
                     g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
                     g = g / rc;
@@ -544,17 +545,22 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     const dim3 rows((N + 255) / 256, C), cols(J, C), blk(256);
     const size_t vs = (size_t)J * sizeof(float);
     hipLaunchKernelGGL(em_init_kernel, dim3(C), blk, 0, s, xyz, o, ids0, N, J, w);
-    // Measured (N = 2048, J = 64; resident / launch sequence): 6 clouds 1.59 / 2.68 ms, 96 clouds 3.0 / 3.9 (3 workgroups per CU, all resident),
-    // 128 clouds 4.0 / 3.94 (4 per CU, 33 spills) or 5.2 (3 per CU: a third of the clouds wait for a second round).  A full chip is bound by the
-    // sweeps' vector instructions either way, so the resident form serves the grids that leave CUs idle: the small batches, where the chain of
-    // 120 launches is pure latency.  OGMM_EM_RESIDENT=0 / =1 force the launch sequence / the resident kernel.
+    // Measured (N = 2048, J = 64; resident / launch sequence): 4 clouds 1.15 / 2.7 ms, 96 clouds 3.0 / 3.25 (3 workgroups per CU, all resident),
+    // 128 clouds 4.0 / 3.7 (4 per CU: spills) or 5.1 (3 per CU: a third of the clouds wait for a second round).  A full chip is bound by the
+    // sweeps' vector instructions either way, so the resident form serves the grids that fit one resident round -- most of all the small
+    // batches, where the chain of 120 launches is pure latency.  OGMM_EM_RESIDENT=0 / =1 force the launch sequence / the resident kernel.
     const char* res_env = getenv("OGMM_EM_RESIDENT");                      // (read per call: the tests switch it)
     const int resident = res_env ? (res_env[0] == '0' ? 0 : 2) : 1;
-    if (J <= 64 && (resident == 2 || (resident == 1 && (int64_t)C * (int64_t)n_chunks_ws <= 384))) {
+    int cus = 256, dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+    // one resident round: three workgroups per CU (FULL form, J == 64: 48 / 64 / 96 clouds 2.09 / 2.55 / 3.00 ms against 2.86 / 2.87 / 3.25)
+    if (J <= 64 && (resident == 2 || (resident == 1 && (int64_t)C * (int64_t)n_chunks_ws <= 3 * (int64_t)cus))) {
         (void)hipMemsetAsync(w.sync, 0, (size_t)(C + 2) * 4, s);
         const dim3 grid((unsigned)(C * n_chunks_ws));
-        if (J <= 32) hipLaunchKernelGGL(em_resident_kernel<32>, grid, blk, 0, s, xyz, C, N, J, (int)n_chunks_ws, iters, sk_iters, inv_tau, inv_eps, epsilon, logq, w, gamma, pi, mu);
-        else hipLaunchKernelGGL(em_resident_kernel<64>, grid, blk, 0, s, xyz, C, N, J, (int)n_chunks_ws, iters, sk_iters, inv_tau, inv_eps, epsilon, logq, w, gamma, pi, mu);
+        #define OGMM_EM_RES(JM, FL) hipLaunchKernelGGL((em_resident_kernel<JM, FL>), grid, blk, 0, s, xyz, C, N, J, (int)n_chunks_ws, iters, sk_iters, inv_tau, inv_eps, epsilon, logq, w, gamma, pi, mu)
+        if (J == 32) OGMM_EM_RES(32, true); else if (J < 32) OGMM_EM_RES(32, false); else if (J == 64) OGMM_EM_RES(64, true); else OGMM_EM_RES(64, false);
+#undef OGMM_EM_RES
         return check_launch("ogmm_gmm_em_multi");
     }
     for (int it = 0; it < iters; ++it) {
@@ -565,8 +571,11 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
         if (fused) {
             // launch k = 1 .. sk_iters; the gamma kernel plays launch sk_iters + 1 for the pending v-update
             for (int k = 1; k <= sk_iters; ++k) {
-                if (J <= 32) hipLaunchKernelGGL(em_sweep_kernel<32>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
-                else hipLaunchKernelGGL(em_sweep_kernel<64>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w);
+#define OGMM_EM_SWEEP(JM, FL) hipLaunchKernelGGL((em_sweep_kernel<JM, FL>), rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w)
+                // (the FULL form of this kernel keeps all 64 exponents of a row between its passes: 171 spills under the 128-register cap of four
+                // workgroups per CU, 6.9 against 3.7 ms -- the run-time tests stay here; the resident kernel, 168 registers, takes it: 1.15 against 1.6 ms)
+                if (J <= 32) OGMM_EM_SWEEP(32, false); else OGMM_EM_SWEEP(64, false);
+#undef OGMM_EM_SWEEP
             }
             hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs + 16 + (size_t)J * sizeof(float4), s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 1,
                                sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, epsilon, logq, xyz, inv_tau);
