@@ -239,24 +239,18 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restric
 //     handed out in order to workgroups that are running, so the lowest unfinished cloud always has all its chunks resident and makes
 //     progress whatever else shares the chip (the GEMM stream next to it, grids larger than the chip): no co-residency assumption.
 //   * Data that crosses workgroups (column partials, M-step partial sums) is written and read with agent-scope atomic accesses (sc1:
-//     coherent across the XCDs' L2s without fences); the barrier is: stores acknowledged (s_waitcnt vmcnt(0) inside __syncthreads) ->
-//     one relaxed atomic add per workgroup -> poll until all chunks have arrived.  A poll limit turns a lost workgroup into an error flag
+//     coherent across the XCDs' L2s without fences); the barrier is: stores acknowledged (an explicit s_waitcnt vmcnt(0): hipcc's
+//     __syncthreads() waits for the LDS counter only on this target -- without the wait 4-5 of 100 clouds read stale partials) ->
+//     workgroup barrier -> one relaxed atomic add per workgroup -> poll until all chunks have arrived.  A poll limit turns a lost workgroup into an error flag
 //     (ws.sync[1]) instead of a hang.
 // Arithmetic per entry is that of the launch sequence; the M-step sums the chunks' fp64 partials in chunk order.
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// stores of exchanged data are atomic EXCHANGES whose old value is returned: the return travels back from the point where agent-scope atomics are
-// performed, so "s_waitcnt vmcnt(0)" means the value is there (a plain sc1 store is acknowledged earlier: measured, 4-5 of 100 clouds read stale partials)
-__device__ __forceinline__ void st_agent(float* p, float v) {
-    const float old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" :: "v"(old));
-}
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double* p, double v) {
-    const double old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" :: "v"(old));
-}
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ void cloud_barrier(int* arrivals, int target, int* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's exchanged values have been written through
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

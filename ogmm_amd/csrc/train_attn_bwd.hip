@@ -34,11 +34,6 @@ constexpr int PP = 34;                   // floats per row of a wave's transposi
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// Workgroup barrier for LDS hand-over only.  __syncthreads() also waits for every outstanding global access (s_waitcnt vmcnt(0)): the dQ
-// stores issued at the end of a tile would be waited for at the top of the next one -- a store's round trip (1-2 us) per 9 us tile.
-// Nothing in this kernel reads back what it stores, so the LDS counter is all a barrier has to wait for.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // step s (0..63) of a contraction over 128 indices takes index sel(s, lh) from lane half lh: two consecutive steps use two adjacent
 // indices, so one 8-byte read feeds both
 __device__ __forceinline__ constexpr int sel(int s, int lh) { return 4 * (s >> 1) + 2 * lh + (s & 1); }
@@ -116,7 +111,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     load_tile(0);
     store_tile();
     for (int tile = 0; tile < n_tiles; ++tile) {
-        lds_barrier();                                                   // (A) tile visible; dSx / Xs of the previous tile are free
+        __syncthreads();                                                   // (A) tile visible; dSx / Xs of the previous tile are free
         if (tile + 1 < n_tiles) load_tile(tile + 1);
         // opaque per tile: keeps the tile-invariant LDS addressing from being hoisted into registers that are needed elsewhere
         int lr_t = lr, lh_t = lh;
@@ -167,7 +162,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
             Xs[(wave * 3 + 1) * 32 + lr_t] = sw;
             Xs[(wave * 3 + 2) * 32 + lr_t] = ew;
         }
-        lds_barrier();                                                   // (X) the four waves' triples
+        __syncthreads();                                                   // (X) the four waves' triples
         float mall = -__builtin_inff();
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) mall = fmaxf(mall, Xs[(w2 * 3 + 0) * 32 + lr_t]);
@@ -228,7 +223,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        lds_barrier();                                                   // (B) dS of all keys; every wave is done with Qs / dOs
+        __syncthreads();                                                   // (B) dS of all keys; every wave is done with Qs / dOs
 
         // ---- dQ block: 32 queries x the wave's 32 columns, over all 128 keys
         f32x16b qacc;
