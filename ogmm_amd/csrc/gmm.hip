@@ -405,6 +405,64 @@ __global__ __launch_bounds__(256) void gmm_feat_mean_kernel(const float* __restr
     }
 }
 
+// K16 for 16 < J <= 64 (BASELINE configs[2], [3]: J = 64, N = 2048): the same sums on v_mfma_f32_32x32x2_f32 -- exact fp32 products, and the
+// operand layout of that instruction IS a contraction over rows: lane l supplies A[j = l % 32][n = l / 32] = gamma[n][j] and
+// B[n = l / 32][d = l % 32] = feats[n][d], both read straight from their row-major maps with the 32 lanes of a half wave on consecutive
+// addresses.  Workgroup = (cloud, half of the channels): 4 waves x (2 cluster blocks x 2 channel blocks) accumulators, two rows per MFMA
+// step, eight steps' loads in flight.  The VALU form above spends 64 fma per loaded feature: 0.70 ms at 128 clouds of 2048 x 512 (see DESIGN).
+using f32x16m = __attribute__((ext_vector_type(16))) float;
+__global__ __launch_bounds__(256) void gmm_feat_mean_mfma_kernel(const float* __restrict__ gamma, const float* __restrict__ pi,
+                                                                 const float* __restrict__ feats, int64_t ld, int N, int J, int D,
+                                                                 float* __restrict__ mu_feat) {
+    const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const int d0 = (blockIdx.x * 4 + wave) * 64;                    // this wave's 64 channels
+    const float* __restrict__ F = feats + (int64_t)c * N * ld;
+    const float* __restrict__ G = gamma + (int64_t)c * N * J;
+    const bool j1 = lr + 32 < J, j0v = lr < J;                      // (J > 16: the first cluster block may still be partial for J < 32)
+    const bool da = d0 + lr < D, db = d0 + 32 + lr < D;
+    f32x16m acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    constexpr int U = 8;                                             // MFMA steps (2 rows each) per batch of loads
+    for (int n0 = 0; n0 < N; n0 += 2 * U) {
+        float ga[U][2], fb[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = n0 + 2 * u + lh;
+            const bool ok = n < N;
+            ga[u][0] = (ok && j0v) ? G[(int64_t)n * J + lr] : 0.0f;
+            ga[u][1] = (ok && j1) ? G[(int64_t)n * J + 32 + lr] : 0.0f;
+            fb[u][0] = (ok && da) ? F[(int64_t)n * ld + d0 + lr] : 0.0f;
+            fb[u][1] = (ok && db) ? F[(int64_t)n * ld + d0 + 32 + lr] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[u][a], fb[u][b], acc[a][b], 0, 0, 0);
+    }
+    // accumulator (a, b): lane = channel d0 + 32 b + lr, register v = cluster 32 a + 8 (v / 4) + 4 lh + v % 4
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int d = d0 + 32 * b + lr;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int j = 32 * a + 8 * (v >> 2) + 4 * lh + (v & 3);
+                if (j < J && d < D) {
+                    const float npi = pi[(int64_t)c * J + j] * (float)N + 1e-5f;
+                    mu_feat[((int64_t)c * J + j) * D + d] = acc[a][b][v] / npi;
+                }
+            }
+        }
+}
+
 // ================================================================================================
 // K18.  Weighted Kabsch (lib/se3.py:256-289) for one pair, executed by one lane in fp64.
 //   cov = sum_n w_n (s_n - cs)(c_n - cc)^T (+1e-5 I);  cov = U S V^T;  R = V diag(1,1,det) U^T
@@ -956,7 +1014,11 @@ __global__ __launch_bounds__(256) void gmm_feat_mean16_kernel(const float* __res
 extern "C" int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,
                                   float* mu_feat, void* stream) {
     OGMM_REQUIRE(gamma && pi && feats && mu_feat && C > 0 && N > 0 && J > 0 && D > 0 && ld >= D, "ogmm_gmm_feat_mean: null pointer or bad sizes");
-    if (J > 16)
+    static const bool valu64 = [] { const char* e = getenv("OGMM_FEAT_MEAN_VALU"); return e && e[0] == '1'; }();      // A/B: the VALU form
+    if (J > 16 && J <= 64 && !valu64)
+        hipLaunchKernelGGL(gmm_feat_mean_mfma_kernel, dim3((D + 255) / 256, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats, ld, N, J, D,
+                           mu_feat);
+    else if (J > 16)
         hipLaunchKernelGGL(gmm_feat_mean_kernel<64>, dim3((D + 63) / 64, (J + 63) / 64, C), dim3(256), 0, ogmm::as_stream(stream), gamma, pi, feats,
                            ld, N, J, D, mu_feat);
     else if (D % 2 == 0 && ld % 2 == 0 && reinterpret_cast<uintptr_t>(feats) % 8 == 0 && reinterpret_cast<uintptr_t>(mu_feat) % 8 == 0)

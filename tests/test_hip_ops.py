@@ -633,6 +633,22 @@ def test_gmm_em_reports_the_sinkhorn_residual(ops):
     assert torch.equal(plain[0], out[0]) and torch.equal(plain[2], out[2])
 
 
+@pytest.mark.parametrize("C,N,J,D", [(3, 2048, 64, 512), (2, 717, 40, 512), (2, 300, 17, 96), (1, 1025, 64, 260)])
+def test_feat_mean_matrix_core_form(ops, C, N, J, D):
+    """K16 for 16 < J <= 64 (v_mfma_f32_32x32x2_f32) against fp64: whole and ragged row counts, partial cluster and channel blocks, a row pitch wider
+    than D (the features are a column view)."""
+    torch.manual_seed(N + J)
+    g = torch.softmax(torch.randn(C, N, J), -1)
+    pi = g.mean(1)
+    wide = torch.randn(C * N, D + 32)
+    fd = dev(wide)[:, 16:16 + D]
+    got = ops.gmm_feat_mean(dev(g), dev(pi), fd, C, N).cpu().double()
+    f64 = wide[:, 16:16 + D].double().view(C, N, D)
+    ref = torch.einsum("cnj,cnd->cjd", g.double(), f64) / (pi.double() * N + 1e-5)[:, :, None]
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("engine", [None, "chip", "multi"])
 @pytest.mark.parametrize("C,N,J", [(4, 1024, 16), (2, 717, 128), (2, 2048, 64), (3, 200, 8)])
 def test_gmm_em_and_feat_mean(ops, C, N, J, engine):
