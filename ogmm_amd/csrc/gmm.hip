@@ -556,6 +556,39 @@ __device__ void kabsch_solve(int J, FS src, FC corr, FW wgt, float* __restrict__
     }
 }
 
+// The same solve by one whole wave: lane n takes clusters n, n + 64, ...; the 7 + 9 sums are wave reductions in fp64.  On one lane the two loops
+// over J are chains of dependent global-memory round trips (one wave per SIMD: nothing hides them): ~90 us at J = 64, the longest part of
+// match_kabsch_kernel.  (Summation order differs from the sequential loops at the 1e-16 level.)
+template <class FS, class FC, class FW>
+__device__ void kabsch_solve_wave(int J, FS src, FC corr, FW wgt, float* __restrict__ R_out, float* __restrict__ t_out) {
+    const int lane = threadIdx.x & 63;
+    double ws = 0.0, cs[3] = {0, 0, 0}, cc[3] = {0, 0, 0};
+    for (int n = lane; n < J; n += 64) {
+        const double w = wgt(n);
+        ws += w;
+        for (int a = 0; a < 3; ++a) { cs[a] += w * src(a, n); cc[a] += w * corr(a, n); }
+    }
+    ws = ogmm::wave_sum_d(ws);
+    for (int a = 0; a < 3; ++a) { cs[a] = ogmm::wave_sum_d(cs[a]) / ws; cc[a] = ogmm::wave_sum_d(cc[a]) / ws; }
+    double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int n = lane; n < J; n += 64) {
+        const double w = wgt(n);
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] += (src(a, n) - cs[a]) * w * (corr(b, n) - cc[b]);
+    }
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] = ogmm::wave_sum_d(cov[a][b]);
+    if (lane != 0) return;
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        if (cov[a][b] != cov[a][b]) cov[a][b] = 0.0;      // nan_to_num(nan=0)
+        if (a == b) cov[a][b] += 1e-5;
+    }
+    double R[3][3];
+    rotation_from_cov(cov, R);
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) R_out[a * 3 + b] = (float)R[a][b];
+        t_out[a] = (float)(-(R[a][0] * cs[0] + R[a][1] * cs[1] + R[a][2] * cs[2]) + cc[a]);
+    }
+}
+
 __global__ void kabsch_kernel(const float* __restrict__ src, const float* __restrict__ corr, const float* __restrict__ w, int B, int J,
                               float* __restrict__ R, float* __restrict__ t) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -754,12 +787,27 @@ __global__ __launch_bounds__(256) void match_kabsch_kernel(const float* __restri
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ Fs = f_s + (int64_t)b * J * D;
     const float* __restrict__ Ft = f_t + (int64_t)b * J * D;
-    for (int r = wave; r < 2 * J; r += 4) {
-        const float* __restrict__ p = r < J ? Fs + (int64_t)r * D : Ft + (int64_t)(r - J) * D;
-        double ss = 0.0;
-        for (int d = lane; d < D; d += 64) ss = fma((double)p[d], (double)p[d], ss);
-        ss = wave_sum_d(ss);
-        if (lane == 0) (r < J ? ns[r] : nt[r - J]) = fmaxf((float)sqrt(ss), 1e-12f);
+    for (int r0 = wave; r0 < 2 * J; r0 += 16) {             // four rows per pass of a wave: their loads travel together
+        double ss[4] = {0.0, 0.0, 0.0, 0.0};
+        const float* __restrict__ p[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = min(r0 + 4 * q, 2 * J - 1);
+            p[q] = r < J ? Fs + (int64_t)r * D : Ft + (int64_t)(r - J) * D;
+        }
+        for (int d = lane; d < D; d += 64) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = p[q][d];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ss[q] = fma((double)v[q], (double)v[q], ss[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 4 * q;
+            const double tot = wave_sum_d(ss[q]);
+            if (lane == 0 && r < 2 * J) (r < J ? ns[r] : nt[r - J]) = fmaxf((float)sqrt(tot), 1e-12f);
+        }
     }
     __syncthreads();
     {
@@ -771,6 +819,31 @@ __global__ __launch_bounds__(256) void match_kabsch_kernel(const float* __restri
         else cosine_block<8>(Fs, Ft, ns, nt, J, D, tid, sim, xs_);
     }
     __syncthreads();
+    if (J <= 64) {
+        // four neighbouring lanes per source cluster, each a quarter of the target clusters: every row at once, and the row reductions are two
+        // lane exchanges inside a quad instead of six across the wave (one wave per row, rows in turn, took 2 us per row)
+        const int n = tid >> 2, part = tid & 3;
+        const int m_lo = part * ((J + 3) / 4), m_hi = min(J, m_lo + (J + 3) / 4);
+        float mx = -__builtin_inff();
+        if (n < J) for (int m = m_lo; m < m_hi; ++m) mx = fmaxf(mx, sim[n * J + m] * inv_temp);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float se = 0.0f;
+        if (n < J) for (int m = m_lo; m < m_hi; ++m) se += expf(sim[n * J + m] * inv_temp - mx);
+        se += __shfl_xor(se, 1, 64); se += __shfl_xor(se, 2, 64);
+        float cx = 0.0f, cy = 0.0f, cz = 0.0f, ws = 0.0f;
+        if (n < J) for (int m = m_lo; m < m_hi; ++m) {
+            const float sc = expf(sim[n * J + m] * inv_temp - mx) / se;
+            if (scores) scores[((int64_t)b * J + n) * J + m] = sc;
+            const float* __restrict__ mt = mu_t + ((int64_t)b * J + m) * 3;
+            cx = fmaf(mt[0], sc, cx); cy = fmaf(mt[1], sc, cy); cz = fmaf(mt[2], sc, cz);
+            ws += sc;
+        }
+        cx += __shfl_xor(cx, 1, 64); cx += __shfl_xor(cx, 2, 64);
+        cy += __shfl_xor(cy, 1, 64); cy += __shfl_xor(cy, 2, 64);
+        cz += __shfl_xor(cz, 1, 64); cz += __shfl_xor(cz, 2, 64);
+        ws += __shfl_xor(ws, 1, 64); ws += __shfl_xor(ws, 2, 64);
+        if (part == 0 && n < J) { corr[n] = cx; corr[J + n] = cy; corr[2 * J + n] = cz; wsum[n] = ws; }
+    } else
     for (int n = wave; n < J; n += 4) {     // softmax over m, one wave per source cluster
         float mx = -__builtin_inff();
         for (int m = lane; m < J; m += 64) mx = fmaxf(mx, sim[n * J + m] * inv_temp);
@@ -790,10 +863,10 @@ __global__ __launch_bounds__(256) void match_kabsch_kernel(const float* __restri
         if (lane == 0) { corr[n] = cx; corr[J + n] = cy; corr[2 * J + n] = cz; wsum[n] = ws; }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {
         const float* __restrict__ ms = mu_s + (int64_t)b * J * 3;
-        kabsch_solve(J, [&](int a, int n) { return (double)ms[n * 3 + a]; }, [&](int a, int n) { return (double)corr[a * J + n]; },
-                     [&](int n) { return (double)wsum[n]; }, R + (int64_t)b * 9, t + (int64_t)b * 3);
+        kabsch_solve_wave(J, [&](int a, int n) { return (double)ms[n * 3 + a]; }, [&](int a, int n) { return (double)corr[a * J + n]; },
+                          [&](int n) { return (double)wsum[n]; }, R + (int64_t)b * 9, t + (int64_t)b * 3);
     }
 }
 
