@@ -431,6 +431,109 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
     }
 }
 
+// ---- gamma + M-step of the fused launch sequence in one pass (J <= 64): the gamma kernel below writes the unnormalised gamma of every entry to
+// the workspace (64 MB at 128 clouds of 2048 x 64) for a second kernel, one workgroup per (cluster, cloud), to read it back column-wise.
+// Here a row chunk forms gamma / rowclip, writes it out only in the last outer iteration, and leaves its fp64 column sums {gamma, gamma x, y, z}
+// per cluster (through the wave's LDS tile, as the sweeps do for their column partials); em_mu_kernel adds the chunks up in chunk order.
+// Same arithmetic and summation order as em_resident_kernel.
+template <int JMAX>
+__global__ __launch_bounds__(256, 3) void em_gamma_mstep_kernel(const float* __restrict__ xyz, float inv_tau, int N, int J, float inv_eps, float eps,
+                                                                 float logq, int first, int parity, EmWs w, float* __restrict__ gamma_out) {
+    __shared__ float vs[JMAX];
+    __shared__ float4 mus[JMAX];
+    __shared__ float tile[4][64][33];
+    __shared__ float pxyz[4][64][3];
+    double (*wd)[JMAX][4] = reinterpret_cast<double (*)[JMAX][4]>(&tile[0][0][0]);
+    const int c = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x, C = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = chunk * 256 + tid;
+    const int64_t vsz = (int64_t)C * J, psz = (int64_t)C * n_chunks * J * 2;
+    em_finish_v(c, J, n_chunks, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz, nullptr, vs);
+    for (int j = tid; j < J; j += 256) mus[j] = w.mu[(int64_t)c * J + j];
+    const bool valid = n < N;
+    const float* __restrict__ pt = xyz + ((int64_t)c * N + (valid ? n : 0)) * 3;
+    const float px = pt[0], py = pt[1], pz = pt[2], pn = sqnorm3(px, py, pz);
+    pxyz[wave][lane][0] = px; pxyz[wave][lane][1] = py; pxyz[wave][lane][2] = pz;
+    __syncthreads();
+    float cst[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const float4 m = mus[j < J ? j : 0];
+        cst[j] = j < J ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
+    }
+    const float un = (valid && !first) ? w.u[(int64_t)c * N + n] : 0.0f;
+    double rs = 0.0;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+        if (j < J) {
+            float g = expf(((-cst[j] + un) + vs[j]) * inv_eps);
+            g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+            rs += (double)g;
+        }
+    const float rc = fmaxf((float)rs, 1e-3f);
+    float* __restrict__ grow = gamma_out ? gamma_out + ((int64_t)c * N + (valid ? n : 0)) * J : nullptr;
+    const int col = lane & 31, rh = lane >> 5;
+    double msum[JMAX / 32][4];
+#pragma unroll
+    for (int h = 0; h < JMAX / 32; ++h) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int j = 32 * h + i;
+            float g = 0.0f;
+            if (valid && j < J) {
+                g = expf(((-cst[j] + un) + vs[j]) * inv_eps);
+                g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
+                g = g / rc;
+                if (grow) grow[j] = g;
+            }
+            tile[wave][lane][i] = g;
+        }
+        double sg = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+            const float g = tile[wave][rh * 32 + r][col];
+            sg += g;
+            sx += (double)g * pxyz[wave][rh * 32 + r][0]; sy += (double)g * pxyz[wave][rh * 32 + r][1]; sz += (double)g * pxyz[wave][rh * 32 + r][2];
+        }
+        sg += __shfl_xor(sg, 32, 64); sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64); sz += __shfl_xor(sz, 32, 64);
+        msum[h][0] = sg; msum[h][1] = sx; msum[h][2] = sy; msum[h][3] = sz;
+    }
+    __syncthreads();                                                           // every wave is done with its tile: the sums go on top
+    if (lane < 32) {
+#pragma unroll
+        for (int h = 0; h < JMAX / 32; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wd[wave][32 * h + col][i] = msum[h][i];
+    }
+    __syncthreads();
+    if (tid < J) {
+        double* __restrict__ mo = w.mpart + (((int64_t)c * n_chunks + chunk) * J + tid) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mo[i] = (wd[0][tid][i] + wd[1][tid][i]) + (wd[2][tid][i] + wd[3][tid][i]);
+    }
+}
+
+// pi_j, mu_j from the chunks' partial sums (chunk order).  grid (C), 64 threads
+__global__ __launch_bounds__(64) void em_mu_kernel(int N, int J, int n_chunks, EmWs w, float* __restrict__ pi_out, float* __restrict__ mu_out) {
+    const int c = blockIdx.x, j = threadIdx.x;
+    if (j >= J) return;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const double* __restrict__ mi = w.mpart + (((int64_t)c * n_chunks + ch) * J + j) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] += mi[i];
+    }
+    const float pj = (float)t[0] / (float)N;
+    const float npi = pj * (float)N + 1e-5f;
+    const float nx = (float)t[1] / npi, ny = (float)t[2] / npi, nz = (float)t[3] / npi;
+    w.mu[(int64_t)c * J + j] = make_float4(nx, ny, nz, sqnorm3(nx, ny, nz));
+    if (pi_out) {
+        pi_out[(int64_t)c * J + j] = pj;
+        float* mo = mu_out + ((int64_t)c * J + j) * 3;
+        mo[0] = nx; mo[1] = ny; mo[2] = nz;
+    }
+}
+
 // gamma = exp(K) (nan -> 0, inf -> FLT_MAX) in place; rclip = max(rowsum, 1e-3); the last iteration also writes gamma / rclip.  grid (N/256, C)
 __global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out, int fused, int first,
                                                        int parity, float eps, float logq, const float* __restrict__ xyz, float inv_tau) {
@@ -570,6 +673,13 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
                 // workgroups per CU, 6.9 against 3.7 ms -- the run-time tests stay here; the resident kernel, 168 registers, takes it: 1.15 against 1.6 ms)
                 if (J <= 32) OGMM_EM_SWEEP(32, false); else OGMM_EM_SWEEP(64, false);
 #undef OGMM_EM_SWEEP
+            }
+            static const bool split_mstep = [] { const char* e = getenv("OGMM_EM_SPLIT_MSTEP"); return e && e[0] == '1'; }();      // A/B: gamma to the workspace + em_mstep_kernel
+            if (!split_mstep) {
+                if (J <= 32) hipLaunchKernelGGL(em_gamma_mstep_kernel<32>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, w, last ? gamma : (float*)nullptr);
+                else hipLaunchKernelGGL(em_gamma_mstep_kernel<64>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, w, last ? gamma : (float*)nullptr);
+                hipLaunchKernelGGL(em_mu_kernel, dim3(C), dim3(64), 0, s, N, J, (int)n_chunks_ws, w, last ? pi : (float*)nullptr, mu);
+                continue;
             }
             hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs + 16 + (size_t)J * sizeof(float4), s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 1,
                                sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, epsilon, logq, xyz, inv_tau);
