@@ -274,7 +274,7 @@ class GMMReg(nn.Module):
             self._packed_fp = self._fingerprint(list(sd.values()))
         return self._packed
 
-    def _transformer(self, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None):
+    def _transformer(self, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None):
         """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D]; the anchors [C, M, D] are rows
         anchor_ids [C, M] of anchor_feats [C*N, D] (of the cloud cloud_map[c], if given): lib/utils.py:111-127."""
         D, H = self.emb_dims, self.config.num_heads
@@ -290,7 +290,8 @@ class GMMReg(nn.Module):
                 mlp0, msg = L["mlp0"], ops.conv1x1(o, L["merge"])
             if ops.DEFAULT_SPLIT and ops.instnorm_fusable(mlp0.get("split"), N):
                 # InstanceNorm fused: statistics in mlp0's epilogue, normalise + ReLU while mlp3 stages its A operand
-                stats = torch.zeros((C, 2 * D, 2), dtype=torch.float64, device=dev)
+                if stats is None:          # (the forward hands in a slice of a buffer zeroed on the side stream during the front end)
+                    stats = torch.zeros((C, 2 * D, 2), dtype=torch.float64, device=dev)
                 z = ops.conv1x1(x, mlp0, x2=msg, col_stats=stats, group_rows=N)
                 a_sc, a_sh = ops.instnorm_finalize(stats, N, BN_EPS)
                 return ops.conv1x1(z, L["mlp3"], res=res, a_affine=(a_sc, a_sh, True), group_rows=N)
@@ -372,9 +373,17 @@ class GMMReg(nn.Module):
         # into the forward): that kernel holds every CU's registers and LDS for ~0.8 ms, and a selection kernel that is still queued then
         # runs after it, next to -- and slowing -- the first GEMM.  In one queue the 5-NN chain (knn, tie resolution, positional front
         # end) and the FPS chains take ~0.4 ms; side by side they are through in time.
+        R = C * N
+        XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
+        stats3 = torch.empty((3, C, 2 * D, 2), dtype=torch.float64, device=dev)
+        extra = torch.empty((R, XW), dtype=torch.float32, device=dev)
         with torch.cuda.stream(side):
             idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
             hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
+            # zero-initialised buffers of the main chain, filled here instead of between its GEMMs (a 4 us fill costs the main stream ~10 us with its
+            # launch gap): the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0
+            stats3.zero_()
+            extra.zero_()
         with torch.cuda.stream(side2):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
             ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
@@ -385,6 +394,8 @@ class GMMReg(nn.Module):
         xyz.record_stream(side)
         for t_ in (ids_a, ids_j, idx5, hd, ha):
             t_.record_stream(main)
+        stats3.record_stream(side)
+        extra.record_stream(side)
         idx = ops.knn(xyz, k)
 
         # ---- DGCNN (models/dgcnn.py:133-154)
@@ -408,14 +419,12 @@ class GMMReg(nn.Module):
         ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:])
 
         # ---- self-attention 1 + conv1 (gmmreg.py:54-57, 62-63)
-        t1 = self._transformer(L["sattn1"], x0, emb, ids_a[0], C, N, res=x0)
+        t1 = self._transformer(L["sattn1"], x0, emb, ids_a[0], C, N, res=x0, stats=stats3[0])
         ft = self._stack3(L["conv1"], t1)
         # ---- cross-attention: keys/values are the OTHER cloud's anchors (gmmreg.py:67-72)
-        f = self._transformer(L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap)
+        f = self._transformer(L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap, stats=stats3[1])
 
         # ---- overlap scores (gmmreg.py:74-89)
-        XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
-        extra = torch.zeros((R, XW), dtype=torch.float32, device=dev)
         ops.conv1x1_head(f, L["proj"]["0"], ACT_RELU, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW)      # proj.0 + proj.3
         if self.fuse_overlap and D % 64 == 0 and ops.overlap_fusable(B, N, D):
             # the N x N similarity never leaves the GEMM's accumulators: its epilogue forms the partial softmax-dots (struct ogmm_gemm.ovl_rowpart)
@@ -454,7 +463,7 @@ class GMMReg(nn.Module):
         o.record_stream(side)
         for t_ in (gamma, pi, mu):
             t_.record_stream(main)
-        f2 = self._transformer(L["sattn2"], f, f, ids_a[2], C, N, res=f)
+        f2 = self._transformer(L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2])
         main.wait_event(em_done)
 
         # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)
