@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 14
+#define OGMM_ABI_VERSION 15
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -226,25 +226,38 @@ int ogmm_overlap_cross_ws(const float* S, int B, int N, const float* o_src, cons
 
 /* ---- K15: overlap-weighted Sinkhorn k-means, the whole E/M loop on chip.  lib/utils.py:269-288
  * (wkeans_plus) with :69-108 (sinkhorn, log domain), :130-140 (gmm_params).  Centres start at
- * xyz[ids0]; p = o / max(sum o, 1e-4); per outer iteration: cost = cdist(xyz, mu)/tau, `sk_iters`
- * Sinkhorn sweeps (the reference's batch-mean early exit, :99-102, never fires on this path and is
- * not implemented), gamma = exp(K), nan->0, rows / max(rowsum, 1e-3), pi = mean, mu = gamma^T xyz /
- * (N pi + 1e-5). */
+ * xyz[ids0]; p = o / max(sum o, 1e-4); per outer iteration: cost = cdist(xyz, mu)/tau, up to `sk_iters`
+ * Sinkhorn sweeps, gamma = exp(K), nan->0, rows / max(rowsum, 1e-3), pi = mean, mu = gamma^T xyz /
+ * (N pi + 1e-5).
+ * Early exit of the sweeps (lib/utils.py:99-102): `thresh` > 0 ends an E-step's sweeps after the first sweep
+ * whose residual sum|u - u0| + sum|v - v0|, averaged over the clouds of one reference call, is below it.  The
+ * clouds [g * group_size, (g + 1) * group_size) form call group g (the reference calls wkeans_plus once for the
+ * B src clouds and once for the B tgt clouds, models/gmmreg.py:100-101: group_size = B; 0 = all C clouds are one
+ * call).  thresh <= 0: every sweep runs.  The exit couples the clouds of a group and nothing else: sharding a
+ * batch over ranks changes the groups exactly as the reference's nn.DataParallel scatter does (train.py:190-191).
+ *   resid  [C][iters][sk_iters] or NULL: every sweep's residual per cloud (NaN: the sweep did not run / was discarded)
+ *   sweeps [C / group_size][iters] int32 or NULL: sweeps every E-step ran per call group (the reference's iteration count)
+ *   exit_ws: ogmm_gmm_em_exit_workspace_bytes(...) bytes, 256-byte aligned; may be NULL when thresh <= 0 and resid == NULL.
+ * ogmm_gmm_em_chip_max_group(N, J): the largest group_size the on-chip kernels accept with thresh > 0 (the clouds of a
+ * group wait for each other's residuals, so one resident round of workgroups must hold a whole group); 0 when the
+ * shape does not run on chip at all.  ogmm_gmm_em_chip_cached(N, J): 1 when the N x J cost matrix stays in LDS
+ * (the fast on-chip form); callers send everything else to ogmm_gmm_em_multi. */
+int64_t ogmm_gmm_em_exit_workspace_bytes(int C, int N, int iters, int sk_iters, int group_size);
+int ogmm_gmm_em_chip_max_group(int N, int J);
+int ogmm_gmm_em_chip_cached(int N, int J);
 int ogmm_gmm_em(const float* xyz, const float* o /*[C][N]*/, const int32_t* ids0 /*[C][J]*/, int C, int N, int J,
-                int iters, int sk_iters, float epsilon, float tau,
-                float* gamma /*[C][N][J]*/, float* pi /*[C][J]*/, float* mu /*[C][J][3]*/, void* stream);
-/* The same with a diagnostic: resid [C][iters][sk_iters] (may be NULL) receives every sweep's sum |u - u0| + sum |v - v0| per cloud, the
- * quantity whose batch mean the reference compares with 1e-2 for its early exit (lib/utils.py:99-102).  NaN where the problem does not run on
- * the LDS-resident kernel.  GMMReg.sinkhorn_exit_margin() turns it into "would the reference have left early". */
-int ogmm_gmm_em_resid(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters, float epsilon,
-                      float tau, float* gamma, float* pi, float* mu, float* resid, void* stream);
+                int iters, int sk_iters, float epsilon, float tau, double thresh, int group_size,
+                float* gamma /*[C][N][J]*/, float* pi /*[C][J]*/, float* mu /*[C][J][3]*/, float* resid, int32_t* sweeps,
+                void* exit_ws, void* stream);
 
 /* K15 for shapes whose N x J cost matrix exceeds one CU's LDS: the same loop as a fixed sequence of grid-wide kernels over a cost
- * matrix kept in `workspace` (ogmm_gmm_em_workspace_bytes, 256-byte aligned), all launched by this one call without host
- * synchronisation.  Same arguments and results as ogmm_gmm_em. */
+ * matrix kept in `workspace` (ogmm_gmm_em_workspace_bytes, 256-byte aligned) -- or, for grids that fit one resident round, one launch whose
+ * workgroups meet at per-cloud barriers -- all enqueued by this one call without host synchronisation.  Same arguments and results as
+ * ogmm_gmm_em, any group size. */
 int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J);
 int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
-                      float epsilon, float tau, float* gamma, float* pi, float* mu, void* workspace, void* stream);
+                      float epsilon, float tau, double thresh, int group_size, float* gamma, float* pi, float* mu, float* resid,
+                      int32_t* sweeps, void* exit_ws, void* workspace, void* stream);
 
 /* ---- K16: mu_feat = gamma^T feats / (N pi + 1e-5).  lib/utils.py:289 / :130-140. */
 int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,

@@ -6,6 +6,7 @@
 // (lib/se3.py:276).  Here the whole E/M loop of one cloud runs inside one workgroup with the state in
 // LDS/registers, and the rigid solve runs one pair per wavefront without leaving the GPU.
 #include "ogmm_common.h"
+#include "gmm_exit.h"
 #include <cstdlib>
 
 namespace {
@@ -42,10 +43,59 @@ __device__ __forceinline__ float cdist_mm(float x, float y, float z, float xn, f
     return sqrtf(fmaxf(acc, 0.0f));
 }
 
+
+// ---- Sinkhorn early exit (gmm_exit.h) in the on-chip kernels.
+// Which cloud this workgroup works on: with the exit on, clouds are handed out by ticket in order of workgroup start (the lowest unfinished call
+// group is then always completely on the chip: its clouds wait for each other's residuals); otherwise the block index.
+__device__ __forceinline__ int em_chip_cloud(const EmExit& x, float* red) {
+    if (!x.on) return blockIdx.x;
+    if (threadIdx.x == 0) red[0] = __int_as_float(atomicAdd(x.ticket, 1));
+    __syncthreads();
+    const int c = __float_as_int(red[0]);
+    __syncthreads();
+    return c;
+}
+
+// End of sweep `sk` (0-based) of E-step `it`, called by the whole workgroup behind the barrier that follows the v update: u / v hold this sweep's
+// result, uprev / vprev the previous sweep's, red[sk & 1] the cloud's sum |du| + sum |dv| of this sweep.  Publishes the residual, then asks for the
+// group's decision about sweep sk - 1 (one sweep of lag: normally nobody waits); true = that sweep ended the E-step and u / v are rolled back to it.
+__device__ __forceinline__ bool em_chip_sweep_end(const EmExit& x, float* red, int c, int it, int sk, int sk_iters, float* u, const float* uprev,
+                                                  float* v, const float* vprev, int N, int J) {
+    if (threadIdx.x == 0) {
+        const float r = red[sk & 1];
+        red[sk & 1] = 0.0f;
+        int stop = 0;
+        if (x.on) {
+            if (sk + 1 < sk_iters) em_exit_publish(x, c, it, sk, r);          // (nobody asks about the last sweep)
+            if (sk >= 1) stop = em_exit_wait(x, c, it, sk - 1) ? 1 : 0;
+        }
+        if (x.resid && !stop) x.resid[((int64_t)c * x.iters + it) * x.sk + sk] = r;          // (a discarded sweep stays NaN)
+        red[2] = __int_as_float(stop);
+    }
+    if (!x.on || sk == 0) return false;
+    __syncthreads();
+    const bool stop = __float_as_int(red[2]) != 0;
+    if (stop) {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) u[n] = uprev[n];
+        for (int j = threadIdx.x; j < J; j += blockDim.x) v[j] = vprev[j];
+    }
+    __syncthreads();
+    return stop;
+}
+
+// a poll ran into its limit somewhere (a lost workgroup): make the result loudly wrong instead of silently so
+__device__ __forceinline__ void em_chip_poison(const EmExit& x, int c, int J, float* pi_out, float* mu_out) {
+    if (!x.on || em_ld_agent(x.err) == 0) return;
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        pi_out[(int64_t)c * J + j] = __builtin_nanf("");
+        mu_out[((int64_t)c * J + j) * 3] = __builtin_nanf("");
+    }
+}
+
 __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ xyz, const float* __restrict__ o,
                                                       const int32_t* __restrict__ ids0, int N, int J, int iters, int sk_iters,
                                                       float inv_eps, float eps, float inv_tau, float* __restrict__ gamma,
-                                                      float* __restrict__ pi_out, float* __restrict__ mu_out) {
+                                                      float* __restrict__ pi_out, float* __restrict__ mu_out, EmExit x) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* pts = reinterpret_cast<float4*>(lds);        // [N]  x, y, z, |p|^2
     const int Npad = (N + 3) / 4 * 4;                     // keeps mu 16-byte aligned
@@ -55,7 +105,12 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
     float4* mu = reinterpret_cast<float4*>(rclip + Npad); // [J]  mx, my, mz, |mu|^2
     float* v = reinterpret_cast<float*>(mu + J);          // [J]
     float* red = v + J;                                   // [16]
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* uprev = red + 16;                              // [N]  u, v of the previous sweep (early exit: gmm_exit.h)
+    float* vprev = uprev + Npad;                          // [J]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = em_chip_cloud(x, red);
+    if (c >= x.C) return;
+    const bool track = x.on || x.resid != nullptr;
     constexpr int NW = EM_T / 64;
     const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
     const float* __restrict__ oc = o + (int64_t)c * N;
@@ -81,6 +136,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
     }
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
     __syncthreads();
+    if (track && tid < 2) red[tid] = 0.0f;          // red[0] / red[1] alternate as the sweep's residual accumulator
 
     for (int it = 0; it < iters; ++it) {
         for (int n = tid; n < N; n += EM_T) u[n] = 0.0f;
@@ -97,7 +153,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
                     const float cst = cdist_mm(p.x, p.y, p.z, p.w, m.x, m.y, m.z, m.w) * inv_tau;
                     lse_push(a, ((-cst + un) + v[j]) * inv_eps);
                 }
-                u[n] = eps * (logp[n] - (a.m + logf(a.s))) + un;
+                const float un1 = eps * (logp[n] - (a.m + logf(a.s))) + un;
+                u[n] = un1;
+                if (track) { uprev[n] = un; atomicAdd(&red[sk & 1], fabsf(un1 - un)); }
             }
             __syncthreads();
             // v^{l+1}: columns on waves
@@ -115,9 +173,14 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
                     LSE b = {__shfl_xor(a.m, off, 64), __shfl_xor(a.s, off, 64)};
                     a = lse_merge(a, b);
                 }
-                if (lane == 0) v[j] = eps * (logq - (a.m + logf(a.s))) + vj;
+                if (lane == 0) {
+                    const float vj1 = eps * (logq - (a.m + logf(a.s))) + vj;
+                    v[j] = vj1;
+                    if (track) { vprev[j] = vj; atomicAdd(&red[sk & 1], fabsf(vj1 - vj)); }
+                }
             }
             __syncthreads();
+            if (track && em_chip_sweep_end(x, red, c, it, sk, sk_iters, u, uprev, v, vprev, N, J)) break;
         }
         // gamma = exp(K); nan -> 0 (inf -> FLT_MAX); row scale 1 / max(rowsum, 1e-3)   (lib/utils.py:281-287)
         const bool last = it + 1 == iters;
@@ -175,6 +238,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
+    em_chip_poison(x, c, J, pi_out, mu_out);
 }
 
 // K15, cached variant (used when the N x J cost matrix fits in LDS, e.g. 64 KB at N=1024, J=16): the cost matrix of an
@@ -190,7 +254,7 @@ template <int JT, bool FAST>
 __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __restrict__ xyz, const float* __restrict__ o,
                                                              const int32_t* __restrict__ ids0, int N, int J, int iters, int sk_iters,
                                                              float inv_eps, float eps, float inv_tau, float* __restrict__ gamma,
-                                                             float* __restrict__ pi_out, float* __restrict__ mu_out, float* __restrict__ resid) {
+                                                             float* __restrict__ pi_out, float* __restrict__ mu_out, EmExit x) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4* pts = reinterpret_cast<float4*>(lds);
     const int Npad = (N + 3) / 4 * 4;
@@ -200,8 +264,13 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
     float4* mu = reinterpret_cast<float4*>(rclip + Npad);
     float* v = reinterpret_cast<float*>(mu + J);
     float* red = v + J;                                   // [16]
-    float* Cs = red + 16;                                 // [J][N] cost, later unnormalised gamma
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* uprev = red + 16;                              // [N]  u, v of the previous sweep (early exit: gmm_exit.h)
+    float* vprev = uprev + Npad;                          // [J]
+    float* Cs = vprev + (J + 3) / 4 * 4;                  // [J][N] cost, later unnormalised gamma
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = em_chip_cloud(x, red);
+    if (c >= x.C) return;
+    const bool track = x.on || x.resid != nullptr;
     constexpr int NW = EM_T / 64;
     const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
     const float* __restrict__ oc = o + (int64_t)c * N;
@@ -223,9 +292,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
     for (int j = tid; j < J; j += EM_T) mu[j] = pts[ids0[(int64_t)c * J + j]];
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
     __syncthreads();
-    // resid != NULL (diagnostics): sum |u - u0| + sum |v - v0| of every Sinkhorn sweep, the quantity whose batch mean the reference tests against
-    // 1e-2 for its early exit (lib/utils.py:99-102) -- which this kernel does not implement.  red[0] / red[1] alternate as the sweep's accumulator.
-    if (resid && tid < 2) red[tid] = 0.0f;
+    // track: sum |u - u0| + sum |v - v0| of every Sinkhorn sweep, the quantity whose batch mean the reference tests against `thresh` for its
+    // early exit (lib/utils.py:99-102; em_chip_sweep_end).  red[0] / red[1] alternate as the sweep's accumulator.
+    if (track && tid < 2) red[tid] = 0.0f;
 
     for (int it = 0; it < iters; ++it) {
         for (int n = tid; n < N; n += EM_T) {
@@ -253,7 +322,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                     for (int j = 0; j < JT; ++j) se += em_exp(t[j] - mx);
                     const float un1 = eps * (logp[n] - (mx + logf(se))) + un;
                     u[n] = un1;
-                    if (resid) atomicAdd(&red[sk & 1], fabsf(un1 - un));
+                    if (track) { uprev[n] = un; atomicAdd(&red[sk & 1], fabsf(un1 - un)); }
                 }
                 __syncthreads();
                 for (int j = wave; j < JT; j += NW) {                     // v^{l+1}: columns on waves, 16 rows per lane
@@ -276,11 +345,11 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                     if (lane == 0) {
                         const float vj1 = eps * (logq - (mx + logf(se))) + vj;
                         v[j] = vj1;
-                        if (resid) atomicAdd(&red[sk & 1], fabsf(vj1 - vj));
+                        if (track) { vprev[j] = vj; atomicAdd(&red[sk & 1], fabsf(vj1 - vj)); }
                     }
                 }
                 __syncthreads();
-                if (resid && tid == 0) { resid[((int64_t)c * iters + it) * sk_iters + sk] = red[sk & 1]; red[sk & 1] = 0.0f; }
+                if (track && em_chip_sweep_end(x, red, c, it, sk, sk_iters, u, uprev, v, vprev, N, J)) break;
                 continue;
             }
             for (int n = tid; n < N; n += EM_T) {                     // u^{l+1}: rows on threads
@@ -291,7 +360,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                 for (int j = 0; j < J; ++j) se += expf(((-Cs[j * N + n] + un) + v[j]) * inv_eps - mx);
                 const float un1 = eps * (logp[n] - (mx + logf(se))) + un;
                 u[n] = un1;
-                if (resid) atomicAdd(&red[sk & 1], fabsf(un1 - un));
+                if (track) { uprev[n] = un; atomicAdd(&red[sk & 1], fabsf(un1 - un)); }
             }
             __syncthreads();
             for (int j = wave; j < J; j += NW) {                      // v^{l+1}: columns on waves
@@ -306,11 +375,11 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                 if (lane == 0) {
                     const float vj1 = eps * (logq - (mx + logf(se))) + vj;
                     v[j] = vj1;
-                    if (resid) atomicAdd(&red[sk & 1], fabsf(vj1 - vj));
+                    if (track) { vprev[j] = vj; atomicAdd(&red[sk & 1], fabsf(vj1 - vj)); }
                 }
             }
             __syncthreads();
-            if (resid && tid == 0) { resid[((int64_t)c * iters + it) * sk_iters + sk] = red[sk & 1]; red[sk & 1] = 0.0f; }
+            if (track && em_chip_sweep_end(x, red, c, it, sk, sk_iters, u, uprev, v, vprev, N, J)) break;
         }
         const bool last = it + 1 == iters;
         for (int n = tid; n < N; n += EM_T) {                         // gamma = exp(K) (in place), row sums
@@ -354,6 +423,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
         }
         __syncthreads();
     }
+    em_chip_poison(x, c, J, pi_out, mu_out);
 }
 
 // ================================================================================================
@@ -966,53 +1036,69 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restri
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- entry points
-extern "C" int ogmm_gmm_em_resid(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
-                                 float epsilon, float tau, float* gamma, float* pi, float* mu, float* resid, void* stream);
-extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
-                           float epsilon, float tau, float* gamma, float* pi, float* mu, void* stream) {
-    return ogmm_gmm_em_resid(xyz, o, ids0, C, N, J, iters, sk_iters, epsilon, tau, gamma, pi, mu, nullptr, stream);
+namespace {
+size_t em_chip_lds(int N, int J, bool cached) {
+    const size_t Npad = (size_t)(N + 3) / 4 * 4, Jp = (size_t)(J + 3) / 4 * 4;   // Npad keeps the float4 mu array 16-byte aligned behind the per-point floats
+    return ((size_t)4 * N + 4 * Npad + 4 * (size_t)J + J + 16 + Jp + (cached ? (size_t)N * J : 0)) * sizeof(float);
+}
+}  // namespace
+
+extern "C" int64_t ogmm_gmm_em_exit_workspace_bytes(int C, int N, int iters, int sk_iters, int group_size) {
+    return (int64_t)ogmm::em_exit_bytes(C, N, iters, sk_iters, group_size);
 }
 
-// The same with a diagnostic output: resid [C][iters][sk_iters] (may be NULL) receives every Sinkhorn sweep's sum |u - u0| + sum |v - v0| per cloud
-// (lib/utils.py:99-101; the reference leaves its sweeps early when the batch mean falls below 1e-2, this library never does).  Filled with NaN
-// when the problem does not run on the LDS-resident kernel (cost matrix beyond 128 KiB).
-extern "C" int ogmm_gmm_em_resid(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
-                                 float epsilon, float tau, float* gamma, float* pi, float* mu, float* resid, void* stream) {
+// Largest call group the on-chip kernels take with the early exit on: the clouds of a group wait for each other, so one resident round of
+// workgroups must hold a whole group (one 1024-thread workgroup per CU at these LDS sizes).  0: the shape does not run on chip.
+extern "C" int ogmm_gmm_em_chip_cached(int N, int J) { return N > 0 && J > 0 && em_chip_lds(N, J, true) <= 128 * 1024 ? 1 : 0; }
+
+extern "C" int ogmm_gmm_em_chip_max_group(int N, int J) {
+    if (N <= 0 || J <= 0 || em_chip_lds(N, J, false) > 160 * 1024) return 0;
+    int cus = 256, dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+    return cus;
+}
+
+// resid [C][iters][sk_iters] (may be NULL) receives every Sinkhorn sweep's sum |u - u0| + sum |v - v0| per cloud (lib/utils.py:99-101), NaN for
+// sweeps that did not run; sweeps [C / group_size][iters] (may be NULL) the number of sweeps each E-step ran for each call group.
+extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
+                           float epsilon, float tau, double thresh, int group_size, float* gamma, float* pi, float* mu, float* resid,
+                           int32_t* sweeps, void* exit_ws, void* stream) {
     OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu, "ogmm_gmm_em: null pointer");
     OGMM_REQUIRE(C > 0 && N > 0 && J > 0 && J <= N && iters > 0 && sk_iters >= 0 && epsilon > 0 && tau > 0, "ogmm_gmm_em: bad sizes C=%d N=%d J=%d", C, N, J);
-    const int Npad = (N + 3) / 4 * 4;   // keeps the float4 mu array 16-byte aligned behind 7 per-point floats
-    const size_t lds = ((size_t)4 * N + 3 * (size_t)Npad + 4 * (size_t)J + J + 16) * sizeof(float);
+    const size_t lds = em_chip_lds(N, J, false);
     OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_gmm_em: N=%d, J=%d needs %zu B of LDS (> 160 KiB)", N, J, lds);
+    ogmm::EmExit x;
+    if (int rc = ogmm::em_exit_setup(x, thresh, group_size, C, N, iters, sk_iters, resid, sweeps, exit_ws, ogmm::as_stream(stream))) return rc;
+    if (x.on) {
+        const int cap = ogmm_gmm_em_chip_max_group(N, J);
+        OGMM_REQUIRE(x.G <= cap, "ogmm_gmm_em: a call group of %d clouds does not fit one resident round (%d) with the early exit on: use ogmm_gmm_em_multi", x.G, cap);
+    }
     static ogmm::PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const float inv_eps = (float)(1.0 / (double)epsilon);   // torch divides by a python scalar as multiply-by-reciprocal
     const float inv_tau = (float)(1.0 / (double)tau);
-    const size_t lds_cached = lds + (size_t)N * J * sizeof(float);
+    const size_t lds_cached = em_chip_lds(N, J, true);
     if (lds_cached <= 128 * 1024) {       // cost matrix resident in LDS
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_cached_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr2 = true;
-        }
         static const int em_mode = [] { const char* e = getenv("OGMM_EM_MODE"); return e ? atoi(e) : 2; }();      // 0 generic, 1 registers (bit-identical to 0), 2 + v_exp_f32 (default)
         if (J == 16 && N <= EM_T && em_mode == 2)
             hipLaunchKernelGGL((gmm_em_cached_kernel<16, true>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
-                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, resid);
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, x);
         else if (J == 16 && N <= EM_T && em_mode == 1)
             hipLaunchKernelGGL((gmm_em_cached_kernel<16, false>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
-                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, resid);
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, x);
         else
             hipLaunchKernelGGL((gmm_em_cached_kernel<0, false>), dim3(C), dim3(EM_T), lds_cached, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters,
-                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, resid);
+                               sk_iters, inv_eps, epsilon, inv_tau, gamma, pi, mu, x);
         return ogmm::check_launch("ogmm_gmm_em(cached)");
     }
-    if (resid) (void)hipMemsetAsync(resid, 0xFF, (size_t)C * iters * sk_iters * sizeof(float), ogmm::as_stream(stream));          // NaN: not measured on this path
     hipLaunchKernelGGL(gmm_em_kernel, dim3(C), dim3(EM_T), lds, ogmm::as_stream(stream), xyz, o, ids0, N, J, iters, sk_iters, inv_eps,
-                       epsilon, inv_tau, gamma, pi, mu);
+                       epsilon, inv_tau, gamma, pi, mu, x);
     return ogmm::check_launch("ogmm_gmm_em");
 }
 

@@ -8,6 +8,7 @@
 // All launches are issued by ONE call (no host synchronisation; the reference needs ~3000 launches and 200 .item() syncs).
 // The arithmetic of every entry is that of gmm_em_cached_kernel; column reductions differ in summation order only.
 #include "ogmm_common.h"
+#include "gmm_exit.h"
 #include <cstdlib>
 
 namespace {
@@ -71,45 +72,63 @@ __global__ __launch_bounds__(256) void em_cost_kernel(const float* __restrict__ 
     }
 }
 
+// Early exit (gmm_exit.h) in the two-launch sweeps: NOT lagged -- the v kernel of sweep m completes the sweep, its last column workgroup per cloud
+// sums the cloud's residual (the u kernel's per-chunk sums + the columns' |dv|, in index order), publishes it, and the last cloud of the call group
+// takes the decision; every later launch of the E-step starts by reading the group's stop flag.
+
 // u^{l+1}: one thread per row, the row's J exponents held in registers between the max and the exp-sum pass.  grid (N/256, C)
 template <int JMAX>
-__global__ __launch_bounds__(256) void em_u_kernel(int N, int J, float inv_eps, float eps, EmWs w) {
-    extern __shared__ float vs[];                      // [J]
+__global__ __launch_bounds__(256) void em_u_kernel(int N, int J, float inv_eps, float eps, EmWs w, int it, EmExit x) {
+    extern __shared__ float vs[];                      // [J], then 4 floats for the residual
     const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (x.on && x.kstop[(c / x.G) * x.iters + it]) return;
     for (int j = threadIdx.x; j < J; j += 256) vs[j] = w.v[(int64_t)c * J + j];
     __syncthreads();
-    if (n >= N) return;
-    const float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
-    const float un = w.u[(int64_t)c * N + n];
-    float x[JMAX];
-    float mx = -__builtin_inff();
+    const bool valid = n < N;
+    float du = 0.0f;
+    if (valid) {
+        const float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
+        const float un = w.u[(int64_t)c * N + n];
+        float t[JMAX];
+        float mx = -__builtin_inff();
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-        x[j] = j < J ? ((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps : -__builtin_inff();
-        mx = fmaxf(mx, x[j]);
+        for (int j = 0; j < JMAX; ++j) {
+            t[j] = j < J ? ((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps : -__builtin_inff();
+            mx = fmaxf(mx, t[j]);
+        }
+        double se = 0.0;          // sums of exponentials in fp64: the E/M is ill-conditioned for J close to N (5e-6 on mu at N=717, J=128)
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) se += j < J ? (double)expf(t[j] - mx) : 0.0;
+        const float un1 = eps * (w.logp[(int64_t)c * N + n] - (mx + logf((float)se))) + un;
+        w.u[(int64_t)c * N + n] = un1;
+        du = fabsf(un1 - un);
     }
-    double se = 0.0;          // sums of exponentials in fp64: the E/M is ill-conditioned for J close to N (5e-6 on mu at N=717, J=128)
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) se += j < J ? (double)expf(x[j] - mx) : 0.0;
-    w.u[(int64_t)c * N + n] = eps * (w.logp[(int64_t)c * N + n] - (mx + logf((float)se))) + un;
+    if (x.on || x.resid) {                              // this chunk's sum |du|
+        float* sred = vs + J;
+        du = wave_sum(du);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = du;
+        __syncthreads();
+        if (threadIdx.x == 0) x.dupart[(int64_t)c * gridDim.x + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    }
 }
 
-// v^{l+1}: one workgroup per (cluster j, cloud).  grid (J, C)
-__global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, float eps, float logq, EmWs w) {
+// v^{l+1}: one workgroup per (cluster j, cloud).  grid (J, C).  m = the sweep (1-based).
+__global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, float eps, float logq, EmWs w, int it, int m, int n_chunks, EmExit x) {
     __shared__ float red[4];
     __shared__ double redd[4];
     const int j = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (x.on && x.kstop[(c / x.G) * x.iters + it]) return;
     const float* __restrict__ Cj = w.cost + ((int64_t)c * J + j) * N;
     const float* __restrict__ u = w.u + (int64_t)c * N;
     const float vj = w.v[(int64_t)c * J + j];
     constexpr int VR = 16;                     // exponents of up to 16 rows per thread stay in registers (N <= 4096), the rest is recomputed
-    float x[VR];
+    float t[VR];
     float mx = -__builtin_inff();
 #pragma unroll
     for (int i = 0; i < VR; ++i) {
         const int n = tid + i * 256;
-        x[i] = n < N ? ((-Cj[n] + u[n]) + vj) * inv_eps : -__builtin_inff();
-        mx = fmaxf(mx, x[i]);
+        t[i] = n < N ? ((-Cj[n] + u[n]) + vj) * inv_eps : -__builtin_inff();
+        mx = fmaxf(mx, t[i]);
     }
     for (int n = tid + VR * 256; n < N; n += 256) mx = fmaxf(mx, ((-Cj[n] + u[n]) + vj) * inv_eps);
     mx = wave_max(mx);
@@ -119,12 +138,28 @@ __global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, 
     __syncthreads();
     double se = 0.0;
 #pragma unroll
-    for (int i = 0; i < VR; ++i) se += tid + i * 256 < N ? (double)expf(x[i] - mx) : 0.0;
+    for (int i = 0; i < VR; ++i) se += tid + i * 256 < N ? (double)expf(t[i] - mx) : 0.0;
     for (int n = tid + VR * 256; n < N; n += 256) se += (double)expf(((-Cj[n] + u[n]) + vj) * inv_eps - mx);
     se = wave_sum_d(se);
     if (lane == 0) redd[wave] = se;
     __syncthreads();
-    if (tid == 0) w.v[(int64_t)c * J + j] = eps * (logq - (mx + logf((float)((redd[0] + redd[1]) + (redd[2] + redd[3]))))) + vj;
+    if (tid == 0) {
+        const float vj1 = eps * (logq - (mx + logf((float)((redd[0] + redd[1]) + (redd[2] + redd[3]))))) + vj;
+        w.v[(int64_t)c * J + j] = vj1;
+        if (x.on || x.resid) {
+            em_st_agent(w.vbuf + (int64_t)c * J + j, fabsf(vj1 - vj));          // (vbuf is free in the two-launch form)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int prev = __hip_atomic_fetch_add(x.ccount + ((int64_t)it * x.sk + (m - 1)) * x.C + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == J - 1) {                       // the cloud's last column: its residual of this sweep
+                float du = 0.0f, dv = 0.0f;
+                for (int ch = 0; ch < n_chunks; ++ch) du += x.dupart[(int64_t)c * n_chunks + ch];
+                for (int jj = 0; jj < J; ++jj) dv += em_ld_agent(w.vbuf + (int64_t)c * J + jj);
+                const float r = du + dv;
+                if (x.resid) x.resid[((int64_t)c * x.iters + it) * x.sk + (m - 1)] = r;
+                if (x.on && m < x.sk) em_exit_publish(x, c, it, m - 1, r);
+            }
+        }
+    }
 }
 
 // ---- fused sweeps (J <= 64): ONE launch and ONE read of the cost matrix per Sinkhorn sweep instead of two.
@@ -138,8 +173,10 @@ __global__ __launch_bounds__(256) void em_v_kernel(int N, int J, float inv_eps, 
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // v of the sweep whose partials are in `part` (or 0 for `first`), into LDS vs[J]; optionally stored to v_out
-__device__ __forceinline__ void em_finish_v(int c, int J, int n_chunks, bool first, float eps, float logq, const float* __restrict__ v_in,
-                                            const float* __restrict__ part, float* __restrict__ v_out, float* vs) {
+// returns this thread's share of sum_j |v - v_in| (the early exit's residual)
+__device__ __forceinline__ float em_finish_v(int c, int J, int n_chunks, bool first, float eps, float logq, const float* __restrict__ v_in,
+                                             const float* __restrict__ part, float* __restrict__ v_out, float* vs) {
+    float dv = 0.0f;
     for (int j = threadIdx.x; j < J; j += blockDim.x) {
         float vcur = 0.0f;
         if (!first) {
@@ -148,11 +185,30 @@ __device__ __forceinline__ void em_finish_v(int c, int J, int n_chunks, bool fir
             for (int ch = 0; ch < n_chunks; ++ch) M = fmaxf(M, pj[(int64_t)ch * J * 2]);
             float S = 0.0f;
             for (int ch = 0; ch < n_chunks; ++ch) S = fmaf(pj[(int64_t)ch * J * 2 + 1], expf(pj[(int64_t)ch * J * 2] - M), S);
-            vcur = eps * (logq - (M + logf(S))) + v_in[(int64_t)c * J + j];
+            const float vold = v_in[(int64_t)c * J + j];
+            vcur = eps * (logq - (M + logf(S))) + vold;
+            dv += fabsf(vcur - vold);
         }
         vs[j] = vcur;
         if (v_out) v_out[(int64_t)c * J + j] = vcur;
     }
+    return dv;
+}
+
+// Early exit (gmm_exit.h) in the fused sweeps: launch m finishes v_{m-1}, so the residual of sweep m - 1 is complete only there (chunk 0 of every
+// cloud: the chunks' sum |du| of launch m - 1 + sum |dv|); its last publisher per call group takes the decision, and launch m + 1 -- the first to
+// see it -- and all later launches of the E-step return at once.  Sweep m itself has then been applied already: u is double-buffered by the
+// sweep's parity (w.u / x.u2) and v lives in vbuf by parity anyway, so the gamma pass simply picks up (u, v) of the sweep that ended the E-step.
+__device__ __forceinline__ void em_fused_residual(const EmExit& x, int c, int it, int m, int n_chunks, float dv_part, bool publish) {
+    // wave 0 of the chunk-0 workgroup of cloud c, at the start of launch m >= 2: residual of sweep m - 1 (J <= 64: all of dv_part sits in wave 0)
+    const float dv = wave_sum(dv_part);
+    if ((threadIdx.x & 63) != 0) return;
+    float du = 0.0f;
+    const float* __restrict__ dp = x.dupart + ((int64_t)((m - 1) & 1) * x.C + c) * n_chunks;
+    for (int ch = 0; ch < n_chunks; ++ch) du += em_ld_agent(dp + ch);
+    const float r = du + dv;
+    if (x.resid) x.resid[((int64_t)c * x.iters + it) * x.sk + (m - 2)] = r;
+    if (publish) em_exit_publish(x, c, it, m - 2, r);
 }
 
 // The costs themselves are NOT read: thread = row recomputes its J distances from the point and the cloud's centres (LDS) with the
@@ -161,21 +217,31 @@ __device__ __forceinline__ void em_finish_v(int c, int J, int n_chunks, bool fir
 // FULL: J == JMAX, every `j < J` test is compile-time true (a quarter of the kernel's instructions were those tests and their selects)
 template <int JMAX, bool FULL>
 __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restrict__ xyz, float inv_tau, int N, int J, float inv_eps, float eps,
-                                                          float logq, int first, int parity, EmWs w) {
+                                                          float logq, int it, int m, EmWs w, EmExit x) {
     __shared__ float vs[JMAX];
     __shared__ float4 mus[JMAX];
     __shared__ float tile[4][64][33];
     __shared__ float wp[4][JMAX][2];
+    __shared__ float sred[4];
     const int c = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x, C = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = chunk * 256 + tid;
+    const int first = m == 1, parity = m & 1;
+    const bool track = x.on || x.resid != nullptr;
+    if (x.on) {          // sweep ks ended this E-step for the cloud's call group: known from launch ks + 2 on (launch ks + 1 is where it is decided)
+        const int ks = x.kstop[(c / x.G) * x.iters + it];
+        if (ks && m >= ks + 2) return;
+    }
     const int64_t vsz = (int64_t)C * J, psz = (int64_t)C * n_chunks * J * 2;
-    // launch k (parity = k & 1): reads v_{k-2} from vbuf[k & 1] and partials_{k-1} from pbuf[(k-1) & 1]; writes v_{k-1} to vbuf[(k+1) & 1]
-    // and partials_k to pbuf[k & 1]
-    em_finish_v(c, J, n_chunks, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz,
-                chunk == 0 ? w.vbuf + (parity ^ 1) * vsz : nullptr, vs);
+    // launch m (parity = m & 1): reads v_{m-2} from vbuf[m & 1] and partials_{m-1} from pbuf[(m-1) & 1]; writes v_{m-1} to vbuf[(m+1) & 1]
+    // and partials_m to pbuf[m & 1]
+    const float dv_part = em_finish_v(c, J, n_chunks, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz,
+                                      chunk == 0 ? w.vbuf + (parity ^ 1) * vsz : nullptr, vs);
+    if (track && chunk == 0 && m >= 2 && wave == 0) em_fused_residual(x, c, it, m, n_chunks, dv_part, x.on != 0);
     for (int j = tid; j < J; j += 256) mus[j] = w.mu[(int64_t)c * J + j];
     __syncthreads();
+    const float* __restrict__ u_in = (x.on && ((m - 1) & 1)) ? x.u2 : w.u;          // u_{m-1}; with the exit on u_m goes to the other buffer
+    float* __restrict__ u_out = (x.on && (m & 1)) ? x.u2 : w.u;
     const bool valid = n < N;
     const float* __restrict__ pt = xyz + ((int64_t)c * N + (valid ? n : 0)) * 3;
     const float px = pt[0], py = pt[1], pz = pt[2], pn = sqnorm3(px, py, pz);
@@ -185,7 +251,7 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restric
         const float4 m = mus[(FULL || j < J) ? j : 0];
         cst[j] = (FULL || j < J) ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
     }
-    const float un = (valid && !first) ? w.u[(int64_t)c * N + n] : 0.0f;          // u = v = 0 at the start of every outer iteration
+    const float un = (valid && !first) ? u_in[(int64_t)c * N + n] : 0.0f;          // u = v = 0 at the start of every outer iteration
     float mx = -__builtin_inff();
 #pragma unroll
     for (int j = 0; j < JMAX; ++j)
@@ -195,7 +261,11 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restric
     for (int j = 0; j < JMAX; ++j)
         if (FULL || j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
     const float unew = valid ? eps * (w.logp[(int64_t)c * N + n] - (mx + logf(se))) + un : 0.0f;
-    if (valid) w.u[(int64_t)c * N + n] = unew;
+    if (valid) u_out[(int64_t)c * N + n] = unew;
+    if (track) {                                                                   // this chunk's sum |du| of sweep m
+        const float du = wave_sum(valid ? fabsf(unew - un) : 0.0f);
+        if (lane == 0) sred[wave] = du;
+    }
     // column partials of the pending v-update, 32 columns at a time through this wave's tile
 #pragma unroll
     for (int h = 0; h < JMAX / 32; ++h) {
@@ -229,6 +299,7 @@ __global__ __launch_bounds__(256, 4) void em_sweep_kernel(const float* __restric
         float* __restrict__ po = w.pbuf + parity * psz + (((int64_t)c * n_chunks + chunk) * J + tid) * 2;
         po[0] = M; po[1] = S;
     }
+    if (track && tid == 0) x.dupart[((int64_t)parity * C + c) * n_chunks + chunk] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
 // ---- resident form (J <= 64): the WHOLE E/M loop in one launch.  A cloud is worked on by its n_chunks workgroups of 256 rows, which stay
@@ -266,13 +337,17 @@ __device__ __forceinline__ void cloud_barrier(int* arrivals, int target, int* er
 template <int JMAX, bool FULL>
 __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __restrict__ xyz, int C, int N, int J, int n_chunks, int iters, int sk_iters,
                                                               float inv_tau, float inv_eps, float eps, float logq, EmWs w,
-                                                              float* __restrict__ gamma_out, float* __restrict__ pi_out, float* __restrict__ mu_out) {
+                                                              float* __restrict__ gamma_out, float* __restrict__ pi_out, float* __restrict__ mu_out, EmExit x) {
     __shared__ float vs[JMAX];
+    __shared__ float vsp[JMAX];                      // v of the sweep before (early exit: gmm_exit.h)
     __shared__ float4 mus[JMAX];
     __shared__ float tile[4][64][33];
     __shared__ float wp[4][JMAX][2];
     __shared__ float pxyz[4][64][3];
+    __shared__ float sred[4];
+    __shared__ int s_stop;
     __shared__ int s_ticket;
+    const bool track = x.on || x.resid != nullptr;
     double (*wd)[JMAX][4] = reinterpret_cast<double (*)[JMAX][4]>(&tile[0][0][0]);      // [4][JMAX][4], over the tiles once every wave is done with them (keeps the kernel at 40 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(w.sync, 1);
@@ -299,23 +374,50 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
             const float4 m = mus[(FULL || j < J) ? j : 0];
             cst[j] = (FULL || j < J) ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
         }
-        float un = 0.0f;
+        float un = 0.0f, un_prev = 0.0f;
         for (int j = tid; j < J; j += 256) vs[j] = 0.0f;
         // sweep k = 1 .. sk_iters, then the gamma pass as sweep sk_iters + 1: each starts by finishing the pending v-update from the previous
         // sweep's column partials (buffer parity (k - 1) & 1)
         for (int k = 1; k <= sk_iters + 1; ++k) {
             if (k > 1) {
                 const float* __restrict__ part = w.pbuf + ((k - 1) & 1) * psz;
+                float dv_part = 0.0f;
                 for (int j = tid; j < J; j += 256) {
                     const float* __restrict__ pj = part + ((int64_t)c * n_chunks * J + j) * 2;
                     float M = -__builtin_inff();
                     for (int ch = 0; ch < n_chunks; ++ch) M = fmaxf(M, ld_agent(pj + (int64_t)ch * J * 2));
                     float S = 0.0f;
                     for (int ch = 0; ch < n_chunks; ++ch) S = fmaf(ld_agent(pj + (int64_t)ch * J * 2 + 1), expf(ld_agent(pj + (int64_t)ch * J * 2) - M), S);
-                    vs[j] = eps * (logq - (M + logf(S))) + vs[j];
+                    const float vold = vs[j], vnew = eps * (logq - (M + logf(S))) + vold;
+                    vsp[j] = vold;
+                    vs[j] = vnew;
+                    dv_part += fabsf(vnew - vold);
+                }
+                // Early exit: the residual of sweep k - 1 is complete here (chunk 0 publishes it); the group's decision about sweep k - 2 was taken
+                // while this cloud ran sweep k - 1 -- if it ended the E-step, (u_{k-2}, v_{k-2}) = (un_prev, vsp) is the state.
+                if (track && wave == 0) {
+                    if (chunk == 0) {
+                        const float dv = wave_sum(dv_part);          // (J <= 64: all of it sits in wave 0)
+                        if (lane == 0) {
+                            float du = 0.0f;
+                            const float* __restrict__ dp = x.dupart + ((int64_t)((k - 1) & 1) * C + c) * n_chunks;
+                            for (int ch = 0; ch < n_chunks; ++ch) du += em_ld_agent(dp + ch);
+                            const float r = du + dv;
+                            if (x.on && k - 1 < sk_iters) em_exit_publish(x, c, it, k - 2, r);
+                            if (x.resid) x.resid[((int64_t)c * x.iters + it) * x.sk + (k - 2)] = r;
+                        }
+                    }
+                    if (x.on && k >= 3 && lane == 0) s_stop = em_exit_wait(x, c, it, k - 3) ? 1 : 0;
                 }
             }
             __syncthreads();
+            if (x.on && k >= 3 && s_stop) {
+                un = un_prev;
+                for (int j = tid; j < J; j += 256) vs[j] = vsp[j];
+                if (x.resid && chunk == 0 && tid == 0) x.resid[((int64_t)c * x.iters + it) * x.sk + (k - 2)] = __builtin_nanf("");          // (the discarded sweep)
+                __syncthreads();
+                break;
+            }
             if (k == sk_iters + 1) break;
             float mx = -__builtin_inff();
 #pragma unroll
@@ -326,6 +428,11 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
             for (int j = 0; j < JMAX; ++j)
                 if (FULL || j < J) se += fexp(((-cst[j] + un) + vs[j]) * inv_eps - mx);
             const float unew = valid ? eps * (logp - (mx + logf(se))) + un : 0.0f;
+            if (track) {                                                           // this chunk's sum |du| of sweep k
+                const float du = wave_sum(valid ? fabsf(unew - un) : 0.0f);
+                if (lane == 0) sred[wave] = du;
+            }
+            un_prev = un;
             un = unew;
 #pragma unroll
             for (int h = 0; h < JMAX / 32; ++h) {
@@ -357,6 +464,7 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
                 float* __restrict__ po = w.pbuf + (k & 1) * psz + (((int64_t)c * n_chunks + chunk) * J + tid) * 2;
                 st_agent(po, M); st_agent(po + 1, S);
             }
+            if (track && tid == 0) em_st_agent(x.dupart + ((int64_t)(k & 1) * C + c) * n_chunks + chunk, (sred[0] + sred[1]) + (sred[2] + sred[3]));
             cloud_barrier(arrivals, (++epoch) * n_chunks, w.sync + 1);
         }
         // ---- gamma (exp(K), nan -> 0, inf -> FLT_MAX), row clip, and the chunk's M-step sums per column in fp64
@@ -429,6 +537,11 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
         }
         // (the next M-step's partials are written only after 1 + sk_iters more barriers: nobody still reads this iteration's)
     }
+    // a poll ran into its limit somewhere (a lost workgroup): make the result loudly wrong instead of silently so
+    if (chunk == 0 && tid < J && (em_ld_agent(w.sync + 1) != 0 || (x.on && em_ld_agent(x.err) != 0))) {
+        pi_out[(int64_t)c * J + tid] = __builtin_nanf("");
+        mu_out[((int64_t)c * J + tid) * 3] = __builtin_nanf("");
+    }
 }
 
 // ---- gamma + M-step of the fused launch sequence in one pass (J <= 64): the gamma kernel below writes the unnormalised gamma of every entry to
@@ -438,7 +551,7 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
 // Same arithmetic and summation order as em_resident_kernel.
 template <int JMAX>
 __global__ __launch_bounds__(256, 3) void em_gamma_mstep_kernel(const float* __restrict__ xyz, float inv_tau, int N, int J, float inv_eps, float eps,
-                                                                 float logq, int first, int parity, EmWs w, float* __restrict__ gamma_out) {
+                                                                 float logq, int it, int sk_iters, EmWs w, float* __restrict__ gamma_out, EmExit x) {
     __shared__ float vs[JMAX];
     __shared__ float4 mus[JMAX];
     __shared__ float tile[4][64][33];
@@ -448,7 +561,18 @@ __global__ __launch_bounds__(256, 3) void em_gamma_mstep_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = chunk * 256 + tid;
     const int64_t vsz = (int64_t)C * J, psz = (int64_t)C * n_chunks * J * 2;
-    em_finish_v(c, J, n_chunks, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz, nullptr, vs);
+    // plays launch sk_iters + 1 for the pending v-update -- unless sweep ks < sk_iters ended the E-step (gmm_exit.h): then (u_ks, v_ks), both still
+    // in their parity buffers, are the state
+    const int first = sk_iters == 0, parity = (sk_iters + 1) & 1;
+    const int ks = x.on ? x.kstop[(c / x.G) * x.iters + it] : 0;
+    if (ks) {
+        for (int j = tid; j < J; j += 256) vs[j] = w.vbuf[(ks & 1) * vsz + (int64_t)c * J + j];
+    } else {
+        const float dv_part = em_finish_v(c, J, n_chunks, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz, nullptr, vs);
+        if (x.resid && chunk == 0 && sk_iters >= 1 && wave == 0) em_fused_residual(x, c, it, sk_iters + 1, n_chunks, dv_part, false);
+    }
+    const int u_par = ks ? (ks & 1) : (sk_iters & 1);
+    const float* __restrict__ u_in = (x.on && u_par) ? x.u2 : w.u;
     for (int j = tid; j < J; j += 256) mus[j] = w.mu[(int64_t)c * J + j];
     const bool valid = n < N;
     const float* __restrict__ pt = xyz + ((int64_t)c * N + (valid ? n : 0)) * 3;
@@ -461,7 +585,7 @@ __global__ __launch_bounds__(256, 3) void em_gamma_mstep_kernel(const float* __r
         const float4 m = mus[j < J ? j : 0];
         cst[j] = j < J ? cdist_mm2(px, py, pz, pn, m.x, m.y, m.z, m.w) * inv_tau : 0.0f;
     }
-    const float un = (valid && !first) ? w.u[(int64_t)c * N + n] : 0.0f;
+    const float un = (valid && !first) ? u_in[(int64_t)c * N + n] : 0.0f;
     double rs = 0.0;
 #pragma unroll
     for (int j = 0; j < JMAX; ++j)
@@ -535,31 +659,18 @@ __global__ __launch_bounds__(64) void em_mu_kernel(int N, int J, int n_chunks, E
 }
 
 // gamma = exp(K) (nan -> 0, inf -> FLT_MAX) in place; rclip = max(rowsum, 1e-3); the last iteration also writes gamma / rclip.  grid (N/256, C)
-__global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out, int fused, int first,
-                                                       int parity, float eps, float logq, const float* __restrict__ xyz, float inv_tau) {
-    extern __shared__ float vs[];                    // [J], then (fused) the centres [J] float4 from the next 16-byte boundary
-    float4* mus = reinterpret_cast<float4*>(vs + (J + 3) / 4 * 4);
+// (two-launch sweeps only: u, v are complete in the workspace, also after an early exit)
+__global__ __launch_bounds__(256) void em_gamma_kernel(int N, int J, float inv_eps, EmWs w, float* __restrict__ gamma_out) {
+    extern __shared__ float vs[];                    // [J]
     const int c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    if (fused) for (int j = threadIdx.x; j < J; j += 256) mus[j] = w.mu[(int64_t)c * J + j];
-    if (fused) {          // after fused sweeps the last v-update is still pending in the partials
-        const int64_t vsz = (int64_t)gridDim.y * J, psz = (int64_t)gridDim.y * gridDim.x * J * 2;
-        em_finish_v(c, J, gridDim.x, first != 0, eps, logq, w.vbuf + parity * vsz, w.pbuf + (parity ^ 1) * psz, nullptr, vs);
-    } else {
-        for (int j = threadIdx.x; j < J; j += 256) vs[j] = w.v[(int64_t)c * J + j];
-    }
+    for (int j = threadIdx.x; j < J; j += 256) vs[j] = w.v[(int64_t)c * J + j];
     __syncthreads();
     if (n >= N) return;
     float* __restrict__ Cc = w.cost + (int64_t)c * J * N + n;
-    const float un = (fused && first) ? 0.0f : w.u[(int64_t)c * N + n];
-    float px = 0.0f, py = 0.0f, pz = 0.0f, pn = 0.0f;
-    if (fused) {          // the fused sweeps never wrote the costs: same arithmetic as em_cost_kernel
-        const float* __restrict__ pt = xyz + ((int64_t)c * N + n) * 3;
-        px = pt[0]; py = pt[1]; pz = pt[2]; pn = sqnorm3(px, py, pz);
-    }
+    const float un = w.u[(int64_t)c * N + n];
     double rs = 0.0;
     for (int j = 0; j < J; ++j) {
-        const float cj = fused ? cdist_mm2(px, py, pz, pn, mus[j].x, mus[j].y, mus[j].z, mus[j].w) * inv_tau : Cc[(int64_t)j * N];
-        float g = expf(((-cj + un) + vs[j]) * inv_eps);
+        float g = expf(((-Cc[(int64_t)j * N] + un) + vs[j]) * inv_eps);
         g = (g != g) ? 0.0f : fminf(g, 3.4028234663852886e38f);
         Cc[(int64_t)j * N] = g;
         rs += (double)g;
@@ -616,13 +727,17 @@ extern "C" int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J) {
 }
 
 extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
-                                 float epsilon, float tau, float* gamma, float* pi, float* mu, void* workspace, void* stream) {
+                                 float epsilon, float tau, double thresh, int group_size, float* gamma, float* pi, float* mu, float* resid,
+                                 int32_t* sweeps, void* exit_ws, void* workspace, void* stream) {
     using namespace ogmm;
     OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu && workspace, "ogmm_gmm_em_multi: null pointer");
     OGMM_REQUIRE(J <= 128, "ogmm_gmm_em_multi: at most 128 clusters (a row of exponents lives in registers), got %d", J);
     OGMM_REQUIRE(C > 0 && C <= 65535 && N > 0 && J > 0 && J <= N && J <= 65535 && iters > 0 && sk_iters >= 0 && epsilon > 0 && tau > 0,
                  "ogmm_gmm_em_multi: bad sizes C=%d N=%d J=%d", C, N, J);
     OGMM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "ogmm_gmm_em_multi: workspace must be 256-byte aligned");
+    hipStream_t s = as_stream(stream);
+    EmExit x;
+    if (int rc = em_exit_setup(x, thresh, group_size, C, N, iters, sk_iters, resid, sweeps, exit_ws, s)) return rc;
     char* p = static_cast<char*>(workspace);
     EmWs w;
     w.cost = reinterpret_cast<float*>(p);  p += align256((size_t)C * J * N * 4);
@@ -638,9 +753,8 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     w.sync = reinterpret_cast<int*>(p);
     const float inv_eps = (float)(1.0 / (double)epsilon), inv_tau = (float)(1.0 / (double)tau);
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
-    hipStream_t s = as_stream(stream);
     const dim3 rows((N + 255) / 256, C), cols(J, C), blk(256);
-    const size_t vs = (size_t)J * sizeof(float);
+    const size_t vs = (size_t)(J + 4) * sizeof(float);
     hipLaunchKernelGGL(em_init_kernel, dim3(C), blk, 0, s, xyz, o, ids0, N, J, w);
     // Measured (N = 2048, J = 64; resident / launch sequence): 4 clouds 1.15 / 2.7 ms, 96 clouds 3.0 / 3.25 (3 workgroups per CU, all resident),
     // 128 clouds 4.0 / 3.7 (4 per CU: spills) or 5.1 (3 per CU: a third of the clouds wait for a second round).  A full chip is bound by the
@@ -651,11 +765,14 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     int cus = 256, dev_id = 0;
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    // one resident round: three workgroups per CU (FULL form, J == 64: 48 / 64 / 96 clouds 2.09 / 2.55 / 3.00 ms against 2.86 / 2.87 / 3.25)
-    if (J <= 64 && (resident == 2 || (resident == 1 && (int64_t)C * (int64_t)n_chunks_ws <= 3 * (int64_t)cus))) {
+    // one resident round: three workgroups per CU (FULL form, J == 64: 48 / 64 / 96 clouds 2.09 / 2.55 / 3.00 ms against 2.86 / 2.87 / 3.25).
+    // With the early exit on, the clouds of a call group wait for each other: a whole group must fit one resident round (tickets are handed
+    // out in order, so the lowest unfinished group is then always completely on the chip), otherwise the launch sequence runs.
+    const bool group_fits = !x.on || (int64_t)x.G * (int64_t)n_chunks_ws <= 3 * (int64_t)cus;
+    if (J <= 64 && group_fits && (resident == 2 || (resident == 1 && (int64_t)C * (int64_t)n_chunks_ws <= 3 * (int64_t)cus))) {
         (void)hipMemsetAsync(w.sync, 0, (size_t)(C + 2) * 4, s);
         const dim3 grid((unsigned)(C * n_chunks_ws));
-        #define OGMM_EM_RES(JM, FL) hipLaunchKernelGGL((em_resident_kernel<JM, FL>), grid, blk, 0, s, xyz, C, N, J, (int)n_chunks_ws, iters, sk_iters, inv_tau, inv_eps, epsilon, logq, w, gamma, pi, mu)
+        #define OGMM_EM_RES(JM, FL) hipLaunchKernelGGL((em_resident_kernel<JM, FL>), grid, blk, 0, s, xyz, C, N, J, (int)n_chunks_ws, iters, sk_iters, inv_tau, inv_eps, epsilon, logq, w, gamma, pi, mu, x)
         if (J == 32) OGMM_EM_RES(32, true); else if (J < 32) OGMM_EM_RES(32, false); else if (J == 64) OGMM_EM_RES(64, true); else OGMM_EM_RES(64, false);
 #undef OGMM_EM_RES
         return check_launch("ogmm_gmm_em_multi");
@@ -664,34 +781,28 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
         const bool last = it + 1 == iters;
         static const bool two_launch = [] { const char* e = getenv("OGMM_EM_MULTI_UNFUSED"); return e && e[0] == '1'; }();      // A/B: u and v kernels
         const bool fused = J <= 64 && !two_launch;
-        if (!fused) hipLaunchKernelGGL(em_cost_kernel, rows, blk, 0, s, xyz, N, J, inv_tau, w);          // (the fused sweeps recompute the costs)
         if (fused) {
-            // launch k = 1 .. sk_iters; the gamma kernel plays launch sk_iters + 1 for the pending v-update
-            for (int k = 1; k <= sk_iters; ++k) {
-#define OGMM_EM_SWEEP(JM, FL) hipLaunchKernelGGL((em_sweep_kernel<JM, FL>), rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, k == 1 ? 1 : 0, k & 1, w)
+            // launch m = 1 .. sk_iters (the fused sweeps recompute the costs); the gamma kernel plays launch sk_iters + 1 for the pending v-update
+            for (int m = 1; m <= sk_iters; ++m) {
+#define OGMM_EM_SWEEP(JM, FL) hipLaunchKernelGGL((em_sweep_kernel<JM, FL>), rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, it, m, w, x)
                 // (the FULL form of this kernel keeps all 64 exponents of a row between its passes: 171 spills under the 128-register cap of four
                 // workgroups per CU, 6.9 against 3.7 ms -- the run-time tests stay here; the resident kernel, 168 registers, takes it: 1.15 against 1.6 ms)
                 if (J <= 32) OGMM_EM_SWEEP(32, false); else OGMM_EM_SWEEP(64, false);
 #undef OGMM_EM_SWEEP
             }
-            static const bool split_mstep = [] { const char* e = getenv("OGMM_EM_SPLIT_MSTEP"); return e && e[0] == '1'; }();      // A/B: gamma to the workspace + em_mstep_kernel
-            if (!split_mstep) {
-                if (J <= 32) hipLaunchKernelGGL(em_gamma_mstep_kernel<32>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, w, last ? gamma : (float*)nullptr);
-                else hipLaunchKernelGGL(em_gamma_mstep_kernel<64>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, w, last ? gamma : (float*)nullptr);
-                hipLaunchKernelGGL(em_mu_kernel, dim3(C), dim3(64), 0, s, N, J, (int)n_chunks_ws, w, last ? pi : (float*)nullptr, mu);
-                continue;
-            }
-            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs + 16 + (size_t)J * sizeof(float4), s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 1,
-                               sk_iters == 0 ? 1 : 0, (sk_iters + 1) & 1, epsilon, logq, xyz, inv_tau);
-        } else {
-            for (int sk = 0; sk < sk_iters; ++sk) {
-                if (J <= 16) hipLaunchKernelGGL(em_u_kernel<16>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
-                else if (J <= 64) hipLaunchKernelGGL(em_u_kernel<64>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
-                else hipLaunchKernelGGL(em_u_kernel<128>, rows, blk, vs, s, N, J, inv_eps, epsilon, w);
-                hipLaunchKernelGGL(em_v_kernel, cols, blk, 0, s, N, J, inv_eps, epsilon, logq, w);
-            }
-            hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr, 0, 0, 0, epsilon, logq, xyz, inv_tau);
+            if (J <= 32) hipLaunchKernelGGL(em_gamma_mstep_kernel<32>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, it, sk_iters, w, last ? gamma : (float*)nullptr, x);
+            else hipLaunchKernelGGL(em_gamma_mstep_kernel<64>, rows, blk, 0, s, xyz, inv_tau, N, J, inv_eps, epsilon, logq, it, sk_iters, w, last ? gamma : (float*)nullptr, x);
+            hipLaunchKernelGGL(em_mu_kernel, dim3(C), dim3(64), 0, s, N, J, (int)n_chunks_ws, w, last ? pi : (float*)nullptr, mu);
+            continue;
         }
+        hipLaunchKernelGGL(em_cost_kernel, rows, blk, 0, s, xyz, N, J, inv_tau, w);
+        for (int m = 1; m <= sk_iters; ++m) {
+            if (J <= 16) hipLaunchKernelGGL(em_u_kernel<16>, rows, blk, vs, s, N, J, inv_eps, epsilon, w, it, x);
+            else if (J <= 64) hipLaunchKernelGGL(em_u_kernel<64>, rows, blk, vs, s, N, J, inv_eps, epsilon, w, it, x);
+            else hipLaunchKernelGGL(em_u_kernel<128>, rows, blk, vs, s, N, J, inv_eps, epsilon, w, it, x);
+            hipLaunchKernelGGL(em_v_kernel, cols, blk, 0, s, N, J, inv_eps, epsilon, logq, w, it, m, (int)n_chunks_ws, x);
+        }
+        hipLaunchKernelGGL(em_gamma_kernel, rows, blk, vs, s, N, J, inv_eps, w, last ? gamma : (float*)nullptr);
         hipLaunchKernelGGL(em_mstep_kernel, cols, blk, 0, s, xyz, N, J, w, last ? pi : (float*)nullptr, mu);
     }
     return check_launch("ogmm_gmm_em_multi");

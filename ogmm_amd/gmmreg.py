@@ -224,6 +224,7 @@ class GMMReg(nn.Module):
         # "f16": REDUCED precision for BASELINE configs[2] (quoted in bf16): the large GEMMs multiply only the leading binary16
         #        terms (11-bit mantissa >= bf16's 8, fp32 accumulate); R / t then agree with the reference to ~1e-4, not 1e-5.
         self.precision = getattr(config, "precision", "f16x3")
+        self.sinkhorn_thresh = 1e-2      # lib/utils.py:73 (`thresh` default, which wkeans_plus :281 does not override); <= 0 runs every sweep
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self.fold_conv2_overlap = True      # conv2.net.6 and overlap.net.0 (two linear maps in a row) as one 1024 -> 256 layer
         self.fuse_overlap = os.environ.get("OGMM_FUSE_OVERLAP", "1") != "0"            # overlap block's softmax-dots in the similarity GEMM's epilogue where the engine takes it (ops.overlap_fusable)
@@ -454,9 +455,11 @@ class GMMReg(nn.Module):
         # ---- GMM E/M (needs only xyz and the overlap scores) on the side stream, next to self-attention 2 (gmmreg.py:92-101)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            # capture=True also records every Sinkhorn sweep's residual (the reference would leave its sweeps early if its batch mean fell below 1e-2,
-            # lib/utils.py:99-102; this path never does): see sinkhorn_exit_margin()
-            em = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, return_resid=capture)
+            # thresh / group_size: the reference's Sinkhorn early exit (lib/utils.py:99-102), per call batch -- the B src clouds and the B tgt
+            # clouds are separate wkeans_plus calls (models/gmmreg.py:100-101).  capture=True also records every sweep's residual and the
+            # number of sweeps every E-step ran: see sinkhorn_exit_margin()
+            em = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=self.sinkhorn_thresh, group_size=B,
+                            return_resid=capture, return_sweeps=capture)
             gamma, pi, mu = em[:3]
             em_done = torch.cuda.Event()
             em_done.record(side)
@@ -485,7 +488,7 @@ class GMMReg(nn.Module):
 
         if capture:
             cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0], o_logit=extra[:, 1],
-                       o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss, sinkhorn_resid=em[3])
+                       o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss, sinkhorn_resid=em[3], sinkhorn_sweeps=em[4])
             self.last_intermediates = cap
         if is_test:
             # models/gmmreg.py:115-117: point-to-point ICP from the network's motion, correspondence radius 2 * overlap_radius
@@ -495,13 +498,14 @@ class GMMReg(nn.Module):
 
     def sinkhorn_exit_margin(self):
         """After forward(..., capture=True): the smallest batch-mean Sinkhorn residual of the call, per call group (src clouds, tgt clouds) as the
-        reference forms it (lib/utils.py:99-101: mean over the clouds of sum |u - u0| + sum |v - v0|), divided by its exit threshold 1e-2.
-        A value > 1 means the reference would not have left any sweep early either, i.e. this path (which always runs all sweeps) computed what
-        the reference computes; <= 1 flags a checkpoint / input on which the two differ.  NaN: the residual is not measured for this shape."""
-        r = self.last_intermediates["sinkhorn_resid"]          # [2B, iters, sweeps]
+        reference forms it (lib/utils.py:99-101: mean over the clouds of sum |u - u0| + sum |v - v0|), divided by its exit threshold.
+        <= 1: some E-step left its sweeps early (as the reference does: `last_intermediates["sinkhorn_sweeps"]` has the counts, [2, iters]);
+        close to 1: the decision is a knife edge, and rounding differences between this path and the reference may flip it."""
+        r = self.last_intermediates["sinkhorn_resid"]          # [2B, iters, sweeps], NaN for sweeps that did not run
         B = r.shape[0] // 2
         means = torch.stack([r[:B].mean(0), r[B:].mean(0)])    # [2, iters, sweeps]
-        return float(means.min().item()) / 1e-2
+        means = torch.where(torch.isnan(means), torch.full_like(means, float("inf")), means)
+        return float(means.min().item()) / (self.sinkhorn_thresh if self.sinkhorn_thresh and self.sinkhorn_thresh > 0 else 1e-2)
 
     def _forward_train(self, src, tgt, fps_starts, capture, is_test=False):
         """`.train()` mode: batch-statistics BatchNorm with running-stat updates and autograd through every differentiable

@@ -522,33 +522,48 @@ def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, two_pass=False):
 
 
 # ---------------------------------------------------------------------------------------------- GMM head
-def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, engine=None, return_resid=False):
-    """-> gamma [C,N,J], pi [C,J], mu [C,J,3]   (lib/utils.py:269-288)."""
+def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=1e-2, group_size=None, engine=None, return_resid=False,
+           return_sweeps=False):
+    """-> gamma [C,N,J], pi [C,J], mu [C,J,3] (, resid [C,iters,sk_iters]) (, sweeps int32 [C/group_size, iters])   (lib/utils.py:269-288).
+    thresh / group_size: the reference's Sinkhorn early exit (lib/utils.py:99-102): an E-step's sweeps end after the first sweep whose residual,
+    averaged over the `group_size` clouds of one reference call (None: all C clouds are one call), is below thresh; thresh <= 0 runs every sweep.
+    resid: every sweep's sum|u - u0| + sum|v - v0| per cloud, NaN for sweeps that did not run; sweeps: the sweeps every E-step ran per call group."""
     C, N, _ = xyz.shape
     J = ids0.shape[1]
     assert o.is_contiguous() and o.shape == (C, N) and ids0.is_contiguous()
-    gamma = torch.empty((C, N, J), dtype=torch.float32, device=xyz.device)
-    pi = torch.empty((C, J), dtype=torch.float32, device=xyz.device)
-    mu = torch.empty((C, J, 3), dtype=torch.float32, device=xyz.device)
+    G = C if group_size is None else int(group_size)
+    if G <= 0 or C % G != 0:
+        raise _lib.OgmmError("gmm_em: %d clouds are not whole call groups of %d" % (C, G))
+    lib = _lib.load()
+    dev = xyz.device
+    gamma = torch.empty((C, N, J), dtype=torch.float32, device=dev)
+    pi = torch.empty((C, J), dtype=torch.float32, device=dev)
+    mu = torch.empty((C, J, 3), dtype=torch.float32, device=dev)
+    exit_on = thresh is not None and thresh > 0 and sk_iters > 1
     if engine is None:       # the on-chip loop while the N x J cost matrix fits one CU's LDS, the grid-wide sequence beyond
-        fits = (4 * N + 3 * ((N + 3) // 4 * 4) + 5 * J + 16 + N * J) * 4 <= 128 * 1024
-        engine = "chip" if fits or J > 128 else "multi"          # (the grid-wide kernels keep a row of J <= 128 exponents in registers)
+        engine = "chip" if lib.ogmm_gmm_em_chip_cached(N, J) == 1 or J > 128 else "multi"          # (the grid-wide kernels keep a row of J <= 128 exponents in registers)
+        if engine == "chip" and exit_on and G > lib.ogmm_gmm_em_chip_max_group(N, J) and J <= 128:
+            engine = "multi"          # the clouds of a call group wait for each other on chip: a group beyond one resident round takes the launch sequence
+    resid = torch.empty((C, iters, sk_iters), dtype=torch.float32, device=dev) if return_resid else None
+    sweeps = torch.empty((C // G, iters), dtype=torch.int32, device=dev) if return_sweeps else None
+    xws = None
+    if exit_on or return_resid:
+        xws = torch.empty(lib.ogmm_gmm_em_exit_workspace_bytes(C, N, iters, sk_iters, G), dtype=torch.uint8, device=dev)
+        xws.record_stream(torch.cuda.current_stream())
+    head = (_p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau, float(thresh or 0.0), G,
+            _p(gamma), _p(pi), _p(mu), _p(resid), _p(sweeps), _p(xws))
     if engine == "multi":
-        ws = torch.empty(_lib.load().ogmm_gmm_em_workspace_bytes(C, N, J), dtype=torch.uint8, device=xyz.device)
-        _lib.call("ogmm_gmm_em_multi", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
-                  _p(gamma), _p(pi), _p(mu), _p(ws), _stream())
+        ws = torch.empty(lib.ogmm_gmm_em_workspace_bytes(C, N, J), dtype=torch.uint8, device=dev)
+        _lib.call("ogmm_gmm_em_multi", *head, _p(ws), _stream())
         ws.record_stream(torch.cuda.current_stream())
-        if return_resid:
-            return gamma, pi, mu, torch.full((C, iters, sk_iters), float("nan"), dtype=torch.float32, device=xyz.device)
-        return gamma, pi, mu
-    if return_resid:          # + every sweep's sum |u - u0| + sum |v - v0| per cloud [C, iters, sk_iters] (NaN where the kernel does not measure it)
-        resid = torch.empty((C, iters, sk_iters), dtype=torch.float32, device=xyz.device)
-        _lib.call("ogmm_gmm_em_resid", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
-                  _p(gamma), _p(pi), _p(mu), _p(resid), _stream())
-        return gamma, pi, mu, resid
-    _lib.call("ogmm_gmm_em", _p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau,
-              _p(gamma), _p(pi), _p(mu), _stream())
-    return gamma, pi, mu
+    else:
+        _lib.call("ogmm_gmm_em", *head, _stream())
+    out = (gamma, pi, mu)
+    if return_resid:
+        out += (resid,)
+    if return_sweeps:
+        out += (sweeps,)
+    return out
 
 
 def gmm_feat_mean(gamma, pi, feats, C, N):

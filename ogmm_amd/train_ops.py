@@ -453,7 +453,9 @@ class TrainOps:
         return ops.fps(xyz, npoint, starts.to(device=xyz.device, dtype=torch.int32).contiguous()).long()
 
     def gmm_em(self, xyz, o, ids_j):
-        return ops.gmm_em(xyz, o.contiguous(), ids_j.to(torch.int32).contiguous(), iters=10, sk_iters=10, epsilon=1e-2, tau=1.0)
+        # (src clouds | tgt clouds: two wkeans_plus calls in the reference, i.e. two call groups of the Sinkhorn early exit)
+        return ops.gmm_em(xyz, o.contiguous(), ids_j.to(torch.int32).contiguous(), iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=1e-2,
+                          group_size=xyz.shape[0] // 2)
 
     def nearest_point(self, xyz, mu):
         """index of the point nearest to each mu (lib/utils.py:244-254) -> [C,J] int64"""

@@ -371,10 +371,11 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
         cap['f2_' + s] = f2[s]
     clu = {}
     for s in pts:                                           # gmmreg.py:100-101, :24-29
-        st = []
-        clu[s] = weighted_em(xyz[s], f2[s].transpose(1, 2), o[s], J, iters=10, tau=1.0, stats=st)
+        st, rs = [], []
+        clu[s] = weighted_em(xyz[s], f2[s].transpose(1, 2), o[s], J, iters=10, tau=1.0, stats=st, resid=rs)
         cap['gamma_' + s], cap['pi_' + s], cap['mu_' + s], cap['muf_' + s], cap['fpsJ_' + s] = clu[s]
-        cap['sk_iters_' + s] = st
+        cap['sk_iters_' + s] = st                               # sweeps every E-step ran (lib/utils.py:99-102: the batch-mean early exit)
+        cap['sk_resid_' + s] = rs                               # every sweep's per-cloud residual [B], in execution order
     R, t, sc = match_and_solve(clu['src'][2], clu['tgt'][2], clu['src'][3], clu['tgt'][3])   # gmmreg.py:102-103
     cap['match_scores'] = sc
     loss = 0

@@ -612,25 +612,75 @@ def test_gmm_em_resident_kernel_equals_the_launch_sequence(ops, monkeypatch, C, 
 
 
 def test_gmm_em_reports_the_sinkhorn_residual(ops):
-    """The reference leaves its Sinkhorn sweeps early when the batch mean of sum|du| + sum|dv| falls below 1e-2 (lib/utils.py:99-102); the kernel
-    always runs all sweeps and can report that quantity per cloud and sweep, so that a parity run on real checkpoints can tell whether the
-    reference would have left early (GMMReg.sinkhorn_exit_margin)."""
+    """The quantity the reference's early exit tests (lib/utils.py:99-102: sum|du| + sum|dv| per cloud and sweep) as a diagnostic output, on every kernel
+    family; reporting it changes nothing, and with the exit off (thresh = 0) all sweeps run."""
     torch.manual_seed(9)
-    C, N, J = 4, 1024, 16
-    xyz = clouds(C, N, seed=33)
+    for C, N, J, engine in ((4, 1024, 16, None), (2, 2048, 64, None), (2, 717, 128, None), (3, 300, 20, "chip"), (2, 2048, 64, "chip")):
+        xyz = clouds(C, N, seed=33)
+        o = torch.sigmoid(torch.randn(C, N))
+        res = []
+        O.weighted_em(xyz, torch.zeros(C, N, 4), o, J, resid=res)
+        ref = torch.stack(res).view(10, 10, C).permute(2, 0, 1)                      # [C, iters, sweeps]
+        ids = ops.fps(dev(xyz), J, None)
+        out = ops.gmm_em(dev(xyz), dev(o), ids, engine=engine, return_resid=True, return_sweeps=True)
+        got = out[3].cpu()
+        assert got.shape == (C, 10, 10) and not torch.isnan(got).any(), (C, N, J, engine)
+        assert ((got - ref).abs() / ref.abs().clamp_min(1e-6)).max().item() < 2e-3, ((got - ref).abs() / ref.abs()).max().item()
+        assert ref.mean(0).min().item() > 1e-2 and bool((out[4] == 10).all())        # the oracle ran all 10 sweeps on this input, like the kernel
+        for kw in (dict(), dict(thresh=0.0)):                                        # without the outputs / with the exit off nothing changes
+            plain = ops.gmm_em(dev(xyz), dev(o), ids, engine=engine, **kw)
+            assert torch.equal(plain[0], out[0]) and torch.equal(plain[2], out[2])
+
+
+EXIT_CASES = [  # C, N, J, group, engine, OGMM_EM_RESIDENT, scale, what
+    (4, 1024, 16, 2, None, None, 0.04, "on-chip kernel, J = 16 register form"),
+    (6, 300, 20, 3, "chip", None, 0.05, "on-chip kernel, generic cached form"),
+    (4, 2048, 64, 2, "chip", None, 0.04, "on-chip kernel, recomputing form"),
+    (4, 2048, 64, 2, "multi", "1", 0.04, "resident kernel"),
+    (4, 2048, 64, 2, "multi", "0", 0.04, "fused launch sequence"),
+    (6, 1500, 32, 3, "multi", "0", 0.04, "fused launch sequence, J = 32, ragged chunks"),
+    (6, 1500, 32, 6, "multi", "1", 0.04, "resident kernel, one group"),
+    (2, 717, 128, 1, None, None, 0.04, "two-launch sweeps (J > 64), every cloud its own call"),
+    (4, 717, 128, 2, None, None, 0.04, "two-launch sweeps (J > 64)"),
+]
+
+
+@pytest.mark.parametrize("C,N,J,G,engine,resident,scale,what", EXIT_CASES)
+def test_gmm_em_early_exit_matches_the_reference_semantics(ops, monkeypatch, C, N, J, G, engine, resident, scale, what):
+    """lib/utils.py:99-102: an E-step's sweeps end after the first sweep whose residual, averaged over the clouds of ONE wkeans_plus call (a group),
+    is below 1e-2.  Scaled-down clouds make that happen after 2-9 sweeps; every kernel family must run exactly the oracle's number of sweeps in
+    every E-step of every group and end with its gamma / pi / mu."""
+    if resident is not None:
+        monkeypatch.setenv("OGMM_EM_RESIDENT", resident)
+    torch.manual_seed(N + J + C)
+    xyz = clouds(C, N, seed=41) * scale
     o = torch.sigmoid(torch.randn(C, N))
-    res = []
-    O.weighted_em(xyz, torch.zeros(C, N, 4), o, J, resid=res)
-    ref = torch.stack(res).view(10, 10, C).permute(2, 0, 1)                      # [C, iters, sweeps]
+    want, pis, mus, gammas, errs = [], [], [], [], []
+    for g in range(C // G):          # the oracle, one call per group -- as the reference calls wkeans_plus once per cloud set
+        h = slice(g * G, (g + 1) * G)
+        st, rs = [], []
+        gamma, pi, mu, _, _ = O.weighted_em(xyz[h], torch.zeros(G, N, 1), o[h], J, stats=st, resid=rs)
+        means = torch.stack(rs).mean(1)
+        assert ((means - 1e-2).abs() / 1e-2).min().item() > 0.01, "test input sits on the decision's knife edge"
+        st64 = []
+        _, pid, mud, _, _ = O.weighted_em(xyz[h].double(), torch.zeros(G, N, 1).double(), o[h].double(), J, stats=st64)
+        errs.append(max((pi - pid).abs().max().item(), (mu - mud).abs().max().item()) if st64 == st else 0.0)
+        want.append(st); pis.append(pi); mus.append(mu); gammas.append(gamma)
+    want = torch.tensor(want, dtype=torch.int32)
+    assert int(want.min()) < 10, "the exit never fired in the oracle: nothing tested"
     ids = ops.fps(dev(xyz), J, None)
-    out = ops.gmm_em(dev(xyz), dev(o), ids, return_resid=True)
-    got = out[3].cpu()
-    assert got.shape == (C, 10, 10) and not torch.isnan(got).any()
-    assert ((got - ref).abs() / ref.abs().clamp_min(1e-6)).max().item() < 2e-3, ((got - ref).abs() / ref.abs()).max().item()
-    assert ref.mean(0).min().item() > 1e-2                                       # the oracle ran all 10 sweeps on this input, like the kernel
-    # without the flag nothing changes
-    plain = ops.gmm_em(dev(xyz), dev(o), ids)
-    assert torch.equal(plain[0], out[0]) and torch.equal(plain[2], out[2])
+    for rep in range(2):             # twice: the workspace counters start from zero every call
+        g_gamma, g_pi, g_mu, g_sweeps = ops.gmm_em(dev(xyz), dev(o), ids, engine=engine, thresh=1e-2, group_size=G, return_sweeps=True)
+        assert torch.equal(g_sweeps.cpu(), want), (what, g_sweeps.cpu(), want)
+        tol = max(4 * max(errs), 5e-7)
+        pi, mu, gamma = torch.cat(pis), torch.cat(mus), torch.cat(gammas)
+        assert not torch.isnan(g_mu).any()
+        assert (g_pi.cpu() - pi).abs().max().item() < tol and (g_mu.cpu() - mu).abs().max().item() < tol, (what, tol)
+        assert (g_gamma.cpu() - gamma).abs().max().item() < 2e-5
+    # and the same clouds as ONE call give different sweep counts unless the groups happen to agree: the grouping is really per call
+    if C // G > 1 and not bool((want[0] == want[1:]).all()):
+        one = ops.gmm_em(dev(xyz), dev(o), ids, engine=engine, thresh=1e-2, group_size=None, return_sweeps=True)[3].cpu()
+        assert one.shape == (1, 10)
 
 
 @pytest.mark.parametrize("C,N,J,D", [(3, 2048, 64, 512), (2, 717, 40, 512), (2, 300, 17, 96), (1, 1025, 64, 260)])

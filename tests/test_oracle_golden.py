@@ -41,7 +41,12 @@ def test_oracle_matches_reference_outputs(golden, name):
         assert np.array_equal(cap["fpsJ_" + s].numpy(), fx["fpsJ_" + s].astype(np.int64))
         assert np.abs(cap["pi_" + s].numpy() - fx["pi_" + s]).max() < 1e-6
         assert np.abs(cap["mu_" + s].numpy() - fx["mu_" + s]).max() < 2e-6
-        assert set(cap["sk_iters_" + s]) == {10}, "Sinkhorn early exit fired: the HIP path assumes it never does"
+    # sweeps every E-step ran (lib/utils.py:99-102, the batch-mean early exit): the `exit_*` fixtures (scaled-down clouds) leave early, on the
+    # unit-sphere fixtures the reference always runs all 10
+    want = fx["sk_iters"] if "sk_iters" in fx else np.full((2, 10), 10)
+    assert np.array_equal(np.array([cap["sk_iters_src"], cap["sk_iters_tgt"]]), want)
+    if name.startswith("exit_"):
+        assert want.min() < 10 and float(fx["sk_margin"]) > 0.03
 
 
 def test_synth_inputs_are_reproducible(golden):

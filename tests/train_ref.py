@@ -114,9 +114,13 @@ class RefTrainOps(TrainOps):
 
     def gmm_em(self, xyz, o, ids_j):
         C, N, _ = xyz.shape
-        gamma, pi, mu, _, ids = O.weighted_em(xyz, xyz.new_zeros(C, N, 1), o, ids_j.shape[1], iters=10, tau=1.0)
-        assert torch.equal(ids, ids_j)
-        return gamma, pi, mu
+        B = C // 2          # src clouds | tgt clouds: two wkeans_plus calls (the Sinkhorn early exit averages over one call's clouds)
+        outs = []
+        for h in (slice(0, B), slice(B, C)):
+            gamma, pi, mu, _, ids = O.weighted_em(xyz[h], xyz.new_zeros(B, N, 1), o[h], ids_j.shape[1], iters=10, tau=1.0)
+            assert torch.equal(ids, ids_j[h])
+            outs.append((gamma, pi, mu))
+        return tuple(torch.cat(t) for t in zip(*outs))
 
 
 def params_from_fixture_spec(D, dtype=torch.float32):
