@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 15
+#define OGMM_ABI_VERSION 16
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -134,6 +134,13 @@ typedef struct ogmm_gemm {
      * the caller zeroes and afterwards sums the mask + 1 copies).  One copy (mask 0) serialises the atomics of every row tile of a group on the same
      * addresses: fine for <= 512 tiles, 12x slower than a separate pass on the 5.2 M-row per-edge maps of the training step (10240 tiles per group). */
     int32_t col_stats_slot_mask; int64_t col_stats_slot_stride;
+    /* Per-layer term budget (OGMM_PREC_F16X3_FRAG): how many binary16 matrix instructions a product block may be evaluated with.
+     *   0 or 3: a_lo w_hi + a_hi w_lo + a_hi w_hi (fp32-class, the default);
+     *   2:      (a_hi + a_lo) w_hi -- the WEIGHT operand B is rounded to binary16 (its lo plane is not read), the activation keeps both terms.
+     * A permission, not an order: engines / shapes without the cheaper form run all three terms (results then differ from the two-term form
+     * by the weight's rounding, 2^-12 relative per product).  Which layers of the path tolerate it -- R, t within 1e-5 of the reference over the
+     * parity distribution -- is measured, not assumed: tools/term_budget.py (CPU oracle with the same rounding) and DESIGN.md section 4. */
+    int32_t terms;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);

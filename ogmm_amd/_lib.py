@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -36,6 +36,7 @@ class GemmDesc(Structure):
         ("rd_w", c_void_p), ("rd_b", c_void_p), ("rd_act", c_int32), ("rd_out", c_void_p), ("rd_ld", c_int64),
         ("a_gather_ids", c_void_p), ("a_gather_map", c_void_p), ("a_gather_S", c_int32), ("a_gather_N", c_int32), ("a_gather_rows", c_int64),
         ("col_stats_slot_mask", c_int32), ("col_stats_slot_stride", c_int64),
+        ("terms", c_int32),
     ]
 
 

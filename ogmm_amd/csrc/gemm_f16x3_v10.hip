@@ -32,8 +32,14 @@ __device__ unsigned long long g_v10_probe[4];
 // OVL: the GEMM is the batched similarity S = fn_src fn_tgt^T of the overlap block (models/gmmreg.py:75-80) and S is never stored: the epilogue
 // forms e = exp(S - 1) (|S| <= 1 for normalised rows, so no running maximum is needed: softmax(S) = e / sum e) and leaves, per tile, the partial
 // softmax-dots of its 256 rows against o_tgt and of its 256 columns against o_src as (1, sum e, sum e o) triples; ogmm_overlap_finalize merges them.
-template <int ABL, bool AFF, bool OVL>
+// TERMS: matrix instructions per product block (struct ogmm_gemm.terms; the per-layer term budget of DESIGN.md section 4).
+//   3  lo*hi + hi*lo + hi*hi: fp32-class, the default
+//   2  lo*hi + hi*hi = (a_hi + a_lo) w_hi: the WEIGHT is rounded to binary16, the activation keeps both terms.  The lo plane of the weight image
+//      is not even fetched: 4 instead of 8 weight DMA instructions and 16 instead of 32 fragment reads per K step and wave.
+// Both run the same instruction schedule: a group is 4 TERMS matrix instructions, and everything else sits in the gaps m = 0..7 of a group.
+template <int ABL, bool AFF, bool OVL, int TERMS = 3>
 __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
+    static_assert(TERMS == 3 || (TERMS == 2 && !AFF), "TERMS = 2 has no InstanceNorm-on-A form (its transform pieces need the gaps of 12 MFMAs)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
 
     const int bid = blockIdx.x;
@@ -173,12 +179,12 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
         const unsigned char* Bs = smem10 + B_OFF + (tau % B_STAGES) * B_STAGE + b_rd;
         const int s = grp >> 2, q = grp & 3;
         bh[grp & 1][c] = *reinterpret_cast<const f16x8*>(Bs + (((2 * q + c) * 2 + s) * 2 + 0) * 1024);
-        bl[grp & 1][c] = *reinterpret_cast<const f16x8*>(Bs + (((2 * q + c) * 2 + s) * 2 + 1) * 1024);
+        if (TERMS == 3) bl[grp & 1][c] = *reinterpret_cast<const f16x8*>(Bs + (((2 * q + c) * 2 + s) * 2 + 1) * 1024);
     };
 
-    // ---- prologue.  DMA order B(0), A(0), A(1): the counted waits below rely on it.
+    // ---- prologue.  DMA order B(0), A(0), A(1): the counted waits below rely on it.  (TERMS < 3: only the hi plane = the even pieces)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) issue_b_piece(0, i);
+    for (int i = 0; i < 8; i += (TERMS == 3 ? 1 : 2)) issue_b_piece(0, i);
 #pragma unroll
     for (int i = 0; i < 8; ++i) issue_a_piece(0, i);
     if (nk > 1) {
@@ -224,8 +230,8 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
             const f16x8 ah1 = __builtin_shufflevector(ahh[1][s][0], ahh[1][s][1], 0, 1, 2, 3, 4, 5, 6, 7);
             const f16x8 al1 = __builtin_shufflevector(alh[1][s][0], alh[1][s][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-            for (int m = 0; m < 12; ++m) {
-                const int prod = m >> 2, rb = (m >> 1) & 1, c = m & 1;
+            for (int m = 0; m < 4 * TERMS; ++m) {
+                const int prod = TERMS == 3 ? m >> 2 : (m >> 2) * 2, rb = (m >> 1) & 1, c = m & 1;          // TERMS = 2: products 0 (lo*hi) and 2 (hi*hi)
                 const f16x8 av = prod == 0 ? (rb ? al1 : al0) : (rb ? ah1 : ah0);
                 const f16x8 bv = prod == 1 ? bl[p][c] : bh[p][c];
                 const bool fresh = FIRST && s == 0 && prod == 0;
@@ -234,8 +240,8 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                 else acc1[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, fresh ? zero : acc1[2 * q + c], 0, 0, 0);
                 // ---- the gap after MFMA m
                 if (!(ABL & 1) && (m == 0 || m == 3)) {
-                    const int pc = 2 * gl + (m == 3);
-                    if (!second) { if (HAS_B) issue_b_piece(t + 1, pc); }
+                    const int pc = 2 * gl + (m == 3);          // (weights: even pieces = hi plane, odd = lo plane)
+                    if (!second) { if (HAS_B && (TERMS == 3 || m == 0)) issue_b_piece(t + 1, pc); }
                     else { if (HAS_A) issue_a_piece(t + 2, pc); }
                 }
                 if (!(ABL & 4) && grp < 7 && (m == 1 || m == 2)) read_b(t, grp + 1, m - 1);
@@ -250,7 +256,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                     const int tau = second ? t + 1 : t, sn = second ? 0 : 1;
                     if (m == 4) {
                         // own activation pieces of stage t+1 landed: younger are the 8 weight pieces of this step and the 2 activation pieces of this group
-                        if (second && !(ABL & 1)) { if (HAS_A) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+                        if (second && !(ABL & 1)) {
+                            if (TERMS == 3) { if (HAS_A) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+                            else { if (HAS_A) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }          // 4 weight pieces per step
+                        }
                         if (!(ABL & 16)) read_a(tau, sn, 0);
                     }
                     if (m == 5 && !(ABL & 16)) read_a(tau, sn, 1);
@@ -416,16 +425,16 @@ bool gemm_f16x3_v10_applicable(const ogmm_gemm& g) {
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 
-template <int ABL, bool AFF = false, bool OVL = false>
+template <int ABL, bool AFF = false, bool OVL = false, int TERMS = 3>
 static int launch_v10(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static ogmm::PerDeviceOnce attr_once;          // per template instance and device
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF, OVL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
     else
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
     return check_launch("ogmm_gemm_nt(f16x3 v10)");
 }
 
@@ -452,7 +461,12 @@ int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
         case 117: return launch_v10<2048 + 8 + 2 + 4 + 16>(g, s);    //   DMA + MFMA + barrier only
         case 118: return launch_v10<2048 + 8 + 1 + 2 + 4 + 16>(g, s);    //   MFMA + barrier only
         case 119: return launch_v10<2048 + 8 + 1 + 2>(g, s);     //   fragment reads + MFMA (no DMA, no split)
-        default: return g.ovl_rowpart ? launch_v10<0, false, true>(g, s) : g.a_scale ? launch_v10<0, true>(g, s) : launch_v10<0>(g, s);
+        case 120: return launch_v10<2048, false, false, 2>(g, s);          // clock probe, two-term form
+        case 121: return launch_v10<2048 + 8, false, false, 2>(g, s);      //   no stores
+        default:
+            if (g.ovl_rowpart) return g.terms == 2 ? launch_v10<0, false, true, 2>(g, s) : launch_v10<0, false, true>(g, s);
+            if (g.a_scale) return launch_v10<0, true>(g, s);          // (the InstanceNorm-on-A form has no two-term variant: terms is a permission, not an order)
+            return g.terms == 2 ? launch_v10<0, false, false, 2>(g, s) : launch_v10<0>(g, s);
     }
 }
 

@@ -258,7 +258,7 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
             OGMM_REQUIRE(gemm_f16x3_v6_applicable(g), "LDS-DMA engine not applicable"); return gemm_nt_f16x3_v6(g, s);
         case 100: case 101: case 102: case 103: case 104: case 105: case 106: case 107: case 108: case 109:            // LDS-DMA engine, 8 x 1 waves (v8)
             OGMM_REQUIRE(gemm_f16x3_v8_applicable(g), "LDS-DMA engine (v8) not applicable"); return gemm_nt_f16x3_v8(g, s);
-        case 110: case 111: case 112: case 113: case 114: case 115: case 116: case 117: case 118: case 119:            // LDS-DMA engine, 4 waves x (64 x 256) (v10)
+        case 110: case 111: case 112: case 113: case 114: case 115: case 116: case 117: case 118: case 119: case 120: case 121:            // LDS-DMA engine, 4 waves x (64 x 256) (v10)
             OGMM_REQUIRE(gemm_f16x3_v10_applicable(g), "LDS-DMA engine (v10) not applicable"); return gemm_nt_f16x3_v10(g, s);
         default: break;
     }

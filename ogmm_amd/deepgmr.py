@@ -94,23 +94,23 @@ class DeepGMR(nn.Module):
         if self._overflow is None or self._overflow.device != dev:
             self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         L = self._layers()
-        ops.DEFAULT_SPLIT, ops.DEFAULT_OVERFLOW, ops.F16_SINGLE_TERM = self.precision == "f16x3", self._overflow, False
+        eng = ops.Engine(self.precision, self._overflow)
         xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()                 # [C,N,3]
         idx = ops.knn(xyz, k)
         R_ = C * N
         xcat = torch.empty((R_, 512), dtype=torch.float32, device=dev)
         emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
-        if ops.DEFAULT_SPLIT and ops.edgeconv_fused_supported(k, emd):
+        if eng.split and ops.edgeconv_fused_supported(k, emd):
             ops.edgeconv_fused(xyz, idx, emd, xcat)
         else:
             h = ops.edgeconv_first(xyz, idx, L["emd1"], xcat[:, 0:64])
-            h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128])
-            h = ops.edgeconv_layer(h, L["emd3"], k, xcat[:, 128:256])
-            ops.edgeconv_layer(h, L["emd4"], k, xcat[:, 256:512], store=False)
-        feats = ops.conv1x1(xcat, L["emd5"], ACT_RELU)                                   # baseline/deepgmr.py:66-67
-        h = ops.conv1x1(feats, L["c0"], ACT_RELU)                                        # :69-70 (`CONV`, used='proj')
-        h = ops.conv1x1(h, L["c3"], ACT_RELU)
-        logits = ops.conv1x1(h, L["c6"], split=False) if J < 32 else ops.conv1x1(h, L["c6"])
+            h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128], eng=eng)
+            h = ops.edgeconv_layer(h, L["emd3"], k, xcat[:, 128:256], eng=eng)
+            ops.edgeconv_layer(h, L["emd4"], k, xcat[:, 256:512], store=False, eng=eng)
+        feats = ops.conv1x1(xcat, L["emd5"], ACT_RELU, eng=eng)                          # baseline/deepgmr.py:66-67
+        h = ops.conv1x1(feats, L["c0"], ACT_RELU, eng=eng)                               # :69-70 (`CONV`, used='proj')
+        h = ops.conv1x1(h, L["c3"], ACT_RELU, eng=eng)
+        logits = ops.conv1x1(h, L["c6"], split=False, eng=eng) if J < 32 else ops.conv1x1(h, L["c6"], eng=eng)
         gamma = ops.softmax_rows_(logits).view(C, N, J)                                  # :71-72, softmax over the J clusters
         # gmm_params(..., return_sigma=True)  (lib/utils.py:130-148): pi, mu, isotropic sigma
         pi = gamma.mean(dim=1)

@@ -27,6 +27,8 @@ from ._lib import OgmmError
 from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
+# measured budget (DESIGN.md section 4 "Per-layer term budget"): the two 1024-wide layers of conv2 feed nothing but the overlap scores
+TERM_BUDGET = {"conv2.0": 2, "conv2.3": 2, "sattn1.q": 2, "cattn.q": 2, "sattn2.q": 2, "similarity": 2}
 
 
 # ------------------------------------------------------------------------------------------ parameters
@@ -224,6 +226,11 @@ class GMMReg(nn.Module):
         # "f16": REDUCED precision for BASELINE configs[2] (quoted in bf16): the large GEMMs multiply only the leading binary16
         #        terms (11-bit mantissa >= bf16's 8, fp32 accumulate); R / t then agree with the reference to ~1e-4, not 1e-5.
         self.precision = getattr(config, "precision", "f16x3")
+        # Per-layer term budget of the fp16 split engine (struct ogmm_gemm.terms): layer -> 2 runs that layer with the WEIGHT operand rounded to
+        # binary16 ((a_hi + a_lo) w_hi: two matrix instructions per product block instead of three, x0.74-0.81 of the layer's time).  Only layers whose
+        # rounding was measured to leave (R, t) within the parity bar are listed -- on the CPU oracle with the same rounding (tools/term_budget.py)
+        # and on the GPU's parity distribution (tools/parity_distribution.py); DESIGN.md section 4 has the table.  {} = three terms everywhere.
+        self.term_budget = dict(TERM_BUDGET)
         self.sinkhorn_thresh = 1e-2      # lib/utils.py:73 (`thresh` default, which wkeans_plus :281 does not override); <= 0 runs every sweep
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self.fold_conv2_overlap = True      # conv2.net.6 and overlap.net.0 (two linear maps in a row) as one 1024 -> 256 layer
@@ -275,32 +282,32 @@ class GMMReg(nn.Module):
             self._packed_fp = self._fingerprint(list(sd.values()))
         return self._packed
 
-    def _transformer(self, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None):
+    def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0):
         """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D]; the anchors [C, M, D] are rows
         anchor_ids [C, M] of anchor_feats [C*N, D] (of the cloud cloud_map[c], if given): lib/utils.py:111-127."""
         D, H = self.emb_dims, self.config.num_heads
         dh, M = D // H, anchor_ids.shape[1]
         dev = x.device
-        q = ops.conv1x1(x, L["q"])
+        q = ops.conv1x1(x, L["q"], eng=eng, terms=q_terms)
         if ops.attention_supported(M, dh):
-            kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map)      # keys | values in one GEMM, rows gathered by its DMA
+            kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map, eng=eng)      # keys | values in one GEMM, rows gathered by its DMA
             o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H)
             if self.fold_merge:
                 mlp0, msg = L["mlp0_folded"], o                       # merge conv folded into mlp0's weights
             else:
-                mlp0, msg = L["mlp0"], ops.conv1x1(o, L["merge"])
-            if ops.DEFAULT_SPLIT and ops.instnorm_fusable(mlp0.get("split"), N):
+                mlp0, msg = L["mlp0"], ops.conv1x1(o, L["merge"], eng=eng)
+            if eng.split and ops.instnorm_fusable(mlp0.get("split"), N):
                 # InstanceNorm fused: statistics in mlp0's epilogue, normalise + ReLU while mlp3 stages its A operand
                 if stats is None:          # (the forward hands in a slice of a buffer zeroed on the side stream during the front end)
                     stats = torch.zeros((C, 2 * D, 2), dtype=torch.float64, device=dev)
-                z = ops.conv1x1(x, mlp0, x2=msg, col_stats=stats, group_rows=N)
+                z = ops.conv1x1(x, mlp0, x2=msg, col_stats=stats, group_rows=N, eng=eng)
                 a_sc, a_sh = ops.instnorm_finalize(stats, N, BN_EPS)
-                return ops.conv1x1(z, L["mlp3"], res=res, a_affine=(a_sc, a_sh, True), group_rows=N)
-            z = ops.conv1x1(x, mlp0, x2=msg)
+                return ops.conv1x1(z, L["mlp3"], res=res, a_affine=(a_sc, a_sh, True), group_rows=N, eng=eng)
+            z = ops.conv1x1(x, mlp0, x2=msg, eng=eng)
             ops.instnorm_relu_(z, C, N, BN_EPS)
-            return ops.conv1x1(z, L["mlp3"], res=res)
+            return ops.conv1x1(z, L["mlp3"], res=res, eng=eng)
         anchors = ops.gather_rows(anchor_feats, D, C, N, D, anchor_ids, cloud_map=cloud_map)
-        kk = ops.conv1x1(anchors.view(C * M, D), L["k"])
+        kk = ops.conv1x1(anchors.view(C * M, D), L["k"], eng=eng)
         vT = torch.empty((C, D, M), dtype=torch.float32, device=dev)            # V^T per cloud: rows = head-major channels
         ops.gemm_nt(L["v"]["W"], D, D, anchors, D, D, M, C=vT, ldc=M, shift=L["v"]["shift"], row_affine=True,
                     batch=(C, 1), sB=(M * D, 0), sC=(D * M, 0))
@@ -310,17 +317,17 @@ class GMMReg(nn.Module):
         ops.softmax_rows_(S.view(C * H * N, M))
         o = torch.empty((C * N, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(S, M, M, vT, M, N, dh, C=o, ldc=D, batch=(C, H), sA=(H * N * M, N * M), sB=(D * M, dh * M), sC=(N * D, dh))
-        msg = ops.conv1x1(o, L["merge"])
-        z = ops.conv1x1(x, L["mlp0"], x2=msg)
+        msg = ops.conv1x1(o, L["merge"], eng=eng)
+        z = ops.conv1x1(x, L["mlp0"], x2=msg, eng=eng)
         ops.instnorm_relu_(z, C, N, BN_EPS)
-        return ops.conv1x1(z, L["mlp3"], res=res)
+        return ops.conv1x1(z, L["mlp3"], res=res, eng=eng)
 
     @staticmethod
-    def _stack3(S, x, x2=None):
+    def _stack3(eng, S, x, x2=None):
         """models/dgcnn.py:19-28 (`CONV`, used='proj') with a Cout > 1 last layer."""
-        h = ops.conv1x1(x, S["0"], ACT_RELU, x2=x2)
-        h = ops.conv1x1(h, S["3"], ACT_RELU)
-        return ops.conv1x1(h, S["6"])
+        h = ops.conv1x1(x, S["0"], ACT_RELU, x2=x2, eng=eng)
+        h = ops.conv1x1(h, S["3"], ACT_RELU, eng=eng)
+        return ops.conv1x1(h, S["6"], eng=eng)
 
     def forward(self, src, tgt, is_test=False, fps_starts=None, capture=False):
         """models/gmmreg.py:50-119.  `fps_starts` (int64/int32 [6,B], optional) pins the six `torch.randint` draws of
@@ -348,9 +355,8 @@ class GMMReg(nn.Module):
             return self._forward_train(src, tgt, fps_starts, capture, is_test)
         L = self._layers()
         cap = {} if capture else None
-        ops.DEFAULT_SPLIT = self.precision in ("f16x3", "f16")
-        ops.F16_SINGLE_TERM = self.precision == "f16"
-        ops.DEFAULT_OVERFLOW = self._overflow
+        eng = ops.Engine(self.precision, self._overflow)          # this model's engine choice travels with every call: no process-wide switch
+        tb = self.term_budget if self.precision == "f16x3" else {}
 
         if fps_starts is None:
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
@@ -403,54 +409,56 @@ class GMMReg(nn.Module):
         R = C * N
         xcat = torch.empty((R, 512), dtype=torch.float32, device=dev)
         emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
-        if ops.DEFAULT_SPLIT and ops.edgeconv_fused_supported(k, emd):
+        if eng.split and ops.edgeconv_fused_supported(k, emd):
             ops.edgeconv_fused(xyz, idx, emd, xcat)                    # per-edge tensors stay on chip
         else:
             h = ops.edgeconv_first(xyz, idx, L["emd1"], xcat[:, 0:64])
-            h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128])
-            h = ops.edgeconv_layer(h, L["emd3"], k, xcat[:, 128:256])
-            ops.edgeconv_layer(h, L["emd4"], k, xcat[:, 256:512], store=False)
+            h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128], eng=eng)
+            h = ops.edgeconv_layer(h, L["emd3"], k, xcat[:, 128:256], eng=eng)
+            ops.edgeconv_layer(h, L["emd4"], k, xcat[:, 256:512], store=False, eng=eng)
             del h
-        emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU)
+        emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU, eng=eng)
 
         # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)
         main.wait_event(sel_done)
         x0 = torch.empty((R, D), dtype=torch.float32, device=dev)
-        ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2])
-        ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:])
+        ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2], eng=eng)
+        ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:], eng=eng)
 
         # ---- self-attention 1 + conv1 (gmmreg.py:54-57, 62-63)
-        t1 = self._transformer(L["sattn1"], x0, emb, ids_a[0], C, N, res=x0, stats=stats3[0])
-        ft = self._stack3(L["conv1"], t1)
+        t1 = self._transformer(eng, L["sattn1"], x0, emb, ids_a[0], C, N, res=x0, stats=stats3[0], q_terms=tb.get("sattn1.q", 0))
+        ft = self._stack3(eng, L["conv1"], t1)
         # ---- cross-attention: keys/values are the OTHER cloud's anchors (gmmreg.py:67-72)
-        f = self._transformer(L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap, stats=stats3[1])
+        f = self._transformer(eng, L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap, stats=stats3[1], q_terms=tb.get("cattn.q", 0))
 
         # ---- overlap scores (gmmreg.py:74-89)
-        ops.conv1x1_head(f, L["proj"]["0"], ACT_RELU, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW)      # proj.0 + proj.3
-        if self.fuse_overlap and D % 64 == 0 and ops.overlap_fusable(B, N, D):
+        ops.conv1x1_head(f, L["proj"]["0"], ACT_RELU, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW, eng=eng)      # proj.0 + proj.3
+        if self.fuse_overlap and D % 64 == 0 and ops.overlap_fusable(B, N, D, eng):
             # the N x N similarity never leaves the GEMM's accumulators: its epilogue forms the partial softmax-dots (struct ogmm_gemm.ovl_rowpart)
             tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)        # B operand: the tgt half, normalised and split in one pass
             ops.overlap_fused(f[:B * N], tgt_img, B, N, D, extra[:B * N, 1], extra[B * N:, 1], XW, extra[:B * N, 0], extra[B * N:, 0], XW,
-                              overflow=self._overflow)
+                              overflow=self._overflow, terms=tb.get("similarity", 0))
         else:
             S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-            if ops.DEFAULT_SPLIT and D % 64 == 0:
+            if eng.split and D % 64 == 0:
                 fn_src = ops.l2norm_rows(f[:B * N])                            # A operand: the src half, normalised
                 tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)
-                ops.gemm_nt(fn_src, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img, overflow=self._overflow)
+                ops.gemm_nt(fn_src, D, D, None, D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sC=(N * N, 0), split=tgt_img, overflow=self._overflow,
+                            single_term=eng.single_term)
             else:
                 fn = ops.l2norm_rows(f)
                 ops.gemm_nt(fn, D, D, fn[B * N:], D, N, N, C=S, ldc=N, batch=(B, 1), sA=(N * D, 0), sB=(N * D, 0), sC=(N * N, 0))
             ops.overlap_cross(S, extra[:B * N, 1], extra[B * N:, 1], XW, extra[:B * N, 0], extra[B * N:, 0], XW)
             del S
         if self.fold_conv2_overlap:
-            h2 = ops.conv1x1(ops.conv1x1(f, L["conv2"]["0"], ACT_RELU, x2=extra), L["conv2"]["3"], ACT_RELU)
-            g = ops.conv1x1(h2, L["conv2_6_overlap_0"], ACT_RELU)            # conv2.net.6 and overlap.net.0 as one layer (pack_weights)
+            h2 = ops.conv1x1(ops.conv1x1(f, L["conv2"]["0"], ACT_RELU, x2=extra, eng=eng, terms=tb.get("conv2.0", 0)), L["conv2"]["3"], ACT_RELU, eng=eng,
+                             terms=tb.get("conv2.3", 0))
+            g = ops.conv1x1(h2, L["conv2_6_overlap_0"], ACT_RELU, eng=eng)            # conv2.net.6 and overlap.net.0 as one layer (pack_weights)
         else:
-            fo = self._stack3(L["conv2"], f, x2=extra)
-            g = ops.conv1x1(fo, L["overlap"]["0"], ACT_RELU)
+            fo = self._stack3(eng, L["conv2"], f, x2=extra)
+            g = ops.conv1x1(fo, L["overlap"]["0"], ACT_RELU, eng=eng)
         o = torch.empty((C, N), dtype=torch.float32, device=dev)
-        ops.conv1x1_head(g, L["overlap"]["3"], ACT_RELU, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1)      # overlap.3 + overlap.6
+        ops.conv1x1_head(g, L["overlap"]["3"], ACT_RELU, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1, eng=eng)      # overlap.3 + overlap.6
 
         # ---- GMM E/M (needs only xyz and the overlap scores) on the side stream, next to self-attention 2 (gmmreg.py:92-101)
         side.wait_stream(main)
@@ -466,7 +474,7 @@ class GMMReg(nn.Module):
         o.record_stream(side)
         for t_ in (gamma, pi, mu):
             t_.record_stream(main)
-        f2 = self._transformer(L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2])
+        f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0))
         main.wait_event(em_done)
 
         # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)
@@ -519,7 +527,6 @@ class GMMReg(nn.Module):
         cap = {} if capture else None
         if self.precision not in ("f16x3", "f32"):
             raise OgmmError("training runs with precision 'f16x3' or 'f32' (the reduced 'f16' mode is inference only)")
-        ops.F16_SINGLE_TERM = False         # module-level engine switch of the eval path: never inherit it from an earlier reduced-precision forward
         backend = self._train_ops if self._train_ops is not None else train_ops.TrainOps(self.precision, self._overflow)
         out = train_graph.forward_train(backend, P, self.config, self.n_clusters, src, tgt, fps_starts.to(src.device), cap)
         if capture:

@@ -29,10 +29,23 @@ def recycle_timing_events(timeline):
     for e0, e1, *_ in timeline:
         _EVENT_POOL.append(e0); _EVENT_POOL.append(e1)
 
-# engine selection for layers that carry pre-split weights (set by GMMReg.forward from model.precision)
-DEFAULT_SPLIT = True
-DEFAULT_OVERFLOW = None      # device int32[1]: set non-zero by the fp16x3 engine when |activation| > 65504 was clamped
-F16_SINGLE_TERM = False      # model.precision == "f16": the large-shape engine multiplies only the leading binary16 terms (reduced precision)
+class Engine:
+    """Which GEMM engine the layers of ONE model run on, and where that model's binary16-overflow flag lives.  Every model owns one and passes it
+    down explicitly (`eng=`): two models with different `precision` in one process -- or on two threads -- do not see each other's choice.
+      split        layers that carry pre-split weights run on the fp16x3 matrix-core engine (False: exact-fp32 engine)
+      single_term  precision "f16": the large-shape engine multiplies only the leading binary16 terms (REDUCED precision)
+      overflow     device int32[1] or None: set non-zero by the fp16 engines when |activation| > 65504 was clamped"""
+    __slots__ = ("split", "single_term", "overflow")
+
+    def __init__(self, precision="f16x3", overflow=None):
+        if precision not in ("f16x3", "f32", "f16"):
+            raise _lib.OgmmError("precision must be 'f16x3', 'f32' or 'f16' (reduced: single binary16 term in the large GEMMs)")
+        self.split = precision in ("f16x3", "f16")
+        self.single_term = precision == "f16"
+        self.overflow = overflow
+
+
+DEFAULT_ENGINE = Engine()      # for direct calls of the functions below (tests, tools); models never modify it
 
 
 def _stream():
@@ -174,7 +187,7 @@ def split_f16_training(W, key, refresh=64, **kw):
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
             pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0,
-            overlap=None, row_rscale=None, head=None, a_gather=None):
+            overlap=None, row_rscale=None, head=None, a_gather=None, single_term=False, terms=0):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -183,7 +196,7 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.B, d.ldb = (B.data_ptr() if B is not None else None), ldb
     if split is not None:
         d.precision = split.get("variant", PREC_F16X3)
-        if F16_SINGLE_TERM and d.precision == PREC_F16X3_FRAG:
+        if single_term and d.precision == PREC_F16X3_FRAG:
             d.precision = PREC_F16_FRAG
         d.B_hi, d.B_lo, d.ldb_h = split["W_hi"].data_ptr(), split["W_lo"].data_ptr(), split.get("ldb_h", split["W_hi"].shape[-1])
         d.overflow = overflow.data_ptr() if overflow is not None else None
@@ -206,6 +219,7 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.act = act
     d.pool_k, d.pool_out, d.ldp, d.store_c = pool_k, (pool_out.data_ptr() if pool_out is not None else None), ldp, 1 if store_c else 0
     d.group_rows = group_rows
+    d.terms = terms          # per-layer term budget (struct ogmm_gemm.terms): 2 = the weight operand rounded to binary16 where the engine has the form
     if col_stats is not None:          # [G, N, 2] or, spread over 2^n copies that the caller sums, [2^n, G, N, 2] (struct ogmm_gemm.col_stats_slot_mask)
         d.col_stats = col_stats.data_ptr()
         if col_stats.dim() == 4:
@@ -259,16 +273,18 @@ def instnorm_finalize(col_stats, rows, eps=1e-5):
     return scale, shift
 
 
-def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0, head=None, store=True):
+def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0, head=None, store=True,
+            eng=None, terms=0):
     """y[rows, Cout] = act((x | x2)[rows, K] @ W^T * scale + shift) + res for a packed layer
     (dict with W [Cout, Kpad], scale, shift -- see gmmreg.pack_*).  x, x2, res, out may be column views
     of wider row-major buffers (last stride 1).  split=True uses the layer's pre-split weights (fp16x3 engine)
-    when the layer carries them."""
+    when the layer carries them; eng: the calling model's Engine (split / overflow default to its settings)."""
     x = _f32(x, "x")
     rows, K1 = x.shape
     assert x.stride(1) == 1
-    split = DEFAULT_SPLIT if split is None else split
-    overflow = DEFAULT_OVERFLOW if overflow is None else overflow
+    eng = eng or DEFAULT_ENGINE
+    split = eng.split if split is None else split
+    overflow = eng.overflow if overflow is None else overflow
     W = layer["W"]
     Cout, Kp = W.shape
     K2 = 0
@@ -285,7 +301,8 @@ def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, ove
             A2=x2, lda2=(x2.stride(0) if x2 is not None else 0), K2=K2,
             scale=layer.get("scale"), shift=layer.get("shift"), act=act,
             res=res, ldr=(res.stride(0) if res is not None else 0),
-            split=(layer.get("split") if split else None), overflow=overflow, col_stats=col_stats, a_affine=a_affine, group_rows=group_rows)
+            split=(layer.get("split") if split else None), overflow=overflow, col_stats=col_stats, a_affine=a_affine, group_rows=group_rows,
+            single_term=eng.single_term, terms=terms)
     return out
 
 
@@ -313,12 +330,13 @@ def edgeconv_fused(xyz, idx, layers, xcat):
     return xcat
 
 
-def edgeconv_layer(h, layer, k, pool_out, store=True, split=None, overflow=None):
+def edgeconv_layer(h, layer, k, pool_out, store=True, split=None, overflow=None, eng=None):
     """conv + BN + ReLU on the per-edge tensor h [E, Cin] with max over each point's k edges fused in
     (models/dgcnn.py:141-148).  Returns the un-pooled [E, Cout] (None when store=False)."""
     E, Cin = h.shape
-    split = DEFAULT_SPLIT if split is None else split
-    overflow = DEFAULT_OVERFLOW if overflow is None else overflow
+    eng = eng or DEFAULT_ENGINE
+    split = eng.split if split is None else split
+    overflow = eng.overflow if overflow is None else overflow
     W = layer["W"]
     Cout = W.shape[0]
     out = torch.empty((E, Cout), dtype=torch.float32, device=h.device) if store else None
@@ -440,35 +458,37 @@ def l2norm_rows(x, out=None):
     return out
 
 
-def conv1x1_gathered(feats, C, N, ids, layer, act=ACT_NONE, cloud_map=None):
+def conv1x1_gathered(feats, C, N, ids, layer, act=ACT_NONE, cloud_map=None, eng=None):
     """conv1x1(gather_rows(feats, ids, cloud_map), layer): a convolution over the anchor rows of every cloud (models/gmmreg.py:54, 67-68).  Where the
     engine takes it, the rows are gathered by the GEMM's own operand DMA (struct ogmm_gemm.a_gather_*) and the anchor tensor is never written."""
     feats, ids = _f32(feats, "feats"), _i32(ids, "ids")
     rows, D = feats.shape
     S = ids.shape[1]
     Cout = layer["W"].shape[0]
-    sp = layer.get("split") if DEFAULT_SPLIT else None
-    if (FUSE_GATHER and sp is not None and sp.get("variant") == PREC_F16X3_FRAG and not F16_SINGLE_TERM and feats.stride(1) == 1 and ids.is_contiguous()
+    eng = eng or DEFAULT_ENGINE
+    sp = layer.get("split") if eng.split else None
+    if (FUSE_GATHER and sp is not None and sp.get("variant") == PREC_F16X3_FRAG and not eng.single_term and feats.stride(1) == 1 and ids.is_contiguous()
             and _lib.load().ogmm_gemm_gather_fusable(C * S, Cout, D, rows) == 1):
         out = torch.empty((C * S, Cout), dtype=torch.float32, device=feats.device)
         cm = _i32(cloud_map, "cloud_map") if cloud_map is not None else None
         gemm_nt(feats, feats.stride(0), D, layer["W"], D, C * S, Cout, C=out, ldc=Cout, scale=layer.get("scale"), shift=layer.get("shift"), act=act,
-                split=sp, overflow=DEFAULT_OVERFLOW, a_gather=(ids, cm, N, rows))
+                split=sp, overflow=eng.overflow, a_gather=(ids, cm, N, rows))
         return out
-    return conv1x1(gather_rows(feats, feats.stride(0), C, N, D, ids, cloud_map=cloud_map).view(C * S, D), layer, act)
+    return conv1x1(gather_rows(feats, feats.stride(0), C, N, D, ids, cloud_map=cloud_map).view(C * S, D), layer, act, eng=eng)
 
 
-def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None):
+def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None, eng=None):
     """out[row * ldy] = head_act(act(conv1x1(x, layer))[row] . w + b): a layer followed by a Cout = 1 convolution (models/gmmreg.py:30-47: proj, overlap).
     Where the engine takes it (N = 256, whole row tiles) the head runs in the layer's epilogue and the 256-wide map is never written."""
     rows, K1 = x.shape
     Cout = layer["W"].shape[0]
     K2 = x2.shape[1] if x2 is not None else 0
-    sp = layer.get("split") if DEFAULT_SPLIT else None
-    if (FUSE_HEAD and sp is not None and sp.get("variant") == PREC_F16X3_FRAG and not F16_SINGLE_TERM and _lib.load().ogmm_gemm_rowdot_fusable(rows, Cout, K1, K2) == 1):
-        conv1x1(x, layer, act, x2=x2, head=(w, b, head_act, out, ldy), store=False)
+    eng = eng or DEFAULT_ENGINE
+    sp = layer.get("split") if eng.split else None
+    if (FUSE_HEAD and sp is not None and sp.get("variant") == PREC_F16X3_FRAG and not eng.single_term and _lib.load().ogmm_gemm_rowdot_fusable(rows, Cout, K1, K2) == 1):
+        conv1x1(x, layer, act, x2=x2, head=(w, b, head_act, out, ldy), store=False, eng=eng)
         return
-    rowdot(conv1x1(x, layer, act, x2=x2), w, b, head_act, out, ldy=ldy)
+    rowdot(conv1x1(x, layer, act, x2=x2, eng=eng), w, b, head_act, out, ldy=ldy)
 
 
 def rowdot(x, w, b, act, out, ldy=1):
@@ -484,9 +504,10 @@ def _overlap_ws(B, N, device):
     return ws
 
 
-def overlap_fusable(B, N, D):
+def overlap_fusable(B, N, D, eng=None):
     """True if the similarity GEMM can run the overlap block's softmax-dots in its epilogue (struct ogmm_gemm.ovl_rowpart)."""
-    return bool(DEFAULT_SPLIT) and not F16_SINGLE_TERM and _lib.load().ogmm_gemm_overlap_fusable(B, N, D) == 1
+    eng = eng or DEFAULT_ENGINE
+    return bool(eng.split) and not eng.single_term and _lib.load().ogmm_gemm_overlap_fusable(B, N, D) == 1
 
 
 def row_rnorm(x):
@@ -497,7 +518,7 @@ def row_rnorm(x):
     return out
 
 
-def overlap_fused(f_src, tgt_img, B, N, D, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, overflow=None):
+def overlap_fused(f_src, tgt_img, B, N, D, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, overflow=None, terms=0):
     """models/gmmreg.py:75-80 without the similarity matrix: S = normalize(f_src) normalize(f_tgt)^T lives only in the GEMM's accumulators.
     f_src [B*N, D] un-normalised (its 1/|row| is a row scale), tgt_img = l2norm_pack_frag_batched(f_tgt); o_* / wo_* as overlap_cross."""
     nt = N // 256
@@ -505,7 +526,7 @@ def overlap_fused(f_src, tgt_img, B, N, D, o_src, o_tgt, ldo_in, wo_src, wo_tgt,
     colpart = torch.empty((B, nt, N, 3), dtype=torch.float32, device=f_src.device)
     rinv = row_rnorm(f_src)
     gemm_nt(f_src, f_src.stride(0), D, None, D, N, N, batch=(B, 1), sA=(N * f_src.stride(0), 0), split=tgt_img, overflow=overflow,
-            overlap=(o_tgt, o_src, ldo_in, rowpart, colpart), row_rscale=rinv)          # the reference weights the ROW softmax with src_o, indexed by column
+            overlap=(o_tgt, o_src, ldo_in, rowpart, colpart), row_rscale=rinv, terms=terms)          # the reference weights the ROW softmax with src_o, indexed by column
     _lib.call("ogmm_overlap_finalize", _p(rowpart), _p(colpart), B, N, _p(wo_src), _p(wo_tgt), ldo, _stream())
     for t in (rowpart, colpart, rinv):
         t.record_stream(torch.cuda.current_stream())

@@ -28,6 +28,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import split_emulation as _emu
+
 BN_EPS = 1e-5  # nn.BatchNorm*/nn.InstanceNorm1d default eps (models/dgcnn.py:126-130, models/attn.py:24)
 
 
@@ -217,7 +219,15 @@ def _bn(P, name, x):
 def _conv(P, name, x):
     w = P[name + '.weight']
     b = P.get(name + '.bias')
+    mode = _emu.mode_of(name)                                  # oracle/split_emulation.py: operand rounding of the HIP engines, off by default
+    if mode is not None:
+        return _emu.conv(x, w, b, mode)
     return F.conv2d(x, w, b) if w.dim() == 4 else F.conv1d(x, w, b)
+
+
+def _einsum(name, eq, a, b):
+    mode = _emu.mode_of(name)
+    return torch.einsum(eq, a, b) if mode is None else _emu.einsum(eq, a, b, mode)
 
 
 def dgcnn_embed(P, x, k, idx=None, cap=None):
@@ -263,8 +273,8 @@ def transformer(P, name, src, anchors, heads):
     q = _conv(P, name + '.attn.proj.0', src).view(B, dh, heads, -1)
     kk = _conv(P, name + '.attn.proj.1', anchors).view(B, dh, heads, -1)
     vv = _conv(P, name + '.attn.proj.2', anchors).view(B, dh, heads, -1)
-    prob = torch.softmax(torch.einsum('bdhn,bdhm->bhnm', q, kk) / dh ** .5, dim=-1)
-    msg = torch.einsum('bhnm,bdhm->bdhn', prob, vv).contiguous().view(B, D, -1)
+    prob = torch.softmax(_einsum(name + '.attn.qk', 'bdhn,bdhm->bhnm', q, kk) / dh ** .5, dim=-1)
+    msg = _einsum(name + '.attn.pv', 'bhnm,bdhm->bdhn', prob, vv).contiguous().view(B, D, -1)
     msg = _conv(P, name + '.attn.merge', msg)
     h = _conv(P, name + '.mlp.0', torch.cat([src, msg], dim=1))
     h = F.relu(F.instance_norm(h, eps=BN_EPS))
@@ -352,7 +362,7 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
         f[s] = transformer(P, 'cattn', ft[s], a1[other[s]], H) + ft[s]
         cap['f_' + s] = f[s]
     fn = {s: F.normalize(f[s]) for s in pts}                # gmmreg.py:74-80
-    sim = torch.einsum('bdm,bdn->bmn', fn['src'], fn['tgt'])
+    sim = _einsum('similarity', 'bdm,bdn->bmn', fn['src'], fn['tgt'])
     for s in pts:
         o_logit[s] = conv_stack(P, 'proj', f[s], False)
     wo = {'src': torch.einsum('bmn,bdn->bdm', torch.softmax(sim, dim=-1), o_logit['src']),

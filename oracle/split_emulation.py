@@ -1,0 +1,104 @@
+"""Operand-rounding emulation for the CPU oracle -- TEST INFRASTRUCTURE ONLY (same rules as oracle/ogmm_oracle.py).
+
+The HIP path's GEMM engine multiplies fp32 operands as sums of binary16 terms on the f16 matrix cores with fp32 accumulation
+(DESIGN.md section 2):   x = hi + lo,  hi = rn16(x),  lo = rn16(x - hi)   (22 significand bits)
+    "x3"   a b ~ hi hi + hi lo + lo hi          the default engine (OGMM_PREC_F16X3*): fp32-class
+    "x2a"  a b ~ hi (hi + lo)                   activation rounded to binary16, weight kept: 2 MFMAs per product block
+    "x2w"  a b ~ (hi + lo) hi                   weight rounded to binary16, activation kept: 2 MFMAs
+    "x1"   a b ~ hi hi                          both rounded (precision = "f16", the labelled reduced mode): 1 MFMA
+    "bf16" both operands rounded to bfloat16    what BASELINE configs[2] literally names; shown for comparison
+    "f32" / None  exact fp32 (the reference's arithmetic)
+This module restates those roundings on the CPU so that the oracle can answer, per layer, "what does rounding THIS layer's operands do to
+(R, t)?" -- the measurement behind the engine's per-layer term budget (tools/term_budget.py) and behind the stated tolerance of the reduced
+precision mode (tests/test_hip_forward.py::test_reduced_precision_mode_against_the_emulating_oracle).  It emulates the operand roundings, not
+the engine's summation order: products are exact in fp32 either way and both accumulate in fp32, so what is left is the order of additions,
+which the reference's own MKL GEMM does not pin either.
+
+Use:   with split_emulation.policy(lambda name: "x1" if name.startswith("conv2.") else None):  O.forward(...)
+Layer names are the reference's state_dict prefixes ("emd.conv2", "sattn1.mlp.0", "conv2.net.3", ...) plus the weight-free contractions
+"similarity" (models/gmmreg.py:75) and "<transformer>.attn.qk" / "<transformer>.attn.pv" (models/attn.py:79-81).
+"""
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+MODES = ("f32", "x3", "x2a", "x2w", "x1", "bf16")
+_POLICY = None          # callable(name) -> mode or None
+
+
+@contextlib.contextmanager
+def policy(fn):
+    """Installs `fn(layer_name) -> mode` for the duration of the block (None / "f32": exact)."""
+    global _POLICY
+    prev, _POLICY = _POLICY, fn
+    try:
+        yield
+    finally:
+        _POLICY = prev
+
+
+def mode_of(name):
+    if _POLICY is None:
+        return None
+    m = _POLICY(name)
+    if m is not None and m not in MODES:
+        raise ValueError("unknown emulation mode %r for %s" % (m, name))
+    return None if m == "f32" else m
+
+
+def rn16(x):
+    """round to nearest binary16 (overflow clamps to +-65504, as the engine's staging does)"""
+    return x.clamp(-65504.0, 65504.0).half().float()
+
+
+def split16(x, scale_pow2=False):
+    """x (fp32) -> (hi, lo, inv_scale): x * 2^e = hi + lo (+ 2^-22 relative); the engine scales WEIGHTS by a per-tensor power of two so that
+    max|W| 2^e is in [2^11, 2^12) and `lo` stays a normal binary16 number (ogmm_amd/ops.py split_f16); activations are split unscaled."""
+    inv = 1.0
+    if scale_pow2:
+        amax = float(x.abs().max())
+        if amax > 0 and math.isfinite(amax):
+            e = max(-24, min(24, 11 - math.floor(math.log2(amax))))
+            x = x * (2.0 ** e)
+            inv = 2.0 ** (-e)
+    hi = rn16(x)
+    return hi, rn16(x - hi), inv
+
+
+def _terms(a, w, mode, contract):
+    """a: activation-side operand, w: weight-side operand, contract(a', w') -> the fp32 contraction"""
+    if mode == "bf16":
+        return contract(a.bfloat16().float(), w.bfloat16().float())
+    ah, al, _ = split16(a)
+    wh, wl, inv = split16(w, scale_pow2=True)
+    y = contract(ah, wh)
+    if mode in ("x3", "x2a"):
+        y = y + contract(ah, wl)
+    if mode in ("x3", "x2w"):
+        y = y + contract(al, wh)
+    return y * inv
+
+
+def conv(x, w, b, mode):
+    """1x1 convolution (conv1d / conv2d by the weight's rank) with the operands rounded per `mode`; bias added in fp32"""
+    f = F.conv2d if w.dim() == 4 else F.conv1d
+    y = _terms(x, w, mode, lambda a_, w_: f(a_, w_))
+    if b is not None:
+        y = y + b.view(1, -1, *([1] * (y.dim() - 2)))
+    return y
+
+
+def einsum(eq, a, b, mode):
+    """weight-free contraction (similarity, attention scores / values): both operands are activations, `b` plays the B-operand role"""
+    if mode == "bf16":
+        return torch.einsum(eq, a.bfloat16().float(), b.bfloat16().float())
+    ah, al, _ = split16(a)
+    bh, bl, _ = split16(b)
+    y = torch.einsum(eq, ah, bh)
+    if mode in ("x3", "x2a"):
+        y = y + torch.einsum(eq, ah, bl)
+    if mode in ("x3", "x2w"):
+        y = y + torch.einsum(eq, al, bh)
+    return y
