@@ -40,7 +40,9 @@ __device__ unsigned long long g_v8_probe[4];
 
 // AFF: A is read as relu?(a * a_scale[group][k] + a_shift[group][k]) (InstanceNorm of the producing layer, models/attn.py:24-25), applied to the raw
 // fragment right after the ds_read, with the constants of the tile's row group staged once in LDS (a half wave reads the same 8 k: broadcast reads).
-template <int ABL, bool AFF, bool HEAD>
+// TERMS (struct ogmm_gemm.terms): 3 = lo*hi + hi*lo + hi*hi; 2 = lo*hi + hi*hi = (a_hi + a_lo) w_hi, the weight rounded to binary16 -- its lo plane is
+// neither fetched (2 instead of 4 weight DMA instructions per step and wave) nor read from LDS.  Same schedule, groups of 2 TERMS matrix instructions.
+template <int ABL, bool AFF, bool HEAD, int TERMS = 3>
 __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles, const int direct_stores) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
 
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
     };
     auto issue_b = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue_b_piece(t, i);
+        for (int i = 0; i < 4; i += (TERMS == 3 ? 1 : 2)) issue_b_piece(t, i);          // (even pieces: the hi plane)
     };
 
     f32x16 acc[NT];
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             bh[grp & 1][c] = *reinterpret_cast<const f16x8*>(Bs + (((2 * q + c) * 2 + s) * 2 + 0) * 1024);
-            bl[grp & 1][c] = *reinterpret_cast<const f16x8*>(Bs + (((2 * q + c) * 2 + s) * 2 + 1) * 1024);
+            if (TERMS == 3) bl[grp & 1][c] = *reinterpret_cast<const f16x8*>(Bs + (((2 * q + c) * 2 + s) * 2 + 1) * 1024);
         }
     };
 
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
             const int s = grp >> 2, q = grp & 3, p = grp & 1;
             __builtin_amdgcn_sched_barrier(0);
             if (!(ABL & 1)) {
-                if (grp < 4) { if (HAS_B) issue_b_piece(t + 1, grp); }
+                if (grp < 4) { if (HAS_B && (TERMS == 3 || !(grp & 1))) issue_b_piece(t + 1, grp); }
                 else { if (HAS_A) issue_a_piece(t + 2, grp - 4); }
             }
             if (grp == 1) read_a(t, 1);                        // raw fragment of k16 block 1 (ra is free: block 0 was split in the previous step)
@@ -206,7 +208,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
             if (grp == 2) split_a(1);                          // VALU in the shadow of this group's MFMAs
             if (HAS_B && grp == 5) {
                 // own activation pieces of stage t+1 landed: younger are the 4 weight pieces of this step and the activation pieces of groups 4, 5
-                if (!(ABL & 1)) { if (HAS_A) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                if (!(ABL & 1)) {
+                    if (TERMS == 3) { if (HAS_A) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    else { if (HAS_A) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }          // 2 weight pieces per step
+                }
                 read_a(t + 1, 0);
             }
             if (HAS_B && grp == 6) split_a(0);                 // ah[0] / al[0] were last used by group 3
@@ -214,8 +219,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
             // the two accumulators of the pair alternate (as v4 / v6 alternate two row blocks); per accumulator: lo*hi, hi*lo, hi*hi
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[p][c], acc[2 * q + c], 0, 0, 0);
+            if (TERMS == 3) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[p][c], acc[2 * q + c], 0, 0, 0);
+                for (int c = 0; c < 2; ++c) acc[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[p][c], acc[2 * q + c], 0, 0, 0);
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[p][c], acc[2 * q + c], 0, 0, 0);
         }
@@ -287,17 +294,17 @@ bool gemm_f16x3_v8_applicable(const ogmm_gemm& g) {
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 
-template <int ABL, bool AFF = false, bool HEAD = false>
+template <int ABL, bool AFF = false, bool HEAD = false, int TERMS = 3>
 static int launch_v8(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static const int direct = [] { const char* e = getenv("OGMM_V8_DIRECT"); return e ? atoi(e) : 1; }();
     static ogmm::PerDeviceOnce attr_once;          // per template instance and device
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL, AFF, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v8_kernel<ABL, AFF, HEAD, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF, HEAD>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles, direct);
+        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF, HEAD, TERMS>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles, direct);
     else
-        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF, HEAD>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles, direct);
+        hipLaunchKernelGGL((gemm_f16x3_v8_kernel<ABL, AFF, HEAD, TERMS>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles, direct);
     return check_launch("ogmm_gemm_nt(f16x3 v8)");
 }
 
@@ -319,7 +326,10 @@ int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s) {
         case 102: return launch_v8<2048>(g, s);                 // clock probe
         case 103: return launch_v8<2048 + 8>(g, s);             // clock probe, no stores
         case 104: return launch_v8<2048 + 8 + 1>(g, s);         //   no DMA after the prologue
-        default: return g.rd_out ? launch_v8<0, false, true>(g, s) : g.a_scale ? launch_v8<0, true>(g, s) : launch_v8<0>(g, s);
+        default:
+            if (g.rd_out) return g.terms == 2 ? launch_v8<0, false, true, 2>(g, s) : launch_v8<0, false, true>(g, s);
+            if (g.a_scale) return launch_v8<0, true>(g, s);          // (terms is a permission: the InstanceNorm-on-A form runs all three)
+            return g.terms == 2 ? launch_v8<0, false, false, 2>(g, s) : launch_v8<0>(g, s);
     }
 }
 

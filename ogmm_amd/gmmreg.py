@@ -432,7 +432,8 @@ class GMMReg(nn.Module):
         f = self._transformer(eng, L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap, stats=stats3[1], q_terms=tb.get("cattn.q", 0))
 
         # ---- overlap scores (gmmreg.py:74-89)
-        ops.conv1x1_head(f, L["proj"]["0"], ACT_RELU, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW, eng=eng)      # proj.0 + proj.3
+        ops.conv1x1_head(f, L["proj"]["0"], ACT_RELU, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW, eng=eng,
+                         terms=tb.get("proj.0", 0))      # proj.0 + proj.3
         if self.fuse_overlap and D % 64 == 0 and ops.overlap_fusable(B, N, D, eng):
             # the N x N similarity never leaves the GEMM's accumulators: its epilogue forms the partial softmax-dots (struct ogmm_gemm.ovl_rowpart)
             tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)        # B operand: the tgt half, normalised and split in one pass
@@ -453,12 +454,13 @@ class GMMReg(nn.Module):
         if self.fold_conv2_overlap:
             h2 = ops.conv1x1(ops.conv1x1(f, L["conv2"]["0"], ACT_RELU, x2=extra, eng=eng, terms=tb.get("conv2.0", 0)), L["conv2"]["3"], ACT_RELU, eng=eng,
                              terms=tb.get("conv2.3", 0))
-            g = ops.conv1x1(h2, L["conv2_6_overlap_0"], ACT_RELU, eng=eng)            # conv2.net.6 and overlap.net.0 as one layer (pack_weights)
+            g = ops.conv1x1(h2, L["conv2_6_overlap_0"], ACT_RELU, eng=eng, terms=tb.get("conv2.6+overlap.0", 0))            # conv2.net.6 and overlap.net.0 as one layer (pack_weights)
         else:
             fo = self._stack3(eng, L["conv2"], f, x2=extra)
             g = ops.conv1x1(fo, L["overlap"]["0"], ACT_RELU, eng=eng)
         o = torch.empty((C, N), dtype=torch.float32, device=dev)
-        ops.conv1x1_head(g, L["overlap"]["3"], ACT_RELU, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1, eng=eng)      # overlap.3 + overlap.6
+        ops.conv1x1_head(g, L["overlap"]["3"], ACT_RELU, L["overlap"]["6"]["w"], L["overlap"]["6"]["b"], ACT_SIGMOID, o, ldy=1, eng=eng,
+                         terms=tb.get("overlap.3", 0))      # overlap.3 + overlap.6
 
         # ---- GMM E/M (needs only xyz and the overlap scores) on the side stream, next to self-attention 2 (gmmreg.py:92-101)
         side.wait_stream(main)

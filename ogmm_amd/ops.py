@@ -17,6 +17,7 @@ GEMM_TIMELINE = None
 FUSE_GATHER = os.environ.get("OGMM_FUSE_GATHER", "1") != "0"      # anchor rows gathered by the consuming GEMM's operand DMA (conv1x1_gathered)
 FUSE_HEAD = os.environ.get("OGMM_FUSE_HEAD", "1") != "0"      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
 GEMM_TIMELINE_ONLY = None      # optional set of variant tags: only those launches are bracketed by events (bench.py: the dominant engine only)
+KERNEL_TIMELINE = None         # bench.py: a list -> the EdgeConv and attention launches are bracketed too: (start_event, end_event, name, algorithmic flops, algorithmic bytes)
 _EVENT_POOL = []               # timing events are recycled: creating two torch events per launch costs more host time than the launch itself
 
 
@@ -28,6 +29,18 @@ def recycle_timing_events(timeline):
     """hand the events of a consumed GEMM_TIMELINE back to the pool"""
     for e0, e1, *_ in timeline:
         _EVENT_POOL.append(e0); _EVENT_POOL.append(e1)
+
+
+def _timed_call(name, flops, nbytes, fn_name, *args):
+    """_lib.call, bracketed by events when bench.py collects KERNEL_TIMELINE"""
+    if KERNEL_TIMELINE is None:
+        _lib.call(fn_name, *args)
+        return
+    e0, e1 = _timing_event(), _timing_event()
+    e0.record()
+    _lib.call(fn_name, *args)
+    e1.record()
+    KERNEL_TIMELINE.append((e0, e1, name, flops, nbytes))
 
 class Engine:
     """Which GEMM engine the layers of ONE model run on, and where that model's binary16-overflow flag lives.  Every model owns one and passes it
@@ -256,7 +269,9 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     # flops, then the launch's algorithmic HBM bytes: A (and A2) read once, C written once, residual read once, weights once
     nb = batch[0] * batch[1]
     abytes = 4.0 * nb * (M * (K1 + K2) + (M * N if store_c else 0) + (M * N if res is not None else 0)) + 4.0 * N * (K1 + K2) * (nb if batch != (1, 1) else 1)
-    GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * nb, variant, abytes))
+    # matrix instructions issued per algorithmic product: 3 (split engines), 2 where the two-term form runs (fragment-major image, no A transform), 1 (fp32 engine, reduced mode)
+    issued = 1 if split is None or (single_term and d.precision == PREC_F16_FRAG) else (2 if terms == 2 and split.get("variant") == PREC_F16X3_FRAG and a_affine is None and pool_k == 0 and N >= 256 else 3)
+    GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * nb, variant, abytes, issued))
 
 
 def instnorm_fusable(layer_split, N):
@@ -326,7 +341,10 @@ def edgeconv_fused(xyz, idx, layers, xcat):
     for l in layers[1:]:
         sp = l["split"]
         args += [_p(sp["W_hi"]), _p(sp["W_lo"]), _p(l["scale"]), _p(l["shift"]), sp["inv_scale"]]
-    _lib.call("ogmm_edgeconv_fused", *args, _p(xcat), xcat.stride(0), _stream())
+    # algorithmic work: the four 1x1 convolutions over C*N*k edges (models/dgcnn.py:121-124); bytes: xyz + idx in, xcat out
+    E = float(C) * N * k
+    _timed_call("edgeconv_fused_kernel", 2.0 * E * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 256), 4.0 * (3 * C * N + E + 512.0 * C * N),
+                "ogmm_edgeconv_fused", *args, _p(xcat), xcat.stride(0), _stream())
     return xcat
 
 
@@ -396,8 +414,10 @@ def attention(q, k, v, C, N, M, H, out=None, use_workspace=True):
     if use_workspace:
         nbytes = _lib.load().ogmm_attention_workspace_bytes(C, M, H, dh)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-    _lib.call("ogmm_attention", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0), C, N, M, H, dh,
-              1.0 / dh ** .5, _p(out), out.stride(0), _p(ws), _stream())
+    # algorithmic work: Q K^T and P V per head; bytes: Q in, O out, K and V in
+    _timed_call("attention_t_kernel", 4.0 * C * N * M * D, 4.0 * (2.0 * C * N * D + 2.0 * C * M * D),
+                "ogmm_attention", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0), C, N, M, H, dh,
+                1.0 / dh ** .5, _p(out), out.stride(0), _p(ws), _stream())
     return out
 
 
@@ -477,7 +497,7 @@ def conv1x1_gathered(feats, C, N, ids, layer, act=ACT_NONE, cloud_map=None, eng=
     return conv1x1(gather_rows(feats, feats.stride(0), C, N, D, ids, cloud_map=cloud_map).view(C * S, D), layer, act, eng=eng)
 
 
-def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None, eng=None):
+def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None, eng=None, terms=0):
     """out[row * ldy] = head_act(act(conv1x1(x, layer))[row] . w + b): a layer followed by a Cout = 1 convolution (models/gmmreg.py:30-47: proj, overlap).
     Where the engine takes it (N = 256, whole row tiles) the head runs in the layer's epilogue and the 256-wide map is never written."""
     rows, K1 = x.shape
@@ -486,9 +506,9 @@ def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None, eng=None):
     eng = eng or DEFAULT_ENGINE
     sp = layer.get("split") if eng.split else None
     if (FUSE_HEAD and sp is not None and sp.get("variant") == PREC_F16X3_FRAG and not eng.single_term and _lib.load().ogmm_gemm_rowdot_fusable(rows, Cout, K1, K2) == 1):
-        conv1x1(x, layer, act, x2=x2, head=(w, b, head_act, out, ldy), store=False, eng=eng)
+        conv1x1(x, layer, act, x2=x2, head=(w, b, head_act, out, ldy), store=False, eng=eng, terms=terms)
         return
-    rowdot(conv1x1(x, layer, act, x2=x2, eng=eng), w, b, head_act, out, ldy=ldy)
+    rowdot(conv1x1(x, layer, act, x2=x2, eng=eng, terms=terms), w, b, head_act, out, ldy=ldy)
 
 
 def rowdot(x, w, b, act, out, ldy=1):

@@ -1,6 +1,7 @@
 """GPU: GMMReg.forward on the HIP path against (a) the golden fixtures produced by the reference itself and
 (b) the CPU oracle run live on the same seeded inputs.  Target (BASELINE.json north_star): R within 1e-5 rad,
 t within 1e-5 units; discrete intermediates (kNN graph, FPS chains) identical."""
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -137,52 +138,136 @@ def test_full_size_properties_config1():
     assert (soh.cpu() - so[32:].cpu()).abs().max().item() < 2e-6
 
 
-@pytest.mark.gpu
-def test_reduced_precision_f16_mode():
-    """precision="f16" (BASELINE configs[2] is quoted in bf16): single binary16 term in the large-shape GEMM engine.  Not a parity
-    mode.  The engine only takes over at >= 512 tiles, so the check runs a full batch of 64 pairs and measures the deviation from
-    the fp16x3 path (itself within 2e-6 rad of the reference) on the same inputs."""
-    B, N, J = 64, 1024, 16
-    src, tgt, _, _ = synth.make_batch(0, B, N, "partial")
-    starts = synth.fps_starts_for(0, B, N)
-    out = {}
-    for prec in ("f16x3", "f16"):
-        cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, precision=prec)
-        model = GMMReg(512, J, cfg)
-        synth.fill_state_dict(model.state_dict())
-        model = model.to("cuda:0").eval()
-        with torch.no_grad():
-            out[prec] = [t_.cpu() for t_ in model(src.cuda(), tgt.cuda(), fps_starts=starts)]
-    r = O.rotation_error_rad(out["f16"][0], out["f16x3"][0])
-    t = O.translation_error(out["f16"][1], out["f16x3"][1])
-    o = (out["f16"][2] - out["f16x3"][2]).abs().max().item()
-    print("PARITY f16(reduced) vs f16x3, 64 pairs: R max=%.2e median=%.2e  t max=%.2e  o max=%.2e" % (r.max(), r.median(), t.max(), o))
-    assert 1e-6 < r.max().item() < 5e-2 and r.median().item() < 2e-3 and t.max().item() < 5e-2
+def _distribution(name, model, P, cfg, first, B, N, kind, threads=16):
+    """every pair of a batch against the oracle (run in chunks of 8 pairs on the host): per-pair R / t / overlap errors"""
+    src, tgt, _, _ = synth.make_batch(first, B, N, kind)
+    starts = synth.fps_starts_for(first, B, N)
+    with torch.no_grad():
+        got = [x.cpu() for x in model(src.cuda(), tgt.cuda(), fps_starts=starts)[:4]]
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(threads, os.cpu_count() or threads))
+    r, t, o = [], [], []
+    try:
+        for a in range(0, B, 8):
+            e = min(B, a + 8)
+            with torch.no_grad():
+                ref = O.forward(P, cfg, src[a:e], tgt[a:e], starts[:, a:e])
+            r.append(O.rotation_error_rad(got[0][a:e], ref[0]))
+            t.append(O.translation_error(got[1][a:e], ref[1]))
+            o.append(torch.maximum((got[2][a:e] - ref[2]).abs().amax(1), (got[3][a:e] - ref[3]).abs().amax(1)))
+    finally:
+        torch.set_num_threads(old)
+    r, t, o = torch.cat(r), torch.cat(t), torch.cat(o)
+    edges = [0.0, 3e-7, 1e-6, 3e-6, 1e-5, 1.0]
+    hist = " ".join("<%.0e:%d" % (hi, int(((r >= lo) & (r < hi)).sum())) for lo, hi in zip(edges[:-1], edges[1:]))
+    print("PARITY-DISTRIBUTION %s: %d pairs  R max %.2e median %.2e [%s]  t max %.2e  overlap max %.2e" % (name, B, r.max(), r.median(), hist, t.max(), o.max()))
+    return r, t, o
 
 
 @pytest.mark.gpu
-def test_full_batch_matches_oracle_on_sampled_pairs():
-    """BASELINE configs[1] at its full size (64 pairs, N = 1024, J = 16): this is the only shape at which the large-shape GEMM engines (the LDS-DMA
-    engine with its fused column statistics / InstanceNorm-on-A forms) run, so the 64-pair forward itself is checked: pairs 0, 21, 42 and 63 of
-    its output against the CPU oracle run on each of those pairs alone (eval-mode pairs are independent; anchor draws pinned per pair)."""
+def test_full_batch_matches_oracle_on_every_pair():
+    """BASELINE configs[1] at its full size (64 pairs, N = 1024, J = 16) -- the batch bench.py times, on the engines it times (the LDS-DMA engines with
+    their fused forms and the per-layer term budget only run at this size): EVERY pair of the 64-pair forward against the CPU oracle, not a sample.
+    The E/M + matching head is ill-conditioned, so the tail decides: max over the pairs of R and t within 1e-5 (north_star)."""
     B, N, J = 64, 1024, 16
     cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
-    model = GMMReg(512, J, cfg)
-    synth.fill_state_dict(model.state_dict())
-    P = {k: v.clone() for k, v in model.state_dict().items()}
-    model = model.to("cuda:0").eval()
-    src, tgt, _, _ = synth.make_batch(0, B, N, "partial")
-    starts = synth.fps_starts_for(0, B, N)
+    model, P = build(cfg, J)
+    r, t, o = _distribution("configs[1] N=1024 J=16", model, P, cfg, 0, B, N, "partial")
+    assert r.max().item() < 1e-5 and t.max().item() < 1e-5 and o.max().item() < 1e-5
+    assert not model.fp16_overflowed()
+
+
+@pytest.mark.gpu
+def test_config2_shape_on_the_large_batch_path_matches_oracle_on_every_pair(monkeypatch):
+    """BASELINE configs[2] (unseen-category-like partial clouds, N = 2048, J = 64, batch 256): 16 pairs through the code path a 256-pair batch takes --
+    the grid-wide E/M launch sequence (a 512-cloud grid does not fit the resident kernel: OGMM_EM_RESIDENT=0 forces the same choice here), the
+    large-shape GEMM engines (65536 rows = 256 row tiles), the matrix-core cluster feature means -- every pair against the oracle."""
+    monkeypatch.setenv("OGMM_EM_RESIDENT", "0")
+    B, N, J = 16, 2048, 64
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
+    model, P = build(cfg, J)
+    r, t, o = _distribution("configs[2] N=2048 J=64 (large-batch path)", model, P, cfg, 2000, B, N, "partial")
+    assert r.max().item() < 1e-5 and t.max().item() < 1e-5 and o.max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_repo_default_shape_matches_oracle_on_every_pair():
+    """The reference repo's own defaults (N = 717, J = 128: J close to N makes the E/M ill-conditioned -- the shape with the thinnest margin): 32 pairs."""
+    B, N, J = 32, 717, 128
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
+    model, P = build(cfg, J)
+    r, t, o = _distribution("repo defaults N=717 J=128", model, P, cfg, 300, B, N, "partial")
+    assert r.max().item() < 1e-5 and t.max().item() < 1e-5 and o.max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_full_size_properties_config2():
+    """BASELINE configs[2] at its full size (256 pairs of 2048 points, J = 64): no oracle at this size in the time budget, so size-independent
+    properties: proper rotations, overlap scores in (0,1), finite loss, every E-step ran the reference's 10 sweeps, and a 64-pair shard of the batch
+    gives what the full batch gives for those pairs (pairs are independent; the Sinkhorn exit -- the only coupling -- does not fire here)."""
+    B, N, J = 256, 2048, 64
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
+    model, _ = build(cfg, J)
+    src, tgt, _, _ = synth.make_batch(2000, B, N, "partial")
+    starts = synth.fps_starts_for(2000, B, N)
     with torch.no_grad():
-        R, t, so, to, _ = [x.cpu() for x in model(src.cuda(), tgt.cuda(), fps_starts=starts)]
-        worst = [0.0, 0.0, 0.0]
-        for i in (0, 21, 42, 63):
-            Ro, to_, soo, too, _ = O.forward(P, cfg, src[i:i + 1], tgt[i:i + 1], starts[:, i:i + 1])
-            worst[0] = max(worst[0], O.rotation_error_rad(R[i:i + 1], Ro).max().item())
-            worst[1] = max(worst[1], O.translation_error(t[i:i + 1], to_).max().item())
-            worst[2] = max(worst[2], (so[i:i + 1] - soo).abs().max().item(), (to[i:i + 1] - too).abs().max().item())
-    print("PARITY full batch (64 pairs) vs oracle on pairs 0/21/42/63: R %.2e rad  t %.2e  overlap %.2e" % tuple(worst))
-    assert worst[0] < 1e-5 and worst[1] < 1e-5 and worst[2] < 1e-5          # north_star: (R, t) within 1e-5 of the reference
+        R, t, so, to, loss = model(src.cuda(), tgt.cuda(), fps_starts=starts, capture=True)
+        assert bool((model.last_intermediates["sinkhorn_sweeps"] == 10).all())
+        Rh, th, soh, _, _ = model(src[64:128].cuda(), tgt[64:128].cuda(), fps_starts=starts[:, 64:128])
+    Rd = R.double().cpu()
+    assert (Rd @ Rd.transpose(1, 2) - torch.eye(3, dtype=torch.double)).abs().max().item() < 1e-5
+    assert (torch.det(Rd) - 1).abs().max().item() < 1e-5
+    assert 0 < float(so.min()) and float(so.max()) < 1 and 0 < float(to.min()) and float(to.max()) < 1 and torch.isfinite(loss)
+    assert O.rotation_error_rad(Rh.cpu(), R[64:128].cpu()).max().item() < 4e-6
+    assert (soh.cpu() - so[64:128].cpu()).abs().max().item() < 4e-6
+    assert not model.fp16_overflowed()
+
+
+# layers that the reduced mode (precision = "f16") multiplies with ONE binary16 term per operand on the large-shape engine (ops.gemm_nt single_term);
+# the EdgeConv kernel, the attention kernel and the small anchor-side projections keep their split terms
+def _f16_mode_policy(name):
+    if name.startswith("emd.conv") and name != "emd.conv5":
+        return "x3"
+    if name.endswith((".attn.qk", ".attn.pv", ".attn.proj.1", ".attn.proj.2")):
+        return "x3"
+    return "x1"
+
+
+@pytest.mark.gpu
+def test_reduced_precision_mode_against_the_emulating_oracle():
+    """BASELINE configs[2] is quoted in bf16.  The labelled reduced mode here is precision = "f16": one binary16 term per operand (11 significand bits
+    >= bf16's 8) in the large GEMMs, fp32 accumulation.  It cannot meet 1e-5, so its tolerance is DERIVED: the CPU oracle with the
+    same operand rounding (oracle/split_emulation.py, mode "x1" on the same layers) gives the deviation that this arithmetic causes in the
+    reference's own algorithm; the HIP path in that mode must stay within 4x of it (max and median over 16 pairs of the configs[2] shape) --
+    rounding noise is chaotic pair by pair, so the comparison is between distributions, both measured against the exact oracle."""
+    from oracle import split_emulation as E
+    B, N, J = 16, 2048, 64
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
+    model, P = build(cfg, J, precision="f16")
+    src, tgt, _, _ = synth.make_batch(2000, B, N, "partial")
+    starts = synth.fps_starts_for(2000, B, N)
+    with torch.no_grad():
+        got = [x.cpu() for x in model(src.cuda(), tgt.cuda(), fps_starts=starts)[:2]]
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    r_hip, r_emu, t_hip, t_emu = [], [], [], []
+    try:
+        for a in range(0, B, 8):
+            with torch.no_grad():
+                exact = O.forward(P, cfg, src[a:a + 8], tgt[a:a + 8], starts[:, a:a + 8])
+                with E.policy(_f16_mode_policy):
+                    emu = O.forward(P, cfg, src[a:a + 8], tgt[a:a + 8], starts[:, a:a + 8])
+            r_hip.append(O.rotation_error_rad(got[0][a:a + 8], exact[0])); t_hip.append(O.translation_error(got[1][a:a + 8], exact[1]))
+            r_emu.append(O.rotation_error_rad(emu[0], exact[0])); t_emu.append(O.translation_error(emu[1], exact[1]))
+    finally:
+        torch.set_num_threads(old)
+    r_hip, r_emu, t_hip, t_emu = torch.cat(r_hip), torch.cat(r_emu), torch.cat(t_hip), torch.cat(t_emu)
+    print("PARITY f16 (reduced) on configs[2] shape, 16 pairs, against the exact oracle: HIP R max %.2e median %.2e t max %.2e | emulating oracle R max %.2e median %.2e t max %.2e"
+          % (r_hip.max(), r_hip.median(), t_hip.max(), r_emu.max(), r_emu.median(), t_emu.max()))
+    assert r_emu.max().item() > 1e-5, "the emulation shows no effect: nothing tested"
+    assert r_hip.max().item() < 4 * r_emu.max().item() and r_hip.median().item() < 4 * r_emu.median().item()
+    assert t_hip.max().item() < 4 * t_emu.max().item()
+    assert r_hip.median().item() > 0.1 * r_emu.median().item(), "the reduced mode is far more accurate than its emulation: it does not run the labelled arithmetic"
 
 
 @pytest.mark.gpu

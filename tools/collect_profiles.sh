@@ -1,27 +1,29 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): everything the round's profiles/ files are made of, written under gpurun_out/collect/.
-#   usage: /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh round2'
+#   usage: /usr/local/graft/bin/gpurun --timeout 2400 -- "bash tools/collect_profiles.sh round3 $(git rev-parse --short HEAD)"
 # rocprofv3 is given the program itself after `--` (python3 bench.py ...); counters are collected in their own passes
 # (--kernel-trace --pmc only), as MI355X_MICROARCH.md prescribes.
 tag=${1:-round}
+commit=${2:-unknown}          # the tree's commit (the box has no .git): goes into every summary's header
 out=gpurun_out/collect
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-sample 0"
 
 # 1. headline bench line (with the CPU baseline and the parity sample) and the other workloads
-timeout 400 python3 bench.py --steps 20 --warmup 5 2> $out/bench_n1.err | tail -1 > $out/${tag}_bench_n1.json
+timeout 600 python3 bench.py --steps 20 --warmup 5 2> $out/bench_n1.err | tail -1 > $out/${tag}_bench_n1.json
 for w in cfg2 cfg3; do timeout 400 python3 bench.py --workload $w --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_bench_$w.json; done
 timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_train_bench_b128.json
 
 # 2. kernel trace + stats of the headline command
 rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format rocpd -- $BENCH > $out/trace.log 2>&1
 db=$(find $out/trace -name "*.db" | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- $BENCH   (7 forwards: 2 warm-up + 5 timed; the first one also packs the weights)"; python3 tools/rocpd_stats.py $db; } > $out/${tag}_kernel_stats.txt
+{ echo "# commit $commit"; echo "# rocprofv3 --kernel-trace --stats -- $BENCH   (9 forwards: 2 warm-up + 1 counting + 5 timed + ...; the first one also packs the weights)"; python3 tools/rocpd_stats.py $db; } > $out/${tag}_kernel_stats.txt
 { echo "# one eval step (B=64, N=1024, J=16) as dispatched: start, gap to the previous kernel's end (negative: overlapped with a side stream), duration, grid"; python3 tools/rocpd_timeline.py $db "knn2_kernel<21>" | head -70; } > $out/${tag}_step_timeline.txt
 
 # 3. PMC passes (separate runs)
 {
+echo "# commit $commit"
 echo "# rocprofv3 --kernel-trace --pmc <counters> -- $BENCH   (separate passes per counter set; per-dispatch means, summed over the XCD instances rocprofv3 reports)"
 echo "# FETCH_SIZE / WRITE_SIZE in KiB; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) -> bench.py doubles it."
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
@@ -56,7 +58,9 @@ dbt=$(find $out/trace_train -name "*.db" | head -1)
   echo "# tools/attn_bwd_time.py"; timeout 200 python3 tools/attn_bwd_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_train_breakdown.txt
 rm -rf $out/trace_train
 
-# 5. parity lines of the GPU tests
-timeout 900 python3 -m pytest tests/test_hip_forward.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|passed|failed" > $out/${tag}_parity.txt
+# 5. parity: the distribution over every pair of a batch per workload, then the PARITY lines of the GPU tests
+{ echo "# commit $commit"; timeout 900 python3 tools/parity_distribution.py 2>&1 | grep -v amdgpu.ids;
+  echo; echo "# PARITY lines of pytest -m gpu (tests/test_hip_forward.py, test_hip_deepgmr.py, test_hip_icp.py)";
+  timeout 1200 python3 -m pytest tests/test_hip_forward.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|passed|failed"; } > $out/${tag}_parity.txt
 rm -rf $out/trace $out/pmc_*          # the rocpd databases exceed what gpurun copies back; the summaries above are what gets committed
 ls -la $out | head -40

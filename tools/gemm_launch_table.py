@@ -34,7 +34,7 @@ with torch.no_grad():
         ops.GEMM_TIMELINE, ops.GEMM_TIMELINE_ONLY = [], None
         model(src, tgt, fps_starts=starts)
         torch.cuda.synchronize()
-        tl = [(e0.elapsed_time(e1) * 1e3, f) for e0, e1, f, v, b in ops.GEMM_TIMELINE]
+        tl = [(e0.elapsed_time(e1) * 1e3, f) for e0, e1, f, *_ in ops.GEMM_TIMELINE]
         ops.GEMM_TIMELINE = None
         best = tl if best is None else [(min(a[0], b[0]), a[1]) for a, b in zip(best, tl)]
 tot = 0.0

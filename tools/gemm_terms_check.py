@@ -19,7 +19,8 @@ def run(A, W, sp, out, terms, A2=None, variant=None, **kw):
     ops.gemm_nt(A, A.stride(0), k1, W, k1 + k2, m, n, C=out, ldc=out.stride(0), A2=A2, lda2=(A2.stride(0) if A2 is not None else 0), K2=k2, split=sp, terms=terms, **kw)
 
 
-for (m, n, k1, k2, has_res, act) in [(65536, 512, 512, 0, True, 1), (70000 // 256 * 256, 1024, 1024, 0, False, 2), (65536, 1024, 512, 32, False, 1), (131072, 512, 96, 0, False, 0)]:
+for (m, n, k1, k2, has_res, act) in [(65536, 512, 512, 0, True, 1), (70000 // 256 * 256, 1024, 1024, 0, False, 2), (65536, 1024, 512, 32, False, 1), (131072, 512, 96, 0, False, 0),
+                                     (131072, 256, 1024, 0, False, 1), (65536, 256, 512, 0, True, 2)]:          # (N = 256: the 8-wave engine)
     A = torch.randn(m, k1, device=dev) * (0.5 + 3 * torch.rand(m, 1, device=dev))          # (O(1) rows: below ~0.1 the activation's lo term is a binary16 subnormal and the split keeps absolute, not relative, precision)
     A2 = torch.randn(m, k2, device=dev) if k2 else None
     W = torch.randn(n, k1 + k2, device=dev) * 0.05
@@ -54,7 +55,7 @@ for (m, n, k1, k2, has_res, act) in [(65536, 512, 512, 0, True, 1), (70000 // 25
     assert e2 < 2e-6 and not torch.isnan(out2).any()
 
 print("timing (interleaved, ms): three terms / two terms")
-for (m, n, k) in [(131072, 1024, 1024), (131072, 1024, 512), (131072, 512, 1024), (131072, 512, 512)]:
+for (m, n, k) in [(131072, 1024, 1024), (131072, 1024, 512), (131072, 512, 1024), (131072, 512, 512), (131072, 256, 1024), (131072, 256, 512), (131072, 256, 256)]:
     A = torch.randn(m, k, device=dev)
     W = torch.randn(n, k, device=dev) * 0.05
     sp = ops.split_f16(W, frag=True)
