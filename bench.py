@@ -91,9 +91,13 @@ def main():
     rank, local_rank, world = odist.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = odist.init("nccl", rank, world, dev)
+    # Test seam (tests/test_dist_gloo.py): OGMM_BENCH_STUB=1 runs THIS control flow -- the world-size guard, the sharding, the barriers around the timed
+    # region, the max over ranks, the rank-0-only JSON line -- on CPU over gloo with a stand-in for the forward.  Never set on a GPU box.
+    stub = os.environ.get("OGMM_BENCH_STUB") == "1"
+    if not stub:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    dist = odist.init("gloo" if stub else "nccl", rank, world, dev)
 
     from ogmm_amd import ops, synth
     from ogmm_amd.gmmreg import GMMReg
@@ -101,8 +105,14 @@ def main():
     model = GMMReg(512, J, CFG)
     synth.fill_state_dict(model.state_dict())
     params_cpu = {k: v.clone() for k, v in model.state_dict().items()}
-    model = model.to(dev).eval()
     model.precision = args.precision
+    if stub:
+        B_PER_GPU, N_POINTS = 2, 64
+        real, model = model, _StubForward(rank)
+        model.precision, model.term_budget, model.sinkhorn_thresh = real.precision, real.term_budget, real.sinkhorn_thresh
+        args.cpu_sample = 0
+    else:
+        model = model.to(dev).eval()
 
     first, _ = odist.shard_pairs(rank, world, B_PER_GPU)         # global pair ids of this rank's shard
     src, tgt, _, _ = synth.make_batch(first, B_PER_GPU, N_POINTS, kind)
@@ -110,7 +120,7 @@ def main():
     src, tgt = src.to(dev), tgt.to(dev)
 
     def barrier():
-        odist.barrier(dist)
+        odist.barrier(dist, cuda=not stub)
 
     dom_tag = "f16x3" if args.precision == "f16" else args.precision
     with torch.no_grad():
@@ -126,8 +136,9 @@ def main():
         ops.recycle_timing_events(ops.GEMM_TIMELINE)
         ops.recycle_timing_events(ops.KERNEL_TIMELINE)
         sampled = [i % EVENT_EVERY == 0 for i in range(args.steps)]
-        ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * per_step * sum(sampled)))
-        torch.cuda.synchronize()
+        if not stub:
+            ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2 * per_step * sum(sampled)))
+            torch.cuda.synchronize()
         barrier()
         ops.GEMM_TIMELINE, ops.KERNEL_TIMELINE = [], None
         ktl = []
@@ -204,7 +215,7 @@ def main():
         "roofline_other": others,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not stub:
         # yard-stick: the vendor library (hipBLASLt through torch.matmul) on the dominant GEMM shape, measured here and now
         lib = {}
         for tag, dt in (("fp32", torch.float32), ("f16", torch.float16)):
@@ -229,6 +240,21 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+class _StubForward:
+    """stand-in for the model under OGMM_BENCH_STUB=1 (CPU test of main()'s multi-process control flow): rank r 'takes' (r + 1) ms per forward"""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def __call__(self, src, tgt, fps_starts=None):
+        time.sleep(1e-3 * (self.rank + 1))
+        B, _, N = src.shape
+        return (torch.eye(3).expand(B, 3, 3), torch.zeros(B, 3), torch.full((B, N), 0.5), torch.full((B, N), 0.5), torch.zeros(()))
+
+    def fp16_overflowed(self):
+        return False
 
 
 def cpu_leg(args, cfg, params_cpu, src, tgt, starts, out):

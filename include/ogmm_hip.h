@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 16
+#define OGMM_ABI_VERSION 17
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -407,6 +407,11 @@ int ogmm_kabsch_bwd(const float* src, const float* corr, const float* w, int B, 
 
 /* ---- T5: index of the point nearest to each centre (lib/utils.py:244-254, torch.cdist + top-1): near [C][J]. */
 int ogmm_nearest_point(const float* xyz, const float* mu /*[C][J][3]*/, int C, int N, int J, int32_t* near, void* stream);
+
+/* Power-of-two scale of a weight for the binary16 split, on the device: scale_out[0] = 2^e with max|W| 2^e in [2^top, 2^(top+1)) (e clamped to +-24),
+ * inv_out[0 .. inv_len) = 2^-e (handed to ogmm_gemm_nt as its per-column `scale`).  The training step splits its weights every step
+ * (train_ops._Linear): no host synchronisation, no cached exponent that could go stale. */
+int ogmm_pow2_scale(const float* W, int64_t count, int top, float* scale_out, float* inv_out, int inv_len, void* stream);
 
 /* ---- T6: constants of the input that feed trainable thin layers, un-fused for training:
  *   ogmm_edge_features: out[(c*N+i)*k + j][0..5] = (x_j - x_i, x_i), j over idx[c][i][:]          (lib/utils.py:47-66)

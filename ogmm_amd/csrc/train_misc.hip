@@ -72,6 +72,35 @@ __global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __res
 
 }  // namespace
 
+namespace {
+// Power-of-two scale of a weight for the binary16 split (ops.split_f16): 2^e with max|W| 2^e in [2^top, 2^(top+1)), e clamped to +-24; one workgroup scans
+// the weight (<= a few MB: ~10 us), writes 2^e and fills a vector with 2^-e that the GEMM takes as its per-column scale (struct ogmm_gemm.scale).  No
+// host round trip and no cache: the training step re-splits ~120 weights (and derived, permuted / transposed copies of them) every step.
+__global__ __launch_bounds__(1024) void pow2_scale_kernel(const float* __restrict__ W, int64_t count, int top, float* __restrict__ scale_out,
+                                                          float* __restrict__ inv_out, int inv_len) {
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(W[i]));          // (NaN is ignored by fmaxf; inf propagates)
+    m = ogmm::wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) m = fmaxf(m, red[w]);
+    int e = 0;
+    if (m > 0.0f && m < __builtin_inff()) e = min(24, max(-24, top - (int)floorf(log2f(m))));
+    const float sc = exp2f((float)e), inv = exp2f((float)-e);
+    if (threadIdx.x == 0) scale_out[0] = sc;
+    for (int i = threadIdx.x; i < inv_len; i += 1024) inv_out[i] = inv;
+}
+}  // namespace
+
+extern "C" int ogmm_pow2_scale(const float* W, int64_t count, int top, float* scale_out, float* inv_out, int inv_len, void* stream) {
+    OGMM_REQUIRE(W && scale_out && inv_out && count > 0 && inv_len > 0 && top >= 0 && top <= 14, "ogmm_pow2_scale: bad arguments");
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1024), 0, ogmm::as_stream(stream), W, count, top, scale_out, inv_out, inv_len);
+    return ogmm::check_launch("ogmm_pow2_scale");
+}
+
 extern "C" int ogmm_edge_features(const float* xyz, const int32_t* idx, int C, int N, int k, float* out, void* stream) {
     OGMM_REQUIRE(xyz && idx && out && C > 0 && N > 0 && k > 0, "ogmm_edge_features: null pointer or empty input");
     const int64_t edges = (int64_t)C * N * k;

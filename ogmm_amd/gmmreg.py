@@ -577,6 +577,14 @@ class GMMReg(nn.Module):
         run.graph = graph
         return run
 
+    def overflow_flag(self, device=None):
+        """the device int32[1] the fp16 engines raise when |value| > 65504 was clamped (created on first use); callers that want to read it without a
+        host round trip per query (the trainer) snapshot it with device ops"""
+        dev = torch.device(device) if device is not None else self.emd.conv1.weight.device
+        if dev.type == "cuda" and (self._overflow is None or self._overflow.device != dev):
+            self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self._overflow
+
     def fp16_overflowed(self):
         """True if any fp16x3 GEMM since the last call clamped an activation beyond +-65504 (synchronises)."""
         if self._overflow is None:

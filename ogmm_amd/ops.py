@@ -127,7 +127,7 @@ def gather_rows(feats, ld, C, N, D, ids, cloud_map=None):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM engine
-def split_f16(W, pad_to=8, frag=False, k1=None, sync=True, exp=None):
+def split_f16(W, pad_to=8, frag=False, k1=None, exp=None):
     """fp32 [N,K] -> dict(W_hi, W_lo binary16, inv_scale): W * 2^e = hi + lo with the power of two chosen so
     that max|W| * 2^e is in [2^11, 2^12) (keeps `lo` a normal binary16 number); inv_scale = 2^-e goes into alpha.
     frag=False: row-major [N, Kpad8] planes (OGMM_PREC_F16X3).  frag=True: the fragment-major image of
@@ -174,27 +174,22 @@ def split_f16(W, pad_to=8, frag=False, k1=None, sync=True, exp=None):
         Ws = torch.cat([Ws, Ws.new_zeros(W.shape[0], Kp - K)], dim=1)
     hi = Ws.half()
     lo = (Ws - hi.float()).half()
-    if not sync:
-        return {"W_hi": hi.contiguous(), "W_lo": lo.contiguous(), "inv_scale_t": torch.exp2(-e_t)}
     e = float(e_t)
     return {"W_hi": hi.contiguous(), "W_lo": lo.contiguous(), "inv_scale": 2.0 ** (-e)}
 
 
-_SPLIT_EXP = {}          # weight storage -> [exponent, uses left]: see split_f16_training
-
-
-def split_f16_training(W, key, refresh=64, **kw):
-    """split_f16 for weights that change a little every step (the trainer's per-step splits): the power-of-two scale is taken from a cache
-    keyed on the parameter and recomputed -- one device reduction + host sync -- only every `refresh` uses.  The cached exponent leaves one
-    binade of headroom (max|W| * 2^e in [2^10, 2^11)), so the weights may double between refreshes before the leading term could overflow."""
-    ent = _SPLIT_EXP.get(key)
-    if ent is None or ent[1] <= 0:
-        import math
-        amax = float(W.detach().abs().max())
-        e = 0 if amax == 0.0 or not math.isfinite(amax) else 10 - math.floor(math.log2(amax))
-        ent = _SPLIT_EXP[key] = [max(-24, min(24, e)), refresh]
-    ent[1] -= 1
-    return split_f16(W, exp=ent[0], **kw)
+def split_f16_training(W, cout, **kw):
+    """split_f16(frag=True) for weights that change every step (the trainer re-splits ~120 of them per step, many as permuted / transposed temporaries):
+    the power-of-two scale is found on the DEVICE (ogmm_pow2_scale: one small launch, no host synchronisation, nothing cached that could go stale or
+    be keyed on a recycled address), leaving one binade of headroom.  The inverse scale cannot ride in the host-side `alpha`, so it comes back as
+    `col_scale` [cout], the GEMM's per-column scale (struct ogmm_gemm.scale); `inv_scale` is 1."""
+    W = W.float().contiguous()
+    sc = torch.empty(1, dtype=torch.float32, device=W.device)
+    inv = torch.empty(cout, dtype=torch.float32, device=W.device)
+    _lib.call("ogmm_pow2_scale", _p(W), W.numel(), 10, _p(sc), _p(inv), cout, _stream())
+    sp = split_f16(W * sc, exp=0, **kw)
+    sp["col_scale"] = inv
+    return sp
 
 
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,

@@ -166,7 +166,8 @@ class _Linear(torch.autograd.Function):
         if b is not None:
             layer["shift"] = b.detach().contiguous()
         if precision == "f16x3":
-            layer["split"] = ops.split_f16_training(layer["W"], ("fwd", W.data_ptr(), tuple(Wd.shape)), frag=True, k1=K1)
+            layer["split"] = ops.split_f16_training(layer["W"], Wd.shape[0], frag=True, k1=K1)
+            layer["scale"] = layer["split"]["col_scale"]
         stats = None
         if stats_rows and precision == "f16x3" and stats_rows % 256 == 0 and W.shape[0] % 4 == 0 and (stats_rows <= 131072 or W.shape[0] >= 256):
             # the normalisation that follows needs sum / sum of squares per (row group, column): the engine's epilogue adds them up
@@ -206,7 +207,8 @@ class _Linear(torch.autograd.Function):
                 Wt = W.detach().t().contiguous()
                 if Wt.shape[0] % 4:
                     Wt = torch.cat([Wt, Wt.new_zeros(4 - Wt.shape[0] % 4, Wt.shape[1])], dim=0)
-                layer = {"W": Wt, "split": ops.split_f16_training(Wt, ("bwd", W.data_ptr(), tuple(Wt.shape)), frag=True)}
+                sp = ops.split_f16_training(Wt, Wt.shape[0], frag=True)
+                layer = {"W": Wt, "split": sp, "scale": sp["col_scale"]}
                 dall = ops.conv1x1(_rm(dy), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
             else:
                 dall = dy @ W
@@ -262,7 +264,8 @@ class _NormLinear(torch.autograd.Function):
         scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
         mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
         Wd = W.detach().contiguous()
-        layer = {"W": Wd, "split": ops.split_f16_training(Wd, ("fwd", W.data_ptr(), tuple(Wd.shape)), frag=True, k1=Wd.shape[1])}
+        sp = ops.split_f16_training(Wd, Wd.shape[0], frag=True, k1=Wd.shape[1])
+        layer = {"W": Wd, "split": sp, "scale": sp["col_scale"]}
         if b is not None:
             layer["shift"] = b.detach().contiguous()
         stats = None
@@ -288,7 +291,8 @@ class _NormLinear(torch.autograd.Function):
         y, scale, shift, mean, rstd, W = ctx.saved_tensors
         dout = _rm(dout)
         Wt = W.detach().t().contiguous()
-        layer = {"W": Wt, "split": ops.split_f16_training(Wt, ("bwd", W.data_ptr(), tuple(Wt.shape)), frag=True)}
+        sp = ops.split_f16_training(Wt, Wt.shape[0], frag=True)
+        layer = {"W": Wt, "split": sp, "scale": sp["col_scale"]}
         dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
         dW = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[6] and not ctx.bias_grad_is_zero

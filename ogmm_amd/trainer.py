@@ -78,15 +78,19 @@ class Trainer:
         self.min_loss_scale = 1.0            # floor: halving below 1 cannot help (the scale only protects small gradients)
         self.growth_interval = 200           # clean steps after which a reduced scale doubles again (as torch's GradScaler)
         self._clean_steps = 0
-        self.forward_overflows = 0
+        self.forward_overflows = 0           # CONSECUTIVE steps whose forward clamped an activation (reset by a clean step)
+        self.max_forward_overflows = 8
         self.skipped_steps = 0
 
-    def _any_rank(self, flag):
-        if self.dist is None or self.world <= 1:
-            return bool(flag)
-        t = torch.tensor([1.0 if flag else 0.0], device=next(self.model.parameters()).device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return bool(t.item() > 0)
+    def _overflow_hits(self, fwd, bwd):
+        """(forward flag, backward flag) -> two bools, the same on every rank: ONE host read (and one MAX all-reduce) per step for both"""
+        if fwd is None:
+            return False, False
+        both = torch.cat([fwd, bwd]).to(torch.float32)
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(both, op=self.dist.ReduceOp.MAX)
+        f, b = both.tolist()
+        return f > 0, b > 0
 
     def local_loss(self, out, src, tgt, transform_gt, src_overlap, tgt_overlap):
         loss, parts = losses.training_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap, self.alpha, self.top_k)
@@ -98,24 +102,39 @@ class Trainer:
         """train.py:53-74 for this rank's shard.  Returns loss (local share), the four parts, mean R / t errors."""
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
+        # The engine's overflow flag (device int32[1]) is shared by forward activations and backward gradients.  It is snapshotted with device ops
+        # after the forward and after the backward and read ONCE, behind the backward: no extra host round trip between the two.
+        flag = self.model.overflow_flag(src.device) if hasattr(self.model, "overflow_flag") and src.is_cuda else None
+        if flag is not None:
+            flag.zero_()
         out = self.model(src, tgt, fps_starts=fps_starts)
-        # The engine's overflow flag is shared by forward activations and backward gradients.  A FORWARD overflow (|activation| > 65504) is not
-        # something the loss scale can cure: read and clear the flag here, count it, and raise when it persists instead of halving the scale to zero.
-        if self.loss_scale != 1.0 and self._any_rank(self.model.fp16_overflowed()):
-            self.forward_overflows += 1
-            if self.forward_overflows > 8:
-                raise FloatingPointError("fp16x3 engine: forward activations beyond +-65504 in %d steps -- the loss scale cannot fix this; "
-                                         "use model.precision = 'f32' or rescale the inputs" % self.forward_overflows)
+        fwd_flag = None
+        if flag is not None:
+            fwd_flag = flag.clone()
+            flag.zero_()
         loss, parts = self.local_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap)
         self._backward_scale = self.loss_scale          # the scale this step's gradients carry (self.loss_scale may grow below)
         (loss * self.loss_scale).backward()
-        overflowed = self.loss_scale != 1.0 and self._any_rank(self.model.fp16_overflowed())
-        if overflowed:
+        fwd_hit, bwd_hit = self._overflow_hits(fwd_flag, flag)
+        overflowed = fwd_hit or bwd_hit
+        if fwd_hit:
+            # |activation| > 65504 in the FORWARD: its outputs and every gradient derived from them are built on clamped values.  The loss scale cannot
+            # cure that (it only lifts small gradients): skip the step without touching the scale, and give up when it persists.
+            self.forward_overflows += 1
+            self.skipped_steps += 1
+            self.optimizer.zero_grad(set_to_none=True)
+            if self.forward_overflows > self.max_forward_overflows:
+                raise FloatingPointError("fp16x3 engine: forward activations beyond +-65504 in %d consecutive steps -- the loss scale cannot fix this; "
+                                         "use model.precision = 'f32' or rescale the inputs" % self.forward_overflows)
+        elif bwd_hit:
+            # a scaled gradient left binary16's range: skip, halve the scale (at scale 1 the step is still skipped: the gradient was clamped)
+            self.forward_overflows = 0
             self.skipped_steps += 1
             self.loss_scale = max(self.min_loss_scale, self.loss_scale * 0.5)
             self._clean_steps = 0
             self.optimizer.zero_grad(set_to_none=True)
         else:
+            self.forward_overflows = 0
             self._clean_steps += 1
             if self.loss_scale < self.initial_loss_scale and self._clean_steps >= self.growth_interval:
                 self.loss_scale = min(self.initial_loss_scale, self.loss_scale * 2.0)
