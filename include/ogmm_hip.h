@@ -136,7 +136,8 @@ typedef struct ogmm_gemm {
     int32_t col_stats_slot_mask; int64_t col_stats_slot_stride;
     /* Per-layer term budget (OGMM_PREC_F16X3_FRAG): how many binary16 matrix instructions a product block may be evaluated with.
      *   0 or 3: a_lo w_hi + a_hi w_lo + a_hi w_hi (fp32-class, the default);
-     *   2:      (a_hi + a_lo) w_hi -- the WEIGHT operand B is rounded to binary16 (its lo plane is not read), the activation keeps both terms.
+     *   2:      (a_hi + a_lo) w_hi -- the WEIGHT operand B is rounded to binary16 (its lo plane is not read), the activation keeps both terms;
+     *   1:      a_hi w_hi -- both operands rounded to binary16 (the 4-wave engine, N >= 512, only).
      * A permission, not an order: engines / shapes without the cheaper form run all three terms (results then differ from the two-term form
      * by the weight's rounding, 2^-12 relative per product).  Which layers of the path tolerate it -- R, t within 1e-5 of the reference over the
      * parity distribution -- is measured, not assumed: tools/term_budget.py (CPU oracle with the same rounding) and DESIGN.md section 4. */

@@ -37,9 +37,12 @@ __device__ unsigned long long g_v10_probe[4];
 //   2  lo*hi + hi*hi = (a_hi + a_lo) w_hi: the WEIGHT is rounded to binary16, the activation keeps both terms.  The lo plane of the weight image
 //      is not even fetched: 4 instead of 8 weight DMA instructions and 16 instead of 32 fragment reads per K step and wave.
 // Both run the same instruction schedule: a group is 4 TERMS matrix instructions, and everything else sits in the gaps m = 0..7 of a group.
+//   1  hi*hi: BOTH operands rounded to binary16 (11 significand bits); no lo term is formed at all.  Four matrix instructions per group: the raw
+//      activation fragments are read in gap 3 of a half step's first group, converted (v_cvt_pk_f16_f32 only) in gap 3 of its second and third.
+//      With a third of the matrix work the loop is bound by its operand DMA (48 KiB per step and CU).
 template <int ABL, bool AFF, bool OVL, int TERMS = 3>
 __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
-    static_assert(TERMS == 3 || (TERMS == 2 && !AFF), "TERMS = 2 has no InstanceNorm-on-A form (its transform pieces need the gaps of 12 MFMAs)");
+    static_assert(TERMS == 3 || ((TERMS == 2 || TERMS == 1) && !AFF), "TERMS < 3 has no InstanceNorm-on-A form (its transform pieces need the gaps of 12 MFMAs)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
 
     const int bid = blockIdx.x;
@@ -156,9 +159,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     };
     auto piece_split = [&](int s, int which, int stage) {
         const f32x4 v = ra[which >> 1][which & 1];
-        if (stage == 0)
+        if (stage == 0) {
             asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5" : "=&v"(h01[which]), "=&v"(h23[which]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-        else if (stage == 1)
+            if (TERMS == 1) ahh[which >> 1][s][which & 1] = f16x4{h01[which][0], h01[which][1], h23[which][0], h23[which][1]};          // (no lo term: done)
+        } else if (stage == 1)
             asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel_hi:[1,0,0]"
                 : "=&v"(l01[which]), "=&v"(l23[which]) : "v"(h01[which]), "v"(h23[which]), "v"(v[0]), "v"(v[2]));
         else {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     read_b(0, 0, 0);
     read_b(0, 0, 1);
 #pragma unroll
-    for (int pi = 0; pi < (AFF ? 28 : 12); ++pi) piece(0, pi);
+    for (int pi = 0; pi < (AFF ? 28 : (TERMS == 1 ? 4 : 12)); ++pi) piece(0, pi);
 
     // One K step = 8 MFMA groups of 12: k16 block s = grp >> 2 against the column-block pair q = grp & 3, for both row blocks; MFMA m of a group is
     // product m >> 2 (lo*hi, hi*lo, hi*hi), row block (m >> 1) & 1, column block m & 1 -- per accumulator the same order as v8.  What the wave issues
@@ -231,10 +235,10 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
             const f16x8 al1 = __builtin_shufflevector(alh[1][s][0], alh[1][s][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int m = 0; m < 4 * TERMS; ++m) {
-                const int prod = TERMS == 3 ? m >> 2 : (m >> 2) * 2, rb = (m >> 1) & 1, c = m & 1;          // TERMS = 2: products 0 (lo*hi) and 2 (hi*hi)
+                const int prod = TERMS == 3 ? m >> 2 : (TERMS == 2 ? (m >> 2) * 2 : 2), rb = (m >> 1) & 1, c = m & 1;          // TERMS = 2: products 0 (lo*hi) and 2 (hi*hi); 1: hi*hi
                 const f16x8 av = prod == 0 ? (rb ? al1 : al0) : (rb ? ah1 : ah0);
                 const f16x8 bv = prod == 1 ? bl[p][c] : bh[p][c];
-                const bool fresh = FIRST && s == 0 && prod == 0;
+                const bool fresh = FIRST && s == 0 && (m >> 2) == 0;          // the accumulator's first product of the tile
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (rb == 0) acc0[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, fresh ? zero : acc0[2 * q + c], 0, 0, 0);
                 else acc1[2 * q + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, fresh ? zero : acc1[2 * q + c], 0, 0, 0);
@@ -252,6 +256,19 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                     __builtin_amdgcn_s_barrier();
                     if (!(ABL & 4)) { read_b(t + 1, 0, 0); read_b(t + 1, 0, 1); }
                 }
+                if (TERMS == 1) {
+                    // four gaps per group: raw fragments of both row blocks in gap 3 of the half step's first group, their conversion in gap 3 of the next two
+                    if (prep && m == 3) {
+                        const int tau = second ? t + 1 : t, sn = second ? 0 : 1;
+                        if (gl == 0) {
+                            if (second && !(ABL & 1)) { if (HAS_A) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                            if (!(ABL & 16)) { read_a(tau, sn, 0); read_a(tau, sn, 1); }
+                        } else if (gl <= 2 && !(ABL & 2)) {
+                            piece_split(sn, 2 * (gl - 1), 0);
+                            piece_split(sn, 2 * (gl - 1) + 1, 0);
+                        }
+                    }
+                } else
                 if (prep && gl == 0) {
                     const int tau = second ? t + 1 : t, sn = second ? 0 : 1;
                     if (m == 4) {
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                     if (m == 5 && !(ABL & 16)) read_a(tau, sn, 1);
                     if (m == 6) read_aff(tau, sn);
                 }
-                if (prep && !(ABL & 2)) {
+                if (TERMS != 1 && prep && !(ABL & 2)) {
                     const int sn = second ? 0 : 1;
                     if (AFF) {
                         if (gl == 0 && m >= 8) piece(sn, m - 8);
@@ -464,9 +481,9 @@ int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
         case 120: return launch_v10<2048, false, false, 2>(g, s);          // clock probe, two-term form
         case 121: return launch_v10<2048 + 8, false, false, 2>(g, s);      //   no stores
         default:
-            if (g.ovl_rowpart) return g.terms == 2 ? launch_v10<0, false, true, 2>(g, s) : launch_v10<0, false, true>(g, s);
-            if (g.a_scale) return launch_v10<0, true>(g, s);          // (the InstanceNorm-on-A form has no two-term variant: terms is a permission, not an order)
-            return g.terms == 2 ? launch_v10<0, false, false, 2>(g, s) : launch_v10<0>(g, s);
+            if (g.ovl_rowpart) return g.terms == 1 ? launch_v10<0, false, true, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, true, 2>(g, s) : launch_v10<0, false, true>(g, s);
+            if (g.a_scale) return launch_v10<0, true>(g, s);          // (the InstanceNorm-on-A form has no reduced variant: terms is a permission, not an order)
+            return g.terms == 1 ? launch_v10<0, false, false, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, false, 2>(g, s) : launch_v10<0>(g, s);
     }
 }
 

@@ -265,7 +265,8 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     nb = batch[0] * batch[1]
     abytes = 4.0 * nb * (M * (K1 + K2) + (M * N if store_c else 0) + (M * N if res is not None else 0)) + 4.0 * N * (K1 + K2) * (nb if batch != (1, 1) else 1)
     # matrix instructions issued per algorithmic product: 3 (split engines), 2 where the two-term form runs (fragment-major image, no A transform), 1 (fp32 engine, reduced mode)
-    issued = 1 if split is None or (single_term and d.precision == PREC_F16_FRAG) else (2 if terms == 2 and split.get("variant") == PREC_F16X3_FRAG and a_affine is None and pool_k == 0 and N >= 256 else 3)
+    issued = 1 if split is None or (single_term and d.precision == PREC_F16_FRAG) else (
+        terms if terms in (1, 2) and split.get("variant") == PREC_F16X3_FRAG and a_affine is None and pool_k == 0 and N >= (512 if terms == 1 else 256) else 3)
     GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * nb, variant, abytes, issued))
 
 

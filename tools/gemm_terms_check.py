@@ -32,8 +32,10 @@ for (m, n, k1, k2, has_res, act) in [(65536, 512, 512, 0, True, 1), (70000 // 25
     kw = dict(res=res, ldr=(n if has_res else 0), scale=scale, shift=shift, act=act)
     out3 = torch.full((m, n), float("nan"), device=dev)
     out2 = torch.full((m, n), float("nan"), device=dev)
+    out1 = torch.full((m, n), float("nan"), device=dev)
     run(A, W, sp, out3, 0, A2=A2, **kw)
     run(A, W, sp, out2, 2, A2=A2, **kw)
+    run(A, W, sp, out1, 1, A2=A2, **kw)
     torch.cuda.synchronize()
     rows = torch.cat([torch.arange(0, 300, device=dev), torch.randint(0, m, (700,), device=dev), torch.arange(m - 300, m, device=dev)])
     Af = (A[rows] if A2 is None else torch.cat([A[rows], A2[rows]], 1)).double()
@@ -53,16 +55,23 @@ for (m, n, k1, k2, has_res, act) in [(65536, 512, 512, 0, True, 1), (70000 // 25
     print("M=%6d N=%4d K=%4d+%2d res=%d act=%d: two-term vs fp64 with rounded weight %.2e | three-term vs fp64 %.2e | two-term vs exact weight %.2e (expected ~2^-12 = 2.4e-4 worst case) nan %d"
           % (m, n, k1, k2, has_res, act, e2, e3, e23, torch.isnan(out2).sum().item()))
     assert e2 < 2e-6 and not torch.isnan(out2).any()
+    if n >= 512:          # one term: both operands rounded (the 4-wave engine only; N = 256 runs all three)
+        ref1 = finish(Af.half().double() @ Wh.t())
+        e1 = ((out1[rows].double() - ref1).abs() / mag).max().item()
+        print("        one-term vs fp64 with both operands rounded %.2e | vs exact operands %.2e" % (e1, ((out1[rows].double() - ref3).abs() / mag).max().item()))
+        assert e1 < 2e-6 and not torch.isnan(out1).any()
+    else:
+        assert torch.equal(out1, out3)
 
-print("timing (interleaved, ms): three terms / two terms")
+print("timing (interleaved, ms): three terms / two terms / one term")
 for (m, n, k) in [(131072, 1024, 1024), (131072, 1024, 512), (131072, 512, 1024), (131072, 512, 512), (131072, 256, 1024), (131072, 256, 512), (131072, 256, 256)]:
     A = torch.randn(m, k, device=dev)
     W = torch.randn(n, k, device=dev) * 0.05
     sp = ops.split_f16(W, frag=True)
     out = torch.empty((m, n), device=dev)
-    ts = {0: [], 2: []}
+    ts = {0: [], 2: [], 1: []}
     for rep in range(6):
-        for terms in (0, 2):
+        for terms in (0, 2, 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
@@ -71,5 +80,5 @@ for (m, n, k) in [(131072, 1024, 1024), (131072, 1024, 512), (131072, 512, 1024)
             torch.cuda.synchronize()
             if rep:
                 ts[terms].append(e0.elapsed_time(e1) / 5)
-    t3, t2 = sorted(ts[0])[len(ts[0]) // 2], sorted(ts[2])[len(ts[2]) // 2]
-    print("  %6d x %4d x %4d: %.3f / %.3f ms  (x%.2f)   %.0f / %.0f TF-alg" % (m, n, k, t3, t2, t2 / t3, 2.0 * m * n * k / t3 / 1e9, 2.0 * m * n * k / t2 / 1e9))
+    t3, t2, t1 = sorted(ts[0])[len(ts[0]) // 2], sorted(ts[2])[len(ts[2]) // 2], sorted(ts[1])[len(ts[1]) // 2]
+    print("  %6d x %4d x %4d: %.3f / %.3f / %.3f ms  (x%.2f, x%.2f)   %.0f / %.0f / %.0f TF-alg" % (m, n, k, t3, t2, t1, t2 / t3, t1 / t3, 2.0 * m * n * k / t3 / 1e9, 2.0 * m * n * k / t2 / 1e9, 2.0 * m * n * k / t1 / 1e9))

@@ -46,6 +46,7 @@ GROUPS = {
 POLICIES = {
     "v1": {"conv2.net.0": "x2w", "conv2.net.3": "x2w"},
     "v2": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "sattn1.attn.proj.0": "x2w", "cattn.attn.proj.0": "x2w", "sattn2.attn.proj.0": "x2w", "similarity": "x2w"},
+    "v4": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "sattn1.attn.proj.0": "x1", "cattn.attn.proj.0": "x1", "sattn2.attn.proj.0": "x1", "similarity": "x1"},
     "v3": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "conv2.net.6": "x2w", "overlap.net.0": "x2w", "overlap.net.3": "x2w", "proj.net.0": "x2w",
            "sattn1.attn.proj.0": "x2w", "cattn.attn.proj.0": "x2w", "sattn2.attn.proj.0": "x2w", "similarity": "x2w"},
 }
