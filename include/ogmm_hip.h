@@ -430,6 +430,7 @@ int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ld
  * clock the kernel really ran at -- rocprofv3 pins the clock, so its counters cannot tell. */
 int ogmm_debug_v6_probe(unsigned long long* host3);
 int ogmm_debug_v8_probe(unsigned long long* host3);
+int ogmm_debug_edgeconv_probe(unsigned long long* host8);          /* OGMM_EDGECONV_PROBE=1: shader cycles per phase of the fused EdgeConv kernel */
 int ogmm_debug_v10_probe(unsigned long long* host3);
 
 #ifdef __cplusplus

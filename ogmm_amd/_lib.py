@@ -116,6 +116,7 @@ PROTOTYPES = {
     "ogmm_l2norm_rows_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_debug_v6_probe": [c_void_p],          # diagnostics of the large-shape GEMM engines (tools/gemm_v6_check.py)
     "ogmm_debug_v8_probe": [c_void_p],
+    "ogmm_debug_edgeconv_probe": [c_void_p],
     "ogmm_debug_v10_probe": [c_void_p],
     "ogmm_transpose_pad": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ogmm_pack_frag_t": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,

@@ -208,7 +208,11 @@ struct EdgeW {
     const void* h4; const void* l4; const float* s4; const float* t4; float inv4;
 };
 
-template <int KC>
+// phase probe (OGMM_EDGECONV_PROBE=1, tools/edgeconv_time.py): thread 0 of every workgroup adds the shader cycles between the tile's barriers
+// {setup -> (1), layer 1 -> (2), layer 2 -> (3), layer 3 -> (4), layer 4 -> (5), flush + loop end} and the number of tiles to a device array
+__device__ unsigned long long g_edgeconv_probe[8];
+
+template <int KC, bool PROBE = false>
 __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, int N, int k,
                                                              int64_t total_pts, int P, int64_t n_tiles, int two_pools, const EdgeW w,
                                                              float* __restrict__ xcat, int64_t ldx) {
@@ -281,6 +285,15 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         }
     };
 
+    long long pc = 0;
+    auto probe = [&](int slot) {
+        if (PROBE && tid == 0) {
+            const long long now = clock64();
+            atomicAdd(&g_edgeconv_probe[slot], (unsigned long long)(now - pc));
+            pc = now;
+        }
+    };
+    if (PROBE && tid == 0) pc = clock64();
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t p0 = tile * P;
         const int pts = (int)min((int64_t)P, total_pts - p0);
@@ -300,6 +313,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         load_weights<4>(wb2, w.h2, w.l2, wave & 1, lane);
         load_weights<4>(wb3, w.h3, w.l3, wave & 3, lane);
         __syncthreads();                                                 // (1) edge features visible; the previous tile is finished
+        probe(0);
 
         // ---- layer 1 (VALU): wave -> point, lane -> channel; the centre term is constant over a point's edges
         // two edges per step: neighbouring lanes trade one of the two values so that each writes a (column pair) of one row with a
@@ -343,6 +357,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         }
         edge_fetch(tile + gridDim.x, j_next);                            // next tile's coordinates travel during layers 2-4
         __syncthreads();                                                 // (2) h1 planes complete
+        probe(1);
 
         // ---- layer 2: 64 -> 64; 2 column blocks x 5 row blocks over 8 waves: waves 0-1 take row blocks {0,1}, waves 2-7 one of {2,3,4}
         if (wave < 2) mfma_layer<4, 2, KC, 0>(regA, LD64, wb2, wave & 1, 0, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
@@ -350,6 +365,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         else if (wave < 6) mfma_layer<4, 1, KC, 3>(regA, LD64, wb2, wave & 1, 3, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
         else mfma_layer<4, 1, KC, 4>(regA, LD64, wb2, wave & 1, 4, sc2, sh2, regB, LD64, pool0, 256, ik16, rows_valid, lane_t);
         __syncthreads();                                                 // (3) h2 planes and x2 maxima complete
+        probe(2);
         flush(pool0, 4, 64, pts, p0);
         if (!two_pools) __syncthreads();
 
@@ -358,6 +374,7 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         if (wave < 4) mfma_layer<4, 3, KC, 0>(regB, LD64, wb3, wave & 3, 0, sc3, sh3, regA, LD128, pool1, 256, ik16, rows_valid, lane_t);
         else mfma_layer<4, 2, KC, 3>(regB, LD64, wb3, wave & 3, 3, sc3, sh3, regA, LD128, pool1, 256, ik16, rows_valid, lane_t);
         __syncthreads();                                                 // (4)
+        probe(3);
         flush(pool1, 5, 128, pts, p0);
         if (!two_pools) __syncthreads();
 
@@ -366,10 +383,12 @@ __global__ __launch_bounds__(512) void edgeconv_fused_kernel(const float* __rest
         mfma_layer<8, 3, KC, 0>(regA, LD128, wb4, wave, 0, sc4, sh4, nullptr, 0, pool0, 256, ik16, rows_valid, lane_t);
         mfma_layer<8, 2, KC, 3>(regA, LD128, wb4, wave, 3, sc4, sh4, nullptr, 0, pool0, 256, ik16, rows_valid, lane_t);
         __syncthreads();                                                 // (5)
+        probe(4);
 #pragma unroll
         for (int i = 0; i < 6; ++i) touch(f[i]);                         // next tile's edge features: in flight since layer 1
         flush(pool0, 6, 256, pts, p0);
         // pool0 is next touched by layer 2 of the following tile, two barriers from here
+        if (PROBE && tid == 0) atomicAdd(&g_edgeconv_probe[6], 1ull);
     }
 }
 
@@ -403,6 +422,11 @@ extern "C" int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, 
     EdgeW w{W1, s1, t1, h2, l2, s2, t2, inv2, h3, l3, s3, t3, inv3, h4, l4, s4, t4, inv4};
     const int64_t n_tiles = (total + P - 1) / P;
     const unsigned blocks = (unsigned)std::min<int64_t>(n_tiles, n_cu);          // one persistent workgroup per CU
+    static const bool probe = [] { const char* e = getenv("OGMM_EDGECONV_PROBE"); return e && e[0] == '1'; }();
+    if (probe && k == 20) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edgeconv_fused_kernel<20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((edgeconv_fused_kernel<20, true>), dim3(blocks), dim3(512), lds, ogmm::as_stream(stream), xyz, idx, N, k, total, P, n_tiles, two_pools, w, xcat, ldx);
+    } else
     if (k == 20)          // the reference's gnn_k: pooling specialised at compile time
         hipLaunchKernelGGL(edgeconv_fused_kernel<20>, dim3(blocks), dim3(512), lds, ogmm::as_stream(stream), xyz, idx, N, k, total, P, n_tiles, two_pools,
                            w, xcat, ldx);
@@ -410,4 +434,12 @@ extern "C" int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, 
         hipLaunchKernelGGL(edgeconv_fused_kernel<0>, dim3(blocks), dim3(512), lds, ogmm::as_stream(stream), xyz, idx, N, k, total, P, n_tiles, two_pools,
                            w, xcat, ldx);
     return ogmm::check_launch("ogmm_edgeconv_fused");
+}
+
+// diagnostic (tools/edgeconv_time.py): read and clear the phase probe
+extern "C" int ogmm_debug_edgeconv_probe(unsigned long long* host8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_edgeconv_probe), sizeof(z)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_edgeconv_probe), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
 }

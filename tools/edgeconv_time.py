@@ -24,3 +24,20 @@ for abl in [0]:
     for _ in range(5): ops.edgeconv_fused(xyz, idx, emd, xcat)
     e1.record(); torch.cuda.synchronize()
     print("edgeconv_fused %.1f us" % (e0.elapsed_time(e1) / 5 * 1e3))
+
+if os.environ.get("OGMM_EDGECONV_PROBE") == "1":
+    import ctypes
+    from ogmm_amd import _lib
+    buf = (ctypes.c_ulonglong * 8)()
+    _lib.call("ogmm_debug_edgeconv_probe", ctypes.cast(buf, ctypes.c_void_p))          # clear
+    ops.edgeconv_fused(xyz, idx, emd, xcat)
+    torch.cuda.synchronize()
+    _lib.call("ogmm_debug_edgeconv_probe", ctypes.cast(buf, ctypes.c_void_p))
+    v = list(buf)
+    tiles = max(1, v[6])
+    names = ["setup -> barrier 1", "layer 1", "layer 2", "layer 3", "layer 4", "flush + turn-around"]
+    tot = sum(v[:5])
+    print("phase probe: %d tiles; shader cycles per tile (thread 0 of each workgroup):" % tiles)
+    for n_, c in zip(names, v[:5]):
+        print("   %-22s %8.0f  (%4.1f %%)" % (n_, c / tiles, 100.0 * c / tot))
+    print("   total %.0f cycles per tile; MFMA-only: 10560 (1320 matrix instructions of 32 cycles on 4 SIMDs)" % (tot / tiles))
