@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 17
+#define OGMM_ABI_VERSION 18
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -170,6 +170,13 @@ int ogmm_edgeconv_first(const float* xyz, const int32_t* idx, int C, int N, int 
  * their weights as OGMM_PREC_F16X3_FRAG images (h*, l*) with folded BN scale/shift (s*, t*) and the image's inverse
  * power-of-two scale (inv*).  No per-edge tensor is written to memory. */
 int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, int N, int k, const float* W1, const float* s1, const float* t1,
+                        const void* h2, const void* l2, const float* s2, const float* t2, float inv2, const void* h3, const void* l3,
+                        const float* s3, const float* t3, float inv3, const void* h4, const void* l4, const float* s4, const float* t4,
+                        float inv4, float* xcat, int64_t ldx, void* stream);
+/* The same chain as a producer / consumer pipeline over 32-row blocks (k = 20 only; edgeconv_pc.hip): four waves compute layers 1-3 of a block
+ * each, four waves multiply every block with layer 4, so that every SIMD holds one vector-ALU-heavy and one matrix-heavy wave; no workgroup
+ * barrier in the loop.  Same arguments, bit-identical xcat. */
+int ogmm_edgeconv_pc(const float* xyz, const int32_t* idx, int C, int N, int k, const float* W1, const float* s1, const float* t1,
                         const void* h2, const void* l2, const float* s2, const float* t2, float inv2, const void* h3, const void* l3,
                         const float* s3, const float* t3, float inv3, const void* h4, const void* l4, const float* s4, const float* t4,
                         float inv4, float* xcat, int64_t ldx, void* stream);
@@ -430,7 +437,8 @@ int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ld
  * clock the kernel really ran at -- rocprofv3 pins the clock, so its counters cannot tell. */
 int ogmm_debug_v6_probe(unsigned long long* host3);
 int ogmm_debug_v8_probe(unsigned long long* host3);
-int ogmm_debug_edgeconv_probe(unsigned long long* host8);          /* OGMM_EDGECONV_PROBE=1: shader cycles per phase of the fused EdgeConv kernel */
+int ogmm_debug_edgeconv_probe(unsigned long long* host8);
+int ogmm_debug_edgeconv_pc_probe(unsigned long long* host8);          /* OGMM_EDGECONV_PROBE=1: shader cycles per phase of the fused EdgeConv kernel */
 int ogmm_debug_v10_probe(unsigned long long* host3);
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -56,6 +56,8 @@ PROTOTYPES = {
     "ogmm_edgeconv_first": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_edgeconv_fused": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p] +
                            [c_void_p, c_void_p, c_void_p, c_void_p, c_float] * 3 + [c_void_p, c_int64, c_void_p],
+    "ogmm_edgeconv_pc": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p] +
+                        [c_void_p, c_void_p, c_void_p, c_void_p, c_float] * 3 + [c_void_p, c_int64, c_void_p],
     "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
     "ogmm_attention_workspace_bytes": [c_int, c_int, c_int, c_int],
     "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_void_p],
@@ -117,6 +119,7 @@ PROTOTYPES = {
     "ogmm_debug_v6_probe": [c_void_p],          # diagnostics of the large-shape GEMM engines (tools/gemm_v6_check.py)
     "ogmm_debug_v8_probe": [c_void_p],
     "ogmm_debug_edgeconv_probe": [c_void_p],
+    "ogmm_debug_edgeconv_pc_probe": [c_void_p],
     "ogmm_debug_v10_probe": [c_void_p],
     "ogmm_transpose_pad": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ogmm_pack_frag_t": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,

@@ -15,6 +15,7 @@ from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16_FRAG, P
 # entries are (start_event, end_event, algorithmic_flops)
 GEMM_TIMELINE = None
 FUSE_GATHER = os.environ.get("OGMM_FUSE_GATHER", "1") != "0"      # anchor rows gathered by the consuming GEMM's operand DMA (conv1x1_gathered)
+EDGECONV_PC = os.environ.get("OGMM_EDGECONV_PC", "1") != "0"      # the EdgeConv chain as a producer / consumer pipeline (k = 20)
 FUSE_HEAD = os.environ.get("OGMM_FUSE_HEAD", "1") != "0"      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
 GEMM_TIMELINE_ONLY = None      # optional set of variant tags: only those launches are bracketed by events (bench.py: the dominant engine only)
 KERNEL_TIMELINE = None         # bench.py: a list -> the EdgeConv and attention launches are bracketed too: (start_event, end_event, name, algorithmic flops, algorithmic bytes)
@@ -339,8 +340,10 @@ def edgeconv_fused(xyz, idx, layers, xcat):
         args += [_p(sp["W_hi"]), _p(sp["W_lo"]), _p(l["scale"]), _p(l["shift"]), sp["inv_scale"]]
     # algorithmic work: the four 1x1 convolutions over C*N*k edges (models/dgcnn.py:121-124); bytes: xyz + idx in, xcat out
     E = float(C) * N * k
+    # k = 20 (the reference's gnn_k): the producer / consumer pipeline (edgeconv_pc.hip, bit-identical); OGMM_EDGECONV_PC=0: the barrier-phased kernel
+    fn = "ogmm_edgeconv_pc" if k == 20 and EDGECONV_PC else "ogmm_edgeconv_fused"
     _timed_call("edgeconv_fused_kernel", 2.0 * E * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 256), 4.0 * (3 * C * N + E + 512.0 * C * N),
-                "ogmm_edgeconv_fused", *args, _p(xcat), xcat.stride(0), _stream())
+                fn, *args, _p(xcat), xcat.stride(0), _stream())
     return xcat
 
 

@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from argparse import Namespace
 import torch
-from ogmm_amd import synth
+from ogmm_amd import ops, synth
 from ogmm_amd.gmmreg import GMMReg
 
 B, N, J = 64, 1024, 16
@@ -15,19 +15,26 @@ for name, attrs in settings:
     m = GMMReg(512, J, cfg)
     synth.fill_state_dict(m.state_dict())
     m = m.cuda().eval()
+    m._ops_attrs = {k[4:]: v for k, v in attrs.items() if k.startswith("ops.")}          # module-level switches of ogmm_amd.ops, set before each of this model's runs
     for k, v in attrs.items():
-        setattr(m, k, v)
+        if not k.startswith("ops."):
+            setattr(m, k, v)
     models.append((name, m))
 src, tgt, _, _ = synth.make_batch(0, B, N, "partial")
 starts = synth.fps_starts_for(0, B, N)
 src, tgt = src.cuda(), tgt.cuda()
 res = {name: [] for name, _ in models}
 with torch.no_grad():
+    def switch(m):
+        for k, v in m._ops_attrs.items():
+            setattr(ops, k, v)
     for name, m in models:
+        switch(m)
         for _ in range(3):
             m(src, tgt, fps_starts=starts)
     for rnd in range(5):
         for name, m in models:
+            switch(m)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(20):
