@@ -48,8 +48,20 @@ def welsch_loss(src, tgt, R, t, src_overlap, tgt_overlap, alpha=10.0, top_k=512)
     s_ids = torch.topk(src_overlap, k=top_k, dim=-1)[1]
     t_ids = torch.topk(tgt_overlap, k=top_k, dim=-1)[1]
     take = lambda p, ids: torch.gather(p, 1, ids[:, :, None].expand(-1, -1, 3))          # noqa: E731
-    z1 = torch.cdist(take(moved, s_ids), tgt).min(dim=-1)[0]
-    z2 = torch.cdist(take(tgt, t_ids), moved).min(dim=-1)[0]
+    if moved.is_cuda:
+        # min over a [B, top_k, N] distance tensor (268 MB per term at 128 x 512 x 1024, plus its backward) = the distance to the NEAREST point: the
+        # index comes from the nearest-point kernel (cdist's matmul form, first minimum), the distance and its gradient -- (p - q*) / |p - q*|, the
+        # sub-gradient torch's min picks -- from the two gathered points
+        from . import ops
+
+        def nearest_dist(a, b):          # a [B,K,3] (grad), b [B,N,3] (grad) -> [B,K]
+            q = take(b, ops.nearest_point(b.detach().contiguous(), a.detach().contiguous()).long())
+            return torch.linalg.vector_norm(a - q, dim=-1)
+        z1 = nearest_dist(take(moved, s_ids), tgt)
+        z2 = nearest_dist(take(tgt, t_ids), moved)
+    else:
+        z1 = torch.cdist(take(moved, s_ids), tgt).min(dim=-1)[0]
+        z2 = torch.cdist(take(tgt, t_ids), moved).min(dim=-1)[0]
     a2 = alpha * alpha
     return (2.0 - torch.exp(-0.5 * z1 * z1 / a2) - torch.exp(-0.5 * z2 * z2 / a2)).sum(dim=1).mean()
 
