@@ -416,7 +416,7 @@ int ogmm_kabsch_bwd(const float* src, const float* corr, const float* w, int B, 
 /* ---- T5: index of the point nearest to each centre (lib/utils.py:244-254, torch.cdist + top-1): near [C][J]. */
 int ogmm_nearest_point(const float* xyz, const float* mu /*[C][J][3]*/, int C, int N, int J, int32_t* near, void* stream);
 
-/* Power-of-two scale of a weight for the binary16 split, on the device: scale_out[0] = 2^e with max|W| 2^e in [2^top, 2^(top+1)) (e clamped to +-24),
+/* Power-of-two scale of a weight for the binary16 split, on the device: scale_out [4 floats, ZERO on entry: [2], [3] are the kernel's scratch]; scale_out[0] = 2^e with max|W| 2^e in [2^top, 2^(top+1)) (e clamped to +-24),
  * inv_out[0 .. inv_len) = 2^-e (handed to ogmm_gemm_nt as its per-column `scale`).  The training step splits its weights every step
  * (train_ops._Linear): no host synchronisation, no cached exponent that could go stale. */
 int ogmm_pow2_scale(const float* W, int64_t count, int top, float* scale_out, float* inv_out, int inv_len, void* stream);

@@ -76,28 +76,41 @@ namespace {
 // Power-of-two scale of a weight for the binary16 split (ops.split_f16): 2^e with max|W| 2^e in [2^top, 2^(top+1)), e clamped to +-24; one workgroup scans
 // the weight (<= a few MB: ~10 us), writes 2^e and fills a vector with 2^-e that the GEMM takes as its per-column scale (struct ogmm_gemm.scale).  No
 // host round trip and no cache: the training step re-splits ~120 weights (and derived, permuted / transposed copies of them) every step.
-__global__ __launch_bounds__(1024) void pow2_scale_kernel(const float* __restrict__ W, int64_t count, int top, float* __restrict__ scale_out,
-                                                          float* __restrict__ inv_out, int inv_len) {
-    __shared__ float red[16];
+__global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict__ W, int64_t count, int top, float* __restrict__ scale_out,
+                                                         float* __restrict__ inv_out, int inv_len) {
+    // grid-wide: every workgroup reduces its slice (a single workgroup scanning a 4 MB weight took 80-285 us: 5 ms per training step), the maxima
+    // meet in scale_out[2] (bit pattern of a non-negative float: integer order = float order) and the last workgroup to arrive (ticket in
+    // scale_out[3]) derives the scale and fills the inverse vector.  scale_out[0..3] must be zero on entry.
+    __shared__ float red[4];
+    __shared__ int s_last;
     float m = 0.0f;
-    for (int64_t i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(W[i]));          // (NaN is ignored by fmaxf; inf propagates)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(W[i]));
     m = ogmm::wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    m = 0.0f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) m = fmaxf(m, red[w]);
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int* bits = reinterpret_cast<int*>(scale_out + 2);
+        int* ticket = reinterpret_cast<int*>(scale_out + 3);
+        __hip_atomic_fetch_max(bits, __float_as_int(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float mx = __int_as_float(__hip_atomic_load(reinterpret_cast<int*>(scale_out + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     int e = 0;
-    if (m > 0.0f && m < __builtin_inff()) e = min(24, max(-24, top - (int)floorf(log2f(m))));
+    if (mx > 0.0f && mx < __builtin_inff()) e = min(24, max(-24, top - (int)floorf(log2f(mx))));
     const float sc = exp2f((float)e), inv = exp2f((float)-e);
     if (threadIdx.x == 0) scale_out[0] = sc;
-    for (int i = threadIdx.x; i < inv_len; i += 1024) inv_out[i] = inv;
+    for (int i = threadIdx.x; i < inv_len; i += 256) inv_out[i] = inv;
 }
 }  // namespace
 
 extern "C" int ogmm_pow2_scale(const float* W, int64_t count, int top, float* scale_out, float* inv_out, int inv_len, void* stream) {
     OGMM_REQUIRE(W && scale_out && inv_out && count > 0 && inv_len > 0 && top >= 0 && top <= 14, "ogmm_pow2_scale: bad arguments");
-    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1024), 0, ogmm::as_stream(stream), W, count, top, scale_out, inv_out, inv_len);
+    const unsigned blocks = (unsigned)std::min<int64_t>(256, (count + 4095) / 4096);
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(blocks), dim3(256), 0, ogmm::as_stream(stream), W, count, top, scale_out, inv_out, inv_len);
     return ogmm::check_launch("ogmm_pow2_scale");
 }
 

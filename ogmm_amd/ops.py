@@ -128,7 +128,7 @@ def gather_rows(feats, ld, C, N, D, ids, cloud_map=None):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM engine
-def split_f16(W, pad_to=8, frag=False, k1=None, exp=None):
+def split_f16(W, pad_to=8, frag=False, k1=None, exp=None, scale_t=None):
     """fp32 [N,K] -> dict(W_hi, W_lo binary16, inv_scale): W * 2^e = hi + lo with the power of two chosen so
     that max|W| * 2^e is in [2^11, 2^12) (keeps `lo` a normal binary16 number); inv_scale = 2^-e goes into alpha.
     frag=False: row-major [N, Kpad8] planes (OGMM_PREC_F16X3).  frag=True: the fragment-major image of
@@ -142,11 +142,14 @@ def split_f16(W, pad_to=8, frag=False, k1=None, exp=None):
         assert k1 % 64 == 0 or k1 == K
         k2 = K - k1
         k1p, k2p = (k1 + 63) // 64 * 64, (k2 + 63) // 64 * 64      # K tiles of 64 (v3 engine); v2 walks them as 2 x 32
-        Wp = W.new_zeros((N + 255) // 256 * 256, k1p + k2p)
-        Wp[:N, :k1] = W[:, :k1]
-        if k2:
-            Wp[:N, k1p:k1p + k2] = W[:, k1:]
-        planes = split_f16(Wp, pad_to=64, exp=exp)
+        if N % 256 == 0 and k2 == 0 and K == k1p:
+            Wp = W          # already whole tiles: no padded copy (two launches per split less: the training step re-splits ~120 weights)
+        else:
+            Wp = W.new_zeros((N + 255) // 256 * 256, k1p + k2p)
+            Wp[:N, :k1] = W[:, :k1]
+            if k2:
+                Wp[:N, k1p:k1p + k2] = W[:, k1:]
+        planes = split_f16(Wp, pad_to=64, exp=exp, scale_t=scale_t)
         Np, Kp = Wp.shape
 
         def image(P):      # [Np, Kp] -> [Np/32][Kp/16][lane = g*32 + r][8]
@@ -155,10 +158,11 @@ def split_f16(W, pad_to=8, frag=False, k1=None, exp=None):
                 "variant": PREC_F16X3_FRAG, "ldb_h": Kp}
     # power of two on the DEVICE (no .item(): the training path splits ~60 weights per step): e = 11 - floor(log2(max|W|)), clamped to +-24;
     # the scale itself stays a device scalar there, and `inv_scale` is a python float only for the pack-once inference path (one sync per pack)
-    if exp is not None:          # caller-supplied exponent (the training path re-uses last steps' one: no device reduction, no host sync)
+    if exp is not None or scale_t is not None:          # caller-supplied scale: a python exponent, or a device scalar 2^e (split_f16_training: no host sync)
         K = W.shape[1]
         Kp = (K + pad_to - 1) // pad_to * pad_to
-        Ws = W * (2.0 ** exp)
+        exp = 0 if exp is None else exp
+        Ws = W * scale_t if scale_t is not None else W * (2.0 ** exp)
         if Kp != K:
             Ws = torch.cat([Ws, Ws.new_zeros(W.shape[0], Kp - K)], dim=1)
         hi = Ws.half()
@@ -185,10 +189,20 @@ def split_f16_training(W, cout, **kw):
     be keyed on a recycled address), leaving one binade of headroom.  The inverse scale cannot ride in the host-side `alpha`, so it comes back as
     `col_scale` [cout], the GEMM's per-column scale (struct ogmm_gemm.scale); `inv_scale` is 1."""
     W = W.float().contiguous()
-    sc = torch.empty(1, dtype=torch.float32, device=W.device)
+    sc = torch.zeros(4, dtype=torch.float32, device=W.device)          # [0] the scale; [2], [3] the grid-wide reduction's scratch (zero on entry)
     inv = torch.empty(cout, dtype=torch.float32, device=W.device)
     _lib.call("ogmm_pow2_scale", _p(W), W.numel(), 10, _p(sc), _p(inv), cout, _stream())
-    sp = split_f16(W * sc, exp=0, **kw)
+    N, K = W.shape
+    k1 = kw.get("k1")
+    if kw.get("frag") and N % 256 == 0 and K % 64 == 0 and (k1 is None or k1 == K or k1 % 64 == 0):
+        # whole tiles and no padding between the A pieces: the split fragment images straight from the scaled weight with the activation packer
+        # (ogmm_pack_frag: the same image; four launches per split instead of a dozen torch ones -- the training step is sensitive to host time)
+        Ws = W * sc[0:1]
+        hi = torch.empty(N * K, dtype=torch.float16, device=W.device)
+        lo = torch.empty_like(hi)
+        _lib.call("ogmm_pack_frag", _p(Ws), K, N, K, _p(hi), _p(lo), _stream())
+        return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "col_scale": inv}
+    sp = split_f16(W, scale_t=sc[0:1], **kw)
     sp["col_scale"] = inv
     return sp
 

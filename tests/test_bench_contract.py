@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/round1_bench_n1.json, written by `python bench.py` on the GPU box) carries every field of the
+"""The committed bench line (profiles/round3_bench_n1.json, written by `python bench.py` on the GPU box) carries every field of the
 driver's contract, and bench.py's command line parses the driver's invocation."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.load(open(os.path.join(ROOT, "profiles", "round1_bench_n1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "round3_bench_n1.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in line, key
     assert line["metric"] == "pairs_per_sec" and line["unit"] == "pairs/s" and line["n_gpus"] == 1 and line["higher_is_better"] is True
