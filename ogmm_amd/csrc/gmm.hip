@@ -57,20 +57,33 @@ __device__ __forceinline__ int em_chip_cloud(const EmExit& x, float* red) {
 }
 
 // End of sweep `sk` (0-based) of E-step `it`, called by the whole workgroup behind the barrier that follows the v update: u / v hold this sweep's
-// result, uprev / vprev the previous sweep's, red[sk & 1] the cloud's sum |du| + sum |dv| of this sweep.  Publishes the residual, then asks for the
-// group's decision about sweep sk - 1 (one sweep of lag: normally nobody waits); true = that sweep ended the E-step and u / v are rolled back to it.
+// result, uprev / vprev the previous sweep's, red[16 + 16 * (sk & 1) + w] wave w's share of the cloud's sum |du| + sum |dv| of this sweep (summed here in
+// wave order: deterministic).  Wave 0 publishes the residual, then forms the group's decision about sweep sk - 1 (one sweep of lag: normally the
+// residuals are all there); true = that sweep ended the E-step and u / v are rolled back to it.
 __device__ __forceinline__ bool em_chip_sweep_end(const EmExit& x, float* red, int c, int it, int sk, int sk_iters, float* u, const float* uprev,
                                                   float* v, const float* vprev, int N, int J) {
-    if (threadIdx.x == 0) {
-        const float r = red[sk & 1];
-        red[sk & 1] = 0.0f;
+    if (threadIdx.x < 64) {
+        const float* part = red + 16 + 16 * (sk & 1);
+        float r = 0.0f;
+#pragma unroll
+        for (int w = 0; w < EM_T / 64; ++w) r += part[w];
         int stop = 0;
         if (x.on) {
-            if (sk + 1 < sk_iters) em_exit_publish(x, c, it, sk, r);          // (nobody asks about the last sweep)
-            if (sk >= 1) stop = em_exit_wait(x, c, it, sk - 1) ? 1 : 0;
+            if (sk + 1 < sk_iters && threadIdx.x == 0)          // (nobody asks about the last sweep)
+                em_st_agent(x.rc + ((int64_t)it * x.sk + sk) * x.C + c, em_exit_publish_value(r));
+            if (sk >= 1) {
+                stop = em_exit_decide_wave(x, c, it, sk - 1) ? 1 : 0;
+                if (stop && threadIdx.x == 0 && c % x.G == 0) {          // the group's first cloud reports the count
+                    const int g = c / x.G;
+                    em_st_agent(x.kstop + g * x.iters + it, sk);
+                    if (x.sweeps) x.sweeps[g * x.iters + it] = sk;
+                }
+            }
         }
-        if (x.resid && !stop) x.resid[((int64_t)c * x.iters + it) * x.sk + sk] = r;          // (a discarded sweep stays NaN)
-        red[2] = __int_as_float(stop);
+        if (threadIdx.x == 0) {
+            if (x.resid && !stop) x.resid[((int64_t)c * x.iters + it) * x.sk + sk] = r;          // (a discarded sweep stays NaN)
+            red[2] = __int_as_float(stop);
+        }
     }
     if (!x.on || sk == 0) return false;
     __syncthreads();
@@ -104,8 +117,8 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
     float* rclip = logp + Npad;                           // [N]  max(rowsum, 1e-3)
     float4* mu = reinterpret_cast<float4*>(rclip + Npad); // [J]  mx, my, mz, |mu|^2
     float* v = reinterpret_cast<float*>(mu + J);          // [J]
-    float* red = v + J;                                   // [16]
-    float* uprev = red + 16;                              // [N]  u, v of the previous sweep (early exit: gmm_exit.h)
+    float* red = v + J;                                   // [48]: scratch, then per-wave residual shares of the even / odd sweeps
+    float* uprev = red + 48;                              // [N]  u, v of the previous sweep (early exit: gmm_exit.h)
     float* vprev = uprev + Npad;                          // [J]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = em_chip_cloud(x, red);
@@ -136,7 +149,6 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
     }
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
     __syncthreads();
-    if (track && tid < 2) red[tid] = 0.0f;          // red[0] / red[1] alternate as the sweep's residual accumulator
 
     for (int it = 0; it < iters; ++it) {
         for (int n = tid; n < N; n += EM_T) u[n] = 0.0f;
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
         __syncthreads();
         for (int sk = 0; sk < sk_iters; ++sk) {
             // u^{l+1}: rows on threads
+            float du = 0.0f, dv = 0.0f;          // this thread's share of the sweep's residual
             for (int n = tid; n < N; n += EM_T) {
                 const float4 p = pts[n];
                 const float un = u[n];
@@ -155,8 +168,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
                 }
                 const float un1 = eps * (logp[n] - (a.m + logf(a.s))) + un;
                 u[n] = un1;
-                if (track) { uprev[n] = un; atomicAdd(&red[sk & 1], fabsf(un1 - un)); }
+                if (track) { uprev[n] = un; du += fabsf(un1 - un); }
             }
+            if (track) { du = wave_sum(du); if (lane == 0) red[16 + 16 * (sk & 1) + wave] = du; }
             __syncthreads();
             // v^{l+1}: columns on waves
             for (int j = wave; j < J; j += NW) {
@@ -176,9 +190,10 @@ __global__ __launch_bounds__(EM_T) void gmm_em_kernel(const float* __restrict__ 
                 if (lane == 0) {
                     const float vj1 = eps * (logq - (a.m + logf(a.s))) + vj;
                     v[j] = vj1;
-                    if (track) { vprev[j] = vj; atomicAdd(&red[sk & 1], fabsf(vj1 - vj)); }
+                    if (track) { vprev[j] = vj; dv += fabsf(vj1 - vj); }
                 }
             }
+            if (track && lane == 0) red[16 + 16 * (sk & 1) + wave] += dv;
             __syncthreads();
             if (track && em_chip_sweep_end(x, red, c, it, sk, sk_iters, u, uprev, v, vprev, N, J)) break;
         }
@@ -263,8 +278,8 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
     float* rclip = logp + Npad;
     float4* mu = reinterpret_cast<float4*>(rclip + Npad);
     float* v = reinterpret_cast<float*>(mu + J);
-    float* red = v + J;                                   // [16]
-    float* uprev = red + 16;                              // [N]  u, v of the previous sweep (early exit: gmm_exit.h)
+    float* red = v + J;                                   // [48]: scratch, then per-wave residual shares of the even / odd sweeps
+    float* uprev = red + 48;                              // [N]  u, v of the previous sweep (early exit: gmm_exit.h)
     float* vprev = uprev + Npad;                          // [J]
     float* Cs = vprev + (J + 3) / 4 * 4;                  // [J][N] cost, later unnormalised gamma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,8 +308,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
     const float logq = logf((float)(1.0 / (double)J) + 1e-8f);
     __syncthreads();
     // track: sum |u - u0| + sum |v - v0| of every Sinkhorn sweep, the quantity whose batch mean the reference tests against `thresh` for its
-    // early exit (lib/utils.py:99-102; em_chip_sweep_end).  red[0] / red[1] alternate as the sweep's accumulator.
-    if (track && tid < 2) red[tid] = 0.0f;
+    // early exit (lib/utils.py:99-102; em_chip_sweep_end).  Summed per wave into red[16 + 16 * (sk & 1) + wave], then in wave order.
 
     for (int it = 0; it < iters; ++it) {
         for (int n = tid; n < N; n += EM_T) {
@@ -309,6 +323,7 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
         __syncthreads();
         for (int sk = 0; sk < sk_iters; ++sk) {
             auto em_exp = [](float x) { return FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x); };
+            float du = 0.0f, dv = 0.0f;          // this thread's share of the sweep's residual
             if constexpr (JT > 0) {
                 if (tid < N) {                                            // u^{l+1}: one row per thread (N <= EM_T)
                     const int n = tid;
@@ -322,8 +337,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                     for (int j = 0; j < JT; ++j) se += em_exp(t[j] - mx);
                     const float un1 = eps * (logp[n] - (mx + logf(se))) + un;
                     u[n] = un1;
-                    if (track) { uprev[n] = un; atomicAdd(&red[sk & 1], fabsf(un1 - un)); }
+                    if (track) { uprev[n] = un; du = fabsf(un1 - un); }
                 }
+                if (track) { du = wave_sum(du); if (lane == 0) red[16 + 16 * (sk & 1) + wave] = du; }
                 __syncthreads();
                 for (int j = wave; j < JT; j += NW) {                     // v^{l+1}: columns on waves, 16 rows per lane
                     const float vj = v[j];
@@ -345,9 +361,10 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                     if (lane == 0) {
                         const float vj1 = eps * (logq - (mx + logf(se))) + vj;
                         v[j] = vj1;
-                        if (track) { vprev[j] = vj; atomicAdd(&red[sk & 1], fabsf(vj1 - vj)); }
+                        if (track) { vprev[j] = vj; dv += fabsf(vj1 - vj); }
                     }
                 }
+                if (track && lane == 0) red[16 + 16 * (sk & 1) + wave] += dv;
                 __syncthreads();
                 if (track && em_chip_sweep_end(x, red, c, it, sk, sk_iters, u, uprev, v, vprev, N, J)) break;
                 continue;
@@ -360,8 +377,9 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                 for (int j = 0; j < J; ++j) se += expf(((-Cs[j * N + n] + un) + v[j]) * inv_eps - mx);
                 const float un1 = eps * (logp[n] - (mx + logf(se))) + un;
                 u[n] = un1;
-                if (track) { uprev[n] = un; atomicAdd(&red[sk & 1], fabsf(un1 - un)); }
+                if (track) { uprev[n] = un; du += fabsf(un1 - un); }
             }
+            if (track) { du = wave_sum(du); if (lane == 0) red[16 + 16 * (sk & 1) + wave] = du; }
             __syncthreads();
             for (int j = wave; j < J; j += NW) {                      // v^{l+1}: columns on waves
                 const float vj = v[j];
@@ -375,9 +393,10 @@ __global__ __launch_bounds__(EM_T) void gmm_em_cached_kernel(const float* __rest
                 if (lane == 0) {
                     const float vj1 = eps * (logq - (mx + logf(se))) + vj;
                     v[j] = vj1;
-                    if (track) { vprev[j] = vj; atomicAdd(&red[sk & 1], fabsf(vj1 - vj)); }
+                    if (track) { vprev[j] = vj; dv += fabsf(vj1 - vj); }
                 }
             }
+            if (track && lane == 0) red[16 + 16 * (sk & 1) + wave] += dv;
             __syncthreads();
             if (track && em_chip_sweep_end(x, red, c, it, sk, sk_iters, u, uprev, v, vprev, N, J)) break;
         }
@@ -1039,7 +1058,7 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restri
 namespace {
 size_t em_chip_lds(int N, int J, bool cached) {
     const size_t Npad = (size_t)(N + 3) / 4 * 4, Jp = (size_t)(J + 3) / 4 * 4;   // Npad keeps the float4 mu array 16-byte aligned behind the per-point floats
-    return ((size_t)4 * N + 4 * Npad + 4 * (size_t)J + J + 16 + Jp + (cached ? (size_t)N * J : 0)) * sizeof(float);
+    return ((size_t)4 * N + 4 * Npad + 4 * (size_t)J + J + 48 + Jp + (cached ? (size_t)N * J : 0)) * sizeof(float);
 }
 }  // namespace
 

@@ -71,6 +71,33 @@ __device__ __forceinline__ void em_exit_publish(const EmExit& x, int c, int it, 
     }
 }
 
+// On-chip kernels, all 64 lanes of one wave: the group's decision about sweep k (0-based) straight from the published residuals -- no arrival counter
+// and no decision word, so a decision costs one store and one (polled) load instead of five dependent trips to memory.  Every cloud of the group reads the
+// group's G residuals (one per lane and round of 64), polls until none is the "not yet" pattern em_exit_setup filled in (all ones: a published residual
+// has its sign bit clear, em_exit_publish_value), and forms the same sum in the same order (lane-strided partials, xor butterfly) -- so all clouds take
+// the same decision.  true = the E-step's sweeps end with sweep k.
+__device__ __forceinline__ float em_exit_publish_value(float r) { return r == r ? fabsf(r) : __builtin_inff(); }          // NaN -> inf: "not below" either way
+__device__ __forceinline__ bool em_exit_decide_wave(const EmExit& x, int c, int it, int k) {
+    const int lane = threadIdx.x & 63, g = c / x.G;
+    const float* __restrict__ rc = x.rc + ((int64_t)it * x.sk + k) * x.C + (int64_t)g * x.G;
+    float s = 0.0f;
+    for (int base = 0; base < x.G; base += 64) {
+        const int i = base + lane;
+        float r = 0.0f;
+        if (i < x.G) {
+            int polls = 0;
+            while (__float_as_uint(r = em_ld_agent(rc + i)) == 0xFFFFFFFFu) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > (1 << 24)) { em_st_agent(x.err, 1); r = 0.0f; break; }
+            }
+        }
+        s += r;
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)x.G;
+    return (double)mean < x.thresh;
+}
+
 // One lane: the group's decision about sweep k (0-based): true = the E-step's sweeps end with sweep k.
 __device__ __forceinline__ bool em_exit_wait(const EmExit& x, int c, int it, int k) {
     const int slot = ((c / x.G) * x.iters + it) * x.sk + k;
@@ -123,7 +150,9 @@ static inline int em_exit_setup(EmExit& x, double thresh, int group_size, int C,
     x.ccount = x.kstop + ng * iters;
     (void)hipMemsetAsync(ip, 0, ints * 4, s);
     p += em_exit_align(ints * 4);
-    x.rc = reinterpret_cast<float*>(p);     p += em_exit_align((size_t)iters * sk * C * 4);
+    x.rc = reinterpret_cast<float*>(p);
+    (void)hipMemsetAsync(x.rc, 0xFF, (size_t)iters * sk * C * 4, s);          // "not yet published" (em_exit_decide_wave)
+    p += em_exit_align((size_t)iters * sk * C * 4);
     x.dupart = reinterpret_cast<float*>(p); p += em_exit_align(2 * (size_t)C * chunks * 4);
     x.u2 = reinterpret_cast<float*>(p);
     return 0;

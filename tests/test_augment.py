@@ -95,3 +95,38 @@ def test_overlap_labels_on_the_gpu_match_brute_force():
     a, b = augment.overlap_labels(src.transpose(1, 2).contiguous().cuda(), tgt.transpose(1, 2).contiguous().cuda(), T.cuda(), 0.05)
     # fp32 distances against the fp64 brute force of synth.overlap_labels: only points within rounding of the radius may differ
     assert (a.cpu() != so).float().mean() < 2e-3 and (b.cpu() != to).float().mean() < 2e-3
+
+
+def _chain_fixture():
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_crop_chain.npz"))
+    for g in range(3):
+        raw = torch.from_numpy(fx["g%d/raw" % g])
+        draws = {k.split("/")[-1]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g%d/draw/" % g)}
+        want = {k.split("/")[-1]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g%d/out/" % g)}
+        yield g, raw, draws, want
+
+
+def _check_chain(device):
+    """The whole chain against what the reference's own transforms made of the same clouds and the same random numbers
+    (tests/golden/make_golden_augment.py): labels and point identities exact, coordinates to fp32 rounding."""
+    for g, raw, draws, want in _chain_fixture():
+        out = augment.crop_pipeline(raw.double().to(device), {k: v.double().to(device) for k, v in draws.items()}, n_out=717)
+        out = {k: v.cpu() for k, v in out.items()}
+        assert torch.equal(out["src_overlap"], want["src_overlap"]) and torch.equal(out["tgt_overlap"], want["tgt_overlap"]), g
+        assert (out["src_xyz"] - want["src_xyz"]).abs().max().item() < 1e-6, g
+        assert (out["tgt_xyz"] - want["tgt_xyz"]).abs().max().item() < 1e-6, g
+        assert (out["transform_gt"][:, :3] - want["transform_gt"]).abs().max().item() < 1e-6, g
+        # every output point is its raw point moved and jittered: identities follow from the coordinates being equal, and the
+        # small-crop group repeats points exactly where the reference does
+        if g == 1:
+            assert all(len(set(out["src_index"][b].tolist())) == int(want["n_kept"][b, 0]) for b in range(2))
+
+
+def test_whole_chain_matches_the_reference_transforms():
+    _check_chain("cpu")
+
+
+@pytest.mark.gpu
+def test_whole_chain_matches_the_reference_transforms_on_the_gpu():
+    _check_chain("cuda")

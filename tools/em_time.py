@@ -9,9 +9,11 @@ xyz = torch.randn(C, N, 3, device="cuda") * 0.5
 o = torch.rand(C, N, device="cuda")
 ids = ops.fps(xyz, J, None)
 for eng in (None, "multi"):
-    for _ in range(2): ops.gmm_em(xyz, o, ids, engine=eng)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5): ops.gmm_em(xyz, o, ids, engine=eng)
-    e1.record(); torch.cuda.synchronize()
-    print("C=%d N=%d J=%d engine=%s  %.1f us" % (C, N, J, eng, e0.elapsed_time(e1) / 5 * 1e3))
+    for thresh in (0.0, 1e-2):          # early exit off / on (two call groups of C / 2 clouds, as GMMReg.forward calls it)
+        kw = dict(engine=eng, thresh=thresh, group_size=C // 2 if C % 2 == 0 else C)
+        for _ in range(2): ops.gmm_em(xyz, o, ids, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): ops.gmm_em(xyz, o, ids, **kw)
+        e1.record(); torch.cuda.synchronize()
+        print("C=%d N=%d J=%d engine=%s thresh=%g  %.1f us" % (C, N, J, eng, thresh, e0.elapsed_time(e1) / 5 * 1e3))
