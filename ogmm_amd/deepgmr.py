@@ -2,7 +2,8 @@
 
 Same constructor `DeepGMR(emb_dims, n_clusters, config)` (config: gnn_k, overlap_radius), same call
 `model(src, tgt, is_test=False)` with float32 [B,3,N] inputs and the same state_dict keys (`backbone.conv1..5`,
-`backbone.bn1..5`, `cluster.net.{0,1,3,4,6}`), eval mode.  Shares with GMMReg: kNN + fused EdgeConv + the dense GEMM engine
+`backbone.bn1..5`, `cluster.net.{0,1,3,4,6}`); `.eval()` runs the fused inference kernels, `.train()` the training graph
+(train_graph.deepgmr_forward_train; the loop of train_base.py:27-75 is trainer.BaselineTrainer).  Shares with GMMReg: kNN + fused EdgeConv + the dense GEMM engine
 (backbone and cluster head), the softmax kernel, the GMM moment kernel, the in-register 3x3 solve and the ICP refinement.
 
 Behaviour kept as is: without `is_test` the second return value is `tsfm[:, 3, 0:3]`, the bottom row of
@@ -84,8 +85,6 @@ class DeepGMR(nn.Module):
     def forward(self, src, tgt, is_test=False):
         if not (isinstance(src, torch.Tensor) and src.is_cuda and tgt.is_cuda):
             raise OgmmError("DeepGMR.forward needs CUDA/ROCm tensors: the MI355X path has no CPU fallback")
-        if self.training:
-            raise NotImplementedError("DeepGMR: eval-mode inference only (the baseline's training loop, train_base.py, is not built)")
         if src.dim() != 3 or src.shape[1] != 3 or src.shape != tgt.shape or src.dtype != torch.float32:
             raise OgmmError("src and tgt must be float32 [B,3,N] of equal shape")
         B, _, N = src.shape
@@ -93,6 +92,8 @@ class DeepGMR(nn.Module):
         dev = src.device
         if self._overflow is None or self._overflow.device != dev:
             self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.training:
+            return self._forward_train(src, tgt, is_test)
         L = self._layers()
         eng = ops.Engine(self.precision, self._overflow)
         xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()                 # [C,N,3]
@@ -128,3 +129,25 @@ class DeepGMR(nn.Module):
         if is_test:                                                                      # :76-78
             return ops.icp_point_to_point(xyz[:B], xyz[B:], Rm, t[:, :, 0].contiguous(), 2.0 * self.config.overlap_radius)
         return Rm, torch.zeros((B, 3), dtype=torch.float32, device=dev)                  # tsfm[:, 3, 0:3]: the bottom row (sic)
+
+    def overflow_flag(self, device):
+        """the engine's device-side overflow word (int32[1]; ogmm_amd/trainer.py snapshots it around forward and backward)"""
+        if self._overflow is None or self._overflow.device != torch.device(device):
+            self._overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._overflow
+
+    def _forward_train(self, src, tgt, is_test=False):
+        """`.train()`: batch-statistics BatchNorm with running-statistics updates and autograd through everything but the kNN
+        (ogmm_amd/train_graph.deepgmr_forward_train over the kernels of ogmm_amd/train_ops.py); train_base.py:27-75 is the loop around it."""
+        from . import train_graph, train_ops
+        if self.precision not in ("f16x3", "f32"):
+            raise OgmmError("training runs with precision 'f16x3' or 'f32' (the reduced 'f16' mode is inference only)")
+        P = dict(self.named_parameters())
+        P.update(dict(self.named_buffers()))
+        R, t = train_graph.deepgmr_forward_train(train_ops.TrainOps(self.precision, self.overflow_flag(src.device)), P, self.config,
+                                                 self.n_clusters, src, tgt)
+        if is_test:                                                                      # baseline/deepgmr.py:76-78 (no gradient through open3d there either)
+            return ops.icp_point_to_point(src.transpose(1, 2).contiguous(), tgt.transpose(1, 2).contiguous(), R.detach(), t.detach().contiguous(),
+                                          2.0 * self.config.overlap_radius)
+        # tsfm[:, 3, 0:3]: the bottom row of the 4x4 (sic, SURVEY appendix B) -- the baseline's loss sees the rotation only
+        return R, torch.zeros((src.shape[0], 3), dtype=torch.float32, device=src.device)

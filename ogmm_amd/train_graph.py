@@ -141,3 +141,33 @@ def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):
         cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, o=o, gamma=gamma, pi=pi, mu=mu,
                    muf=muf, near=near)
     return R, t, o[:B], o[B:], clu
+
+
+def deepgmr_forward_train(ops, P, cfg, n_clusters, src, tgt, cap=None):
+    """The DeepGMR baseline in `.train()` (baseline/deepgmr.py:64-79; its loop is train_base.py:27-75): backbone and cluster head with batch-statistics
+    BatchNorm per call (src call, then tgt call: two statistics groups, as in GMMReg), soft assignments, `gmm_params(..., return_sigma=True)`
+    (lib/utils.py:130-148) and `gmm_register` (baseline/deepgmr.py:17-37) as differentiable tensor operations on the [C,N,J] / [C,J,*] maps.
+    P: name -> tensor with the baseline's own keys (`backbone.*`, `cluster.*`).  Returns (R [B,3,3], t [B,3]) of `tsfm`; the module hands the caller
+    what the reference does (ogmm_amd/deepgmr.py)."""
+    B, _, N = src.shape
+    C, k, J = 2 * B, cfg.gnn_k, n_clusters
+    xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()              # [C,N,3]
+    idx = ops.knn(xyz, k)
+    Pb = {"emd." + key[len("backbone."):]: v for key, v in P.items() if key.startswith("backbone.")}
+    feats = dgcnn(ops, Pb, xyz, idx)                                              # deepgmr.py:66-67
+    logits = conv_stack(ops, P, "cluster", feats, True)                           # :69-70  [C*N, J]
+    gamma = torch.softmax(logits, dim=1).view(C, N, J)                            # :71-72
+    pi = gamma.mean(dim=1)                                                        # lib/utils.py:136-140
+    npi = pi * N + 1e-5
+    mu = torch.bmm(gamma.transpose(1, 2), xyz) / npi[:, :, None]                  # [C,J,3]
+    d2 = ((xyz[:, :, None, :] - mu[:, None, :, :]) ** 2).sum(dim=-1)              # lib/utils.py:143-147: isotropic sigma
+    sigma = (d2 * gamma).sum(dim=1) / npi                                         # [C,J]
+    pi_s, mu_s, mu_t, sig_t = pi[:B], mu[:B], mu[B:], sigma[B:]
+    c_s = torch.bmm(pi_s[:, None, :], mu_s)                                       # deepgmr.py:24-27: both centred with the SOURCE weights
+    c_t = torch.bmm(pi_s[:, None, :], mu_t)
+    Ms = torch.bmm((pi_s[:, :, None] * (mu_s - c_s)).transpose(1, 2), (mu_t - c_t) / sig_t[:, :, None])
+    R = ops.rotation_from_cov(torch.nan_to_num(Ms, nan=0.0) + 1e-4)               # :28-34
+    t = (c_t.transpose(1, 2) - torch.bmm(R, c_s.transpose(1, 2)))[:, :, 0]         # :35
+    if cap is not None:
+        cap.update(knn_idx=idx, feats=feats, gamma=gamma, pi=pi, mu=mu, sigma=sigma)
+    return R, t

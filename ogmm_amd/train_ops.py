@@ -439,6 +439,29 @@ class _Kabsch(torch.autograd.Function):
         return ops.kabsch_bwd(src, corr, w, gR, gt)
 
 
+class _RotationFromCov(torch.autograd.Function):
+    """R = V diag(1, 1, det(V U^T)) U^T of M = U S V^T (baseline/deepgmr.py:28-34) on ogmm_rotation_from_cov.  Backward: M is the covariance of a
+    four-point fit -- src = (e0, e1, e2, -(e0+e1+e2)) has centroid 0, so sum_j (src_j - 0)(corr_j - c)^T = sum_j src_j corr_j^T = M for corr_j = M[j, :]
+    (j < 3), corr_3 = 0 -- so dL/dM[j, :] is ogmm_kabsch_bwd's gradient for corr_j: the closed-form derivative through the 3x3 SVD (fp64, finite for equal
+    singular values), shared with the main head.  (That kernel's covariance carries the reference's + 1e-5 I of lib/se3.py:281; it is taken off M first.)"""
+
+    @staticmethod
+    def forward(ctx, M):
+        ctx.save_for_backward(M)
+        return ops.rotation_from_cov(M)
+
+    @staticmethod
+    def backward(ctx, gR):
+        (M,) = ctx.saved_tensors
+        B = M.shape[0]
+        eye = torch.eye(3, dtype=M.dtype, device=M.device)
+        src = torch.cat([eye, -torch.ones(3, 1, dtype=M.dtype, device=M.device)], dim=1).expand(B, 3, 4).contiguous()       # [B,3,J=4], points as columns
+        corr = torch.cat([(M - 1e-5 * eye).transpose(1, 2), M.new_zeros(B, 3, 1)], dim=2).contiguous()
+        w = M.new_ones(B, 4)
+        _, g_corr, _ = ops.kabsch_bwd(src, corr, w, gR.contiguous(), torch.zeros(B, 3, dtype=M.dtype, device=M.device))
+        return g_corr[:, :, :3].transpose(1, 2).contiguous()
+
+
 class TrainOps:
     """precision: "f16x3" (dense forward layers on the split-binary16 matrix-core engine) or "f32" (exact-fp32 engine)."""
 
@@ -603,3 +626,7 @@ class TrainOps:
     def kabsch(self, src, corr, w):
         """weighted rigid fit src -> corr, points as rows: src, corr [B,J,3], w [B,J] -> R [B,3,3], t [B,3]"""
         return _Kabsch.apply(src.transpose(1, 2).contiguous(), corr.transpose(1, 2).contiguous(), w.contiguous())
+
+    def rotation_from_cov(self, M):
+        """baseline/deepgmr.py:28-34: M [B,3,3] -> R [B,3,3], differentiable"""
+        return _RotationFromCov.apply(M.contiguous())

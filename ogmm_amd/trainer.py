@@ -92,6 +92,9 @@ class Trainer:
         f, b = both.tolist()
         return f > 0, b > 0
 
+    def _forward(self, src, tgt, fps_starts):
+        return self.model(src, tgt, fps_starts=fps_starts)
+
     def local_loss(self, out, src, tgt, transform_gt, src_overlap, tgt_overlap):
         loss, parts = losses.training_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap, self.alpha, self.top_k)
         if self.world > 1:      # this rank's share of the DataParallel loss (see the module docstring)
@@ -107,7 +110,7 @@ class Trainer:
         flag = self.model.overflow_flag(src.device) if hasattr(self.model, "overflow_flag") and src.is_cuda else None
         if flag is not None:
             flag.zero_()
-        out = self.model(src, tgt, fps_starts=fps_starts)
+        out = self._forward(src, tgt, fps_starts)
         fwd_flag = None
         if flag is not None:
             fwd_flag = flag.clone()
@@ -150,3 +153,20 @@ class Trainer:
             r_err = metric.rotation_error(out[0], transform_gt[:, :3, :3]).mean()
             t_err = metric.translation_error(out[1], transform_gt[:, :3, 3].reshape(B, 3)).mean()
         return {"loss": loss.detach(), "skipped": overflowed, "parts": {k: v.detach() for k, v in parts.items()}, "r_err_deg": r_err, "t_err": t_err, "out": out}
+
+
+class BaselineTrainer(Trainer):
+    """One optimisation step of the DeepGMR baseline's loop (train_base.py:27-75, :168): Adam(lr, weight_decay=1e-4), loss = `dcp_loss` of the model's two
+    outputs with NaN -> 0 -- nothing else (no overlap, clustering or Welsch term).  Under DataParallel the loss is a mean over the gathered batch: each
+    rank back-propagates its share / W and the gradients are SUM-all-reduced like the main model's; loss scaling and overflow handling as in `Trainer`."""
+
+    def local_loss(self, out, src, tgt, transform_gt, src_overlap=None, tgt_overlap=None):
+        B = out[0].shape[0]
+        dcp = losses.dcp_loss(out[0], transform_gt[:, :3, :3], out[1], transform_gt[:, :3, 3].reshape(B, 3))
+        return torch.nan_to_num(dcp / self.world, nan=0.0), {"dcp": dcp}
+
+    def _forward(self, src, tgt, fps_starts):
+        return self.model(src, tgt)
+
+    def step(self, src, tgt, transform_gt, src_overlap=None, tgt_overlap=None, fps_starts=None):
+        return super().step(src, tgt, transform_gt, src_overlap, tgt_overlap)

@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("train_", "metrics_", "deepgmr_")))   # train_*: tests/train_util.py
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("train_", "metrics_", "deepgmr_", "augment_")))   # train_*: tests/train_util.py
 
 
 @pytest.fixture(scope="session")

@@ -112,6 +112,13 @@ class RefTrainOps(TrainOps):
         t = c_c - (R @ c_s[:, :, None])[:, :, 0]
         return R, t
 
+    def rotation_from_cov(self, M):
+        U, _, Vh = torch.linalg.svd(M)                                  # baseline/deepgmr.py:28-34
+        V = Vh.transpose(1, 2)
+        S = torch.eye(3, dtype=M.dtype, device=M.device).repeat(M.shape[0], 1, 1)
+        S[:, 2, 2] = torch.det(V @ U.transpose(1, 2))
+        return V @ S @ U.transpose(1, 2)
+
     def gmm_em(self, xyz, o, ids_j):
         C, N, _ = xyz.shape
         B = C // 2          # src clouds | tgt clouds: two wkeans_plus calls (the Sinkhorn early exit averages over one call's clouds)
@@ -128,6 +135,19 @@ def params_from_fixture_spec(D, dtype=torch.float32):
     from ogmm_amd import gmmreg, synth
     P = {k: torch.zeros(s) if "num_batches" not in k else torch.zeros((), dtype=torch.long) for k, s in gmmreg.state_spec(D)}
     synth.fill_state_dict(P)
+    P = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in P.items()}
+    for k, v in P.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    return P
+
+
+def deepgmr_params_from_fixture_spec(D, J, c6_scale, dtype=torch.float32):
+    """the DeepGMR baseline's parameters with the closed-form fill and the sharpened cluster logits of its fixtures"""
+    from ogmm_amd import deepgmr, synth
+    P = {k: torch.zeros(s) if "num_batches" not in k else torch.zeros((), dtype=torch.long) for k, s in deepgmr.state_spec(D, J)}
+    synth.fill_state_dict(P)
+    P["cluster.net.6.weight"].mul_(c6_scale)
     P = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in P.items()}
     for k, v in P.items():
         if v.is_floating_point() and "running" not in k:

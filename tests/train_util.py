@@ -29,7 +29,7 @@ def filled_state(module_or_spec):
     return synth.fill_state_dict(module_or_spec)
 
 
-def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None, max_outlier_frac=0.1):
+def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None, max_outlier_frac=0.1, outlier_cap=None):
     """grads: {key: tensor or None}.  Yard-stick: the fp64 oracle gradient stored in the fixture ("truth"); unit: the
     reference's OWN fp32 distance from that truth (`gerr/<key>`; median 4e-4..6e-4, max 3e-3..5e-3 on the fixtures --
     fp32 gradients of this network are ill-conditioned, tests/golden/make_golden_train.py).
@@ -42,7 +42,8 @@ def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None, max_outlier_frac
     largest distances the reference itself shows.  Hence up to `max_outlier_frac` of the parameters may exceed their own
     bound, but none by more than factor * (the reference's LARGEST distance), and the median of distance/bound over all
     parameters must stay below 1.  Parameters whose reference gradient is structurally zero (norm < 1e-6 of the total) must stay below 1e-5 of
-    the total; parameters the forward never touches must have no gradient.  Returns the worst distance/bound."""
+    the total; parameters the forward never touches must have no gradient.  `outlier_cap`: an explicit ceiling for those few outliers where the
+    fixture's own kink sensitivity has been measured (tools/deepgmr_kink_sensitivity.py).  Returns the worst distance/bound."""
     total = float(fx["gnorm_total"])
     live = [float(fx[f]) for f in fx.files if f.startswith("gerr/") and float(fx["gnorm/" + f[5:]]) >= 1e-6 * total]
     typical, largest = float(np.median(live)), float(np.max(live))
@@ -68,7 +69,7 @@ def check_grads(fx, grads, factor=4.0, floor=3e-4, report=None, max_outlier_frac
         ratios.append(err / allowed)
         if err > allowed:
             outliers.append((key, err, allowed))
-            assert err <= max(factor * largest, floor), "%s: gradient error vs fp64 truth %.3e > %.1f x the reference's largest (%.3e)" % (
+            assert err <= max(factor * largest, floor, outlier_cap or 0.0), "%s: gradient error vs fp64 truth %.3e > %.1f x the reference's largest (%.3e)" % (
                 key, err, factor, largest)
     assert len(outliers) <= max_outlier_frac * len(ratios), "too many parameters beyond their bound: %s" % (
         ", ".join("%s %.2e>%.2e" % o for o in outliers))
