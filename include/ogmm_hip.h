@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 18
+#define OGMM_ABI_VERSION 19
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -432,10 +432,11 @@ int ogmm_pos_features(const float* xyz, const int32_t* idx, int C, int N, int k,
 int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t rows, int D, float* dx, int64_t lddx, void* stream);
 
 /* ---- diagnostics (tools/gemm_v6_check.py; not part of the hot path).  The large-shape GEMM engines have ablation builds selected by
- * `precision` codes 60..86 (gemm_f16x3_v6.hip), 100..104 (gemm_f16x3_v8.hip) and 110..119 (gemm_f16x3_v10.hip) whose workgroups add their duration in shader cycles and in
+ * `precision` codes 100..104 (gemm_f16x3_v8.hip) and 110..121 (gemm_f16x3_v10.hip) whose workgroups add their duration in shader cycles and in
  * 100 MHz wall ticks to a device counter: host3 = {cycles, ticks, workgroups} since the last call (read and cleared).  The ratio is the shader
  * clock the kernel really ran at -- rocprofv3 pins the clock, so its counters cannot tell. */
-int ogmm_debug_v6_probe(unsigned long long* host3);
+/* (the first LDS-DMA engine, gemm_f16x3_v6.hip, with its ablation codes 60..89 and ogmm_debug_v6_probe is built into the tools-only
+ * libogmm_probe.so -- ogmm_probe_gemm_v6(desc, stream) -- and is not part of this library or its ABI) */
 int ogmm_debug_v8_probe(unsigned long long* host3);
 int ogmm_debug_edgeconv_probe(unsigned long long* host8);
 int ogmm_debug_edgeconv_pc_probe(unsigned long long* host8);          /* OGMM_EDGECONV_PROBE=1: shader cycles per phase of the fused EdgeConv kernel */

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -116,7 +116,6 @@ PROTOTYPES = {
     "ogmm_edge_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_pos_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_l2norm_rows_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
-    "ogmm_debug_v6_probe": [c_void_p],          # diagnostics of the large-shape GEMM engines (tools/gemm_v6_check.py)
     "ogmm_debug_v8_probe": [c_void_p],
     "ogmm_debug_edgeconv_probe": [c_void_p],
     "ogmm_debug_edgeconv_pc_probe": [c_void_p],

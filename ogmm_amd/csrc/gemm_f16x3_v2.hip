@@ -224,8 +224,6 @@ namespace ogmm {
 
 bool gemm_f16x3_large_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s);
-bool gemm_f16x3_v6_applicable(const ogmm_gemm& g);
-int gemm_nt_f16x3_v6(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v8_applicable(const ogmm_gemm& g);
 int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v10_applicable(const ogmm_gemm& g);
@@ -254,15 +252,13 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         case 18: case 19: case 23: case 24: case 25: case 26: case 27: case 28: case 29:            // large-shape engine and its ablations (tools/gemm_bench.py)
         case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40:
             OGMM_REQUIRE(gemm_f16x3_large_applicable(g), "large-shape engine not applicable"); return gemm_nt_f16x3_v4(g, s);
-        case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 79: case 80: case 81: case 82: case 83: case 84: case 85: case 86: case 87: case 88: case 89:            // LDS-DMA engine (v6) and its ablations
-            OGMM_REQUIRE(gemm_f16x3_v6_applicable(g), "LDS-DMA engine not applicable"); return gemm_nt_f16x3_v6(g, s);
         case 100: case 101: case 102: case 103: case 104: case 105: case 106: case 107: case 108: case 109:            // LDS-DMA engine, 8 x 1 waves (v8)
             OGMM_REQUIRE(gemm_f16x3_v8_applicable(g), "LDS-DMA engine (v8) not applicable"); return gemm_nt_f16x3_v8(g, s);
         case 110: case 111: case 112: case 113: case 114: case 115: case 116: case 117: case 118: case 119: case 120: case 121:            // LDS-DMA engine, 4 waves x (64 x 256) (v10)
             OGMM_REQUIRE(gemm_f16x3_v10_applicable(g), "LDS-DMA engine (v10) not applicable"); return gemm_nt_f16x3_v10(g, s);
         default: break;
     }
-    // the LDS-DMA engines (v10: 4 waves of 64 x 256; v8: 8 waves of 32 x 256) wherever they apply; its first form (v6: 4 x 2 waves, the ablation vehicle of DESIGN.md) only by its variant codes
+    // the LDS-DMA engines (v10: 4 waves of 64 x 256; v8: 8 waves of 32 x 256) wherever they apply (their first form, v6, lives in the tools-only libogmm_probe.so)
     if (g.a_gather_ids) {
         OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && g.N >= 512 && gemm_f16x3_v10_applicable(g), "ogmm_gemm_nt: gathered A rows need the fragment-major fp16x3 engine, N >= 512, one A piece (ogmm_gemm_gather_fusable)");
         return gemm_nt_f16x3_v10(g, s);

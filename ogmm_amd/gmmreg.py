@@ -237,6 +237,9 @@ class GMMReg(nn.Module):
         self.fold_conv2_overlap = True      # conv2.net.6 and overlap.net.0 (two linear maps in a row) as one 1024 -> 256 layer
         self.fuse_overlap = os.environ.get("OGMM_FUSE_OVERLAP", "1") != "0"            # overlap block's softmax-dots in the similarity GEMM's epilogue where the engine takes it (ops.overlap_fusable)
         self._overflow = None
+        self._overflow_host = self._overflow_event = None
+        self._overflow_pending = False
+        self.overflow_policy = "deferred"          # what an fp16 range overflow in an eval forward does: _post_overflow_check
         self._side = None
         self._side2 = None
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
@@ -354,6 +357,7 @@ class GMMReg(nn.Module):
             raise OgmmError("GMMReg parameters live on %s but the inputs on %s: call model.to(device) first" % (self.emd.conv1.weight.device, dev))
         if self.training:
             return self._forward_train(src, tgt, fps_starts, capture, is_test)
+        self._raise_pending_overflow()
         L = self._layers()
         cap = {} if capture else None
         eng = ops.Engine(self.precision, self._overflow)          # this model's engine choice travels with every call: no process-wide switch
@@ -505,7 +509,46 @@ class GMMReg(nn.Module):
             # models/gmmreg.py:115-117: point-to-point ICP from the network's motion, correspondence radius 2 * overlap_radius
             # (lib/o3dutils.py:176).  The reference hands every pair to open3d on the CPU; here the whole batch stays on the GPU.
             rot, trans = ops.icp_point_to_point(xyz[:B], xyz[B:], rot, trans, 2.0 * cfg.overlap_radius)
+        self._post_overflow_check(dev)
         return rot, trans, o[:B], o[B:], loss
+
+    # ---- binary16 range: an activation beyond +-65504 is clamped by the fp16x3 engines and raises a device-side flag.  Results built on a clamped value
+    # must not pass silently (a trained checkpoint with large activations): `overflow_policy`
+    #   "deferred" (default)  the flag travels to pinned host memory behind the forward (asynchronous: no host synchronisation in a serving loop) and is
+    #                         looked at when it has arrived -- at the latest at the start of the NEXT forward or in fp16_overflowed() -- and raises then;
+    #   "sync"                every forward waits for its own flag and raises itself (one host synchronisation per call);
+    #   "ignore"              poll fp16_overflowed() yourself.
+    def _post_overflow_check(self, dev):
+        if self.precision == "f32" or self._overflow is None or self.overflow_policy == "ignore" or torch.cuda.is_current_stream_capturing():
+            return
+        if self.overflow_policy == "sync":
+            if self.fp16_overflowed():
+                raise OgmmError(self._OVERFLOW_TEXT % "this")
+            return
+        if self._overflow_host is None:
+            self._overflow_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._overflow_event = torch.cuda.Event()
+        elif self._overflow_pending and not self._overflow_event.query():
+            self._overflow_event.synchronize()          # (two forwards in flight share one host word: the older one first)
+        self._raise_pending_overflow()
+        self._overflow_host.copy_(self._overflow, non_blocking=True)
+        self._overflow.zero_()
+        self._overflow_event.record()
+        self._overflow_pending = True
+
+    _OVERFLOW_TEXT = ("fp16x3 engine: an activation beyond +-65504 was clamped in %s forward -- its results are not the reference's.  "
+                      "Run this model with precision='f32' (exact fp32 engine) or rescale the inputs; overflow_policy='ignore' restores polling.")
+
+    def _raise_pending_overflow(self, wait=False):
+        if not self._overflow_pending or torch.cuda.is_current_stream_capturing():          # (an event query would invalidate a stream capture)
+            return
+        if wait:
+            self._overflow_event.synchronize()
+        if self._overflow_event.query():
+            self._overflow_pending = False
+            if int(self._overflow_host[0]) != 0:
+                self._overflow_host.zero_()
+                raise OgmmError(self._OVERFLOW_TEXT % "an earlier")
 
     def sinkhorn_exit_margin(self):
         """After forward(..., capture=True): the smallest batch-mean Sinkhorn residual of the call, per call group (src clouds, tgt clouds) as the
@@ -561,6 +604,7 @@ class GMMReg(nn.Module):
                 self.forward(s_src, s_tgt, fps_starts=s_starts)
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
+        self._raise_pending_overflow(wait=True)          # the warm-up forwards' range check, before anything is recorded
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             outs = self.forward(s_src, s_tgt, fps_starts=s_starts)
@@ -592,4 +636,9 @@ class GMMReg(nn.Module):
             return False
         hit = bool(self._overflow.item())
         self._overflow.zero_()
+        if self._overflow_pending:          # a deferred check that has not been looked at yet
+            self._overflow_event.synchronize()
+            self._overflow_pending = False
+            hit = hit or int(self._overflow_host[0]) != 0
+            self._overflow_host.zero_()
         return hit

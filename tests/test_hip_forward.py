@@ -315,3 +315,41 @@ def test_hip_graph_replay_is_bit_identical():
             assert torch.equal(a, b)
     with pytest.raises(Exception):
         run(torch.zeros(2, 3, N, device="cuda:0"), torch.zeros(2, 3, N, device="cuda:0"))
+
+
+@pytest.mark.gpu
+def test_eval_forward_does_not_pass_an_fp16_range_overflow_silently():
+    """An activation beyond +-65504 is clamped by the fp16x3 engines; results built on it are not the reference's.  Policy "sync": the forward raises
+    itself; "deferred" (default): no host synchronisation, the flag arrives behind the forward and the NEXT call (or fp16_overflowed()) reports it;
+    the exact-fp32 engine has no such range and runs the same weights without complaint."""
+    from ogmm_amd._lib import OgmmError
+    B, N = 2, 512
+    src, tgt, _, _ = synth.make_batch(5, B, N, "partial")
+    starts = synth.fps_starts_for(5, B, N)
+    src, tgt = src.cuda(), tgt.cuda()
+
+    def model_with_large_activations(precision):
+        m = GMMReg(512, 16, Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, precision=precision))
+        synth.fill_state_dict(m.state_dict())
+        with torch.no_grad():
+            m.state_dict()["conv1.net.0.weight"].mul_(1.0e5)          # conv1's hidden map ~1e5: beyond binary16
+        return m.cuda().eval()
+    m = model_with_large_activations("f16x3")
+    m.overflow_policy = "sync"
+    with torch.no_grad(), pytest.raises(OgmmError, match="65504"):
+        m(src, tgt, fps_starts=starts)
+    m = model_with_large_activations("f16x3")
+    assert m.overflow_policy == "deferred"
+    with torch.no_grad():
+        m(src, tgt, fps_starts=starts)          # returns (nothing waited for) ...
+        torch.cuda.synchronize()
+        with pytest.raises(OgmmError, match="earlier forward"):
+            m(src, tgt, fps_starts=starts)      # ... and the next call reports it
+    m = model_with_large_activations("f16x3")
+    with torch.no_grad():
+        m(src, tgt, fps_starts=starts)
+    assert m.fp16_overflowed() and not m.fp16_overflowed()
+    m = model_with_large_activations("f32")
+    with torch.no_grad():
+        out = m(src, tgt, fps_starts=starts)
+    assert torch.isfinite(out[0]).all() and not m.fp16_overflowed()
