@@ -436,7 +436,7 @@ int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ld
  * 100 MHz wall ticks to a device counter: host3 = {cycles, ticks, workgroups} since the last call (read and cleared).  The ratio is the shader
  * clock the kernel really ran at -- rocprofv3 pins the clock, so its counters cannot tell. */
 /* (the first LDS-DMA engine, gemm_f16x3_v6.hip, with its ablation codes 60..89 and ogmm_debug_v6_probe is built into the tools-only
- * libogmm_probe.so -- ogmm_probe_gemm_v6(desc, stream) -- and is not part of this library or its ABI) */
+ * libogmm_probe.so (its entry takes the same descriptor) and is not part of this library or its ABI) */
 int ogmm_debug_v8_probe(unsigned long long* host3);
 int ogmm_debug_edgeconv_probe(unsigned long long* host8);
 int ogmm_debug_edgeconv_pc_probe(unsigned long long* host8);          /* OGMM_EDGECONV_PROBE=1: shader cycles per phase of the fused EdgeConv kernel */
