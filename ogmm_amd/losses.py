@@ -17,12 +17,15 @@ def info_nce(anchor, positive, tau):
     sim = torch.bmm(both, both.transpose(1, 2)) / tau                 # blocks [[xx, xy], [yx, yy]]
     i = torch.arange(n, device=anchor.device)
     pos = torch.cat([sim[:, i, n + i], sim[:, n + i, i]], dim=1)      # [B,2n]: xy_ii for the x rows, yx_ii for the y rows
-    # the negatives are every entry of a row except the two "diagonals" (self-similarity and the positive)
-    mask = torch.ones(2 * n, 2 * n, dtype=torch.bool, device=anchor.device)
-    mask[torch.arange(2 * n), torch.arange(2 * n)] = False
-    mask[i, n + i] = False
-    mask[n + i, i] = False
-    neg = sim[:, mask].view(B, 2 * n, 2 * n - 2)
+    # the negatives are every entry of a row except the two "diagonals" (self-similarity and the positive): row r drops columns r and (r + n) mod 2n.
+    # As a gather with computed column indices (ascending, as a boolean mask would select them): no index_put, no mask -> nonzero, i.e. no host
+    # synchronisation -- the loss can sit inside a recorded (HIP graph) training step.
+    r = torch.arange(2 * n, device=anchor.device)[:, None]
+    lo, hi = torch.minimum(r, (r + n) % (2 * n)), torch.maximum(r, (r + n) % (2 * n))
+    c = torch.arange(2 * n - 2, device=anchor.device)[None, :].expand(2 * n, -1)
+    c = c + (c >= lo).long()
+    c = c + (c >= hi).long()
+    neg = torch.gather(sim, 2, c[None].expand(B, -1, -1))
     logits = torch.cat([pos[:, :, None], neg], dim=2).reshape(B * 2 * n, 2 * n - 1)
     return F.cross_entropy(logits, torch.zeros(logits.shape[0], dtype=torch.long, device=anchor.device))
 

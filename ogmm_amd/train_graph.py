@@ -108,7 +108,7 @@ def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):
     idx, idx5 = ops.knn(xyz, k), ops.knn(xyz, 5)
     ids_a = ops.fps(xyz, M, starts)                                               # [3,C,M]
     ids_j = ops.fps(xyz, J, None)                                                 # [C,J]
-    swap = torch.cat([torch.arange(B, C), torch.arange(0, B)]).to(xyz.device)
+    swap = torch.cat([torch.arange(B, C, device=xyz.device), torch.arange(0, B, device=xyz.device)])          # (made on the device: no host copy inside a recorded step)
 
     # a map with several consumers goes through ops.fanout: one handle per consumer, their gradients are added in one pass
     emb = dgcnn(ops, P, xyz, idx)

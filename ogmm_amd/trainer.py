@@ -61,8 +61,12 @@ def broadcast_buffers(model, dist, world, src=0):
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, weight_decay=1e-4, welsch_alpha=10.0, welsch_top_k=512, dist=None, world=1, loss_scale=None):
+    def __init__(self, model, lr=1e-4, weight_decay=1e-4, welsch_alpha=10.0, welsch_top_k=512, dist=None, world=1, loss_scale=None, graph=False):
         """lr / alpha / top_k defaults: configs/cfgs.py:55,41,44; weight decay: train.py:199.
+        graph=True: forward + loss + backward of a step -- about 2500 kernel launches, whose enqueueing on the host takes as long as the GPU needs to run
+        them -- are recorded ONCE per input shape into a HIP graph (after `graph_warmup` eager steps) and replayed with one launch per step; the inputs
+        travel through static buffers, the overflow flags, loss parts and outputs come back as static tensors, and everything the host decides (skip /
+        loss-scale policy, gradient all-reduce, un-scaling, Adam) stays eager behind the replay.  Same kernels, same order: bit-identical steps.
         loss_scale: power of two the loss is multiplied by before backward (gradients are divided by it again before the
         optimizer; both exact in fp32).  It exists for the fp16x3 engine's backward GEMMs, whose operands are split into
         binary16 terms: unscaled activation gradients (1e-6 .. 0.2) would fall into binary16's subnormal range.  Default
@@ -81,6 +85,9 @@ class Trainer:
         self.forward_overflows = 0           # CONSECUTIVE steps whose forward clamped an activation (reset by a clean step)
         self.max_forward_overflows = 8
         self.skipped_steps = 0
+        self.graph, self.graph_warmup = bool(graph), 2
+        self._g = None                       # the captured step: dict(key, graph, static inputs / outputs)
+        self._eager_steps = 0
 
     def _overflow_hits(self, fwd, bwd):
         """(forward flag, backward flag) -> two bools, the same on every rank: ONE host read (and one MAX all-reduce) per step for both"""
@@ -95,16 +102,19 @@ class Trainer:
     def _forward(self, src, tgt, fps_starts):
         return self.model(src, tgt, fps_starts=fps_starts)
 
+    def _drop_grads(self):
+        """a skipped step's gradients are not used; with a recorded step they are the graph's static tensors and stay (the next replay overwrites them)"""
+        if self._g is None:
+            self.optimizer.zero_grad(set_to_none=True)
+
     def local_loss(self, out, src, tgt, transform_gt, src_overlap, tgt_overlap):
         loss, parts = losses.training_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap, self.alpha, self.top_k)
         if self.world > 1:      # this rank's share of the DataParallel loss (see the module docstring)
             loss = torch.nan_to_num((10 * parts["dcp"] + parts["mse"] + 0.01 * parts["welsch"]) / self.world + parts["clu"], nan=0.0)
         return loss, parts
 
-    def step(self, src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts=None):
-        """train.py:53-74 for this rank's shard.  Returns loss (local share), the four parts, mean R / t errors."""
-        self.model.train()
-        self.optimizer.zero_grad(set_to_none=True)
+    def _traced(self, src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts, scale):
+        """forward + loss + backward: everything of a step that is pure device work (what graph=True records).  scale: python float or device scalar."""
         # The engine's overflow flag (device int32[1]) is shared by forward activations and backward gradients.  It is snapshotted with device ops
         # after the forward and after the backward and read ONCE, behind the backward: no extra host round trip between the two.
         flag = self.model.overflow_flag(src.device) if hasattr(self.model, "overflow_flag") and src.is_cuda else None
@@ -116,8 +126,49 @@ class Trainer:
             fwd_flag = flag.clone()
             flag.zero_()
         loss, parts = self.local_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap)
+        (loss * scale).backward()
+        return out, loss, parts, fwd_flag, (flag.clone() if flag is not None else None)
+
+    def _replay(self, src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts):
+        """graph=True: the recorded step on this batch (captured on first use per shape)"""
+        B, _, N = src.shape
+        if fps_starts is None:          # the reference's six torch.randint draws (lib/utils.py:190), on the host as the eager path makes them
+            fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
+        given = [src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts]
+        key = tuple((tuple(t.shape), t.dtype) for t in given if t is not None)
+        g = self._g
+        if g is None or g["key"] != key:
+            dev = src.device
+            static = [None if t is None else torch.empty(t.shape, dtype=t.dtype, device=dev) for t in given]
+            for st, t in zip(static, given):
+                if st is not None:
+                    st.copy_(t)
+            scale_t = torch.full((), self.loss_scale, dtype=torch.float32, device=dev)
+            self.optimizer.zero_grad(set_to_none=True)          # the recorded backward creates the gradients: static from here on
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = self._traced(*static, scale_t)
+            g = self._g = {"key": key, "graph": graph, "static": static, "scale": scale_t, "res": res}
+        for st, t in zip(g["static"], given):
+            if st is not None:
+                st.copy_(t, non_blocking=True)
+        g["scale"].fill_(self.loss_scale)
+        g["graph"].replay()
+        return g["res"]
+
+    def step(self, src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts=None):
+        """train.py:53-74 for this rank's shard.  Returns loss (local share), the four parts, mean R / t errors."""
+        self.model.train()
         self._backward_scale = self.loss_scale          # the scale this step's gradients carry (self.loss_scale may grow below)
-        (loss * self.loss_scale).backward()
+        use_graph = self.graph and src.is_cuda and self._eager_steps >= self.graph_warmup
+        if use_graph:
+            out, loss, parts, fwd_flag, flag = self._replay(src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts)
+        else:
+            self._eager_steps += 1
+            self._g = None
+            self.optimizer.zero_grad(set_to_none=True)
+            out, loss, parts, fwd_flag, flag = self._traced(src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts, self.loss_scale)
         fwd_hit, bwd_hit = self._overflow_hits(fwd_flag, flag)
         overflowed = fwd_hit or bwd_hit
         if fwd_hit:
@@ -125,7 +176,7 @@ class Trainer:
             # cure that (it only lifts small gradients): skip the step without touching the scale, and give up when it persists.
             self.forward_overflows += 1
             self.skipped_steps += 1
-            self.optimizer.zero_grad(set_to_none=True)
+            self._drop_grads()
             if self.forward_overflows > self.max_forward_overflows:
                 raise FloatingPointError("fp16x3 engine: forward activations beyond +-65504 in %d consecutive steps -- the loss scale cannot fix this; "
                                          "use model.precision = 'f32' or rescale the inputs" % self.forward_overflows)
@@ -135,7 +186,7 @@ class Trainer:
             self.skipped_steps += 1
             self.loss_scale = max(self.min_loss_scale, self.loss_scale * 0.5)
             self._clean_steps = 0
-            self.optimizer.zero_grad(set_to_none=True)
+            self._drop_grads()
         else:
             self.forward_overflows = 0
             self._clean_steps += 1

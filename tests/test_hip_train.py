@@ -346,3 +346,33 @@ def test_trainer_steps_on_ragged_shapes(B, N, J, k, M, topk):
     assert tr.skipped_steps <= 2 and tr.loss_scale >= 65536.0 / 4
     assert all(torch.isfinite(p).all().item() for p in model.parameters())
     assert all(torch.isfinite(b).all().item() for b in model.buffers())
+
+
+def test_graph_replayed_steps_equal_eager_steps():
+    """Trainer(graph=True): forward + loss + backward recorded once into a HIP graph and replayed -- the same kernels in the same order, so six steps
+    (two eager, the recording one, three replays; the batch changes from step to step, a loss-scale change included) leave exactly the parameters,
+    BatchNorm statistics and losses of six eager steps."""
+    from argparse import Namespace
+    from ogmm_amd.trainer import Trainer
+    B, N, J = 3, 512, 16
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035)
+
+    def run(graph):
+        model = GMMReg(512, J, cfg)
+        synth.fill_state_dict(model.state_dict())
+        model = model.to(DEV)
+        tr = Trainer(model, welsch_top_k=256, graph=graph)
+        seen = []
+        for i in range(6):
+            batch = [t_.to(DEV) for t_ in synth.make_train_batch(10 * i, B, N)]
+            if i == 4:
+                tr.loss_scale = tr.loss_scale / 4          # (travels into the recorded step as a device scalar: no re-recording)
+            info = tr.step(*batch, fps_starts=synth.fps_starts_for(10 * i, B, N))
+            seen.append((float(info["loss"]), bool(info["skipped"]), float(info["r_err_deg"])))
+        return model, tr, seen
+    m_e, _, seen_e = run(False)
+    m_g, tr_g, seen_g = run(True)
+    assert tr_g._g is not None          # (the recorded step was used)
+    assert seen_e == seen_g, (seen_e, seen_g)
+    for (k_, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k_
