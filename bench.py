@@ -341,8 +341,8 @@ def train_main(args):
     batch = [t.to(dev) for t in synth.make_train_batch(first, B, N, "partial")]
     starts = synth.fps_starts_for(first, B, N)
     # forward + loss + backward replayed from a HIP graph (Trainer(graph=True): ~2500 launches per step, whose enqueueing takes the host as long as the GPU
-    # needs to run them); OGMM_TRAIN_GRAPH=1 selects it (default: the eager step).  The first steps are eager, the next one records: all inside the warm-up.
-    use_graph = os.environ.get("OGMM_TRAIN_GRAPH", "0") == "1"
+    # needs to run them); OGMM_TRAIN_GRAPH=0 times the eager step.  The first steps are eager, the next one records: all inside the warm-up.
+    use_graph = os.environ.get("OGMM_TRAIN_GRAPH", "1") != "0"
     trainer = Trainer(model, dist=dist, world=world, graph=use_graph)
     for _ in range(max(args.warmup, trainer.graph_warmup + 2) if use_graph else args.warmup):
         info = trainer.step(*batch, fps_starts=starts)

@@ -127,7 +127,11 @@ class Trainer:
             flag.zero_()
         loss, parts = self.local_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap)
         (loss * scale).backward()
-        return out, loss, parts, fwd_flag, (flag.clone() if flag is not None else None)
+        # Detached: nothing a caller keeps from one step may hold that step's autograd graph alive into the next one.  (Not only tidiness: with the
+        # previous step's outputs -- and through their grad_fn its graph -- still alive, ending the capture of a recorded step crashed inside the HIP
+        # runtime on this ROCm; tools/train_capture_debug.py reproduces it.)
+        return (tuple(o.detach() for o in out), loss.detach(), {k: v.detach() for k, v in parts.items()}, fwd_flag,
+                (flag.clone() if flag is not None else None))
 
     def _replay(self, src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts):
         """graph=True: the recorded step on this batch (captured on first use per shape)"""
@@ -203,7 +207,7 @@ class Trainer:
             B = src.shape[0]
             r_err = metric.rotation_error(out[0], transform_gt[:, :3, :3]).mean()
             t_err = metric.translation_error(out[1], transform_gt[:, :3, 3].reshape(B, 3)).mean()
-        return {"loss": loss.detach(), "skipped": overflowed, "parts": {k: v.detach() for k, v in parts.items()}, "r_err_deg": r_err, "t_err": t_err, "out": out}
+        return {"loss": loss, "skipped": overflowed, "parts": parts, "r_err_deg": r_err, "t_err": t_err, "out": out}
 
 
 class BaselineTrainer(Trainer):
