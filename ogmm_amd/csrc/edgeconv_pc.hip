@@ -164,7 +164,6 @@ __device__ __forceinline__ void produce_block(const float4* efd, const float4* e
         float ctr[3];
 #pragma unroll
         for (int i = 0; i <= P1 - P0; ++i) {
-            constexpr int dummy = 0; (void)dummy;
             const int row = (P0 + i) * KE > B * 32 ? (P0 + i) * KE - B * 32 : 0;          // a row of point P0 + i inside this block
             const float4 c = efc[row];
             ctr[i] = fmaf(wv[5], c.z, fmaf(wv[4], c.y, wv[3] * c.x));
