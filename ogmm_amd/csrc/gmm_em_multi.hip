@@ -202,13 +202,15 @@ __device__ __forceinline__ float em_finish_v(int c, int J, int n_chunks, bool fi
 __device__ __forceinline__ void em_fused_residual(const EmExit& x, int c, int it, int m, int n_chunks, float dv_part, bool publish) {
     // wave 0 of the chunk-0 workgroup of cloud c, at the start of launch m >= 2: residual of sweep m - 1 (J <= 64: all of dv_part sits in wave 0)
     const float dv = wave_sum(dv_part);
-    if ((threadIdx.x & 63) != 0) return;
-    float du = 0.0f;
-    const float* __restrict__ dp = x.dupart + ((int64_t)((m - 1) & 1) * x.C + c) * n_chunks;
-    for (int ch = 0; ch < n_chunks; ++ch) du += em_ld_agent(dp + ch);
-    const float r = du + dv;
-    if (x.resid) x.resid[((int64_t)c * x.iters + it) * x.sk + (m - 2)] = r;
-    if (publish) em_exit_publish(x, c, it, m - 2, r);
+    float r = 0.0f;
+    if ((threadIdx.x & 63) == 0) {
+        float du = 0.0f;
+        const float* __restrict__ dp = x.dupart + ((int64_t)((m - 1) & 1) * x.C + c) * n_chunks;
+        for (int ch = 0; ch < n_chunks; ++ch) du += em_ld_agent(dp + ch);
+        r = du + dv;
+        if (x.resid) x.resid[((int64_t)c * x.iters + it) * x.sk + (m - 2)] = r;
+    }
+    if (publish) em_exit_publish_wave(x, c, it, m - 2, r);          // (the whole wave: a last arriver sums its group's residuals in parallel)
 }
 
 // The costs themselves are NOT read: thread = row recomputes its J distances from the point and the cloud's centres (LDS) with the
@@ -398,14 +400,15 @@ __global__ __launch_bounds__(256, 3) void em_resident_kernel(const float* __rest
                 if (track && wave == 0) {
                     if (chunk == 0) {
                         const float dv = wave_sum(dv_part);          // (J <= 64: all of it sits in wave 0)
+                        float r = 0.0f;
                         if (lane == 0) {
                             float du = 0.0f;
                             const float* __restrict__ dp = x.dupart + ((int64_t)((k - 1) & 1) * C + c) * n_chunks;
                             for (int ch = 0; ch < n_chunks; ++ch) du += em_ld_agent(dp + ch);
-                            const float r = du + dv;
-                            if (x.on && k - 1 < sk_iters) em_exit_publish(x, c, it, k - 2, r);
+                            r = du + dv;
                             if (x.resid) x.resid[((int64_t)c * x.iters + it) * x.sk + (k - 2)] = r;
                         }
+                        if (x.on && k - 1 < sk_iters) em_exit_publish_wave(x, c, it, k - 2, r);
                     }
                     if (x.on && k >= 3 && lane == 0) s_stop = em_exit_wait(x, c, it, k - 3) ? 1 : 0;
                 }
