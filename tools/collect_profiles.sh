@@ -14,6 +14,7 @@ BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-sample 0"
 timeout 600 python3 bench.py --steps 20 --warmup 5 2> $out/bench_n1.err | tail -1 > $out/${tag}_bench_n1.json
 for w in cfg2 cfg3; do timeout 400 python3 bench.py --workload $w --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_bench_$w.json; done
 timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_train_bench_b128.json
+OGMM_TRAIN_GRAPH=0 timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_train_bench_b128_eager.json
 
 # 2. kernel trace + stats of the headline command
 rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format rocpd -- $BENCH > $out/trace.log 2>&1
@@ -53,13 +54,13 @@ unset OGMM_V6_MIN_TILES OGMM_V4_MIN_TILES OGMM_V8_MIN_TILES OGMM_V10_MIN_TILES
 # 4b. the training step (BASELINE configs[4], 128 pairs per GPU): kernel statistics, per-operation breakdown, attention backward alone
 rocprofv3 --kernel-trace --stats -d $out/trace_train -o r --output-format rocpd -- python3 bench.py --workload train --steps 3 --warmup 2 --cpu-sample 0 > $out/trace_train.log 2>&1
 dbt=$(find $out/trace_train -name "*.db" | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload train --steps 3 --warmup 2 --cpu-sample 0   (5 training steps of 128 pairs)"; python3 tools/rocpd_stats.py $dbt | head -80; } > $out/${tag}_train_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload train --steps 3 --warmup 2 --cpu-sample 0   (training steps of 128 pairs: 2 eager + the recording one + 1 warm-up replay + 3 timed replays + 1 eager bracketed step)"; python3 tools/rocpd_stats.py $dbt | head -80; } > $out/${tag}_train_kernel_stats.txt
 { echo "# tools/train_breakdown.py 128: forward / backward of the autograd functions of one training step (events)"; timeout 300 python3 tools/train_breakdown.py 128 2>&1 | grep -v amdgpu.ids;
   echo "# tools/attn_bwd_time.py"; timeout 200 python3 tools/attn_bwd_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_train_breakdown.txt
 rm -rf $out/trace_train
 
 # 5. parity: the distribution over every pair of a batch per workload, then the PARITY lines of the GPU tests
-{ echo "# commit $commit"; timeout 1200 python3 tools/parity_distribution.py --workloads cfg1,cfg2,cfg3,n717 --pairs 64,32,16,32 2>&1 | grep -v amdgpu.ids;
+{ echo "# commit $commit"; timeout 1800 python3 tools/parity_distribution.py --workloads cfg1,cfg2,cfg3,n717 --pairs 256,64,32,128 2>&1 | grep -v amdgpu.ids;
   echo; echo "# PARITY lines of pytest -m gpu (tests/test_hip_forward.py, test_hip_deepgmr.py, test_hip_icp.py)";
   timeout 1200 python3 -m pytest tests/test_hip_forward.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|passed|failed"; } > $out/${tag}_parity.txt
 rm -rf $out/trace $out/pmc_*          # the rocpd databases exceed what gpurun copies back; the summaries above are what gets committed
