@@ -28,6 +28,7 @@ import time
 from argparse import Namespace
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required by RCCL on this pool's driver (multi-process runs)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # replayed HIP graphs mixed with other launches fault on ROCm 7.2 otherwise (ogmm_amd/__init__.py)
 
 import torch  # noqa: E402
 

@@ -590,6 +590,10 @@ class GMMReg(nn.Module):
         the outputs are views of the graph's static buffers and are overwritten by the next call."""
         if self.training:
             raise OgmmError("capture_graph is for eval mode")
+        from . import graph_replay_safe
+        if not graph_replay_safe():
+            raise OgmmError("capture_graph: the HIP runtime was initialised before ogmm_amd could set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (replays mixed with "
+                            "other launches fault on this ROCm with the runtime's graph packet capture on): export it, or import ogmm_amd before touching the GPU")
         dev = torch.device(device) if device is not None else self.emd.conv1.weight.device
         s_src = torch.zeros((batch, 3, n_points), dtype=torch.float32, device=dev)
         s_tgt = torch.zeros_like(s_src)

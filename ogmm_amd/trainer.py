@@ -85,6 +85,12 @@ class Trainer:
         self.forward_overflows = 0           # CONSECUTIVE steps whose forward clamped an activation (reset by a clean step)
         self.max_forward_overflows = 8
         self.skipped_steps = 0
+        if graph:
+            from . import graph_replay_safe
+            if not graph_replay_safe():
+                raise RuntimeError("Trainer(graph=True): the HIP runtime of this process was initialised before ogmm_amd could set "
+                                   "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; with the runtime's graph packet capture on, replays mixed with other launches end in a "
+                                   "GPU memory fault on this ROCm.  Export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (or import ogmm_amd before touching the GPU).")
         self.graph, self.graph_warmup = bool(graph), 2
         self._g = None                       # the captured step: dict(key, graph, static inputs / outputs)
         self._eager_steps = 0

@@ -350,42 +350,60 @@ def test_trainer_steps_on_ragged_shapes(B, N, J, k, M, topk):
 
 def test_graph_replayed_steps_match_eager_steps():
     """Trainer(graph=True): forward + loss + backward recorded once into a HIP graph and replayed -- the same kernels in the same order.  Six steps (two
-    eager, the recording one, three replays; the batch changes from step to step, a loss-scale change included) against six eager steps.  Two eager
-    runs are not bit-identical themselves (fp32 / fp64 atomics in the statistics and gradient reductions: 1e-6 relative in the loss from the second
-    step on), so the comparison is held to what run-to-run noise does over six Adam steps, far below what a wrong buffer or a stale input would do
-    (each step draws a different batch: a replay that ignored its inputs would be off by O(1))."""
+    eager, the recording one, three replays; a different batch every step, a loss-scale change included).  The state in front of every step (parameters,
+    BatchNorm statistics, Adam moments) is saved; afterwards an eager trainer takes each step from its saved state, and loss, skip decision and
+    gradients must agree to single-step run-to-run noise (two eager runs are not bit-identical themselves: fp32 / fp64 atomics in the reductions, 1e-6
+    relative in the loss; over WHOLE runs that noise is amplified chaotically -- Adam turns noise-level gradients into +-lr updates -- to 3e-3 after five
+    steps, hence step-wise from saved states).  A replay that ignored its inputs, or wrote its gradients somewhere else, would be off by O(1).
+    (Between the replays the test copies states and gradients to the host: a few thousand ordinary launches -- what made a replayed graph fault on this
+    ROCm before ogmm_amd/__init__.py switched the runtime's graph packet capture off; tools/train_capture_debug.py has the bare reproductions.)"""
+    import copy
     from argparse import Namespace
     from ogmm_amd.trainer import Trainer
     B, N, J = 3, 512, 16
     cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035)
 
-    def run(graph):
+    def make(graph):
         model = GMMReg(512, J, cfg)
         synth.fill_state_dict(model.state_dict())
         model = model.to(DEV)
-        tr = Trainer(model, welsch_top_k=256, graph=graph)
-        seen = []
-        for i in range(6):
-            batch = [t_.to(DEV) for t_ in synth.make_train_batch(10 * i, B, N)]
-            if i == 4:
-                tr.loss_scale = tr.loss_scale / 4          # (travels into the recorded step as a device scalar: no re-recording)
-            info = tr.step(*batch, fps_starts=synth.fps_starts_for(10 * i, B, N))
-            seen.append((float(info["loss"]), bool(info["skipped"]), float(info["r_err_deg"])))
-        return model, tr, seen
-    m_e, _, seen_e = run(False)
-    m_g, tr_g, seen_g = run(True)
+        return model, Trainer(model, welsch_top_k=256, graph=graph)
+
+    def to_cpu(obj):
+        if isinstance(obj, torch.Tensor):
+            return obj.detach().cpu().clone()
+        if isinstance(obj, dict):
+            return {k: to_cpu(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(to_cpu(v) for v in obj)
+        return copy.deepcopy(obj)
+    m_g, tr_g = make(True)
+    rec = []
+    for i in range(6):
+        batch = [t_.to(DEV) for t_ in synth.make_train_batch(10 * i, B, N)]
+        if i == 4:
+            tr_g.loss_scale = tr_g.loss_scale / 4          # (travels into the recorded step as a device scalar: no re-recording)
+        snap = (to_cpu(m_g.state_dict()), to_cpu(tr_g.optimizer.state_dict()), tr_g.loss_scale)
+        info = tr_g.step(*batch, fps_starts=synth.fps_starts_for(10 * i, B, N))
+        grads = [None if p.grad is None else p.grad.detach().cpu().clone() for p in m_g.parameters()]
+        rec.append((snap, float(info["loss"]), bool(info["skipped"]), grads))
     assert tr_g._g is not None          # (the recorded step was used)
-    print("GRAPH-STEP eager", seen_e, "graph", seen_g)
-    for (le, se, re_), (lg, sg, rg) in zip(seen_e, seen_g):
-        assert se == sg and abs(le - lg) <= 1e-3 * abs(le) and abs(re_ - rg) <= 1e-2 * max(1.0, abs(re_))
-    worst = 0.0
-    for (k_, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
-        if a.is_floating_point():
-            d = (a - b).abs()
-            worst = max(worst, d.max().item())
-            if "running" in k_:          # BatchNorm statistics follow the activations, not the learning rate
-                assert torch.allclose(a, b, rtol=5e-3, atol=5e-3), k_
-            else:
-                assert d.max().item() < 3e-4 and d.mean().item() < 2e-5, k_          # (six Adam steps of lr 1e-4 move a weight by at most 6e-4 in all)
-        else:
-            assert torch.equal(a, b), k_
+    m_e, tr_e = make(False)
+    for i, (snap, lg, sg, grads_g) in enumerate(rec):
+        batch = [t_.to(DEV) for t_ in synth.make_train_batch(10 * i, B, N)]
+        m_e.load_state_dict(snap[0])
+        tr_e.optimizer.load_state_dict(snap[1])
+        tr_e.loss_scale = snap[2]
+        info = tr_e.step(*batch, fps_starts=synth.fps_starts_for(10 * i, B, N))
+        le, se = float(info["loss"]), bool(info["skipped"])
+        num = den = 0.0
+        for p, g in zip(m_e.parameters(), grads_g):
+            if sg:          # a skipped step: the eager trainer drops its gradients, the recorded one keeps its static tensors (unused)
+                continue
+            assert (p.grad is None) == (g is None)
+            if g is not None:
+                num += float((p.grad.cpu() - g).double().pow(2).sum())
+                den += float(g.double().pow(2).sum())
+        rel = (num / den) ** 0.5 if den > 0 else 0.0
+        print("GRAPH-STEP %d loss eager %.7f graph %.7f skipped %s/%s gradient distance %.2e" % (i, le, lg, se, sg, rel))
+        assert se == sg and abs(le - lg) <= 1e-4 * abs(le) and (sg or rel < 2e-3)
