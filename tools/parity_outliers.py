@@ -5,7 +5,8 @@
 Per pair: the HIP forward with the default term budget, with three terms everywhere and on the exact-fp32 engine, each against the CPU oracle in fp32 (the
 reference's arithmetic, 16 threads) -- and, as yard-sticks of the pair itself, the oracle against ITSELF: fp32 at 1 thread against 16 threads (the
 reference's own run-to-run reproducibility) and fp32 against an fp64 evaluation with the fp32 run's kNN graph pinned (how well the reference's own
-fp32 result is defined).  R distances in rad."""
+fp32 result is defined).  R distances in rad.  (One pair per forward: at that size the small-tile engines run, which always issue three terms -- the
+"budget" column equals the "3 terms" one; the batch-level figure with the budget is the distribution's own.)"""
 import os
 import sys
 from argparse import Namespace
