@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 19
+#define OGMM_ABI_VERSION 20
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -201,6 +201,10 @@ int ogmm_pos_hidden(const float* xyz, const int32_t* idx, int idx_ld, int k_pos,
 int64_t ogmm_attention_workspace_bytes(int C, int M, int H, int dh);
 int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
                    int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream);
+/* The same with a term budget for the score product q k^T: qk_terms 0 / 3 = three binary16 terms (fp32-class), 1 = both operands
+ * rounded to binary16 -- one matrix instruction per block instead of three, no lo part of Q (a permission: kernels without that form run three). */
+int ogmm_attention_terms(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
+                         int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, void* workspace, void* stream);
 
 /* ---- K9 middle (unfused fallback): in-place softmax over the last axis (keys).  models/attn.py:80. cols <= 1024. */
 int ogmm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream);

@@ -476,6 +476,20 @@ __device__ __forceinline__ void split8_fast(f32x4 a, f32x4 b, f16x8& hi, f16x8& 
     lo = f16x8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
 }
 
+// hi part only (rn16 of 8 values): the score product with both operands rounded to binary16 (QK1) needs no lo part
+template <bool CLAMP>
+__device__ __forceinline__ void round8_fast(f32x4 a, f32x4 b, f16x8& hi) {
+    if (CLAMP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = __builtin_amdgcn_fmed3f(a[e], -65504.0f, 65504.0f); b[e] = __builtin_amdgcn_fmed3f(b[e], -65504.0f, 65504.0f); }
+    }
+    f16x2 h0, h1, h2, h3;
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\tv_cvt_pk_f16_f32 %2, %8, %9\n\tv_cvt_pk_f16_f32 %3, %10, %11"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    hi = f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
     f16x2 h, l;
     split_pair(a[0], a[1], h, l); hi[0] = h[0]; hi[1] = h[1]; lo[0] = l[0]; lo[1] = l[1];
@@ -486,7 +500,9 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
 
 // FUSED: no packed images -- the workgroup splits its (cloud, head)'s K and V rows itself while staging them (with one workgroup per (cloud, head),
 // as at B = 64, nothing is split twice, and the pack kernel with its workspace round trip disappears: -25 us per call).
-template <int MK, bool FUSED>
+// QK1: the score product q k^T with BOTH operands rounded to binary16 (one matrix instruction per block instead of three, no lo part of Q): the
+// per-layer term budget's entry for the attention scores (measured insensitive like the Q projection itself).  P V keeps three.
+template <int MK, bool FUSED, bool QK1 = false>
 __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restrict__ q, int64_t ldq, const f16x8* __restrict__ kimg,
                                                           const f16x8* __restrict__ vimg, const float* __restrict__ kraw, int64_t ldk,
                                                           const float* __restrict__ vraw, int64_t ldv, int N, int H, float scale,
@@ -590,7 +606,10 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
     const f16x8* __restrict__ Vl = Vs + lane_t;
     f16x8 qh[KS], ql[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) split8_fast<true>(qa[s], qb[s], qh[s], ql[s]);
+    for (int s = 0; s < KS; ++s) {
+        if (QK1) round8_fast<true>(qa[s], qb[s], qh[s]);
+        else split8_fast<true>(qa[s], qb[s], qh[s], ql[s]);
+    }
     if (tile + (int)gridDim.x < n_tiles) load_q(tile + gridDim.x);
 
     // ---- S^T = K Q^T: row blocks = 32 keys each, A fragments from LDS
@@ -601,21 +620,20 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < MK; ++j) {
             ah[j] = Kl[(j * KS + s) * 64];
-            al[j] = Kl[GROUPS + (j * KS + s) * 64];
+            if (!QK1) al[j] = Kl[GROUPS + (j * KS + s) * 64];
         }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (QK1) {
 #pragma unroll
-        for (int j = 0; j < MK; ++j) {
-            if (s == 0) {
-                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], qh[s], zero, 0, 0, 0);
-            } else {
-                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], qh[s], sacc[j], 0, 0, 0);
-            }
+            for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], qh[s], s == 0 ? zero : sacc[j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], qh[s], s == 0 ? zero : sacc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], ql[s], sacc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], qh[s], sacc[j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], ql[s], sacc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < MK; ++j) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], qh[s], sacc[j], 0, 0, 0);
     }
 
     // ---- softmax over the keys of this lane's query: registers of this lane and of lane ^ 32
@@ -688,7 +706,7 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
 
 template <int MK>
 int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H,
-                       float scale, float* out, int64_t ldo, void* workspace, hipStream_t s) {
+                       float scale, float* out, int64_t ldo, void* workspace, hipStream_t s, int qk_terms = 0) {
     constexpr int M = MK * 32;
     constexpr int GROUPS = M * DH / 8;
     const size_t lds = (size_t)4 * GROUPS * sizeof(f16x8);
@@ -698,6 +716,7 @@ int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk,
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     // query tiles per workgroup: as many as leave at least two workgroups per CU (the K / V images are staged once per workgroup)
     const int n_tiles = (N + QT2 - 1) / QT2;
@@ -709,6 +728,8 @@ int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk,
     if (packed) {
         hipLaunchKernelGGL((attention_pack_kernel<MK, true>), dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
         hipLaunchKernelGGL((attention_t_kernel<MK, false>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
+    } else if (qk_terms == 1) {
+        hipLaunchKernelGGL((attention_t_kernel<MK, true, true>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
     } else {
         hipLaunchKernelGGL((attention_t_kernel<MK, true>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
     }
@@ -754,8 +775,18 @@ extern "C" int64_t ogmm_attention_workspace_bytes(int C, int M, int H, int dh) {
     return (int64_t)C * H * 2 /*K,V*/ * 2 /*hi,lo*/ * M * dh * (int64_t)sizeof(_Float16);
 }
 
+extern "C" int ogmm_attention_terms(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
+                                    int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, void* workspace, void* stream);
+
 extern "C" int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
                               int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream) {
+    return ogmm_attention_terms(q, ldq, k, ldk, v, ldv, C, N, M, H, dh, scale, out, ldo, 0, workspace, stream);
+}
+
+// qk_terms: 0 / 3 = the score product in three binary16 terms (fp32-class); 1 = both operands rounded to binary16 (a permission: only the transposed
+// kernel with a workspace has the form, the others run three terms)
+extern "C" int ogmm_attention_terms(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
+                                    int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, void* workspace, void* stream) {
     OGMM_REQUIRE(q && k && v && out && C > 0 && N > 0 && H > 0, "ogmm_attention: null pointer or empty input");
     OGMM_REQUIRE(dh == DH, "ogmm_attention: head dimension %d not supported (built for %d)", dh, DH);
     OGMM_REQUIRE(M == 32 || M == 64 || M == 128, "ogmm_attention: %d anchors not supported (32, 64 or 128)", M);
@@ -770,9 +801,9 @@ extern "C" int ogmm_attention(const float* q, int64_t ldq, const float* k, int64
             if (M == 64) return launch_attention_frag<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
             return launch_attention_frag<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
         }
-        if (M == 32) return launch_attention_t<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
-        if (M == 64) return launch_attention_t<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
-        return launch_attention_t<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
+        if (M == 32) return launch_attention_t<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, qk_terms);
+        if (M == 64) return launch_attention_t<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, qk_terms);
+        return launch_attention_t<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, qk_terms);
     }
     if (M == 32) return launch_attention<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);
     if (M == 64) return launch_attention<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, s);

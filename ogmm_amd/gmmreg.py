@@ -28,7 +28,10 @@ from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
 # measured budget (DESIGN.md section 4 "Per-layer term budget"): the two 1024-wide layers of conv2 feed nothing but the overlap scores
-TERM_BUDGET = {"conv2.0": 2, "conv2.3": 2, "sattn1.q": 1, "cattn.q": 1, "sattn2.q": 1, "similarity": 1}
+TERM_BUDGET = {"conv2.0": 2, "conv2.3": 2, "similarity": 1,
+               **{"%s.%s" % (t_, l_): 1 for t_ in ("sattn1", "cattn", "sattn2") for l_ in ("q", "qk")}}          # (tools/term_budget.py policy v5 without its "kv" entries)
+# ("<transformer>.kv": 1 is admissible too (+0.6 %), but the anchors' K | V GEMM is small enough that a half batch falls back to the small-tile kernels, which
+#  have no reduced form: the same pairs would then differ by 2e-6 between a 64- and a 32-pair batch.  Left out for the sake of shard invariance.)
 
 
 # ------------------------------------------------------------------------------------------ parameters
@@ -286,7 +289,7 @@ class GMMReg(nn.Module):
             self._packed_fp = self._fingerprint(list(sd.values()))
         return self._packed
 
-    def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0):
+    def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0, kv_terms=0, qk_terms=0):
         """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D]; the anchors [C, M, D] are rows
         anchor_ids [C, M] of anchor_feats [C*N, D] (of the cloud cloud_map[c], if given): lib/utils.py:111-127."""
         D, H = self.emb_dims, self.config.num_heads
@@ -294,8 +297,8 @@ class GMMReg(nn.Module):
         dev = x.device
         q = ops.conv1x1(x, L["q"], eng=eng, terms=q_terms)
         if ops.attention_supported(M, dh):
-            kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map, eng=eng)      # keys | values in one GEMM, rows gathered by its DMA
-            o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H)
+            kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map, eng=eng, terms=kv_terms)      # keys | values in one GEMM, rows gathered by its DMA
+            o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H, qk_terms=qk_terms if eng.split else 0)
             if self.fold_merge:
                 mlp0, msg = L["mlp0_folded"], o                       # merge conv folded into mlp0's weights
             else:
@@ -431,10 +434,10 @@ class GMMReg(nn.Module):
         ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:], eng=eng)
 
         # ---- self-attention 1 + conv1 (gmmreg.py:54-57, 62-63)
-        t1 = self._transformer(eng, L["sattn1"], x0, emb, ids_a[0], C, N, res=x0, stats=stats3[0], q_terms=tb.get("sattn1.q", 0))
+        t1 = self._transformer(eng, L["sattn1"], x0, emb, ids_a[0], C, N, res=x0, stats=stats3[0], q_terms=tb.get("sattn1.q", 0), kv_terms=tb.get("sattn1.kv", 0), qk_terms=tb.get("sattn1.qk", 0))
         ft = self._stack3(eng, L["conv1"], t1)
         # ---- cross-attention: keys/values are the OTHER cloud's anchors (gmmreg.py:67-72)
-        f = self._transformer(eng, L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap, stats=stats3[1], q_terms=tb.get("cattn.q", 0))
+        f = self._transformer(eng, L["cattn"], ft, ft, ids_a[1], C, N, res=ft, cloud_map=swap, stats=stats3[1], q_terms=tb.get("cattn.q", 0), kv_terms=tb.get("cattn.kv", 0), qk_terms=tb.get("cattn.qk", 0))
 
         # ---- overlap scores (gmmreg.py:74-89)
         ops.conv1x1_head(f, L["proj"]["0"], ACT_RELU, L["proj"]["3"]["w"], L["proj"]["3"]["b"], ACT_NONE, extra[:, 1], ldy=XW, eng=eng,
@@ -481,7 +484,7 @@ class GMMReg(nn.Module):
         o.record_stream(side)
         for t_ in (gamma, pi, mu):
             t_.record_stream(main)
-        f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0))
+        f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0), kv_terms=tb.get("sattn2.kv", 0), qk_terms=tb.get("sattn2.qk", 0))
         main.wait_event(em_done)
 
         # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)

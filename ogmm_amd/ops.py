@@ -415,9 +415,9 @@ def l2norm_pack_frag_batched(x, batch, rows):
     return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K}
 
 
-def attention(q, k, v, C, N, M, H, out=None, use_workspace=True):
+def attention(q, k, v, C, N, M, H, out=None, use_workspace=True, qk_terms=0):
     """Fused anchor attention (models/attn.py:78-82).  q [C*N, D], k, v [C*M, D] (row-major views, last stride 1), head-major
-    channels; returns [C*N, D]."""
+    channels; returns [C*N, D].  qk_terms = 1: the score product with both operands rounded to binary16 (the term budget's entry "<transformer>.qk")."""
     D = q.shape[1]
     dh = D // H
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and q.shape[0] == C * N and k.shape[0] == C * M
@@ -429,8 +429,8 @@ def attention(q, k, v, C, N, M, H, out=None, use_workspace=True):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
     # algorithmic work: Q K^T and P V per head; bytes: Q in, O out, K and V in
     _timed_call("attention_t_kernel", 4.0 * C * N * M * D, 4.0 * (2.0 * C * N * D + 2.0 * C * M * D),
-                "ogmm_attention", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0), C, N, M, H, dh,
-                1.0 / dh ** .5, _p(out), out.stride(0), _p(ws), _stream())
+                "ogmm_attention_terms", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0), C, N, M, H, dh,
+                1.0 / dh ** .5, _p(out), out.stride(0), int(qk_terms), _p(ws), _stream())
     return out
 
 
@@ -491,7 +491,7 @@ def l2norm_rows(x, out=None):
     return out
 
 
-def conv1x1_gathered(feats, C, N, ids, layer, act=ACT_NONE, cloud_map=None, eng=None):
+def conv1x1_gathered(feats, C, N, ids, layer, act=ACT_NONE, cloud_map=None, eng=None, terms=0):
     """conv1x1(gather_rows(feats, ids, cloud_map), layer): a convolution over the anchor rows of every cloud (models/gmmreg.py:54, 67-68).  Where the
     engine takes it, the rows are gathered by the GEMM's own operand DMA (struct ogmm_gemm.a_gather_*) and the anchor tensor is never written."""
     feats, ids = _f32(feats, "feats"), _i32(ids, "ids")
@@ -505,9 +505,9 @@ def conv1x1_gathered(feats, C, N, ids, layer, act=ACT_NONE, cloud_map=None, eng=
         out = torch.empty((C * S, Cout), dtype=torch.float32, device=feats.device)
         cm = _i32(cloud_map, "cloud_map") if cloud_map is not None else None
         gemm_nt(feats, feats.stride(0), D, layer["W"], D, C * S, Cout, C=out, ldc=Cout, scale=layer.get("scale"), shift=layer.get("shift"), act=act,
-                split=sp, overflow=eng.overflow, a_gather=(ids, cm, N, rows))
+                split=sp, overflow=eng.overflow, a_gather=(ids, cm, N, rows), terms=terms)
         return out
-    return conv1x1(gather_rows(feats, feats.stride(0), C, N, D, ids, cloud_map=cloud_map).view(C * S, D), layer, act, eng=eng)
+    return conv1x1(gather_rows(feats, feats.stride(0), C, N, D, ids, cloud_map=cloud_map).view(C * S, D), layer, act, eng=eng, terms=terms)
 
 
 def conv1x1_head(x, layer, act, w, b, head_act, out, ldy=1, x2=None, eng=None, terms=0):

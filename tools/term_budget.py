@@ -47,6 +47,9 @@ POLICIES = {
     "v1": {"conv2.net.0": "x2w", "conv2.net.3": "x2w"},
     "v2": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "sattn1.attn.proj.0": "x2w", "cattn.attn.proj.0": "x2w", "sattn2.attn.proj.0": "x2w", "similarity": "x2w"},
     "v4": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "sattn1.attn.proj.0": "x1", "cattn.attn.proj.0": "x1", "sattn2.attn.proj.0": "x1", "similarity": "x1"},
+    # v4 + the K / V projections and the attention's score product q k^T with both operands rounded (round 3, late)
+    "v5": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x1",
+           **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "proj.1", "proj.2", "qk")}},
     "v3": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "conv2.net.6": "x2w", "overlap.net.0": "x2w", "overlap.net.3": "x2w", "proj.net.0": "x2w",
            "sattn1.attn.proj.0": "x2w", "cattn.attn.proj.0": "x2w", "sattn2.attn.proj.0": "x2w", "similarity": "x2w"},
 }
