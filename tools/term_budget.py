@@ -50,6 +50,10 @@ POLICIES = {
     # v4 + the K / V projections and the attention's score product q k^T with both operands rounded (round 3, late)
     "v5": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x1",
            **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "proj.1", "proj.2", "qk")}},
+    # v5 without the K / V projections, + the value product with V rounded (the default budget at the end of round 3)
+    "v6": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x1",
+           **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")},
+           **{"%s.attn.pv" % t: "x2w" for t in ("sattn1", "cattn", "sattn2")}},
     "v3": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "conv2.net.6": "x2w", "overlap.net.0": "x2w", "overlap.net.3": "x2w", "proj.net.0": "x2w",
            "sattn1.attn.proj.0": "x2w", "cattn.attn.proj.0": "x2w", "sattn2.attn.proj.0": "x2w", "similarity": "x2w"},
 }
