@@ -54,6 +54,13 @@ POLICIES = {
     "v6": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x1",
            **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")},
            **{"%s.attn.pv" % t: "x2w" for t in ("sattn1", "cattn", "sattn2")}},
+    # candidates: conv2's two wide layers with both operands rounded (v7), one of them only (v7a / v7b)
+    "v7": {"conv2.net.0": "x1", "conv2.net.3": "x1", "similarity": "x1",
+           **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")}},
+    "v7a": {"conv2.net.0": "x1", "conv2.net.3": "x2w", "similarity": "x1",
+            **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")}},
+    "v7b": {"conv2.net.0": "x2w", "conv2.net.3": "x1", "similarity": "x1",
+            **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")}},
     "v3": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "conv2.net.6": "x2w", "overlap.net.0": "x2w", "overlap.net.3": "x2w", "proj.net.0": "x2w",
            "sattn1.attn.proj.0": "x2w", "cattn.attn.proj.0": "x2w", "sattn2.attn.proj.0": "x2w", "similarity": "x2w"},
 }
