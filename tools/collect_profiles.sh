@@ -61,6 +61,8 @@ rm -rf $out/trace_train
 
 # 5. parity: the distribution over every pair of a batch per workload, then the PARITY lines of the GPU tests
 { echo "# commit $commit"; timeout 1800 python3 tools/parity_distribution.py --workloads cfg1,cfg2,cfg3,n717 --pairs 256,64,32,128 2>&1 | grep -v amdgpu.ids;
+  echo; echo "# tools/parity_outliers.py on the tail pairs: HIP with the term budget / three terms / exact-fp32 engine against the oracle, and the oracle against itself";
+  timeout 900 python3 tools/parity_outliers.py cfg1:128,188,0 cfg2:2060,2000 n717:413,334,365,300 2>&1 | grep -v amdgpu.ids;
   echo; echo "# PARITY lines of pytest -m gpu (tests/test_hip_forward.py, test_hip_deepgmr.py, test_hip_icp.py)";
   timeout 1200 python3 -m pytest tests/test_hip_forward.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|passed|failed"; } > $out/${tag}_parity.txt
 rm -rf $out/trace $out/pmc_*          # the rocpd databases exceed what gpurun copies back; the summaries above are what gets committed
