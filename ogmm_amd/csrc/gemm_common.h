@@ -375,6 +375,7 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
                 }
             }
             float sum1 = 0.0f, sum2 = 0.0f;
+            float yv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float y = fmaf(acc[j][r], s1, t1);
@@ -382,8 +383,27 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
                 else if (KIND == OGMM_ACT_LEAKY02) y = y > 0.0f ? y : 0.2f * y;
                 else if (KIND == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
                 if (Rm) y += rr[r];
-                cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
+                if (Cm) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
+                yv[r] = y;
                 if (stats) { sum1 += y; sum2 = fmaf(y, y, sum2); }
+            }
+            if (g.C_half) {
+                // binary16 copy (struct ogmm_gemm.C_half): a lane holds one column and 16 rows; neighbouring lanes swap one value per row pair (quad_perm
+                // [1,0,3,2]) so that the even lane packs columns (c, c+1) of the pair's first row and the odd lane those of its second row: dword stores,
+                // 64 B contiguous per row and instruction.  Clamp + v_cvt_pk_f16_f32: exactly what the consumer would do to the fp32 value.
+                const bool odd = lr & 1;
+                _Float16* __restrict__ hp = reinterpret_cast<_Float16*>(g.C_half) + (int64_t)(row0 + 4 * lh + (odd ? 1 : 0)) * g.ldc_half + (col - (odd ? 1 : 0));
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const int r = 2 * rp;
+                    const float snd = odd ? yv[r] : yv[r + 1];
+                    const float rcv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0xB1, 0xF, 0xF, true));
+                    const float first = __builtin_amdgcn_fmed3f(odd ? rcv : yv[r], -65504.0f, 65504.0f);
+                    const float second = __builtin_amdgcn_fmed3f(odd ? yv[r + 1] : rcv, -65504.0f, 65504.0f);
+                    f16x2 hi;
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(first), "v"(second));
+                    *reinterpret_cast<f16x2*>(hp + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc_half) = hi;
+                }
             }
             if (stats) {
                 sum1 += __shfl_xor(sum1, 32, 64);

@@ -437,7 +437,8 @@ bool gemm_f16x3_v10_applicable(const ogmm_gemm& g) {
     const bool gather_ok = !g.a_gather_ids || (g.K2 == 0 && !g.a_scale && g.batch_outer * g.batch_inner == 1 && g.a_gather_S > 0 && g.a_gather_N > 0 &&
                                                (int64_t)g.a_gather_rows * g.lda * 4 < (1ll << 32));
     const bool ovl_ok = !g.ovl_rowpart || (whole_tiles && g.ovl_colpart && g.ovl_orow && g.ovl_ocol && g.ovl_ld >= 1 && !g.a_scale && !g.col_stats && !g.Res && g.batch_inner == 1);
-    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok &&
+    const bool half_ok = !g.C_half || (whole_tiles && !g.ovl_rowpart && g.batch_outer * g.batch_inner == 1 && (reinterpret_cast<uintptr_t>(g.C_half) & 3) == 0 && g.ldc_half % 2 == 0);
+    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok && half_ok &&
            (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
