@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 21
+#define OGMM_ABI_VERSION 20
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -142,10 +142,6 @@ typedef struct ogmm_gemm {
      * by the weight's rounding, 2^-12 relative per product).  Which layers of the path tolerate it -- R, t within 1e-5 of the reference over the
      * parity distribution -- is measured, not assumed: tools/term_budget.py (CPU oracle with the same rounding) and DESIGN.md section 4. */
     int32_t terms;
-    /* The stored value ALSO (or only: C may then be NULL) rounded to binary16, row-major [M][ldc_half] (clamped to +-65504 first): for a consumer that
-     * rounds its operand anyway -- the attention's score product under the term budget reads Q this way (ogmm_attention_terms, q_half) -- so that the
-     * map travels at half the bytes.  LDS-DMA engines on whole 256 x 256 tiles only: ogmm_gemm_half_out_ok tells. */
-    void* C_half; int64_t ldc_half;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
@@ -154,8 +150,6 @@ int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
 int ogmm_gemm_overlap_fusable(int B, int N, int D);
 /* 1 if ogmm_gemm_nt takes a fused Cout = 1 head (rd_out) behind an M x N layer with K1 + K2 input channels, else 0 */
 int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2);
-/* 1 if ogmm_gemm_nt writes a binary16 copy of its output (ogmm_gemm.C_half) for an M x N layer with K1 + K2 input channels, else 0 */
-int ogmm_gemm_half_out_ok(int M, int N, int K1, int K2);
 /* 1 if ogmm_gemm_nt takes gathered A rows (a_gather_ids) for an M x N layer with K input channels over `rows` source rows, else 0 */
 int ogmm_gemm_gather_fusable(int M, int N, int K, int64_t rows);
 /* second half of the fused overlap block: merges the (1, sum, dot) triples the similarity GEMM left (models/gmmreg.py:79-80):
@@ -211,10 +205,6 @@ int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, con
  * rounded to binary16 -- one matrix instruction per block instead of three, no lo part of Q (a permission: kernels without that form run three). */
 int ogmm_attention_terms(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
                          int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, void* workspace, void* stream);
-/* qk_terms = 1 with Q given as binary16 [C*N][ldq_half] (the projection's C_half output: the value the kernel would round Q to anyway -- bit-identical
- * results, half the bytes of the largest operand). */
-int ogmm_attention_qhalf(const void* q_half, int64_t ldq_half, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
-                         int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream);
 
 /* ---- K9 middle (unfused fallback): in-place softmax over the last axis (keys).  models/attn.py:80. cols <= 1024. */
 int ogmm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream);

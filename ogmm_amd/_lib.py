@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 21
+ABI_VERSION = 20
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -37,7 +37,6 @@ class GemmDesc(Structure):
         ("a_gather_ids", c_void_p), ("a_gather_map", c_void_p), ("a_gather_S", c_int32), ("a_gather_N", c_int32), ("a_gather_rows", c_int64),
         ("col_stats_slot_mask", c_int32), ("col_stats_slot_stride", c_int64),
         ("terms", c_int32),
-        ("C_half", c_void_p), ("ldc_half", c_int64),
     ]
 
 
@@ -52,7 +51,6 @@ PROTOTYPES = {
     "ogmm_gemm_overlap_fusable": [c_int, c_int, c_int],
     "ogmm_gemm_rowdot_fusable": [c_int, c_int, c_int, c_int],
     "ogmm_gemm_gather_fusable": [c_int, c_int, c_int, c_int64],
-    "ogmm_gemm_half_out_ok": [c_int, c_int, c_int, c_int],
     "ogmm_overlap_finalize": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_row_rnorm": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p],
     "ogmm_edgeconv_first": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
@@ -63,7 +61,6 @@ PROTOTYPES = {
     "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
     "ogmm_attention_workspace_bytes": [c_int, c_int, c_int, c_int],
     "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_void_p],
-    "ogmm_attention_qhalf": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_attention_terms": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     "ogmm_add_n": [c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_attention_bwd_supported": [c_int, c_int],

@@ -502,8 +502,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
 // as at B = 64, nothing is split twice, and the pack kernel with its workspace round trip disappears: -25 us per call).
 // QK1: the score product q k^T with BOTH operands rounded to binary16 (one matrix instruction per block instead of three, no lo part of Q): the
 // per-layer term budget's entry for the attention scores (measured insensitive like the Q projection itself).  P V keeps three.
-// QH (with QK1): Q arrives as binary16 (the projection's C_half copy: the value QK1 would round it to anyway) -- the fragment is loaded as it is.
-template <int MK, bool FUSED, bool QK1 = false, bool QH = false>
+template <int MK, bool FUSED, bool QK1 = false>
 __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restrict__ q, int64_t ldq, const f16x8* __restrict__ kimg,
                                                           const f16x8* __restrict__ vimg, const float* __restrict__ kraw, int64_t ldk,
                                                           const float* __restrict__ vraw, int64_t ldv, int N, int H, float scale,
@@ -557,17 +556,9 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
     // Q rows of a tile: lane = query, 8 consecutive d per k-step (B operand of S^T).  The workgroup walks the query tiles
     // blockIdx.x, + gridDim.x, ... of its (cloud, head); the next tile's rows are fetched before the current tile is computed.
     const int n_tiles = (N + QT2 - 1) / QT2;
-    static_assert(!QH || QK1, "binary16 Q is the one-term score product's input");
     f32x4 qa[KS], qb[KS];
-    f16x8 qf[KS];
     auto load_q = [&](int tile) {
         const int row = min(tile * QT2 + wave * 32 + lr, N - 1);
-        if (QH) {
-            const _Float16* __restrict__ qp = reinterpret_cast<const _Float16*>(q) + ((int64_t)c * N + row) * ldq + h * DH;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 16 + lh * 8);
-            return;
-        }
         const float* __restrict__ qp = q + ((int64_t)c * N + row) * ldq + h * DH;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -616,8 +607,7 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
     f16x8 qh[KS], ql[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        if (QH) qh[s] = qf[s];
-        else if (QK1) round8_fast<true>(qa[s], qb[s], qh[s]);
+        if (QK1) round8_fast<true>(qa[s], qb[s], qh[s]);
         else split8_fast<true>(qa[s], qb[s], qh[s], ql[s]);
     }
     if (tile + (int)gridDim.x < n_tiles) load_q(tile + gridDim.x);
@@ -716,7 +706,7 @@ __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restric
 
 template <int MK>
 int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int H,
-                       float scale, float* out, int64_t ldo, void* workspace, hipStream_t s, int qk_terms = 0, bool q_half = false) {
+                       float scale, float* out, int64_t ldo, void* workspace, hipStream_t s, int qk_terms = 0) {
     constexpr int M = MK * 32;
     constexpr int GROUPS = M * DH / 8;
     const size_t lds = (size_t)4 * GROUPS * sizeof(f16x8);
@@ -727,7 +717,6 @@ int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_t_kernel<MK, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     // query tiles per workgroup: as many as leave at least two workgroups per CU (the K / V images are staged once per workgroup)
     const int n_tiles = (N + QT2 - 1) / QT2;
@@ -739,8 +728,6 @@ int launch_attention_t(const float* q, int64_t ldq, const float* k, int64_t ldk,
     if (packed) {
         hipLaunchKernelGGL((attention_pack_kernel<MK, true>), dim3((GROUPS + 255) / 256, H, C), dim3(256), 0, s, k, ldk, v, ldv, H, kimg, vimg);
         hipLaunchKernelGGL((attention_t_kernel<MK, false>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
-    } else if (q_half) {
-        hipLaunchKernelGGL((attention_t_kernel<MK, true, true, true>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
     } else if (qk_terms == 1) {
         hipLaunchKernelGGL((attention_t_kernel<MK, true, true>), dim3(gx, H, C), dim3(512), lds, s, q, ldq, kimg, vimg, k, ldk, v, ldv, N, H, scale, out, ldo);
     } else {
@@ -798,27 +785,12 @@ extern "C" int ogmm_attention(const float* q, int64_t ldq, const float* k, int64
 
 // qk_terms: 0 / 3 = the score product in three binary16 terms (fp32-class); 1 = both operands rounded to binary16 (a permission: only the transposed
 // kernel with a workspace has the form, the others run three terms)
-static int attention_impl(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
-                          int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, bool q_half_in, void* workspace, void* stream);
-
 extern "C" int ogmm_attention_terms(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
                                     int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, void* workspace, void* stream) {
-    return attention_impl(q, ldq, k, ldk, v, ldv, C, N, M, H, dh, scale, out, ldo, qk_terms, false, workspace, stream);
-}
-
-// Q as binary16 [C*N][ldq_half] (ogmm_gemm.C_half of the projection): the one-term score product on the value it would round Q to anyway
-extern "C" int ogmm_attention_qhalf(const void* q_half, int64_t ldq_half, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
-                                    int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream) {
-    OGMM_REQUIRE(workspace != nullptr && ldq_half % 8 == 0, "ogmm_attention_qhalf: needs the workspace form and rows of whole 16-byte groups");
-    return attention_impl(reinterpret_cast<const float*>(q_half), ldq_half, k, ldk, v, ldv, C, N, M, H, dh, scale, out, ldo, 1, true, workspace, stream);
-}
-
-static int attention_impl(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
-                          int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, bool q_half_in, void* workspace, void* stream) {
     OGMM_REQUIRE(q && k && v && out && C > 0 && N > 0 && H > 0, "ogmm_attention: null pointer or empty input");
     OGMM_REQUIRE(dh == DH, "ogmm_attention: head dimension %d not supported (built for %d)", dh, DH);
     OGMM_REQUIRE(M == 32 || M == 64 || M == 128, "ogmm_attention: %d anchors not supported (32, 64 or 128)", M);
-    OGMM_REQUIRE((q_half_in || ldq % 4 == 0) && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ogmm::aligned16(q) && ogmm::aligned16(k) && ogmm::aligned16(v) && ogmm::aligned16(out),
+    OGMM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ogmm::aligned16(q) && ogmm::aligned16(k) && ogmm::aligned16(v) && ogmm::aligned16(out),
                  "ogmm_attention: row strides must be multiples of 4 and pointers 16-byte aligned");
     hipStream_t s = ogmm::as_stream(stream);
     if (workspace) {
@@ -828,11 +800,6 @@ static int attention_impl(const float* q, int64_t ldq, const float* k, int64_t l
             if (M == 32) return launch_attention_frag<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
             if (M == 64) return launch_attention_frag<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
             return launch_attention_frag<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s);
-        }
-        if (q_half_in) {
-            if (M == 32) return launch_attention_t<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, 1, true);
-            if (M == 64) return launch_attention_t<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, 1, true);
-            return launch_attention_t<4>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, 1, true);
         }
         if (M == 32) return launch_attention_t<1>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, qk_terms);
         if (M == 64) return launch_attention_t<2>(q, ldq, k, ldk, v, ldv, C, N, H, scale, out, ldo, workspace, s, qk_terms);

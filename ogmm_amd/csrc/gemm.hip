@@ -167,7 +167,7 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.sA_o % 4 == 0 && g.sA_i % 4 == 0 && g.sB_o % 4 == 0 && g.sB_i % 4 == 0 && g.sA2_o % 4 == 0 && g.sA2_i % 4 == 0,
                  "ogmm_gemm_nt: batch strides of A/B must be multiples of 4");
     OGMM_REQUIRE(g.batch_outer >= 1 && g.batch_inner >= 1, "ogmm_gemm_nt: batch counts must be >= 1");
-    OGMM_REQUIRE(g.C || g.C_half || g.pool_k > 0 || g.ovl_rowpart || g.rd_out, "ogmm_gemm_nt: no output");
+    OGMM_REQUIRE(g.C || g.pool_k > 0 || g.ovl_rowpart || g.rd_out, "ogmm_gemm_nt: no output");
     OGMM_REQUIRE(g.act >= OGMM_ACT_NONE && g.act <= OGMM_ACT_SIGMOID, "ogmm_gemm_nt: bad act %d", g.act);
     hipStream_t s = ogmm::as_stream(stream);
     const bool frag = g.precision == OGMM_PREC_F16X3_FRAG || g.precision == OGMM_PREC_F16_FRAG || g.precision >= 18;
@@ -207,17 +207,6 @@ extern "C" int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2) {
     g.precision = OGMM_PREC_F16X3_FRAG; g.ldb_h = (K1 + 63) / 64 * 64 + (K2 + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy;
     g.rd_out = dummy; g.rd_w = dummy; g.rd_ld = 1;
     return ogmm::gemm_f16x3_v8_applicable(g) ? 1 : 0;
-}
-
-// Would ogmm_gemm_nt write the binary16 copy of its output (ogmm_gemm.C_half) for this layer?  (1 / 0)
-extern "C" int ogmm_gemm_half_out_ok(int M, int N, int K1, int K2) {
-    if (M <= 0 || N < 512 || K1 <= 0 || K2 < 0) return 0;
-    static float dummy[4];
-    ogmm_gemm g = {};
-    g.A = dummy; g.lda = K1; g.K1 = K1; g.A2 = K2 ? dummy : nullptr; g.lda2 = K2 ? K2 : 0; g.K2 = K2; g.M = M; g.N = N; g.batch_outer = 1; g.batch_inner = 1;
-    g.precision = OGMM_PREC_F16X3_FRAG; g.ldb_h = (K1 + 63) / 64 * 64 + (K2 + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy; g.C = dummy;
-    g.C_half = dummy; g.ldc_half = N;
-    return ogmm::gemm_f16x3_v10_applicable(g) ? 1 : 0;
 }
 
 // Would ogmm_gemm_nt take gathered A rows (ogmm_gemm.a_gather_ids) for an M x N layer with K input channels over `rows` source rows?  (1 / 0)

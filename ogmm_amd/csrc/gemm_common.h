@@ -341,9 +341,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
 // column and statistic per tile (per wave it would be 4096 atomics per tile: measured +10 % on the 1024-wide layers that feed a normalisation).
 // RES_AHEAD (a caller with ~128 registers to spare: the 512-register engine): all NB * 16 residual values of the slab are requested before the first
 // one is used, so that their latency is exposed once per slab instead of once per column block.
-// HALF: the instantiation that also writes the binary16 copy (struct ogmm_gemm.C_half); kept apart so that the plain form's store sequence stays exactly
-// what it was -- keeping the 16 values of a column block alive for the packing cost the plain epilogue 10 % of the whole GEMM when it was one body.
-template <int NB, bool RES_AHEAD = false, bool HALF = false>
+template <int NB, bool RES_AHEAD = false>
 __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, int col0, float alpha, float* stat_lds, int stat_slot = -1) {
     const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5, wave = stat_slot >= 0 ? stat_slot : (int)(threadIdx.x >> 6);
     float* __restrict__ Cm = g.C;
@@ -377,46 +375,15 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
                 }
             }
             float sum1 = 0.0f, sum2 = 0.0f;
-            if constexpr (!HALF) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float y = fmaf(acc[j][r], s1, t1);
-                    if (KIND == OGMM_ACT_RELU) y = fmaxf(y, 0.0f);
-                    else if (KIND == OGMM_ACT_LEAKY02) y = y > 0.0f ? y : 0.2f * y;
-                    else if (KIND == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                    if (Rm) y += rr[r];
-                    cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
-                    if (stats) { sum1 += y; sum2 = fmaf(y, y, sum2); }
-                }
-            } else {
-                float yv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float y = fmaf(acc[j][r], s1, t1);
-                    if (KIND == OGMM_ACT_RELU) y = fmaxf(y, 0.0f);
-                    else if (KIND == OGMM_ACT_LEAKY02) y = y > 0.0f ? y : 0.2f * y;
-                    else if (KIND == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                    if (Rm) y += rr[r];
-                    if (Cm) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
-                    yv[r] = y;
-                    if (stats) { sum1 += y; sum2 = fmaf(y, y, sum2); }
-                }
-                // binary16 copy (struct ogmm_gemm.C_half): a lane holds one column and 16 rows; neighbouring lanes swap one value per row pair (quad_perm
-                // [1,0,3,2]) so that the even lane packs columns (c, c+1) of the pair's first row and the odd lane those of its second row: dword stores,
-                // 64 B contiguous per row and instruction.  Clamp + v_cvt_pk_f16_f32: exactly what the consumer would do to the fp32 value.
-                const bool odd = lr & 1;
-                _Float16* __restrict__ hp = reinterpret_cast<_Float16*>(g.C_half) + (int64_t)(row0 + 4 * lh + (odd ? 1 : 0)) * g.ldc_half + (col - (odd ? 1 : 0));
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const int r = 2 * rp;
-                    const float snd = odd ? yv[r] : yv[r + 1];
-                    const float rcv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0xB1, 0xF, 0xF, true));
-                    const float first = __builtin_amdgcn_fmed3f(odd ? rcv : yv[r], -65504.0f, 65504.0f);
-                    const float second = __builtin_amdgcn_fmed3f(odd ? yv[r + 1] : rcv, -65504.0f, 65504.0f);
-                    f16x2 hi;
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(first), "v"(second));
-                    *reinterpret_cast<f16x2*>(hp + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc_half) = hi;
-                }
+            for (int r = 0; r < 16; ++r) {
+                float y = fmaf(acc[j][r], s1, t1);
+                if (KIND == OGMM_ACT_RELU) y = fmaxf(y, 0.0f);
+                else if (KIND == OGMM_ACT_LEAKY02) y = y > 0.0f ? y : 0.2f * y;
+                else if (KIND == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                if (Rm) y += rr[r];
+                cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
+                if (stats) { sum1 += y; sum2 = fmaf(y, y, sum2); }
             }
             if (stats) {
                 sum1 += __shfl_xor(sum1, 32, 64);

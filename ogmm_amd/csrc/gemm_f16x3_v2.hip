@@ -245,11 +245,6 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         OGMM_REQUIRE(g.C && (g.N & 3) == 0 && (g.ldc & 3) == 0 && aligned16(g.C) && !g.Res, "ogmm_gemm_nt(f16x3 frag): col_stats needs the wide epilogue (N, ldc %% 4 == 0, no residual)");
         (void)probe;
     }
-    if (g.C_half) {          // binary16 copy of the output: the 4-wave engine's row-block epilogue only (the caller asked ogmm_gemm_half_out_ok)
-        OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && g.N >= 512 && gemm_f16x3_v10_applicable(g),
-                     "ogmm_gemm_nt: C_half needs the fragment-major fp16x3 engine on whole 256 x 256 tiles, N >= 512 (ogmm_gemm_half_out_ok)");
-        return gemm_nt_f16x3_v10(g, s);
-    }
     if (g.pool_k > 0) return g.N <= 64 ? launch_v2<5, 1, 1, 2, true>(g, s) : launch_v2<5, 1, 1, 4, true>(g, s);
     switch (g.precision) {
         case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves

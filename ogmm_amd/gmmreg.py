@@ -295,15 +295,7 @@ class GMMReg(nn.Module):
         D, H = self.emb_dims, self.config.num_heads
         dh, M = D // H, anchor_ids.shape[1]
         dev = x.device
-        q_half = None
-        if eng.split and q_terms == 1 and qk_terms == 1 and ops.attention_supported(M, dh) and ops.half_out_ok(C * N, D, D):
-            # Q projection and score product both under the one-term budget: Q is rounded to binary16 where it is consumed anyway, so the projection
-            # writes THAT value (struct ogmm_gemm.C_half) and the fp32 map is never stored: half the bytes out and in, bit-identical scores
-            q_half = torch.empty((C * N, D), dtype=torch.float16, device=dev)
-            ops.conv1x1(x, L["q"], eng=eng, terms=q_terms, out_half=q_half, store=False)
-            q = q_half
-        else:
-            q = ops.conv1x1(x, L["q"], eng=eng, terms=q_terms)
+        q = ops.conv1x1(x, L["q"], eng=eng, terms=q_terms)
         if ops.attention_supported(M, dh):
             kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map, eng=eng, terms=kv_terms)      # keys | values in one GEMM, rows gathered by its DMA
             o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H, qk_terms=qk_terms if eng.split else 0)

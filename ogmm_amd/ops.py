@@ -210,7 +210,7 @@ def split_f16_training(W, cout, **kw):
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
             pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0,
-            overlap=None, row_rscale=None, head=None, a_gather=None, single_term=False, terms=0, c_half=None):
+            overlap=None, row_rscale=None, head=None, a_gather=None, single_term=False, terms=0):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -227,8 +227,6 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
         if "sB" in split:
             sB = (split["sB"], 0)
     d.C, d.ldc = (C.data_ptr() if C is not None else None), ldc
-    if c_half is not None:          # binary16 copy of the output (struct ogmm_gemm.C_half)
-        d.C_half, d.ldc_half = c_half.data_ptr(), c_half.stride(0)
     d.Res, d.ldr = (res.data_ptr() if res is not None else None), ldr
     d.M, d.N = M, N
     d.batch_outer, d.batch_inner = batch
@@ -302,7 +300,7 @@ def instnorm_finalize(col_stats, rows, eps=1e-5):
 
 
 def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0, head=None, store=True,
-            eng=None, terms=0, out_half=None):
+            eng=None, terms=0):
     """y[rows, Cout] = act((x | x2)[rows, K] @ W^T * scale + shift) + res for a packed layer
     (dict with W [Cout, Kpad], scale, shift -- see gmmreg.pack_*).  x, x2, res, out may be column views
     of wider row-major buffers (last stride 1).  split=True uses the layer's pre-split weights (fp16x3 engine)
@@ -330,7 +328,7 @@ def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, ove
             scale=layer.get("scale"), shift=layer.get("shift"), act=act,
             res=res, ldr=(res.stride(0) if res is not None else 0),
             split=(layer.get("split") if split else None), overflow=overflow, col_stats=col_stats, a_affine=a_affine, group_rows=group_rows,
-            single_term=eng.single_term, terms=terms, c_half=out_half)
+            single_term=eng.single_term, terms=terms)
     return out
 
 
@@ -417,14 +415,6 @@ def l2norm_pack_frag_batched(x, batch, rows):
     return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K}
 
 
-Q_HALF = os.environ.get("OGMM_Q_HALF", "1") != "0"          # A/B: 0 = the Q projection writes fp32 also under the one-term budget (bit-identical results)
-
-
-def half_out_ok(M, N, K1, K2=0):
-    """Would the engine write a binary16 copy of an M x N layer's output (conv1x1(..., out_half=...))?  (ogmm_gemm_half_out_ok)"""
-    return Q_HALF and bool(_lib.load().ogmm_gemm_half_out_ok(M, N, K1, K2))
-
-
 def attention(q, k, v, C, N, M, H, out=None, use_workspace=True, qk_terms=0):
     """Fused anchor attention (models/attn.py:78-82).  q [C*N, D], k, v [C*M, D] (row-major views, last stride 1), head-major
     channels; returns [C*N, D].  qk_terms = 1: the score product with both operands rounded to binary16 (the term budget's entry "<transformer>.qk")."""
@@ -433,13 +423,6 @@ def attention(q, k, v, C, N, M, H, out=None, use_workspace=True, qk_terms=0):
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and q.shape[0] == C * N and k.shape[0] == C * M
     if out is None:
         out = torch.empty((C * N, D), dtype=torch.float32, device=q.device)
-    if q.dtype == torch.float16:          # the projection's binary16 copy: the one-term score product reads it as it is (bit-identical to rounding fp32 Q)
-        nbytes = _lib.load().ogmm_attention_workspace_bytes(C, M, H, dh)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-        _timed_call("attention_t_kernel", 4.0 * C * N * M * D, 4.0 * (1.5 * C * N * D + 2.0 * C * M * D),
-                    "ogmm_attention_qhalf", _p(q), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0), C, N, M, H, dh,
-                    1.0 / dh ** .5, _p(out), out.stride(0), _p(ws), _stream())
-        return out
     ws = None
     if use_workspace:
         nbytes = _lib.load().ogmm_attention_workspace_bytes(C, M, H, dh)
