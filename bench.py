@@ -78,6 +78,8 @@ def main():
                          "(room clouds, N=2048, J=64, B=64); train = configs[4]: full training step, N=1024, J=16, 128 pairs per GPU (global 1024 on 8)")
     ap.add_argument("--train-batch", type=int, default=128, help="pairs per GPU and step for --workload train")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)          # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks and never touches a GPU
     if args.workload == "train":
         return train_main(args)
 
@@ -95,6 +97,8 @@ def main():
     # Test seam (tests/test_dist_gloo.py): OGMM_BENCH_STUB=1 runs THIS control flow -- the world-size guard, the sharding, the barriers around the timed
     # region, the max over ranks, the rank-0-only JSON line -- on CPU over gloo with a stand-in for the forward.  Never set on a GPU box.
     stub = os.environ.get("OGMM_BENCH_STUB") == "1"
+    if stub and os.environ.get("OGMM_BENCH_FAIL_RANK") == str(rank):          # test seam: a rank that dies before the rendezvous
+        raise SystemExit(3)
     if not stub:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
@@ -241,6 +245,51 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start N fresh child processes of this same command, one rank
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / a free MASTER_PORT in their environment -- what `python -m
+    torch.distributed.run --nproc-per-node N` would set), pass rank 0's stdout (the ONE JSON line) through, everything else to stderr, and exit with the
+    worst child status.  The reference's own multi-GPU mechanism is one process driving all GPUs (`nn.DataParallel`, train.py:190-192); here it is one
+    process per GPU over RCCL, and this parent only waits: it makes no HIP call (a process that has initialised the GPU must not fork / exec workers)."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # like torchrun: a rank that dies takes the job down (its peers would sit in the rendezvous / a collective until their timeouts otherwise); the children
+    # are ended by their exact PIDs
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.05)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    reader.join(timeout=10)
+    sys.stdout.write(out0[0] if out0 else "")
+    sys.stdout.flush()
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        print("[bench] rank exit codes: %s" % rcs, file=sys.stderr)
+        raise SystemExit(worst if worst < 256 else 1)
 
 
 class _StubForward:

@@ -7,13 +7,35 @@ import torch as _torch
 # graph faults on GPU memory once a few thousand ordinary kernel launches have gone through the same device between two replays -- found with the
 # ~1800-node training step (tools/train_capture_debug.py launch30000 / twin), gone with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.  The runtime reads the flag
 # when it initialises, so it is set here, at import; `graph_replay_safe()` tells whether that was early enough.
-_SET_BEFORE_INIT = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" or not _torch.cuda.is_initialized()
+def _runtime_untouched():
+    """True if nothing in this process has initialised the HIP runtime yet.  torch.cuda.is_initialized() only tracks torch's own lazy initialisation;
+    torch.cuda.is_available() (hipGetDeviceCount), a ctypes HIP call or a profiler's preloaded library initialise CLR -- which reads its flags then --
+    without torch knowing, and torch caches nothing that would tell (`_cached_device_count` is only set after torch's initialisation).  What every such
+    path leaves behind is the ROCr runtime's open handle on the compute driver: a file descriptor on /dev/kfd (amdsmi's device count, which
+    torch.cuda.device_count() uses on ROCm, does not open it)."""
+    if _torch.cuda.is_initialized():
+        return False
+    try:
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return False
+            except OSError:
+                continue
+    except OSError:
+        pass          # no procfs: fall back on torch's word
+    return True
+
+
+_SET_BEFORE_INIT = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" or _runtime_untouched()
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
 def graph_replay_safe():
     """True if this process's HIP runtime runs (or will run) with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: replayed graphs may then be mixed with other work on
-    the device.  False: the runtime was already initialised without the flag when ogmm_amd was imported, or the flag was set to something else."""
+    the device.  Safe means: the variable was ALREADY '0' in the environment when ogmm_amd was imported (export it before launch: the documented way,
+    and the only one that also covers profilers and other libraries that touch the GPU first), or nothing had touched the runtime by then (neither
+    torch.cuda's initialisation nor a device-count query).  False otherwise, or when the flag was set to something else."""
     return _SET_BEFORE_INIT and _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 
 

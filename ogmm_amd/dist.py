@@ -16,8 +16,10 @@ def shard_pairs(rank, world, pairs_per_rank, first_pair=0):
     return lo, lo + pairs_per_rank
 
 
-def init(backend, rank, world, device=None):
-    if world <= 1:
+def init(backend, rank, world, device=None, force=False):
+    """process group for `world` ranks; None at world 1 (no collective is needed then) unless `force`: a one-rank group, so that the collective code paths
+    -- RCCL's initialisation, the flat gradient bucket's all-reduce, the buffer broadcast -- run on a single GPU too (tests/test_hip_train.py)."""
+    if world <= 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

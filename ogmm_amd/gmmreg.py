@@ -27,11 +27,15 @@ from ._lib import OgmmError
 from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
-# measured budget (DESIGN.md section 4 "Per-layer term budget"): the two 1024-wide layers of conv2 feed nothing but the overlap scores
-TERM_BUDGET = {"conv2.0": 2, "conv2.3": 2, "similarity": 1,
-               **{"%s.%s" % (t_, l_): 1 for t_ in ("sattn1", "cattn", "sattn2") for l_ in ("q", "qk")}}          # (tools/term_budget.py policy v5 without its "kv" entries)
-# ("<transformer>.kv": 1 is admissible too (+0.6 %), but the anchors' K | V GEMM is small enough that a half batch falls back to the small-tile kernels, which
-#  have no reduced form: the same pairs would then differ by 2e-6 between a 64- and a 32-pair batch.  Left out for the sake of shard invariance.)
+# Measured budget (DESIGN.md section 4 "Per-layer term budget").  Round 4: an entry stays only if the layer's rounding holds the 1e-5 bar on BOTH weight
+# families of the parity suite -- the closed-form default fill AND synth.fill_state_dict(profile="sharp") (peaked attention, saturated overlap scores).
+# Round 3's entries for conv2.0 / conv2.3 (weight rounded), the three Q projections and the attention's score product (both rounded) were measured on
+# the default fill only, where the attention is uniform to 1e-4 and every overlap score is 0.496 +- 0.003: on the sharp family each of them alone moves
+# R by 1e-5 ... 5e-4 (tools/term_budget.py --profile sharp; profiles/round4_term_budget.txt).  What survives is the N x N cosine similarity: its
+# entries lie in [-1, 1] and pass an un-tempered softmax, on either family one binary16 term moves R by ~1e-6 (the noise level of three terms).
+TERM_BUDGET = {"similarity": 1}
+TERM_BUDGET_ROUND3 = {"conv2.0": 2, "conv2.3": 2, "similarity": 1,
+                      **{"%s.%s" % (t_, l_): 1 for t_ in ("sattn1", "cattn", "sattn2") for l_ in ("q", "qk")}}          # kept for A/B records only: NOT parity-safe
 
 
 # ------------------------------------------------------------------------------------------ parameters

@@ -159,10 +159,23 @@ def _hash_uniform(name, numel):
     return (x >> np.uint64(40)).astype(np.float64) / float(1 << 24)
 
 
-def fill_state_dict(state_dict):
+# profile "sharp" (round 4): the default fill leaves the network in a degenerate regime -- attention logits within +-0.03 of each other (a uniform softmax
+# over the 128 anchors), overlap scores within 0.493 ... 0.500 -- in which rounding of the Q / K / score operands cannot matter.  A trained checkpoint is
+# not like that.  The sharp family keeps the closed form and multiplies chosen tensors by constants (found by experiment on the CPU oracle:
+# tools/weight_profile_stats.py prints what they achieve) so that (i) every transformer's logits span >= +-10 (peaked softmax: mean max probability
+# 0.3 ... 0.8), (ii) the overlap scores span (0.01, 0.99), (iii) BatchNorm running statistics and affine parameters vary by 8x in variance.
+SHARP_GAINS = {}        # filled below, after the function that uses it (kept next to the numbers' provenance)
+
+
+def fill_state_dict(state_dict, profile="default"):
     """Overwrites every entry of a GMMReg state_dict (ours or the reference's: same 153 keys)
     in place with the closed-form fill.  conv weights/biases: U(-b, b), b = 1/sqrt(fan_in);
-    BN weight U(0.5,1.5), bias U(-0.2,0.2), running_mean U(-0.2,0.2), running_var U(0.5,1.5)."""
+    BN weight U(0.5,1.5), bias U(-0.2,0.2), running_mean U(-0.2,0.2), running_var U(0.5,1.5).
+    profile="sharp": the same hash with wider BatchNorm ranges (weight U(0.4,2.0), bias U(-0.5,0.5), running_mean U(-0.5,0.5), running_var
+    U(0.25,2.0)) and the per-tensor gains of SHARP_GAINS (peaked attention, saturated overlap scores)."""
+    if profile not in ("default", "sharp"):
+        raise ValueError("unknown weight profile %r" % profile)
+    sharp = profile == "sharp"
     for name, t in state_dict.items():
         if name.endswith("num_batches_tracked"):
             t.zero_()
@@ -170,7 +183,9 @@ def fill_state_dict(state_dict):
         u = _hash_uniform(name, t.numel()).reshape(tuple(t.shape))
         leaf = name.rsplit(".", 1)[1]
         is_norm = t.dim() == 1 and (name + "x").replace(leaf + "x", "running_var") in state_dict
-        if is_norm:
+        if is_norm and sharp:
+            v = {"weight": 0.4 + 1.6 * u, "bias": u - 0.5, "running_mean": u - 0.5, "running_var": 0.25 + 1.75 * u}[leaf]
+        elif is_norm:
             v = {"weight": 0.5 + u, "bias": 0.4 * u - 0.2, "running_mean": 0.4 * u - 0.2, "running_var": 0.5 + u}[leaf]
         else:
             if t.dim() >= 2:
@@ -180,5 +195,26 @@ def fill_state_dict(state_dict):
                 fan_in = int(np.prod(w.shape[1:]))
             b = 1.0 / np.sqrt(fan_in)
             v = (2.0 * u - 1.0) * b
+        if sharp:
+            g = SHARP_GAINS.get(name)
+            if g is not None:
+                v = v * g[0] + g[1]
         t.copy_(torch.from_numpy(np.ascontiguousarray(v)).to(t.dtype))
     return state_dict
+
+
+def _sharp_gains():
+    g = {}
+    for tr, gq in (("sattn1", 25.0), ("cattn", 23.0), ("sattn2", 8.5)):
+        for i in (0, 1):                       # Q and K projections (models/attn.py:96-97): logits scale with the product of the two gains
+            g["%s.attn.proj.%d.weight" % (tr, i)] = (gq, 0.0)
+            g["%s.attn.proj.%d.bias" % (tr, i)] = (gq, 0.0)
+    # the chain behind the overlap scores (models/gmmreg.py:83-89): BatchNorm gains of overlap.net and its last convolution, bias re-centred
+    g["overlap.net.1.weight"] = (3.0, 0.0)
+    g["overlap.net.4.weight"] = (3.0, 0.0)
+    g["overlap.net.6.weight"] = (20.0, 0.0)
+    g["overlap.net.6.bias"] = (1.0, 7.0)
+    return g
+
+
+SHARP_GAINS.update(_sharp_gains())

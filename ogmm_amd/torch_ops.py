@@ -250,7 +250,7 @@ match_kabsch.register_autograd(_match_bwd, setup_context=_match_setup)
 
 
 # ------------------------------------------------------------------------------------------ weight-bearing stages (eval mode: BatchNorm folded into packed_w)
-@custom_op("ogmm::edgeconv_dgcnn", mutates_args=(), device_types="cuda")
+@custom_op("ogmm::edgeconv_dgcnn", mutates_args=("overflow",), device_types="cuda")
 def edgeconv_dgcnn(xyz: Tensor, idx: Tensor, packed_w: List[Tensor], inv_scales: List[float], meta: List[int], precision: int,
                    overflow: Optional[Tensor]) -> Tensor:
     """models/dgcnn.py:133-154: graph features + conv1..4 (+BN+ReLU, max over k) + conv5: xyz [C,N,3], idx int32 [C,N,k], the five packed layers
@@ -275,7 +275,7 @@ def _(xyz, idx, packed_w, inv_scales, meta, precision, overflow):
     return xyz.new_empty((xyz.shape[0] * xyz.shape[1], packed_w[20].shape[0]))
 
 
-@custom_op("ogmm::pos_encoding", mutates_args=(), device_types="cuda")
+@custom_op("ogmm::pos_encoding", mutates_args=("overflow",), device_types="cuda")
 def pos_encoding(xyz: Tensor, idx5: Tensor, front: List[Tensor], packed_w: List[Tensor], inv_scales: List[float], meta: List[int], precision: int,
                  overflow: Optional[Tensor]) -> Tensor:
     """models/attn.py:59-75: xyz [C,N,3], idx5 = knn_idx(xyz, 5) -> [C*N, D] (distance channels | angle channels).  front = the six small tensors of
@@ -297,7 +297,7 @@ def _(xyz, idx5, front, packed_w, inv_scales, meta, precision, overflow):
     return xyz.new_empty((xyz.shape[0] * xyz.shape[1], 2 * packed_w[0].shape[0]))
 
 
-@custom_op("ogmm::conv_mlp", mutates_args=(), device_types="cuda")
+@custom_op("ogmm::conv_mlp", mutates_args=("overflow",), device_types="cuda")
 def conv_mlp(x: Tensor, x2: Optional[Tensor], packed_w: List[Tensor], inv_scales: List[float], meta: List[int], acts: List[int], precision: int,
              overflow: Optional[Tensor], res: Optional[Tensor]) -> Tensor:
     """models/dgcnn.py:16-38 (`CONV`): a chain of 1x1 convolutions with folded BatchNorm and the activation acts[i] after layer i, on point-major
@@ -317,7 +317,7 @@ def _(x, x2, packed_w, inv_scales, meta, acts, precision, overflow, res):
     return x.new_empty((x.shape[0], packed_w[5 * (len(acts) - 1)].shape[0]))
 
 
-@custom_op("ogmm::anchor_transformer", mutates_args=(), device_types="cuda")
+@custom_op("ogmm::anchor_transformer", mutates_args=("overflow",), device_types="cuda")
 def anchor_transformer(x: Tensor, anchor_feats: Tensor, anchor_ids: Tensor, cloud_map: Optional[Tensor], n_points: int, heads: int,
                        packed_w: List[Tensor], inv_scales: List[float], meta: List[int], precision: int, overflow: Optional[Tensor]) -> Tensor:
     """models/attn.py:78-111 (`Transformer`): x [C*N, D] attends to the anchors = rows anchor_ids [C,M] of anchor_feats [C*N, D] (of cloud
@@ -350,7 +350,7 @@ def _(x, anchor_feats, anchor_ids, cloud_map, n_points, heads, packed_w, inv_sca
     return torch.empty_like(x)
 
 
-@custom_op("ogmm::overlap_cross", mutates_args=(), device_types="cuda")
+@custom_op("ogmm::overlap_cross", mutates_args=("overflow",), device_types="cuda")
 def overlap_cross(fs: Tensor, ft: Tensor, o_s: Tensor, o_t: Tensor, precision: int, overflow: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
     """models/gmmreg.py:74-80: fs, ft [B,N,D] (un-normalised), o_s, o_t [B,N] overlap logits -> (wo_s, wo_t) [B,N]: the row- / column-softmax of the
     N x N cosine similarity applied to the logits.  The similarity lives only in the GEMM's accumulators where the engine takes the shape."""
@@ -382,15 +382,16 @@ def _(fs, ft, o_s, o_t, precision, overflow):
     return torch.empty_like(o_s), torch.empty_like(o_t)
 
 
-# SURVEY.md section 8b's operator list -> the registered schema (checked by tests/test_torch_ops.py)
+# SURVEY.md section 8b's operator list -> the registered schema (checked by tests/test_torch_ops.py).  `overflow` is declared as MUTATED (Tensor(a!)?):
+# the engines raise that device flag; functionalisation under torch.compile / export must not drop or reorder the write.
 SCHEMAS = {
     "knn_idx": "ogmm::knn_idx(Tensor xyz, SymInt k) -> Tensor",
-    "edgeconv_dgcnn": "ogmm::edgeconv_dgcnn(Tensor xyz, Tensor idx, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt precision, Tensor? overflow) -> Tensor",
+    "edgeconv_dgcnn": "ogmm::edgeconv_dgcnn(Tensor xyz, Tensor idx, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt precision, Tensor(a6!)? overflow) -> Tensor",
     "fps": "ogmm::fps(Tensor xyz, SymInt n, Tensor? start, bool center_start) -> Tensor",
-    "pos_encoding": "ogmm::pos_encoding(Tensor xyz, Tensor idx5, Tensor[] front, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt precision, Tensor? overflow) -> Tensor",
-    "anchor_transformer": "ogmm::anchor_transformer(Tensor x, Tensor anchor_feats, Tensor anchor_ids, Tensor? cloud_map, SymInt n_points, SymInt heads, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt precision, Tensor? overflow) -> Tensor",
-    "conv_mlp": "ogmm::conv_mlp(Tensor x, Tensor? x2, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt[] acts, SymInt precision, Tensor? overflow, Tensor? res) -> Tensor",
-    "overlap_cross": "ogmm::overlap_cross(Tensor fs, Tensor ft, Tensor o_s, Tensor o_t, SymInt precision, Tensor? overflow) -> (Tensor, Tensor)",
+    "pos_encoding": "ogmm::pos_encoding(Tensor xyz, Tensor idx5, Tensor[] front, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt precision, Tensor(a7!)? overflow) -> Tensor",
+    "anchor_transformer": "ogmm::anchor_transformer(Tensor x, Tensor anchor_feats, Tensor anchor_ids, Tensor? cloud_map, SymInt n_points, SymInt heads, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt precision, Tensor(a10!)? overflow) -> Tensor",
+    "conv_mlp": "ogmm::conv_mlp(Tensor x, Tensor? x2, Tensor[] packed_w, float[] inv_scales, SymInt[] meta, SymInt[] acts, SymInt precision, Tensor(a7!)? overflow, Tensor? res) -> Tensor",
+    "overlap_cross": "ogmm::overlap_cross(Tensor fs, Tensor ft, Tensor o_s, Tensor o_t, SymInt precision, Tensor(a5!)? overflow) -> (Tensor, Tensor)",
     "gmm_em": "ogmm::gmm_em(Tensor xyz, Tensor o, Tensor ids0, SymInt iters, SymInt sk_iters, float eps, float thresh, float tau, SymInt group_size) -> (Tensor, Tensor, Tensor)",
     "gmm_feat_mean": "ogmm::gmm_feat_mean(Tensor gamma, Tensor pi, Tensor feats) -> Tensor",
     "match_kabsch": "ogmm::match_kabsch(Tensor mu_s, Tensor mu_t, Tensor f_s, Tensor f_t, float temp) -> (Tensor, Tensor)",

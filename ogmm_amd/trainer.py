@@ -34,7 +34,7 @@ def unflatten_into_grads(flat, owners):
 
 def allreduce_gradients(model, dist, world):
     """SUM all-reduce of every gradient as one bucket.  Every rank must own gradients for the same parameters."""
-    if dist is None or world <= 1:
+    if dist is None:          # (a process group handed in at world 1 -- dist.init(..., force=True) -- runs the collective: the one-GPU test of this path)
         return 0
     flat, owners = flatten_grads(list(model.parameters()))
     if flat is None:
@@ -46,7 +46,7 @@ def allreduce_gradients(model, dist, world):
 
 def broadcast_buffers(model, dist, world, src=0):
     """BatchNorm running statistics of rank `src` win (DataParallel re-broadcasts replica 0 every step)."""
-    if dist is None or world <= 1:
+    if dist is None:
         return
     bufs = [b for b in model.buffers() if b.is_floating_point()]
     flat = torch.cat([b.reshape(-1) for b in bufs])
@@ -100,7 +100,7 @@ class Trainer:
         if fwd is None:
             return False, False
         both = torch.cat([fwd, bwd]).to(torch.float32)
-        if self.dist is not None and self.world > 1:
+        if self.dist is not None:
             self.dist.all_reduce(both, op=self.dist.ReduceOp.MAX)
         f, b = both.tolist()
         return f > 0, b > 0

@@ -265,7 +265,7 @@ def pos_encoding(P, pts, k=5, idx=None):
     return torch.cat([dis, ang], dim=1)
 
 
-def transformer(P, name, src, anchors, heads):
+def transformer(P, name, src, anchors, heads, cap=None):
     """models/attn.py:78-111 (`attention`, `MultiHeadAttention`, `MLP`, `Transformer`):
     src [B,D,N] attends to anchors [B,D,M]; returns mlp(cat[src, message]) [B,D,N] (no residual)."""
     B, D, _ = src.shape
@@ -274,6 +274,9 @@ def transformer(P, name, src, anchors, heads):
     kk = _conv(P, name + '.attn.proj.1', anchors).view(B, dh, heads, -1)
     vv = _conv(P, name + '.attn.proj.2', anchors).view(B, dh, heads, -1)
     prob = torch.softmax(_einsum(name + '.attn.qk', 'bdhn,bdhm->bhnm', q, kk) / dh ** .5, dim=-1)
+    if cap is not None:                                       # diagnostic only: how peaked the attention is (mean over queries of the largest probability; 1/M = uniform)
+        cap.setdefault('attn_maxprob_list_' + name, []).append(prob.max(dim=-1)[0].mean().item())
+        cap['attn_maxprob_' + name] = sum(cap['attn_maxprob_list_' + name]) / len(cap['attn_maxprob_list_' + name])
     msg = _einsum(name + '.attn.pv', 'bhnm,bdhm->bdhn', prob, vv).contiguous().view(B, D, -1)
     msg = _conv(P, name + '.attn.merge', msg)
     h = _conv(P, name + '.mlp.0', torch.cat([src, msg], dim=1))
@@ -354,12 +357,12 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
         pos = pos_encoding(P, pts[s], 5, cap['knn_idx_' + s][:, :, :5] if k >= 5 and 'knn_idx_' + s in inject else None)
         cap['pos_' + s] = pos
         x = emb[s] + pos
-        ft[s] = conv_stack(P, 'conv1', transformer(P, 'sattn1', x, a0[s], H) + x, True)
+        ft[s] = conv_stack(P, 'conv1', transformer(P, 'sattn1', x, a0[s], H, cap) + x, True)
         cap['ft_' + s] = ft[s]
     for s in pts:                                           # gmmreg.py:67-70
         a1[s] = anchors(s, ft[s], 1)
     for s in pts:                                           # gmmreg.py:71-72
-        f[s] = transformer(P, 'cattn', ft[s], a1[other[s]], H) + ft[s]
+        f[s] = transformer(P, 'cattn', ft[s], a1[other[s]], H, cap) + ft[s]
         cap['f_' + s] = f[s]
     fn = {s: F.normalize(f[s]) for s in pts}                # gmmreg.py:74-80
     sim = _einsum('similarity', 'bdm,bdn->bmn', fn['src'], fn['tgt'])
@@ -377,7 +380,7 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
     for s in pts:                                           # gmmreg.py:92-95
         a2[s] = anchors(s, f[s], 2)
     for s in pts:                                           # gmmreg.py:96-97
-        f2[s] = transformer(P, 'sattn2', f[s], a2[s], H) + f[s]
+        f2[s] = transformer(P, 'sattn2', f[s], a2[s], H, cap) + f[s]
         cap['f2_' + s] = f2[s]
     clu = {}
     for s in pts:                                           # gmmreg.py:100-101, :24-29

@@ -43,12 +43,18 @@ CASES = {
     "exit_room_b1_n2048_j64": (1, 2048, 64, "room", 920, 20, 128, 0.03),
     "exit_partial_b2_n717_j128": (2, 717, 128, "partial", 1020, 20, 128, 0.03),
     "exit_partial_b3_n200_j8_k12": (3, 200, 8, "partial", 1110, 12, 32, 0.03),
+    # round 4: a second, non-degenerate weight family (9th entry; synth.fill_state_dict(profile="sharp")): peaked attention (logits spanning +-10,
+    # mean max probability 0.3-0.5 over the 128 anchors), overlap scores spanning (0.002, 0.999), wider BatchNorm statistics.  With the default
+    # fill the attention is uniform to 1e-4 and every overlap score is 0.496 +- 0.003, a regime in which rounding Q / K / the scores cannot matter.
+    "sharp_partial_b2_n1024_j16": (2, 1024, 16, "partial", 0, 20, 128, 1.0, "sharp"),      # BASELINE configs[1]
+    "sharp_partial_b1_n2048_j64": (1, 2048, 64, "partial", 2000, 20, 128, 1.0, "sharp"),   # BASELINE configs[2] shape
+    "sharp_partial_b1_n717_j128": (1, 717, 128, "partial", 300, 20, 128, 1.0, "sharp"),    # the repo's own defaults
 }
 
 
-def run_reference(ref_mod, cfg, J, src, tgt, starts):
+def run_reference(ref_mod, cfg, J, src, tgt, starts, profile="default"):
     net = ref_mod.GMMReg(512, J, cfg).eval()
-    synth.fill_state_dict(net.state_dict())
+    synth.fill_state_dict(net.state_dict(), profile=profile)
     calls = [0]
     real_randint = torch.randint
 
@@ -78,12 +84,13 @@ def main():
         if only and name not in only:
             continue
         (B, N, J, kind, first, k, M), scale = case[:7], (case[7] if len(case) > 7 else 1.0)
+        profile = case[8] if len(case) > 8 else "default"
         cfg = default_config(n_clusters=J, gnn_k=k, km_clusters=M)
         src, tgt, R_gt, t_gt = synth.make_batch(first, B, N, kind)
         if scale != 1.0:
             src, tgt, t_gt = src * scale, tgt * scale, t_gt * scale
         starts = synth.fps_starts_for(first, B, N)
-        (R, t, so, to, loss), P = run_reference(ref_mod, cfg, J, src, tgt, starts)
+        (R, t, so, to, loss), P = run_reference(ref_mod, cfg, J, src, tgt, starts, profile)
         cap = {}
         with torch.no_grad():
             oR, ot, oso, oto, oloss = O.forward(P, cfg, src, tgt, starts, cap)
@@ -92,6 +99,8 @@ def main():
         fx = dict(src=src.numpy(), tgt=tgt.numpy(), fps_starts=starts.numpy(), R_gt=R_gt.numpy(), t_gt=t_gt.numpy(),
                   R=R.numpy(), t=t.numpy(), src_o=so.numpy(), tgt_o=to.numpy(), loss=loss.numpy(),
                   meta=np.array([B, N, J, k, M, 512, 4]))
+        if profile != "default":
+            fx["profile"] = np.array(profile)
         for s in ("src", "tgt"):
             fx["knn_idx_" + s] = cap["knn_idx_" + s].numpy().astype(np.int16)
             for st in (0, 1, 2):
@@ -111,16 +120,26 @@ def main():
         fx["sk_margin"] = np.float32(((means - 1e-2).abs() / 1e-2).min().item())      # how close any decision came to the threshold (relative)
         print("   sweeps src %s tgt %s, closest decision %.3f of the threshold away" % (cap["sk_iters_src"], cap["sk_iters_tgt"], fx["sk_margin"]))
         assert fx["sk_margin"] > 0.03, "a decision within 3 % of the threshold: rounding differences between two correct implementations could flip it"
-        if scale != 1.0:
+        if profile != "default":
+            # what makes the family non-degenerate, recorded with the fixture: the attention's sharpness is a property of the weights + inputs that the
+            # oracle reports (mean over queries of the largest probability, per transformer), the overlap scores' range is in the outputs themselves
+            fx["attn_maxprob"] = np.array([cap["attn_maxprob_" + tr_] for tr_ in ("sattn1", "cattn", "sattn2")], dtype=np.float32)
+            print("   attention mean max-probability %s, overlap scores %.4f ... %.4f" % (fx["attn_maxprob"], min(so.min(), to.min()), max(so.max(), to.max())))
+            assert fx["attn_maxprob"].min() > 0.1 and min(so.min(), to.min()) < 0.02 and max(so.max(), to.max()) > 0.98
+        if scale != 1.0 or profile != "default":
             # scaled-down clouds are often ill-conditioned: on many seeds the reference's own R moves by 3e-6 ... 1e-5 rad when only its thread count
             # changes (summation order).  A fixture has to be a case where "within 1e-5 of the reference" means something.
             torch.set_num_threads(1)
             with torch.no_grad():
-                R1 = O.forward(P, cfg, src, tgt, starts)[0]
+                R1, _, so1, to1, _ = O.forward(P, cfg, src, tgt, starts)
             torch.set_num_threads(8)
             noise = O.rotation_error_rad(R1, R).max().item()
-            print("   reference R, 1 thread against 8: %.2e rad" % noise)
-            assert noise < 1e-6, "ill-conditioned case: pick another seed / scale"
+            fx["ref_thread_noise_o"] = np.float32(max((so1 - so).abs().max().item(), (to1 - to).abs().max().item()))
+            print("   reference R, 1 thread against 8: %.2e rad; overlap scores %.2e" % (noise, fx["ref_thread_noise_o"]))
+            fx["ref_thread_noise"] = np.float32(noise)
+            # (the sharp family amplifies rounding: the reference's own R moves by 1e-6 ... 3e-6 rad between thread counts on most pairs, 9e-6 on some;
+            #  a fixture may carry up to 3e-6 of it -- recorded with the fixture -- against the 1e-5 bar)
+            assert noise < (3e-6 if profile != "default" else 1e-6), "ill-conditioned case: pick another seed / scale"
         path = os.path.join(here, name + ".npz")
         np.savez_compressed(path, **fx)
         print("%-28s %7.1f KB  R[0,0]=%+.6f loss=%.6f" % (name, os.path.getsize(path) / 1024, R[0, 0, 0], loss))

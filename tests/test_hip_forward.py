@@ -21,10 +21,10 @@ O_TOL = 5e-6      # overlap scores in (0,1)
 LOSS_TOL = 5e-5
 
 
-def build(cfg, J, precision="f16x3"):
+def build(cfg, J, precision="f16x3", profile="default"):
     m = GMMReg(512, J, cfg)
     m.precision = precision
-    synth.fill_state_dict(m.state_dict())
+    synth.fill_state_dict(m.state_dict(), profile=profile)
     P = {k: v.clone() for k, v in m.state_dict().items()}
     return m.cuda().eval(), P
 
@@ -35,7 +35,7 @@ def test_forward_matches_reference_golden(golden, name, precision):
     fx = golden(name)
     B, N, J, k, M, D, H = [int(v) for v in fx["meta"]]
     cfg = Namespace(gnn_k=k, num_heads=H, km_clusters=M, overlap_radius=0.035, n_clusters=J)
-    model, _ = build(cfg, J, precision)
+    model, _ = build(cfg, J, precision, str(fx["profile"]) if "profile" in fx else "default")      # sharp_*: the second weight family (peaked attention, saturated scores)
     src, tgt = torch.from_numpy(fx["src"]).cuda(), torch.from_numpy(fx["tgt"]).cuda()
     with torch.no_grad():
         R, t, so, to, loss = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]), capture=True)
@@ -80,7 +80,10 @@ def test_forward_matches_reference_golden(golden, name, precision):
     for key in ("emb", "ft", "f", "f2"):
         assert rep[key] < 2e-5, (key, rep)
     assert rep["R"] < R_TOL and rep["t"] < T_TOL, rep
-    assert rep["o"] < O_TOL and rep["loss"] < LOSS_TOL, rep
+    # sharp family: the head's gain makes the reference's OWN scores move by 2e-5 between 1 and 8 host threads (recorded with the fixture by
+    # make_golden.py); the bar on the scores is then 3 x that, the bar on (R, t) stays the north star's 1e-5
+    o_tol = max(O_TOL, 3.0 * float(fx["ref_thread_noise_o"])) if "profile" in fx else O_TOL
+    assert rep["o"] < o_tol and rep["loss"] < LOSS_TOL, rep
 
 
 def test_forward_matches_oracle_live_batch():

@@ -15,10 +15,10 @@ from ogmm_amd import synth
 from ogmm_amd.gmmreg import state_spec
 
 
-def filled_params(J):
+def filled_params(J, profile="default"):
     sd = {k: torch.zeros(shape, dtype=torch.int64 if k.endswith("num_batches_tracked") else torch.float32)
           for k, shape in state_spec(512)}
-    return synth.fill_state_dict(sd)
+    return synth.fill_state_dict(sd, profile=profile)
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -29,10 +29,18 @@ def test_oracle_matches_reference_outputs(golden, name):
     src, tgt = torch.from_numpy(fx["src"]), torch.from_numpy(fx["tgt"])
     cap = {}
     with torch.no_grad():
-        R, t, so, to, loss = O.forward(filled_params(J), cfg, src, tgt, torch.from_numpy(fx["fps_starts"]), cap)
-    assert O.rotation_error_rad(R, torch.from_numpy(fx["R"])).max() < 2e-6
+        R, t, so, to, loss = O.forward(filled_params(J, str(fx["profile"]) if "profile" in fx else "default"), cfg, src, tgt, torch.from_numpy(fx["fps_starts"]), cap)
+    if "profile" in fx:
+        # the sharp weight family (synth.fill_state_dict(profile="sharp")): the fixture is only worth something if the regime is what it claims --
+        # peaked attention (1/128 = 0.0078 is uniform) and overlap scores that reach both ends of (0, 1)
+        assert min(cap["attn_maxprob_" + tr] for tr in ("sattn1", "cattn", "sattn2")) > 0.1
+        assert min(float(so.min()), float(to.min())) < 0.02 and max(float(so.max()), float(to.max())) > 0.98
+    # on another host's BLAS the sharp family moves by what the reference itself moves between thread counts there (recorded with the fixture)
+    noise = float(fx["ref_thread_noise"]) if "profile" in fx else 0.0
+    assert O.rotation_error_rad(R, torch.from_numpy(fx["R"])).max() < 2e-6 + 2 * noise
     assert O.translation_error(t, torch.from_numpy(fx["t"])).max() < 2e-6
-    assert np.abs(so.numpy() - fx["src_o"]).max() < 2e-6 and np.abs(to.numpy() - fx["tgt_o"]).max() < 2e-6
+    noise_o = float(fx["ref_thread_noise_o"]) if "profile" in fx else 0.0          # (sharp: the reference's own scores move by 2e-5 between thread counts)
+    assert np.abs(so.numpy() - fx["src_o"]).max() < 2e-6 + 2 * noise_o and np.abs(to.numpy() - fx["tgt_o"]).max() < 2e-6 + 2 * noise_o
     assert abs(float(loss) - float(fx["loss"])) < 1e-5
     for s in ("src", "tgt"):
         assert np.array_equal(cap["knn_idx_" + s].numpy(), fx["knn_idx_" + s].astype(np.int64))

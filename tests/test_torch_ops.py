@@ -69,6 +69,11 @@ def test_opcheck_on_three_ops():
     feats = torch.randn(2 * 128, D, device="cuda", requires_grad=True)
     opcheck(torch.ops.ogmm.gmm_feat_mean, (gamma, gamma.mean(1), feats))
     opcheck(torch.ops.ogmm.knn_idx, (torch.randn(2, 200, 3, device="cuda"), 8))
+    # an op that writes the engines' fp16-range flag: declared as mutated, which opcheck's schema test verifies against what the
+    # kernel actually touches
+    ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    fs, ft = torch.randn(2, 256, 64, device="cuda"), torch.randn(2, 256, 64, device="cuda")
+    opcheck(torch.ops.ogmm.overlap_cross, (fs, ft, torch.randn(2, 256, device="cuda"), torch.randn(2, 256, device="cuda"), 1, ovf))
 
 
 @pytest.mark.gpu
@@ -120,6 +125,10 @@ def test_a_forward_assembled_from_the_registered_ops_alone_equals_the_model():
             return o.anchor_transformer(x, feats, ids, cmap, N, H, *P([T_["q"], T_["kv"], T_["mlp0_folded"], T_["mlp3"]]), 1, None)
         t1 = tr("sattn1", x0, emb, ids_a[0])
         ft = o.conv_mlp(t1, None, *P([L["conv1"]["0"], L["conv1"]["3"], L["conv1"]["6"]]), [T.ACT_RELU, T.ACT_RELU, T.ACT_NONE], 1, None, None)
+        # the engines' fp16-range flag through the dispatcher (declared as a mutated argument): an input beyond +-65504 must raise it
+        ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+        o.conv_mlp(t1 * 1e7, None, *P([L["conv1"]["0"], L["conv1"]["3"], L["conv1"]["6"]]), [T.ACT_RELU, T.ACT_RELU, T.ACT_NONE], 1, ovf, None)
+        assert int(ovf.item()) != 0
         f = tr("cattn", ft, ft, ids_a[1], swap)
         head = {"W": L["proj"]["3"]["w"].view(1, -1).contiguous(), "shift": L["proj"]["3"]["b"]}
         ol = o.conv_mlp(f, None, *P([L["proj"]["0"], head]), [T.ACT_RELU, T.ACT_NONE], 1, None, None).view(C, N)

@@ -8,6 +8,7 @@ commit=${2:-unknown}          # the tree's commit (the box has no .git): goes in
 out=gpurun_out/collect
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0          # before anything (rocprofv3's preloaded library included) initialises the HIP runtime: ogmm_amd.graph_replay_safe()
 BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-sample 0"
 
 # 1. headline bench line (with the CPU baseline and the parity sample) and the other workloads

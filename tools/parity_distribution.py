@@ -43,24 +43,30 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="cfg1,cfg2,n717")
     ap.add_argument("--pairs", default="64,32,32")
-    ap.add_argument("--budget", default="default", choices=["default", "none"])
+    ap.add_argument("--budget", default="default", choices=["default", "none", "r3"], help="r3 = round 3's default budget (kept for the record: it does not hold on the sharp family)")
+    ap.add_argument("--profile", default="default", choices=["default", "sharp"], help="weight family (synth.fill_state_dict)")
+    ap.add_argument("--first", default="", help="first global pair id per workload (comma list; default: the workload's)")
     ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--threads", type=int, default=0)
     args = ap.parse_args()
     names = args.workloads.split(",")
     counts = [int(v) for v in args.pairs.split(",")]
-    print("# parity distribution: HIP forward (precision %s, term budget %s) against the CPU oracle; R in rad, t in cloud units" % (args.precision, args.budget))
+    print("# parity distribution: HIP forward (precision %s, term budget %s, weight family %s) against the CPU oracle; R in rad, t in cloud units" % (args.precision, args.budget, args.profile))
     worst = {}
-    for name, n_pairs in zip(names, counts):
+    firsts = [int(v) for v in args.first.split(",")] if args.first else [None] * len(names)
+    for name, n_pairs, first_ in zip(names, counts, firsts):
         N, J, first, kind = WORK[name]
+        first = first if first_ is None else first_
         cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
         model = GMMReg(512, J, cfg)
-        synth.fill_state_dict(model.state_dict())
+        synth.fill_state_dict(model.state_dict(), profile=args.profile)
         P = {k: v.clone() for k, v in model.state_dict().items()}
         model = model.cuda().eval()
         model.precision = args.precision
         if args.budget == "none":
             model.term_budget = {}
+        elif args.budget == "r3":
+            model.term_budget = {"conv2.0": 2, "conv2.3": 2, "similarity": 1, **{"%s.%s" % (t_, l_): 1 for t_ in ("sattn1", "cattn", "sattn2") for l_ in ("q", "qk")}}
         src, tgt, _, _ = synth.make_batch(first, n_pairs, N, kind)
         starts = synth.fps_starts_for(first, n_pairs, N)
         if name in ("cfg2", "cfg3"):

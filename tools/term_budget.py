@@ -61,6 +61,16 @@ POLICIES = {
             **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")}},
     "v7b": {"conv2.net.0": "x2w", "conv2.net.3": "x1", "similarity": "x1",
             **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")}},
+    # the default budget of round 3 as shipped (gmmreg.TERM_BUDGET: v5 without its K / V entries)
+    "r3": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x1",
+           **{"%s.attn.%s" % (t, l): "x1" for t in ("sattn1", "cattn", "sattn2") for l in ("proj.0", "qk")}},
+    # round 4 candidates, measured on BOTH weight families: r3 without the score product's entry / without any attention entry / conv2 only
+    "r4": {"similarity": "x1"},          # the default budget from round 4 on: what holds on both families
+    "r4p": {"similarity": "x1", "proj.net.0": "x1"},
+    "r4a": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x1", **{"%s.attn.proj.0" % t: "x1" for t in ("sattn1", "cattn", "sattn2")}},
+    "r4b": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x1"},
+    "r4c": {"conv2.net.0": "x2w", "conv2.net.3": "x2w"},
+    "r4d": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "similarity": "x2w", **{"%s.attn.proj.0" % t: "x2w" for t in ("sattn1", "cattn", "sattn2")}},
     "v3": {"conv2.net.0": "x2w", "conv2.net.3": "x2w", "conv2.net.6": "x2w", "overlap.net.0": "x2w", "overlap.net.3": "x2w", "proj.net.0": "x2w",
            "sattn1.attn.proj.0": "x2w", "cattn.attn.proj.0": "x2w", "sattn2.attn.proj.0": "x2w", "similarity": "x2w"},
 }
@@ -74,12 +84,16 @@ def main():
     ap.add_argument("--modes", default="x2a,x2w,x1")
     ap.add_argument("--groups", action="store_true", help="layer groups instead of single layers")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--profile", default="default", choices=["default", "sharp"], help="weight family (synth.fill_state_dict)")
+    ap.add_argument("--first", type=int, default=None, help="first global pair id (default: the workload's)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     N, J, first = {"cfg1": (1024, 16, 0), "n717": (717, 128, 300), "cfg2": (2048, 64, 2000)}[args.workload]
     cfg = default_config(n_clusters=J)
     sd = {k: torch.zeros(shape, dtype=torch.int64 if k.endswith("num_batches_tracked") else torch.float32) for k, shape in state_spec(512)}
-    P = synth.fill_state_dict(sd)
+    P = synth.fill_state_dict(sd, profile=args.profile)
+    if args.first is not None:
+        first = args.first
     src, tgt, _, _ = synth.make_batch(first, args.pairs, N, "partial")
     starts = synth.fps_starts_for(first, args.pairs, N)
 
@@ -89,7 +103,7 @@ def main():
 
     t0 = time.time()
     base = run(lambda n: None)
-    print("# workload %s: %d pairs, N=%d, J=%d; exact forward %.1f s" % (args.workload, args.pairs, N, J, time.time() - t0))
+    print("# workload %s, weight family %s: pairs %d ... %d, N=%d, J=%d; exact forward %.1f s" % (args.workload, args.profile, first, first + args.pairs - 1, N, J, time.time() - t0))
     x3 = run(lambda n: "x3")
     print("%-62s %-5s R max %.2e  median %.2e   t max %.2e" % ("ALL layers (the default engine's rounding)", "x3",
           O.rotation_error_rad(x3[0], base[0]).max().item(), O.rotation_error_rad(x3[0], base[0]).median().item(), O.translation_error(x3[1], base[1]).max().item()))
