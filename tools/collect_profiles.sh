@@ -9,11 +9,11 @@ out=gpurun_out/collect
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0          # before anything (rocprofv3's preloaded library included) initialises the HIP runtime: ogmm_amd.graph_replay_safe()
-BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-sample 0"
+BENCH="python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --secondary 0"
 
 # 1. headline bench line (with the CPU baseline and the parity sample) and the other workloads
 timeout 600 python3 bench.py --steps 20 --warmup 5 2> $out/bench_n1.err | tail -1 > $out/${tag}_bench_n1.json
-for w in cfg2 cfg3; do timeout 400 python3 bench.py --workload $w --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_bench_$w.json; done
+for w in cfg2 cfg3; do timeout 400 python3 bench.py --workload $w --steps 5 --warmup 2 --cpu-sample 0 --secondary 0 2>/dev/null | tail -1 > $out/${tag}_bench_$w.json; done
 timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_train_bench_b128.json
 OGMM_TRAIN_GRAPH=0 timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_train_bench_b128_eager.json
 
@@ -60,11 +60,14 @@ dbt=$(find $out/trace_train -name "*.db" | head -1)
   echo "# tools/attn_bwd_time.py"; timeout 200 python3 tools/attn_bwd_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_train_breakdown.txt
 rm -rf $out/trace_train
 
-# 5. parity: the distribution over every pair of a batch per workload, then the PARITY lines of the GPU tests
+# 5. parity: the distribution over every pair of a batch per workload on both weight families, then the PARITY lines of the GPU tests
 { echo "# commit $commit"; timeout 1800 python3 tools/parity_distribution.py --workloads cfg1,cfg2,cfg3,n717 --pairs 256,64,32,128 2>&1 | grep -v amdgpu.ids;
-  echo; echo "# tools/parity_outliers.py on the tail pairs: HIP with the term budget / three terms / exact-fp32 engine against the oracle, and the oracle against itself";
-  timeout 900 python3 tools/parity_outliers.py cfg1:128,188,0 cfg2:2060,2000 n717:413,334,365,300 2>&1 | grep -v amdgpu.ids;
-  echo; echo "# PARITY lines of pytest -m gpu (tests/test_hip_forward.py, test_hip_deepgmr.py, test_hip_icp.py)";
-  timeout 1200 python3 -m pytest tests/test_hip_forward.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|passed|failed"; } > $out/${tag}_parity.txt
+  echo; echo "# PARITY lines of pytest -m gpu (tests/test_hip_forward.py, test_hip_parity_tail.py, test_hip_deepgmr.py, test_hip_icp.py)";
+  timeout 1500 python3 -m pytest tests/test_hip_forward.py tests/test_hip_parity_tail.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|TRAINED|passed|failed"; } > $out/${tag}_parity.txt
+{ echo "# commit $commit"; echo "# weight family sharp (synth.fill_state_dict(profile='sharp')): the shipped budget, three terms everywhere, round 3's budget (for the record: NOT parity-safe), the exact-fp32 engine";
+  timeout 900 python3 tools/parity_distribution.py --profile sharp --workloads cfg1,cfg2,n717 --pairs 128,32,128 2>&1 | grep -v amdgpu.ids;
+  timeout 600 python3 tools/parity_distribution.py --profile sharp --budget none --workloads cfg1,n717 --pairs 64,64 2>&1 | grep -v amdgpu.ids;
+  timeout 600 python3 tools/parity_distribution.py --profile sharp --budget r3 --workloads cfg1,n717 --pairs 64,64 2>&1 | grep -v amdgpu.ids;
+  timeout 600 python3 tools/parity_distribution.py --profile sharp --precision f32 --workloads cfg1,n717 --pairs 64,64 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_parity_sharp.txt
 rm -rf $out/trace $out/pmc_*          # the rocpd databases exceed what gpurun copies back; the summaries above are what gets committed
 ls -la $out | head -40
