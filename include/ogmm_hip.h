@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 20
+#define OGMM_ABI_VERSION 22
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -82,6 +82,8 @@ int ogmm_gather_rows(const float* feats, int64_t ld, int C, int N, int D, const 
  * InstanceNorm forms included, K1 + K2 <= 4096 with a_scale); other large shapes on the register-staged engine (gemm_f16x3_v4.hip); small
  * ones on 128 x 128 / 256 x 256 tiles (gemm_f16x3_v2.hip). */
 enum { OGMM_ACT_NONE = 0, OGMM_ACT_RELU = 1, OGMM_ACT_LEAKY02 = 2, OGMM_ACT_SIGMOID = 3 };
+/* bits of the device status word that kernels with on-chip / cross-workgroup protocols raise on a timed-out wait (checked by the host like the fp16 range flag) */
+enum { OGMM_STATUS_EDGECONV_PROTOCOL = 2, OGMM_STATUS_EM_EXIT_PROTOCOL = 4 };
 enum { OGMM_PREC_F32 = 0, OGMM_PREC_F16X3 = 1, OGMM_PREC_F16X3_FRAG = 2, OGMM_PREC_F16_FRAG = 3 };
 /* OGMM_PREC_F16_FRAG (reduced precision, for BASELINE configs[2] which is quoted in bf16): the operands of OGMM_PREC_F16X3_FRAG, but
  * only the leading binary16 term of A and B is multiplied (11-bit mantissa, fp32 accumulate; 1/3 of the matrix instructions); shapes
@@ -175,11 +177,14 @@ int ogmm_edgeconv_fused(const float* xyz, const int32_t* idx, int C, int N, int 
                         float inv4, float* xcat, int64_t ldx, void* stream);
 /* The same chain as a producer / consumer pipeline over 32-row blocks (k = 20 only; edgeconv_pc.hip): four waves compute layers 1-3 of a block
  * each, four waves multiply every block with layer 4, so that every SIMD holds one vector-ALU-heavy and one matrix-heavy wave; no workgroup
- * barrier in the loop.  Same arguments, bit-identical xcat. */
+ * barrier in the loop.  Same arguments, bit-identical xcat.  `status` (device int32[1] or NULL): the waves of a workgroup hand blocks over through LDS
+ * sequence counters with bounded waits; a wait that runs into its limit (a protocol error: never observed, but a hung GPU is not an acceptable failure
+ * mode) ORs OGMM_STATUS_EDGECONV_PROTOCOL into *status -- the host checks that word behind the forward, as it does the fp16 range flag -- and the
+ * output is NaN-poisoned as well. */
 int ogmm_edgeconv_pc(const float* xyz, const int32_t* idx, int C, int N, int k, const float* W1, const float* s1, const float* t1,
                         const void* h2, const void* l2, const float* s2, const float* t2, float inv2, const void* h3, const void* l3,
                         const float* s3, const float* t3, float inv3, const void* h4, const void* l4, const float* s4, const float* t4,
-                        float inv4, float* xcat, int64_t ldx, void* stream);
+                        float inv4, float* xcat, int64_t ldx, int32_t* status, void* stream);
 
 /* ---- K7 front half: PositionEncoding up to its two 64-channel hidden maps.  models/attn.py:65-73:
  * centroid, g=|p-c|^2 -> conv_dis.0 (1->64)+BN+LeakyReLU -> hid_dis; 5-NN offsets, cosine with the
@@ -257,6 +262,9 @@ int ogmm_overlap_cross_ws(const float* S, int B, int N, const float* o_src, cons
  *   resid  [C][iters][sk_iters] or NULL: every sweep's residual per cloud (NaN: the sweep did not run / was discarded)
  *   sweeps [C / group_size][iters] int32 or NULL: sweeps every E-step ran per call group (the reference's iteration count)
  *   exit_ws: ogmm_gmm_em_exit_workspace_bytes(...) bytes, 256-byte aligned; may be NULL when thresh <= 0 and resid == NULL.
+ *            Its int32 word 1 (byte offset 4) is the call's PROTOCOL-ERROR word: the clouds of a group wait for each other's residuals with bounded
+ *            polls, and a poll that runs into its limit (a lost workgroup) sets it to 1 and NaN-poisons pi / mu.  The host reads it behind the call
+ *            (OGMM_STATUS_EM_EXIT_PROTOCOL in the model's status word), as it reads the fp16 range flag.
  * ogmm_gmm_em_chip_max_group(N, J): the largest group_size the on-chip kernels accept with thresh > 0 (the clouds of a
  * group wait for each other's residuals, so one resident round of workgroups must hold a whole group); 0 when the
  * shape does not run on chip at all.  ogmm_gmm_em_chip_cached(N, J): 1 when the N x J cost matrix stays in LDS
@@ -435,16 +443,12 @@ int ogmm_pos_features(const float* xyz, const int32_t* idx, int C, int N, int k,
 /* ---- T7: backward of ogmm_l2norm_rows (models/gmmreg.py:74): dx = g/n - x (x.g)/n^3, n = max(|x|, 1e-12). */
 int ogmm_l2norm_rows_bwd(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t rows, int D, float* dx, int64_t lddx, void* stream);
 
-/* ---- diagnostics (tools/gemm_v6_check.py; not part of the hot path).  The large-shape GEMM engines have ablation builds selected by
- * `precision` codes 100..104 (gemm_f16x3_v8.hip) and 110..121 (gemm_f16x3_v10.hip) whose workgroups add their duration in shader cycles and in
- * 100 MHz wall ticks to a device counter: host3 = {cycles, ticks, workgroups} since the last call (read and cleared).  The ratio is the shader
- * clock the kernel really ran at -- rocprofv3 pins the clock, so its counters cannot tell. */
-/* (the first LDS-DMA engine, gemm_f16x3_v6.hip, with its ablation codes 60..89 and ogmm_debug_v6_probe is built into the tools-only
- * libogmm_probe.so (its entry takes the same descriptor) and is not part of this library or its ABI) */
-int ogmm_debug_v8_probe(unsigned long long* host3);
+/* ---- diagnostics (tools/edgeconv_time.py; not part of the hot path): OGMM_EDGECONV_PROBE=1 makes the fused EdgeConv kernels add the shader cycles of
+ * their phases to a device counter, read and cleared here.  (The GEMM engines' ablation / clock-probe builds -- `precision` codes 12..40, 60..89,
+ * 100..121 -- their ogmm_debug_v6/v8/v10_probe readers, the retired first LDS-DMA engine and the row-major-planes engine OGMM_PREC_F16X3 are a second
+ * build of the engine sources in the tools-only libogmm_probe.so (entry ogmm_probe_gemm_nt, same descriptor); none of it is in this library or its ABI.) */
 int ogmm_debug_edgeconv_probe(unsigned long long* host8);
 int ogmm_debug_edgeconv_pc_probe(unsigned long long* host8);          /* OGMM_EDGECONV_PROBE=1: shader cycles per phase of the fused EdgeConv kernel */
-int ogmm_debug_v10_probe(unsigned long long* host3);
 
 #ifdef __cplusplus
 }

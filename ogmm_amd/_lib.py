@@ -7,10 +7,11 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 22
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
+STATUS_EDGECONV_PROTOCOL, STATUS_EM_EXIT_PROTOCOL = 2, 4          # bits of the device status word (include/ogmm_hip.h)
 
 
 class GemmDesc(Structure):
@@ -57,7 +58,7 @@ PROTOTYPES = {
     "ogmm_edgeconv_fused": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p] +
                            [c_void_p, c_void_p, c_void_p, c_void_p, c_float] * 3 + [c_void_p, c_int64, c_void_p],
     "ogmm_edgeconv_pc": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p] +
-                        [c_void_p, c_void_p, c_void_p, c_void_p, c_float] * 3 + [c_void_p, c_int64, c_void_p],
+                        [c_void_p, c_void_p, c_void_p, c_void_p, c_float] * 3 + [c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_pos_hidden": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p],
     "ogmm_attention_workspace_bytes": [c_int, c_int, c_int, c_int],
     "ogmm_attention": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_void_p],
@@ -117,10 +118,8 @@ PROTOTYPES = {
     "ogmm_edge_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_pos_features": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_l2norm_rows_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
-    "ogmm_debug_v8_probe": [c_void_p],
     "ogmm_debug_edgeconv_probe": [c_void_p],
     "ogmm_debug_edgeconv_pc_probe": [c_void_p],
-    "ogmm_debug_v10_probe": [c_void_p],
     "ogmm_transpose_pad": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ogmm_pack_frag_t": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                          c_void_p],

@@ -64,7 +64,8 @@ __device__ __forceinline__ void lds_wait_ge(const int* p, int target, int* dead)
     int polls = 0;
     while (lds_load(p) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++polls > (1 << 20) || ((polls & 1023) == 0 && lds_load(dead))) { __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+        // dead[1]: the poll limit (2^20; OGMM_EDGECONV_POLL_LIMIT lowers it for the test of this path)
+        if (++polls > dead[1] || ((polls & 1023) == 0 && lds_load(dead))) { __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -299,7 +300,8 @@ __device__ __forceinline__ void consume_block(const _Float16* slot, const f16x8 
 
 template <bool PROBE, bool PRIO = false>
 __global__ __launch_bounds__(512) void edgeconv_pc_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, int N, int64_t total_pts,
-                                                          int64_t n_tiles, const EdgeW w, float* __restrict__ xcat, int64_t ldx) {
+                                                          int64_t n_tiles, const EdgeW w, float* __restrict__ xcat, int64_t ldx, int32_t* status,
+                                                          int poll_limit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* ring = reinterpret_cast<_Float16*>(smem + OFF_RING);
     _Float16* w2img = reinterpret_cast<_Float16*>(smem + OFF_W2);          // [hi 8 KiB | lo 8 KiB], fragment-major
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(512) void edgeconv_pc_kernel(const float* __restric
 
     // ---- prologue: flags and pools zeroed, layer 2's weight image staged
     for (int i = tid; i < 2 * TP * 512; i += 512) pools[i] = 0;
-    if (tid < 16) flags[tid] = 0;
+    if (tid < 16) flags[tid] = tid == 13 ? poll_limit : 0;
     {
         const int4* __restrict__ sh = reinterpret_cast<const int4*>(w.h2);
         const int4* __restrict__ sl = reinterpret_cast<const int4*>(w.l2);
@@ -473,7 +475,12 @@ __global__ __launch_bounds__(512) void edgeconv_pc_kernel(const float* __restric
             }
         }
     }
-    if (lane == 0 && lds_load(dead)) xcat[0] = __builtin_nanf("");          // a wait ran into its limit: make the result loudly wrong
+    // a wait ran into its limit (a protocol error): reported through the caller's status word (bit OGMM_STATUS_EDGECONV_PROTOCOL; atomically, so that the
+    // report cannot be overwritten as an output element could), and the result is made loudly wrong as well -- NaN into this workgroup's first output row
+    if (lane == 0 && lds_load(dead)) {
+        if (status) atomicOr(status, OGMM_STATUS_EDGECONV_PROTOCOL);
+        xcat[(int64_t)blockIdx.x * TP * ldx] = __builtin_nanf("");
+    }
     if (PROBE && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) if (tot[i]) atomicAdd(&g_pc_probe[i], tot[i]);
@@ -486,9 +493,11 @@ __global__ __launch_bounds__(512) void edgeconv_pc_kernel(const float* __restric
 extern "C" int ogmm_edgeconv_pc(const float* xyz, const int32_t* idx, int C, int N, int k, const float* W1, const float* s1, const float* t1,
                                 const void* h2, const void* l2, const float* s2, const float* t2, float inv2, const void* h3,
                                 const void* l3, const float* s3, const float* t3, float inv3, const void* h4, const void* l4,
-                                const float* s4, const float* t4, float inv4, float* xcat, int64_t ldx, void* stream) {
+                                const float* s4, const float* t4, float inv4, float* xcat, int64_t ldx, int32_t* status, void* stream) {
     OGMM_REQUIRE(xyz && idx && W1 && s1 && t1 && h2 && l2 && s2 && t2 && h3 && l3 && s3 && t3 && h4 && l4 && s4 && t4 && xcat,
                  "ogmm_edgeconv_pc: null pointer");
+    const char* pl = getenv("OGMM_EDGECONV_POLL_LIMIT");          // (read per call: a test lowers it to force the protocol-error path)
+    const int poll_limit = pl && atoi(pl) > 0 ? atoi(pl) : (1 << 20);
     OGMM_REQUIRE(C > 0 && N > 0 && k == KE && ldx >= 512 && ldx % 4 == 0 && reinterpret_cast<uintptr_t>(xcat) % 16 == 0,
                  "ogmm_edgeconv_pc: k must be 20, ldx >= 512 and a multiple of 4 (C=%d N=%d k=%d ldx=%lld)", C, N, k, (long long)ldx);
     const int64_t total = (int64_t)C * N;
@@ -510,10 +519,10 @@ extern "C" int ogmm_edgeconv_pc(const float* xyz, const int32_t* idx, int C, int
     static const bool noprio = [] { const char* e = getenv("OGMM_EDGECONV_PRIO"); return e && e[0] == '1'; }();
     if (noprio) {          // (kept for A/B: consumers at s_setprio 2 -- measured 704 against 675 us: the producers then become the pole)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edgeconv_pc_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((edgeconv_pc_kernel<false, true>), dim3(blocks), dim3(512), LDS_BYTES, ogmm::as_stream(stream), xyz, idx, N, total, n_tiles, w, xcat, ldx);
+        hipLaunchKernelGGL((edgeconv_pc_kernel<false, true>), dim3(blocks), dim3(512), LDS_BYTES, ogmm::as_stream(stream), xyz, idx, N, total, n_tiles, w, xcat, ldx, status, poll_limit);
     } else
-    if (probe) hipLaunchKernelGGL(edgeconv_pc_kernel<true>, dim3(blocks), dim3(512), LDS_BYTES, ogmm::as_stream(stream), xyz, idx, N, total, n_tiles, w, xcat, ldx);
-    else hipLaunchKernelGGL(edgeconv_pc_kernel<false>, dim3(blocks), dim3(512), LDS_BYTES, ogmm::as_stream(stream), xyz, idx, N, total, n_tiles, w, xcat, ldx);
+    if (probe) hipLaunchKernelGGL(edgeconv_pc_kernel<true>, dim3(blocks), dim3(512), LDS_BYTES, ogmm::as_stream(stream), xyz, idx, N, total, n_tiles, w, xcat, ldx, status, poll_limit);
+    else hipLaunchKernelGGL(edgeconv_pc_kernel<false>, dim3(blocks), dim3(512), LDS_BYTES, ogmm::as_stream(stream), xyz, idx, N, total, n_tiles, w, xcat, ldx, status, poll_limit);
     return ogmm::check_launch("ogmm_edgeconv_pc");
 }
 

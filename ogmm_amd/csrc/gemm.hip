@@ -180,7 +180,13 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
                          g.batch_outer * g.batch_inner == 1,
                      "ogmm_gemm_nt: pooling needs pool_out, ReLU, 4 <= pool_k <= 160, M %% pool_k == 0, no batching");
     if (frag) return ogmm::gemm_nt_f16x3_frag(g, s);
+#ifdef OGMM_ABLATIONS
     if (g.precision != OGMM_PREC_F32) return ogmm::gemm_nt_f16x3(g, s);
+#else
+    // the first fp16x3 engine (row-major split planes, gemm_f16x3.hip) is not reachable from any model path: it lives in the tools-only libogmm_probe.so
+    OGMM_REQUIRE(g.precision == OGMM_PREC_F32, "ogmm_gemm_nt: OGMM_PREC_F16X3 (row-major split planes) is served by libogmm_probe.so (ogmm_probe_gemm_nt); "
+                 "the product engines take the fragment-major image (OGMM_PREC_F16X3_FRAG)");
+#endif
     if (g.pool_k > 0) {
         return g.N <= 64 ? launch<5, 1, 1, 2, true>(g, s) : launch<5, 1, 1, 4, true>(g, s);
     }

@@ -457,6 +457,7 @@ static int launch_v10(const ogmm_gemm& g, hipStream_t s) {
 
 }  // namespace ogmm
 
+#ifdef OGMM_ABLATIONS          // tools-only build (libogmm_probe.so): the product library carries neither the ablation instantiations nor this symbol
 // diagnostic (tools/gemm_v6_check.py): read and clear the clock probe {shader cycles, 100 MHz wall ticks, workgroups}
 extern "C" int ogmm_debug_v10_probe(unsigned long long* host3) {
     unsigned long long z[4] = {0, 0, 0, 0};
@@ -464,11 +465,13 @@ extern "C" int ogmm_debug_v10_probe(unsigned long long* host3) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_v10_probe), z, sizeof(z)) != hipSuccess) return 1;
     return 0;
 }
+#endif
 
 namespace ogmm {
 
 int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {
+#ifdef OGMM_ABLATIONS
         case 111: return launch_v10<8>(g, s);                    // no output stores
         case 112: return launch_v10<2048>(g, s);                 // clock probe
         case 113: return launch_v10<2048 + 8>(g, s);             // clock probe, no stores
@@ -480,6 +483,7 @@ int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
         case 119: return launch_v10<2048 + 8 + 1 + 2>(g, s);     //   fragment reads + MFMA (no DMA, no split)
         case 120: return launch_v10<2048, false, false, 2>(g, s);          // clock probe, two-term form
         case 121: return launch_v10<2048 + 8, false, false, 2>(g, s);      //   no stores
+#endif
         default:
             if (g.ovl_rowpart) return g.terms == 1 ? launch_v10<0, false, true, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, true, 2>(g, s) : launch_v10<0, false, true>(g, s);
             if (g.a_scale) return launch_v10<0, true>(g, s);          // (the InstanceNorm-on-A form has no reduced variant: terms is a permission, not an order)

@@ -248,7 +248,9 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
     if (g.pool_k > 0) return g.N <= 64 ? launch_v2<5, 1, 1, 2, true>(g, s) : launch_v2<5, 1, 1, 4, true>(g, s);
     switch (g.precision) {
         case 21: return launch_v2<2, 2, 2, 2, false>(g, s);    // 128 x 128, 4 waves
+#ifdef OGMM_ABLATIONS          // tools-only build (libogmm_probe.so): tile-shape experiment; the ablation codes below reach engines that only carry them in that build
         case 22: return launch_v2<4, 2, 1, 4, false>(g, s);    // 128 x 256, 4 waves of 128 x 64: two independent workgroups per CU
+#endif
         case 18: case 19: case 23: case 24: case 25: case 26: case 27: case 28: case 29:            // large-shape engine and its ablations (tools/gemm_bench.py)
         case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40:
             OGMM_REQUIRE(gemm_f16x3_large_applicable(g), "large-shape engine not applicable"); return gemm_nt_f16x3_v4(g, s);

@@ -318,6 +318,7 @@ static int launch_v4(const ogmm_gemm& g, hipStream_t s) {
 
 int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {          // 26..29: ablations for tools/gemm_bench.py (wrong results by construction)
+#ifdef OGMM_ABLATIONS          // tools-only build (libogmm_probe.so)
         case 26: return launch_v4<7>(g, s);     // MFMA + barrier only
         case 29: return launch_v4<3>(g, s);     // + A global loads / split / LDS writes only
         case 19: return launch_v4<15>(g, s);    // MFMA only, no epilogue stores
@@ -338,10 +339,13 @@ int gemm_nt_f16x3_v4(const ogmm_gemm& g, hipStream_t s) {
         case 24: return launch_v4<32 + 2048 + 4096 + 8192>(g, s);    // + A loads spread over the first two k-steps
         case 25: return launch_v4<32 + 2048 + 4096 + 8192 + 8>(g, s);   // same, no stores
         case 40: return launch_v4<32 + 2048 + 4096 + 8192 + 16384>(g, s);   // same, all tiles store to one 256 x 256 patch of C
+#endif
         case OGMM_PREC_F16_FRAG: return launch_v4<32 + 1024>(g, s);     // single binary16 term
         default: {
+#ifdef OGMM_ABLATIONS
             static const char* env = getenv("OGMM_V4_OLD");
             if (env && env[0] == '1') return launch_v4<32>(g, s);     // previous default (1-step B prefetch, double-buffered A fragments)
+#endif
             // B fragments 3 k-steps ahead (no matrix-pipe wait ever falls behind the A loads in the in-order vmcnt queue), one
             // A-fragment register set (the SIMD's other wave covers the LDS latency), A loads spread over two k-steps: +3 %
             return launch_v4<32 + 2048 + 4096 + 8192>(g, s);

@@ -310,6 +310,7 @@ static int launch_v8(const ogmm_gemm& g, hipStream_t s) {
 
 }  // namespace ogmm
 
+#ifdef OGMM_ABLATIONS          // tools-only build (libogmm_probe.so)
 // diagnostic (tools/gemm_v6_check.py): read and clear the clock probe {shader cycles, 100 MHz wall ticks, workgroups}
 extern "C" int ogmm_debug_v8_probe(unsigned long long* host3) {
     unsigned long long z[4] = {0, 0, 0, 0};
@@ -317,15 +318,18 @@ extern "C" int ogmm_debug_v8_probe(unsigned long long* host3) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_v8_probe), z, sizeof(z)) != hipSuccess) return 1;
     return 0;
 }
+#endif
 
 namespace ogmm {
 
 int gemm_nt_f16x3_v8(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {
+#ifdef OGMM_ABLATIONS
         case 101: return launch_v8<8>(g, s);                    // no output stores
         case 102: return launch_v8<2048>(g, s);                 // clock probe
         case 103: return launch_v8<2048 + 8>(g, s);             // clock probe, no stores
         case 104: return launch_v8<2048 + 8 + 1>(g, s);         //   no DMA after the prologue
+#endif
         default:
             if (g.rd_out) return g.terms == 2 ? launch_v8<0, false, true, 2>(g, s) : launch_v8<0, false, true>(g, s);
             if (g.a_scale) return launch_v8<0, true>(g, s);          // (terms is a permission: the InstanceNorm-on-A form runs all three)

@@ -70,7 +70,7 @@ __device__ __forceinline__ bool em_chip_sweep_end(const EmExit& x, float* red, i
         int stop = 0;
         if (x.on) {
             if (sk + 1 < sk_iters && threadIdx.x == 0)          // (nobody asks about the last sweep)
-                em_st_agent(x.rc + ((int64_t)it * x.sk + sk) * x.C + c, em_exit_publish_value(r));
+                if (c != x.lose_cloud) em_st_agent(x.rc + ((int64_t)it * x.sk + sk) * x.C + c, em_exit_publish_value(r));
             if (sk >= 1) {
                 stop = em_exit_decide_wave(x, c, it, sk - 1) ? 1 : 0;
                 if (stop && threadIdx.x == 0 && c % x.G == 0) {          // the group's first cloud reports the count
@@ -1075,7 +1075,11 @@ extern "C" int ogmm_gmm_em_chip_max_group(int N, int J) {
     int cus = 256, dev_id = 0;
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    return cus;
+    // Half of the CUs, not all of them: the clouds of a group wait for each other, so a group must be able to become completely resident.  With the cap at
+    // the full CU count, two exit-on launches running side by side (two models / streams / processes) could each hold a partial group on the chip and
+    // stall each other until the poll limit; with half, two such launches fit, and larger groups take the launch sequence
+    // (ogmm_gmm_em_multi), which has no cross-workgroup wait at all.
+    return cus / 2;
 }
 
 // resid [C][iters][sk_iters] (may be NULL) receives every Sinkhorn sweep's sum |u - u0| + sum |v - v0| per cloud (lib/utils.py:99-101), NaN for

@@ -26,7 +26,10 @@ struct EmExit {
     int G, n_groups;    // clouds per call group, number of groups (C = G * n_groups)
     int C, iters, sk;
     int* ticket;        // [1]  on-chip kernels: next cloud to hand out
-    int* err;           // [1]  set when a poll ran into its limit (a lost workgroup): the outputs are NaN-poisoned
+    int* err;           // [1]  set when a poll ran into its limit (a lost workgroup): the outputs are NaN-poisoned; word 1 of the exit workspace, which the
+                        //      host reads behind the call (ogmm_amd/ops.py gmm_em: `protocol_error`)
+    int poll_limit;     // polls before a wait gives up (2^24; OGMM_EM_POLL_LIMIT lowers it for the test of this path)
+    int lose_cloud;     // debug knob OGMM_EM_DEBUG_LOSE_CLOUD: this cloud never publishes its residuals, as a lost workgroup would not (-1: off)
     int* gcount;        // [n_groups][iters][sk]  arrivals
     int* decision;      // [n_groups][iters][sk]  0 pending, 1 go on, 2 stop after this sweep
     int* kstop;         // [n_groups][iters]      1-based sweep after which the E-step stopped (0: it did not); the launch sequences' flag
@@ -54,6 +57,7 @@ __device__ __forceinline__ bool em_exit_mean_below(const EmExit& x, int g, int i
 
 // One lane per cloud and sweep: publish this cloud's residual of sweep k (0-based) of E-step `it`.  The last cloud of the group to arrive takes the decision.
 __device__ __forceinline__ void em_exit_publish(const EmExit& x, int c, int it, int k, float r) {
+    if (c == x.lose_cloud) return;
     const int g = c / x.G;
     em_st_agent(x.rc + ((int64_t)it * x.sk + k) * x.C + c, r);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // written through before the arrival is counted
@@ -88,7 +92,7 @@ __device__ __forceinline__ bool em_exit_decide_wave(const EmExit& x, int c, int 
             int polls = 0;
             while (__float_as_uint(r = em_ld_agent(rc + i)) == 0xFFFFFFFFu) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++polls > (1 << 24)) { em_st_agent(x.err, 1); r = 0.0f; break; }
+                if (++polls > x.poll_limit) { em_st_agent(x.err, 1); r = 0.0f; break; }
             }
         }
         s += r;
@@ -102,6 +106,7 @@ __device__ __forceinline__ bool em_exit_decide_wave(const EmExit& x, int c, int 
 // the lanes (lane-strided partials, xor butterfly) -- one lane summing a 256-cloud group with dependent agent-scope loads kept the launch's last
 // workgroup busy for ~0.25 ms per sweep (the launch sequence of a 256-pair batch: 16.5 against 12.9 ms without the exit).
 __device__ __forceinline__ void em_exit_publish_wave(const EmExit& x, int c, int it, int k, float r) {
+    if (c == x.lose_cloud) return;
     const int lane = threadIdx.x & 63, g = c / x.G;
     const int slot = (g * x.iters + it) * x.sk + k;
     int prev = 0;
@@ -132,7 +137,7 @@ __device__ __forceinline__ bool em_exit_wait(const EmExit& x, int c, int it, int
     int d, polls = 0;
     while ((d = em_ld_agent(x.decision + slot)) == 0) {
         __builtin_amdgcn_s_sleep(2);
-        if (++polls > (1 << 26)) { em_st_agent(x.err, 1); return false; }
+        if (++polls > 4 * (int64_t)x.poll_limit) { em_st_agent(x.err, 1); return false; }
     }
     return d == 2;
 }
@@ -162,6 +167,10 @@ static inline int em_exit_setup(EmExit& x, double thresh, int group_size, int C,
     x.n_groups = C / x.G;
     x.C = C; x.iters = iters; x.sk = sk;
     x.sweeps = sweeps; x.resid = resid;
+    const char* pl = getenv("OGMM_EM_POLL_LIMIT");          // (read per call: tests of the timeout path set and clear them)
+    x.poll_limit = pl && atoi(pl) > 0 ? atoi(pl) : (1 << 24);
+    const char* lc = getenv("OGMM_EM_DEBUG_LOSE_CLOUD");
+    x.lose_cloud = lc && lc[0] ? atoi(lc) : -1;
     if (resid) (void)hipMemsetAsync(resid, 0xFF, (size_t)C * iters * sk * sizeof(float), s);          // NaN: sweep not run
     if (sweeps) (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sweeps), sk, (size_t)x.n_groups * iters, s);
     if (!x.on && !resid) return 0;

@@ -243,7 +243,8 @@ class GMMReg(nn.Module):
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self.fold_conv2_overlap = True      # conv2.net.6 and overlap.net.0 (two linear maps in a row) as one 1024 -> 256 layer
         self.fuse_overlap = os.environ.get("OGMM_FUSE_OVERLAP", "1") != "0"            # overlap block's softmax-dots in the similarity GEMM's epilogue where the engine takes it (ops.overlap_fusable)
-        self._overflow = None
+        self._overflow = None          # device int32[1]: the engines' fp16 range flag ...
+        self._status = None            # ... and its neighbour word: protocol errors of kernels with bounded on-chip / cross-workgroup waits (_lib.STATUS_*)
         self._overflow_host = self._overflow_event = None
         self._overflow_pending = False
         self.overflow_policy = "deferred"          # what an fp16 range overflow in an eval forward does: _post_overflow_check
@@ -358,8 +359,8 @@ class GMMReg(nn.Module):
         dev = src.device
         if self.precision not in ("f16x3", "f32", "f16"):
             raise OgmmError("precision must be 'f16x3', 'f32' or 'f16' (reduced: single binary16 term in the large GEMMs)")
-        if dev.type == "cuda" and (self._overflow is None or self._overflow.device != dev):
-            self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        if dev.type == "cuda":
+            self.overflow_flag(dev)
         if self.emd.conv1.weight.device != dev:
             raise OgmmError("GMMReg parameters live on %s but the inputs on %s: call model.to(device) first" % (self.emd.conv1.weight.device, dev))
         if self.training:
@@ -422,7 +423,7 @@ class GMMReg(nn.Module):
         xcat = torch.empty((R, 512), dtype=torch.float32, device=dev)
         emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
         if eng.split and ops.edgeconv_fused_supported(k, emd):
-            ops.edgeconv_fused(xyz, idx, emd, xcat)                    # per-edge tensors stay on chip
+            ops.edgeconv_fused(xyz, idx, emd, xcat, status=self._status)                    # per-edge tensors stay on chip
         else:
             h = ops.edgeconv_first(xyz, idx, L["emd1"], xcat[:, 0:64])
             h = ops.edgeconv_layer(h, L["emd2"], k, xcat[:, 64:128], eng=eng)
@@ -481,7 +482,7 @@ class GMMReg(nn.Module):
             # clouds are separate wkeans_plus calls (models/gmmreg.py:100-101).  capture=True also records every sweep's residual and the
             # number of sweeps every E-step ran: see sinkhorn_exit_margin()
             em = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=self.sinkhorn_thresh, group_size=B,
-                            return_resid=capture, return_sweeps=capture)
+                            return_resid=capture, return_sweeps=capture, status=self._status)
             gamma, pi, mu = em[:3]
             em_done = torch.cuda.Event()
             em_done.record(side)
@@ -526,23 +527,25 @@ class GMMReg(nn.Module):
     #   "sync"                every forward waits for its own flag and raises itself (one host synchronisation per call);
     #   "ignore"              poll fp16_overflowed() yourself.
     def _post_overflow_check(self, dev):
-        if self.precision == "f32" or self._overflow is None or self.overflow_policy == "ignore" or torch.cuda.is_current_stream_capturing():
+        if self._overflow is None or self.overflow_policy == "ignore" or torch.cuda.is_current_stream_capturing():
             return
         if self.overflow_policy == "sync":
             if self.fp16_overflowed():
                 raise OgmmError(self._OVERFLOW_TEXT % "this")
             return
         if self._overflow_host is None:
-            self._overflow_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._overflow_host = torch.zeros(2, dtype=torch.int32).pin_memory()
             self._overflow_event = torch.cuda.Event()
         elif self._overflow_pending and not self._overflow_event.query():
-            self._overflow_event.synchronize()          # (two forwards in flight share one host word: the older one first)
+            self._overflow_event.synchronize()          # (two forwards in flight share one host buffer: the older one first)
         self._raise_pending_overflow()
-        self._overflow_host.copy_(self._overflow, non_blocking=True)
-        self._overflow.zero_()
+        self._overflow_host.copy_(self._flags, non_blocking=True)          # range flag and protocol status word in one copy
+        self._flags.zero_()
         self._overflow_event.record()
         self._overflow_pending = True
 
+    _STATUS_TEXT = ("kernel protocol error in %s forward (status word %d: 2 = EdgeConv producer / consumer hand-over, 4 = E/M early-exit group wait): a bounded "
+                    "wait between waves / workgroups ran into its limit -- the outputs of that forward are NaN-poisoned, not the reference's.")
     _OVERFLOW_TEXT = ("fp16x3 engine: an activation beyond +-65504 was clamped in %s forward -- its results are not the reference's.  "
                       "Run this model with precision='f32' (exact fp32 engine) or rescale the inputs; overflow_policy='ignore' restores polling.")
 
@@ -553,9 +556,10 @@ class GMMReg(nn.Module):
             self._overflow_event.synchronize()
         if self._overflow_event.query():
             self._overflow_pending = False
-            if int(self._overflow_host[0]) != 0:
+            ovf, st = int(self._overflow_host[0]), int(self._overflow_host[1])
+            if ovf or st:
                 self._overflow_host.zero_()
-                raise OgmmError(self._OVERFLOW_TEXT % "an earlier")
+                raise OgmmError(self._STATUS_TEXT % ("an earlier", st) if st else self._OVERFLOW_TEXT % "an earlier")
 
     def sinkhorn_exit_margin(self):
         """After forward(..., capture=True): the smallest batch-mean Sinkhorn residual of the call, per call group (src clouds, tgt clouds) as the
@@ -638,18 +642,21 @@ class GMMReg(nn.Module):
         host round trip per query (the trainer) snapshot it with device ops"""
         dev = torch.device(device) if device is not None else self.emd.conv1.weight.device
         if dev.type == "cuda" and (self._overflow is None or self._overflow.device != dev):
-            self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._flags = torch.zeros(2, dtype=torch.int32, device=dev)          # one buffer: both words travel to the host in one copy
+            self._overflow, self._status = self._flags[0:1], self._flags[1:2]
         return self._overflow
 
     def fp16_overflowed(self):
         """True if any fp16x3 GEMM since the last call clamped an activation beyond +-65504 (synchronises)."""
         if self._overflow is None:
             return False
-        hit = bool(self._overflow.item())
-        self._overflow.zero_()
+        ovf, st = self._flags.tolist()
+        self._flags.zero_()
         if self._overflow_pending:          # a deferred check that has not been looked at yet
             self._overflow_event.synchronize()
             self._overflow_pending = False
-            hit = hit or int(self._overflow_host[0]) != 0
+            ovf, st = ovf or int(self._overflow_host[0]), st or int(self._overflow_host[1])
             self._overflow_host.zero_()
-        return hit
+        if st:
+            raise OgmmError(self._STATUS_TEXT % ("a", st))
+        return bool(ovf)

@@ -345,8 +345,9 @@ def edgeconv_fused_supported(k, layers):
     return 7 <= k <= 32 and all(l.get("split") is not None and l["split"].get("variant") == PREC_F16X3_FRAG for l in layers[1:])
 
 
-def edgeconv_fused(xyz, idx, layers, xcat):
-    """The whole EdgeConv chain in one kernel: layers = [emd1, emd2, emd3, emd4] packed dicts; fills xcat[:, :512]."""
+def edgeconv_fused(xyz, idx, layers, xcat, status=None):
+    """The whole EdgeConv chain in one kernel: layers = [emd1, emd2, emd3, emd4] packed dicts; fills xcat[:, :512].
+    status: device int32[1] (or None) that the producer / consumer kernel ORs STATUS_EDGECONV_PROTOCOL into when one of its bounded waits times out."""
     C, N, k = idx.shape
     args = [_p(_f32(xyz, "xyz")), _p(_i32(idx, "idx")), C, N, k, _p(layers[0]["W"]), _p(layers[0]["scale"]), _p(layers[0]["shift"])]
     for l in layers[1:]:
@@ -356,8 +357,9 @@ def edgeconv_fused(xyz, idx, layers, xcat):
     E = float(C) * N * k
     # k = 20 (the reference's gnn_k): the producer / consumer pipeline (edgeconv_pc.hip, bit-identical); OGMM_EDGECONV_PC=0: the barrier-phased kernel
     fn = "ogmm_edgeconv_pc" if k == 20 and EDGECONV_PC else "ogmm_edgeconv_fused"
+    tail = (_p(status),) if fn == "ogmm_edgeconv_pc" else ()
     _timed_call("edgeconv_fused_kernel", 2.0 * E * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 256), 4.0 * (3 * C * N + E + 512.0 * C * N),
-                fn, *args, _p(xcat), xcat.stride(0), _stream())
+                fn, *args, _p(xcat), xcat.stride(0), *tail, _stream())
     return xcat
 
 
@@ -577,11 +579,13 @@ def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, two_pass=False):
 
 # ---------------------------------------------------------------------------------------------- GMM head
 def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=1e-2, group_size=None, engine=None, return_resid=False,
-           return_sweeps=False):
+           return_sweeps=False, status=None):
     """-> gamma [C,N,J], pi [C,J], mu [C,J,3] (, resid [C,iters,sk_iters]) (, sweeps int32 [C/group_size, iters])   (lib/utils.py:269-288).
     thresh / group_size: the reference's Sinkhorn early exit (lib/utils.py:99-102): an E-step's sweeps end after the first sweep whose residual,
     averaged over the `group_size` clouds of one reference call (None: all C clouds are one call), is below thresh; thresh <= 0 runs every sweep.
-    resid: every sweep's sum|u - u0| + sum|v - v0| per cloud, NaN for sweeps that did not run; sweeps: the sweeps every E-step ran per call group."""
+    resid: every sweep's sum|u - u0| + sum|v - v0| per cloud, NaN for sweeps that did not run; sweeps: the sweeps every E-step ran per call group.
+    status: device int32[1] (or None): with the exit on, the call's protocol-error word (a bounded wait between the clouds of a group timed out: pi / mu
+    are NaN-poisoned) is ORed into it as STATUS_EM_EXIT_PROTOCOL behind the kernels -- two tiny device ops, no host synchronisation."""
     C, N, _ = xyz.shape
     J = ids0.shape[1]
     assert o.is_contiguous() and o.shape == (C, N) and ids0.is_contiguous()
@@ -612,6 +616,9 @@ def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=1e
         ws.record_stream(torch.cuda.current_stream())
     else:
         _lib.call("ogmm_gmm_em", *head, _stream())
+    if status is not None and exit_on and xws is not None:
+        err = xws[4:8].view(torch.int32)          # word 1 of the exit workspace (include/ogmm_hip.h)
+        torch.bitwise_or(status, err * _lib.STATUS_EM_EXIT_PROTOCOL, out=status)
     out = (gamma, pi, mu)
     if return_resid:
         out += (resid,)

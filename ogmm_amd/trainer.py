@@ -109,9 +109,14 @@ class Trainer:
         return self.model(src, tgt, fps_starts=fps_starts)
 
     def _drop_grads(self):
-        """a skipped step's gradients are not used; with a recorded step they are the graph's static tensors and stay (the next replay overwrites them)"""
+        """a skipped step's gradients are not used.  Eager: dropped.  Recorded step: they are the graph's static tensors and must stay allocated (the next
+        replay overwrites them) -- they are zeroed instead, so that nobody inspecting p.grad after a skipped step sees the clamped values"""
         if self._g is None:
             self.optimizer.zero_grad(set_to_none=True)
+        else:
+            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+            if grads:
+                torch._foreach_zero_(grads)
 
     def local_loss(self, out, src, tgt, transform_gt, src_overlap, tgt_overlap):
         loss, parts = losses.training_loss(out, src, tgt, transform_gt, src_overlap, tgt_overlap, self.alpha, self.top_k)
@@ -165,7 +170,10 @@ class Trainer:
                 st.copy_(t, non_blocking=True)
         g["scale"].fill_(self.loss_scale)
         g["graph"].replay()
-        return g["res"]
+        # what the caller gets must not alias the graph's static tensors (the next replay overwrites them: a loop that collects info["loss"] per step
+        # would read the LAST step's value for every entry); a handful of small clones, one tiny launch each
+        out, loss, parts, fwd_flag, flag = g["res"]
+        return tuple(o.clone() for o in out), loss.clone(), {k: v.clone() for k, v in parts.items()}, fwd_flag, flag
 
     def step(self, src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts=None):
         """train.py:53-74 for this rank's shard.  Returns loss (local share), the four parts, mean R / t errors."""

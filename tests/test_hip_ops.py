@@ -123,7 +123,7 @@ def _gemm_ref(A, B):
     return (A.double() @ B.double().t())
 
 
-ENGINES = ["f32", "f16x3", "f16x3_frag"]
+ENGINES = ["f32", "f16x3_frag"]          # (the row-major-planes engine "f16x3" is no model path: it moved to the tools-only libogmm_probe.so)
 
 
 def _split(ops, B, engine):
@@ -173,8 +173,10 @@ def test_gemm_f16x3_accuracy_is_fp32_class_and_flags_overflow(ops):
     assert e16 < 3 * e32 + 1e-6
     assert int(flag.item()) == 0
     A[3, 5] = 1e5
-    ops.gemm_nt(dev(A), K, K, None, K, M, N, C=o16, ldc=N, split=ops.split_f16(dev(B)), overflow=flag)
+    ops.gemm_nt(dev(A), K, K, None, K, M, N, C=o16, ldc=N, split=ops.split_f16(dev(B), frag=True), overflow=flag)
     assert int(flag.item()) == 1
+    with pytest.raises(Exception, match="libogmm_probe"):          # row-major split planes: not a product engine any more
+        ops.gemm_nt(dev(A), K, K, None, K, M, N, C=o16, ldc=N, split=ops.split_f16(dev(B)), overflow=flag)
 
 
 @pytest.mark.parametrize("engine", ENGINES)
@@ -681,6 +683,57 @@ def test_gmm_em_early_exit_matches_the_reference_semantics(ops, monkeypatch, C, 
     if C // G > 1 and not bool((want[0] == want[1:]).all()):
         one = ops.gmm_em(dev(xyz), dev(o), ids, engine=engine, thresh=1e-2, group_size=None, return_sweeps=True)[3].cpu()
         assert one.shape == (1, 10)
+
+
+@pytest.mark.parametrize("N,J,resident,what", [(1024, 16, None, "on-chip, J = 16"), (500, 24, None, "on-chip, generic J"), (2048, 64, "1", "resident kernel")])
+def test_gmm_em_exit_protocol_timeout_is_reported_not_hung(ops, monkeypatch, N, J, resident, what):
+    """The clouds of a call group wait for each other's residuals with BOUNDED polls.  Debug knobs force the failure the bound exists for: cloud 1 never
+    publishes (OGMM_EM_DEBUG_LOSE_CLOUD: what a lost workgroup looks like to its group) and the poll limit is lowered (OGMM_EM_POLL_LIMIT) so that the test
+    does not take the production limit's second.  The kernels must come back, pi / mu must be NaN-poisoned, and the status word handed to the call
+    must carry STATUS_EM_EXIT_PROTOCOL; with the knobs gone the same call is clean again."""
+    from ogmm_amd import _lib
+    if resident is not None:
+        monkeypatch.setenv("OGMM_EM_RESIDENT", resident)
+    C = 4
+    xyz = dev(clouds(C, N, seed=7) * 0.03)          # scaled down: the exit is live (decisions are being taken)
+    o = dev(torch.sigmoid(torch.randn(C, N)))
+    ids = ops.fps(xyz, J, None)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("OGMM_EM_DEBUG_LOSE_CLOUD", "1")
+    monkeypatch.setenv("OGMM_EM_POLL_LIMIT", "2000")
+    _, pi, mu = ops.gmm_em(xyz, o, ids, thresh=1e-2, group_size=C, status=status)[:3]
+    torch.cuda.synchronize()
+    assert int(status.item()) & _lib.STATUS_EM_EXIT_PROTOCOL, what
+    assert bool(torch.isnan(pi).any()) and bool(torch.isnan(mu).any()), what
+    monkeypatch.delenv("OGMM_EM_DEBUG_LOSE_CLOUD")
+    monkeypatch.delenv("OGMM_EM_POLL_LIMIT")
+    status.zero_()
+    _, pi, mu = ops.gmm_em(xyz, o, ids, thresh=1e-2, group_size=C, status=status)[:3]
+    assert int(status.item()) == 0 and not bool(torch.isnan(pi).any()) and not bool(torch.isnan(mu).any())
+
+
+def test_edgeconv_pipeline_protocol_timeout_is_reported_and_the_model_raises(ops, monkeypatch):
+    """The producer / consumer EdgeConv kernel hands blocks over through LDS sequence counters with bounded waits.  OGMM_EDGECONV_POLL_LIMIT=1 makes every
+    ordinary wait "time out": the kernel must come back, OR STATUS_EDGECONV_PROTOCOL into the status word (not rely on a poisoned output element that
+    another workgroup's store could overwrite), and a model forward must raise instead of returning results built on it."""
+    from argparse import Namespace
+    from ogmm_amd import _lib, synth
+    from ogmm_amd.gmmreg import GMMReg
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    model = GMMReg(512, 16, cfg)
+    synth.fill_state_dict(model.state_dict())
+    model = model.cuda().eval()
+    model.overflow_policy = "sync"
+    src, tgt, _, _ = synth.make_batch(0, 2, 512, "partial")
+    starts = synth.fps_starts_for(0, 2, 512)
+    with torch.no_grad():
+        model(src.cuda(), tgt.cuda(), fps_starts=starts)          # clean
+        monkeypatch.setenv("OGMM_EDGECONV_POLL_LIMIT", "1")
+        with pytest.raises(_lib.OgmmError, match="protocol error"):
+            model(src.cuda(), tgt.cuda(), fps_starts=starts)
+        monkeypatch.delenv("OGMM_EDGECONV_POLL_LIMIT")
+        out = model(src.cuda(), tgt.cuda(), fps_starts=starts)          # and clean again: the status word was consumed
+    assert bool(torch.isfinite(out[0]).all())
 
 
 @pytest.mark.parametrize("C,N,J,D", [(3, 2048, 64, 512), (2, 717, 40, 512), (2, 300, 17, 96), (1, 1025, 64, 260)])

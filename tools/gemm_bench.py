@@ -6,6 +6,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ogmm_amd import ops
+import probe          # tools/probe.py: the ablation codes live in libogmm_probe.so
+probe.install()
 
 variants = [int(v) for v in sys.argv[1:]] or [0, 1]
 M = 131072

@@ -12,37 +12,13 @@ torch.manual_seed(0)
 dev = "cuda"
 
 
-_PROBE = None
-
-
-def probe_lib():
-    """libogmm_probe.so: the retired v6 engine and its ablation builds (codes 60..89), outside the product library"""
-    global _PROBE
-    if _PROBE is None:
-        import ctypes
-        from ogmm_amd import _lib
-        _lib.load()
-        _PROBE = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libogmm_probe.so"))
-    return _PROBE
+import probe          # tools/probe.py: every GEMM descriptor of this tool goes to libogmm_probe.so (the engines' build WITH ablation / clock-probe codes)
+probe.install()
 
 
 def run(v, A, k1, W, m, n, out, A2=None, k2=0, split=None, **kw):
     split = dict(split); split["variant"] = v
-    call = lambda: ops.gemm_nt(A, A.stride(0), k1, W, k1 + k2, m, n, C=out, ldc=out.stride(0), A2=A2, lda2=(A2.stride(0) if A2 is not None else 0), K2=k2, split=split, **kw)  # noqa: E731
-    if not 60 <= v < 90:
-        return call()
-    real = ops._lib.call          # the descriptor ops.gemm_nt builds goes to the probe library's entry instead of ogmm_gemm_nt
-
-    def routed(name, *a):
-        if name != "ogmm_gemm_nt":
-            return real(name, *a)
-        if probe_lib().ogmm_probe_gemm_v6(*a) != 0:
-            raise RuntimeError("ogmm_probe_gemm_v6 failed")
-    ops._lib.call = routed
-    try:
-        call()
-    finally:
-        ops._lib.call = real
+    ops.gemm_nt(A, A.stride(0), k1, W, k1 + k2, m, n, C=out, ldc=out.stride(0), A2=A2, lda2=(A2.stride(0) if A2 is not None else 0), K2=k2, split=split, **kw)
 
 
 if not time_only:
@@ -153,7 +129,7 @@ if "--clock" in sys.argv:          # in-kernel clock probes (variants 80..86): t
     for rnd in range(2):
         for v in variants:
             for _ in range(3): run(v, A, k1, W, m, n, out, split=sp)
-            probe = L.ogmm_debug_v10_probe if v >= 110 else (L.ogmm_debug_v8_probe if v >= 100 else probe_lib().ogmm_debug_v6_probe)
+            probe = lambda b_, v=v: __import__('probe').clock_probe(v, b_)  # noqa: E731
             torch.cuda.synchronize(); probe(buf)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
