@@ -126,8 +126,11 @@ __device__ __forceinline__ void mark_le(unsigned& m, float d, float thr) {
     asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d), "v"(thr) : "vcc");
 }
 
+// rank-k ties of this workgroup's rows, resolved in place (defined behind block_introselect)
+__device__ void resolve_ties_in_block(const float4* pts, int N, int k, int q0, int32_t* idx_cloud, void* scratch, bool have_lists);
+
 template <int KL>
-__global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ xyz, int N, int k, int32_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ xyz, int N, int k, int32_t* __restrict__ idx, int fold_ties) {
     static_assert(OGMM_KNN_CHUNK == 32, "the chunk is one 32-bit mask");
     extern __shared__ __attribute__((aligned(16))) float4 pts[];   // [N], then the candidate lists [2 (KL-1)][256] int16
     short* __restrict__ buf = reinterpret_cast<short*>(pts + N) + threadIdx.x;          // entry i of this thread at buf[i * 256]
@@ -138,8 +141,10 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ xyz
         pts[j] = make_float4(x, y, z, sqnorm3(x, y, z));
     }
     __syncthreads();
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= N) return;
+    const int q_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q_raw >= N && !fold_ties) return;
+    const bool live = q_raw < N;          // (with the tie resolution folded in, every thread stays for the workgroup barriers behind the scans)
+    const int q = live ? q_raw : N - 1;
     const float4 pq = pts[q];
     constexpr int CHK = 32;
     // ---- scan A: the k+1 smallest distances
@@ -246,9 +251,30 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ xyz
         }
     }
     int32_t* out = idx + ((int64_t)c * N + q) * k;
+    if (live) {
 #pragma unroll
-    for (int p = 0; p < KL - 1; ++p)
-        if (p < k) out[p] = (p == 0 && boundary_tie) ? ~ik[0] : ik[p];
+        for (int p = 0; p < KL - 1; ++p)
+            if (p < k) out[p] = (p == 0 && boundary_tie) ? ~ik[0] : ik[p];
+    }
+    if (!fold_ties) return;
+    // ---- rows with an exact tie at rank k (~6e-5 of them): torch.topk's own selection, by this workgroup, in the LDS the candidate lists no longer need
+    // (a separate launch for them sat on the forward's critical path in front of the EdgeConv kernel: 47 us + a launch gap for eight rows)
+    if (!__syncthreads_or(live && boundary_tie)) return;
+    __shared__ int tie_rows[256];
+    __shared__ int n_tie;
+    if (threadIdx.x == 0) n_tie = 0;
+    __syncthreads();
+    if (live && boundary_tie) tie_rows[atomicAdd(&n_tie, 1)] = q;
+    __syncthreads();
+    // (ascending row order: the order the separate kernel processes them in is irrelevant -- rows are independent -- but keep it deterministic)
+    const int nt = n_tie;
+    int prev = -1;
+    for (int f = 0; f < nt; ++f) {
+        int row = 0x7fffffff;
+        for (int g = 0; g < nt; ++g) { const int r = tie_rows[g]; if (r > prev && r < row) row = r; }          // the next flagged row (same in every thread)
+        prev = row;
+        resolve_ties_in_block(pts, N, k, row, idx + (int64_t)c * N * k, reinterpret_cast<void*>(pts + N), fold_ties == 2);
+    }
 }
 
 // ---- std::nth_element's partition, by the whole workgroup, with the element moves of the sequential loop
@@ -337,6 +363,40 @@ __device__ void block_introselect(ogmm_select::Cand* q, int nth, int n, int* Lpo
     if (tid == 0) ogmm_select::introselect_range(q, nth, first, last, depth);
     __syncthreads();
     (void)ctl;
+}
+
+// One flagged row, by the whole workgroup, from the cloud already in LDS (knn2_kernel's tail): the row's N candidates in index order, torch.topk's
+// selection (torch_topk_select.h), the kept set written in (distance, index) order.  scratch: N Cand (+ 2 N ints when have_lists).
+__device__ void resolve_ties_in_block(const float4* pts, int N, int k, int q, int32_t* idx_cloud, void* scratch, bool have_lists) {
+    __shared__ int wave_tot_f[4];
+    ogmm_select::Cand* cand = reinterpret_cast<ogmm_select::Cand*>(scratch);
+    int* Lpos = reinterpret_cast<int*>(cand + N);
+    int* Rpos = Lpos + N;
+    const int tid = threadIdx.x;
+    const float4 pq = pts[q];
+    for (int j = tid; j < N; j += 256) {
+        cand[j].v = knn_dist(pq, pts[j]);
+        cand[j].i = j;
+    }
+    __syncthreads();
+    if ((long long)k * 64 <= N) {              // torch's heap-select branch: one thread
+        if (tid == 0) ogmm_select::heap_select(cand, k, N);
+    } else if (have_lists) {
+        block_introselect(cand, k - 1, N, Lpos, Rpos, wave_tot_f, nullptr);
+    } else {
+        if (tid == 0) ogmm_select::introselect(cand, k - 1, N);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int a = 1; a < k; ++a) {       // order the kept set by (distance, index)
+            const ogmm_select::Cand v = cand[a];
+            int b = a;
+            while (b > 0 && (v.v < cand[b - 1].v || (v.v == cand[b - 1].v && v.i < cand[b - 1].i))) { cand[b] = cand[b - 1]; --b; }
+            cand[b] = v;
+        }
+        for (int a = 0; a < k; ++a) idx_cloud[(int64_t)q * k + a] = cand[a].i;
+    }
+    __syncthreads();
 }
 
 // Rows marked by knn_kernel: rebuild the row's N candidates in index order and keep what torch.topk keeps
@@ -510,9 +570,20 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     const size_t lds2 = lds + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
     static const int two_scans = [] { const char* e = getenv("OGMM_KNN_TWO_SCANS"); return e ? atoi(e) : 1; }();
     // (for k <= 8 the single scan stays: its ladder is short, 85 against 88 us at N = 1024, k = 5; k = 20: 175 -> 140 us)
+    // tie resolution folded into knn2_kernel's tail when its scratch (N candidates of 8 B, + 2 N position ints on the nth_element branch) fits into the
+    // LDS of the candidate lists, which are dead by then; 0 = separate launch, 1 = folded (heap / serial branch), 2 = folded with position lists
+    static const int fold_env = [] { const char* e = getenv("OGMM_KNN_FOLD_TIES"); return e ? atoi(e) : 1; }();
+    int fold = 0;
+    if (two_scans && k > 8 && lds2 <= 64 * 1024 && fold_env) {
+        const size_t lists_bytes = lds2 - lds;
+        const bool heap = (long long)k * 64 <= N;
+        if (!heap && (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)) <= lists_bytes) fold = 2;
+        else if (heap && (size_t)N * sizeof(ogmm_select::Cand) <= lists_bytes) fold = 1;
+    }
     if (two_scans && k > 8 && lds2 <= 64 * 1024) {
-        if (k <= 20) hipLaunchKernelGGL(knn2_kernel<21>, grid, dim3(256), lds2, s, xyz, N, k, idx);
-        else hipLaunchKernelGGL(knn2_kernel<33>, grid, dim3(256), lds2, s, xyz, N, k, idx);
+        if (k <= 20) hipLaunchKernelGGL(knn2_kernel<21>, grid, dim3(256), lds2, s, xyz, N, k, idx, fold);
+        else hipLaunchKernelGGL(knn2_kernel<33>, grid, dim3(256), lds2, s, xyz, N, k, idx, fold);
+        if (fold) return ogmm::check_launch("ogmm_knn");
     } else if (k <= 8) hipLaunchKernelGGL(knn_kernel<9>, grid, dim3(256), lds, s, xyz, N, k, idx);
     else if (k <= 20) hipLaunchKernelGGL(knn_kernel<21>, grid, dim3(256), lds, s, xyz, N, k, idx);
     else hipLaunchKernelGGL(knn_kernel<33>, grid, dim3(256), lds, s, xyz, N, k, idx);
