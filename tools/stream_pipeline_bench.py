@@ -42,3 +42,25 @@ for S, shared in ((1, True), (2, True), (2, False), (3, True), (1, True), (2, Tr
             best = max(best, B * steps / (time.perf_counter() - t0))
         same = all(torch.equal(a, b) for a, b in zip(out, ref))
     print("streams %d (%s): %.0f pairs/s  (%.3f ms per forward of %d pairs); outputs identical to the warm-up's: %s" % (S, "one model" if shared else "a model per stream", best, 1e3 * B / best, B, same), flush=True)
+
+# ---- the same question without the host in the way: every forward a HIP-graph replay (GMMReg.capture_graph: one launch per forward), replayed round-robin
+# on S streams from S separately captured graphs (own static buffers)
+if "--graphs" in sys.argv:
+    for S in (1, 2, 1, 2):
+        models = [make() for _ in range(S)]
+        streams = [torch.cuda.Stream(dev) for _ in range(S)]
+        runs = []
+        for m, st in zip(models, streams):
+            with torch.cuda.stream(st):
+                runs.append(m.capture_graph(B, N))
+        torch.cuda.synchronize()
+        sdev = starts.to(dev)
+        best = 0.0
+        for rep in range(3):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                with torch.cuda.stream(streams[i % S]):
+                    out = runs[i % S](src, tgt, sdev)
+            torch.cuda.synchronize()
+            best = max(best, B * steps / (time.perf_counter() - t0))
+        print("graph replays on %d stream(s): %.0f pairs/s (%.3f ms per forward)" % (S, best, 1e3 * B / best), flush=True)
