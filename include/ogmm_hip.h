@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 22
+#define OGMM_ABI_VERSION 23
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -144,6 +144,12 @@ typedef struct ogmm_gemm {
      * by the weight's rounding, 2^-12 relative per product).  Which layers of the path tolerate it -- R, t within 1e-5 of the reference over the
      * parity distribution -- is measured, not assumed: tools/term_budget.py (CPU oracle with the same rounding) and DESIGN.md section 4. */
     int32_t terms;
+    /* Normalisation-backward fusion (training; round 4): the GEMM computes dh = dY W (the gradient w.r.t. the ACTIVATION a = act(x * nb_scale + nb_shift) of a
+     * normalised map x) and its epilogue turns it into dz = dh * act'(x * nb_scale + nb_shift), stores dz and accumulates the normalisation backward's two
+     * column sums per group -- col_stats[g][c] = {sum dz, sum dz * xhat}, xhat = (x - nb_mean) * nb_rstd -- so that the separate reduction pass over (x, dh)
+     * disappears; ogmm_norm_bwd_apply(x, dy = dz, act = NONE, sums = col_stats) finishes.  x = Res / ldr (same shape as C; no residual is added in this mode),
+     * nb_* are [groups][N] float, group = row / group_rows (group_rows %% 256 == 0), nb_act in {RELU, LEAKY02}.  LDS-DMA engine (N >= 512, whole tiles) only. */
+    const float* nb_mean; const float* nb_rstd; const float* nb_scale; const float* nb_shift; int32_t nb_act;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
@@ -154,6 +160,7 @@ int ogmm_gemm_overlap_fusable(int B, int N, int D);
 int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2);
 /* 1 if ogmm_gemm_nt takes gathered A rows (a_gather_ids) for an M x N layer with K input channels over `rows` source rows, else 0 */
 int ogmm_gemm_gather_fusable(int M, int N, int K, int64_t rows);
+int ogmm_gemm_normbwd_fusable(int M, int N, int K, int group_rows);          /* the normalisation-backward fusion (ogmm_gemm.nb_*): 1 / 0 */
 /* second half of the fused overlap block: merges the (1, sum, dot) triples the similarity GEMM left (models/gmmreg.py:79-80):
  * wo_src[(b N + i) ldo] = softmax(S_b, dim = 1)[i] . o_tgt, wo_tgt[(b N + j) ldo] = softmax(S_b^T, dim = 1)[j] . o_src */
 int ogmm_overlap_finalize(const float* rowpart, const float* colpart, int B, int N, float* wo_src, float* wo_tgt, int64_t ldo, void* stream);

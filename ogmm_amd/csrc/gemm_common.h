@@ -341,12 +341,50 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
 // column and statistic per tile (per wave it would be 4096 atomics per tile: measured +10 % on the 1024-wide layers that feed a normalisation).
 // RES_AHEAD (a caller with ~128 registers to spare: the 512-register engine): all NB * 16 residual values of the slab are requested before the first
 // one is used, so that their latency is exposed once per slab instead of once per column block.
-template <int NB, bool RES_AHEAD = false>
+// NBS (its own instantiation of the calling kernel: an option inside the shared body cost every launch 10 % in round 3): the normalisation-backward fusion of
+// struct ogmm_gemm.nb_* -- the value becomes dz = y * act'(x * nb_scale + nb_shift) with x read like a residual (Res / ldr), dz is stored, and the column
+// statistics are {sum dz, sum dz * xhat} instead of {sum y, sum y^2}.
+template <int NB, bool RES_AHEAD = false, bool NBS = false>
 __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x16 (&acc)[NB], int row0, int col0, float alpha, float* stat_lds, int stat_slot = -1) {
     const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5, wave = stat_slot >= 0 ? stat_slot : (int)(threadIdx.x >> 6);
     float* __restrict__ Cm = g.C;
     const float* __restrict__ Rm = g.Res;
     const bool stats = g.col_stats != nullptr;
+    if constexpr (NBS) {
+        const int64_t gb = (int64_t)(row0 / g.group_rows) * g.N;          // the 32 rows of a block lie in one group (group_rows % 256 == 0)
+        float xa[NB][16];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {          // every x value of the slab requested before the first one is used
+            const float* __restrict__ rp = Rm + (int64_t)(row0 + 4 * lh) * g.ldr + col0 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xa[j][r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = col0 + j * 32 + lr;
+            const float s1 = (g.scale ? g.scale[col] : 1.0f) * alpha, t1 = g.shift ? g.shift[col] : 0.0f;
+            const float nsc = g.nb_scale[gb + col], nsh = g.nb_shift[gb + col], nm = g.nb_mean[gb + col], nr = g.nb_rstd[gb + col];
+            float* __restrict__ cp = Cm + (int64_t)(row0 + 4 * lh) * g.ldc + col;
+            float sum1 = 0.0f, sum2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float y = fmaf(acc[j][r], s1, t1);
+                const float x = xa[j][r];
+                const float z = fmaf(x, nsc, nsh);
+                const float dz = g.nb_act == OGMM_ACT_LEAKY02 ? (z > 0.0f ? y : 0.2f * y) : (z > 0.0f ? y : 0.0f);
+                cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = dz;
+                sum1 += dz;
+                sum2 = fmaf(dz, (x - nm) * nr, sum2);
+            }
+            sum1 += __shfl_xor(sum1, 32, 64);
+            sum2 += __shfl_xor(sum2, 32, 64);
+            if (lh == 0) {
+                stat_lds[(wave * NB * 32 + j * 32 + lr) * 2] = sum1;
+                stat_lds[(wave * NB * 32 + j * 32 + lr) * 2 + 1] = sum2;
+            }
+        }
+        return;
+    }
     auto run = [&](auto kind_c) {
         constexpr int KIND = decltype(kind_c)::value;
         float rra[RES_AHEAD ? NB : 1][16];

@@ -40,7 +40,7 @@ __device__ unsigned long long g_v10_probe[4];
 //   1  hi*hi: BOTH operands rounded to binary16 (11 significand bits); no lo term is formed at all.  Four matrix instructions per group: the raw
 //      activation fragments are read in gap 3 of a half step's first group, converted (v_cvt_pk_f16_f32 only) in gap 3 of its second and third.
 //      With a third of the matrix work the loop is bound by its operand DMA (48 KiB per step and CU).
-template <int ABL, bool AFF, bool OVL, int TERMS = 3>
+template <int ABL, bool AFF, bool OVL, int TERMS = 3, bool NBS = false>
 __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
     static_assert(TERMS == 3 || ((TERMS == 2 || TERMS == 1) && !AFF), "TERMS < 3 has no InstanceNorm-on-A form (its transform pieces need the gaps of 12 MFMAs)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     const bool inside = m0 + BM <= m_end && n0 + BN <= g.N && !g.row_affine;
     if (inside) {
         float* stat_lds = reinterpret_cast<float*>(smem10);          // [8 row blocks][256 columns][2]: the rings are dead (barrier above)
-        gemm_epilogue_rowblock<NT, true>(gz, acc0, m0 + wave * 64, n0, g.alpha, stat_lds, wave * 2);
-        gemm_epilogue_rowblock<NT, true>(gz, acc1, m0 + wave * 64 + 32, n0, g.alpha, stat_lds, wave * 2 + 1);
+        gemm_epilogue_rowblock<NT, true, NBS>(gz, acc0, m0 + wave * 64, n0, g.alpha, stat_lds, wave * 2);
+        gemm_epilogue_rowblock<NT, true, NBS>(gz, acc1, m0 + wave * 64 + 32, n0, g.alpha, stat_lds, wave * 2 + 1);
         if (g.col_stats) {
             __syncthreads();
             // thread = column: add the eight row blocks' partial sums (fp64), one atomic per column and statistic per tile
@@ -437,21 +437,24 @@ bool gemm_f16x3_v10_applicable(const ogmm_gemm& g) {
     const bool gather_ok = !g.a_gather_ids || (g.K2 == 0 && !g.a_scale && g.batch_outer * g.batch_inner == 1 && g.a_gather_S > 0 && g.a_gather_N > 0 &&
                                                (int64_t)g.a_gather_rows * g.lda * 4 < (1ll << 32));
     const bool ovl_ok = !g.ovl_rowpart || (whole_tiles && g.ovl_colpart && g.ovl_orow && g.ovl_ocol && g.ovl_ld >= 1 && !g.a_scale && !g.col_stats && !g.Res && g.batch_inner == 1);
-    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok &&
+    const bool nb_ok = !g.nb_mean || (whole_tiles && g.nb_rstd && g.nb_scale && g.nb_shift && g.col_stats && g.Res && g.C && !g.a_scale && !g.ovl_rowpart && !g.a_gather_ids &&
+                                      g.group_rows > 0 && g.group_rows % BM == 0 && g.batch_outer * g.batch_inner == 1 && g.N >= 512 &&
+                                      (g.nb_act == OGMM_ACT_RELU || g.nb_act == OGMM_ACT_LEAKY02));
+    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok && nb_ok &&
            (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 
-template <int ABL, bool AFF = false, bool OVL = false, int TERMS = 3>
+template <int ABL, bool AFF = false, bool OVL = false, int TERMS = 3, bool NBS = false>
 static int launch_v10(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static ogmm::PerDeviceOnce attr_once;          // per template instance and device
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
     else
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
     return check_launch("ogmm_gemm_nt(f16x3 v10)");
 }
 
@@ -486,6 +489,7 @@ int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
 #endif
         default:
             if (g.ovl_rowpart) return g.terms == 1 ? launch_v10<0, false, true, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, true, 2>(g, s) : launch_v10<0, false, true>(g, s);
+            if (g.nb_mean) return launch_v10<0, false, false, 3, true>(g, s);          // normalisation-backward fusion (training): its own instantiation
             if (g.a_scale) return launch_v10<0, true>(g, s);          // (the InstanceNorm-on-A form has no reduced variant: terms is a permission, not an order)
             return g.terms == 1 ? launch_v10<0, false, false, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, false, 2>(g, s) : launch_v10<0>(g, s);
     }

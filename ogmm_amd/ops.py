@@ -14,6 +14,7 @@ from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16_FRAG, P
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_flops)
 GEMM_TIMELINE = None
+NORM_BWD_FUSED = os.environ.get("OGMM_NORM_BWD_FUSED", "1") != "0"          # training: the normalisation backward's reduction in the dh GEMM's epilogue (A/B switch)
 FUSE_GATHER = os.environ.get("OGMM_FUSE_GATHER", "1") != "0"      # anchor rows gathered by the consuming GEMM's operand DMA (conv1x1_gathered)
 EDGECONV_PC = os.environ.get("OGMM_EDGECONV_PC", "1") != "0"      # the EdgeConv chain as a producer / consumer pipeline (k = 20)
 FUSE_HEAD = os.environ.get("OGMM_FUSE_HEAD", "1") != "0"      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
@@ -210,7 +211,7 @@ def split_f16_training(W, cout, **kw):
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
             pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0,
-            overlap=None, row_rscale=None, head=None, a_gather=None, single_term=False, terms=0):
+            overlap=None, row_rscale=None, head=None, a_gather=None, single_term=False, terms=0, norm_bwd=None):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -250,6 +251,12 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
             d.col_stats_slot_mask, d.col_stats_slot_stride = col_stats.shape[0] - 1, col_stats.stride(0)
     if a_affine is not None:
         d.a_scale, d.a_shift, d.a_relu = a_affine[0].data_ptr(), a_affine[1].data_ptr(), 1 if a_affine[2] else 0
+    if norm_bwd is not None:          # (x, mean, rstd, scale, shift, act): struct ogmm_gemm.nb_* -- x travels as Res, the sums come out of col_stats
+        xnb = norm_bwd[0]
+        assert res is None and col_stats is not None and xnb.stride(1) == 1 and tuple(xnb.shape) == (M, N)
+        d.Res, d.ldr = xnb.data_ptr(), xnb.stride(0)
+        d.nb_mean, d.nb_rstd, d.nb_scale, d.nb_shift, d.nb_act = (norm_bwd[1].data_ptr(), norm_bwd[2].data_ptr(), norm_bwd[3].data_ptr(),
+                                                                 norm_bwd[4].data_ptr(), norm_bwd[5])
     if overlap is not None:          # (o_row, o_col, ld, rowpart, colpart): the fused overlap block, S is not stored (struct ogmm_gemm)
         d.ovl_orow, d.ovl_ocol, d.ovl_ld = overlap[0].data_ptr(), overlap[1].data_ptr(), overlap[2]
         d.ovl_rowpart, d.ovl_colpart = overlap[3].data_ptr(), overlap[4].data_ptr()
@@ -300,7 +307,7 @@ def instnorm_finalize(col_stats, rows, eps=1e-5):
 
 
 def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0, head=None, store=True,
-            eng=None, terms=0):
+            eng=None, terms=0, norm_bwd=None):
     """y[rows, Cout] = act((x | x2)[rows, K] @ W^T * scale + shift) + res for a packed layer
     (dict with W [Cout, Kpad], scale, shift -- see gmmreg.pack_*).  x, x2, res, out may be column views
     of wider row-major buffers (last stride 1).  split=True uses the layer's pre-split weights (fp16x3 engine)
@@ -328,7 +335,7 @@ def conv1x1(x, layer, act=ACT_NONE, out=None, x2=None, res=None, split=None, ove
             scale=layer.get("scale"), shift=layer.get("shift"), act=act,
             res=res, ldr=(res.stride(0) if res is not None else 0),
             split=(layer.get("split") if split else None), overflow=overflow, col_stats=col_stats, a_affine=a_affine, group_rows=group_rows,
-            single_term=eng.single_term, terms=terms)
+            single_term=eng.single_term, terms=terms, norm_bwd=norm_bwd)
     return out
 
 
@@ -752,6 +759,20 @@ def norm_bwd(x, dy, group_rows, scale, shift, mean, rstd, act, dpool=None, arg=N
     return dx, sums
 
 
+def norm_bwd_fusable(rows, cols, k, group_rows):
+    """would the engine take the normalisation backward's reduction into the epilogue of the [rows, k] x [cols, k]^T GEMM that produces dh (ogmm_gemm.nb_*)?"""
+    return NORM_BWD_FUSED and _lib.load().ogmm_gemm_normbwd_fusable(rows, cols, k, group_rows) == 1
+
+
+def norm_bwd_apply(x, dz, group_rows, scale, shift, mean, rstd, sums):
+    """second half of norm_bwd when its reduction came out of the producing GEMM's epilogue: dz = dy * act'(.) is stored already, sums = {sum dz, sum dz xhat}"""
+    rows, cols = x.shape
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    _lib.call("ogmm_norm_bwd_apply", _p(_f32(x, "x")), x.stride(0), _p(_f32(dz, "dz")), dz.stride(0), _p(None), 0, _p(None), 0, rows, cols, group_rows,
+              _p(_f32(scale, "scale")), _p(_f32(shift, "shift")), _p(_f32(mean, "mean")), _p(_f32(rstd, "rstd")), ACT_NONE, _p(sums), _p(dx), dx.stride(0), _stream())
+    return dx
+
+
 def affine_act_pool(x, k, group_rows, scale, shift, act, want_y=True):
     """-> (y or None, pooled [P, cols], arg uint8 [P, cols]) with P = rows / k"""
     rows, cols = x.shape
@@ -783,17 +804,22 @@ def maxpool_k_bwd(dout, arg, k):
     return dh
 
 
-def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False):
+def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=None, keep_parts=False):
     """dW = dY^T [x_0 | x_1 | ...] on the fp16x3 engine: dy [R, n], xs = list of [R, k_i] (last stride 1) -> [n, sum k_i].
     x_affine (one x only): (scale [G, k], shift [G, k], relu, group_rows) -- x is a pre-normalisation map, X = relu(x * scale + shift).
     colsum=True: -> (dW, db) with db = dy.sum(0) gathered while dY^T is written (fp64 partial sums), no extra pass over dy.
     dY^T is materialised once (fp32, chunk-major), every x_i becomes per-chunk split fragment images of x_i^T, the contraction
-    over r runs as split-K batches of the engine and the partial products are summed (kernels T3 of include/ogmm_hip.h)."""
+    over r runs as split-K batches of the engine and the partial products are summed (kernels T3 of include/ogmm_hip.h).
+    chunk_rows / keep_parts: the row chunks are given (a multiple of 64 that divides R) and the per-chunk products are RETURNED, not summed:
+    [R / chunk_rows, n, k] = a batch of independent X_b^T-style products dY_b^T X_b (the overlap block's backward: dS[b]^T fn_src[b])."""
     R, n = dy.shape
     assert dy.stride(1) == 1
     tiles_mn = ((n + 255) // 256) * max((max(x.shape[1] for x in xs) + 255) // 256, 1)
     S = max(1, min((512 + tiles_mn - 1) // tiles_mn, (R + 255) // 256))        # >= 512 tiles: the large-shape engine's threshold
     chunk = ((R + S - 1) // S + 63) // 64 * 64
+    if chunk_rows is not None:
+        assert chunk_rows % 64 == 0 and R % chunk_rows == 0 and len(xs) == 1 and not colsum
+        chunk = chunk_rows
     S = (R + chunk - 1) // chunk
     pitch = chunk + 64
     dyt = torch.empty((S, n, pitch), dtype=torch.float32, device=dy.device)
@@ -813,9 +839,28 @@ def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False):
         part = torch.empty((S, n, k), dtype=torch.float32, device=dy.device)
         split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
         gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow)
+        if keep_parts:
+            return part
         outs.append(part.sum(dim=0) if S > 1 else part[0])
     dW = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     return (dW, csum.sum(dim=0).float()) if colsum else dW
+
+
+def batched_a_times_x(A, x, overflow=None):
+    """A [B, N, N] (row-major), x [B*N, D] -> [B*N, D] with out[b] = A[b] x[b], on the fp16x3 engine: x[b]^T becomes a split fragment image per batch
+    (ogmm_pack_frag_t with one chunk per batch: the weight gradient's operand packer), A is read as it lies.  N % 64 == 0."""
+    B, N, _ = A.shape
+    D = x.shape[1]
+    assert A.is_contiguous() and x.stride(1) == 1 and x.shape[0] == B * N and N % 64 == 0
+    pitch = N + 64
+    n_pad = (D + 255) // 256 * 256
+    hi = torch.empty(B * n_pad * pitch, dtype=torch.float16, device=A.device)
+    lo = torch.empty_like(hi)
+    _lib.call("ogmm_pack_frag_t", _p(_f32(x, "x")), x.stride(0), B * N, D, N, pitch, B, n_pad, _p(hi), _p(lo), _p(overflow), _p(None), _p(None), 0, 0, _stream())
+    out = torch.empty((B * N, D), dtype=torch.float32, device=A.device)
+    split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
+    gemm_nt(A, N, N, None, 0, N, D, C=out, ldc=D, batch=(B, 1), sA=(N * N, 0), sC=(N * D, 0), split=split, overflow=overflow)
+    return out
 
 
 def kabsch_bwd(src, corr, w, gR, gt):

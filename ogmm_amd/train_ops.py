@@ -293,7 +293,16 @@ class _NormLinear(torch.autograd.Function):
         Wt = W.detach().t().contiguous()
         sp = ops.split_f16_training(Wt, Wt.shape[0], frag=True)
         layer = {"W": Wt, "split": sp, "scale": sp["col_scale"]}
-        dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
+        rows, cin = y.shape
+        fused = ops.norm_bwd_fusable(rows, cin, dout.shape[1], ctx.group_rows)
+        if fused:
+            # the normalisation backward's reduction pass (sum dz, sum dz xhat per group and channel: a read of y and of dh, 2 x 1 GB per 1024-wide map) rides in
+            # the epilogue of the GEMM that produces dh: it reads y there, stores dz = dh * relu'(.) instead of dh and leaves the two sums in col_stats
+            sums = torch.zeros((rows // ctx.group_rows, cin, 2), dtype=torch.float64, device=y.device)
+            dz = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow, col_stats=sums, group_rows=ctx.group_rows,
+                             norm_bwd=(y, mean, rstd, scale, shift, ops.ACT_RELU))
+        else:
+            dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
         dW = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[6] and not ctx.bias_grad_is_zero
         if ctx.needs_input_grad[5]:
@@ -302,7 +311,10 @@ class _NormLinear(torch.autograd.Function):
                 dW, db = dW
         if ctx.has_bias and ctx.needs_input_grad[6] and db is None:
             db = torch.zeros(dout.shape[1], dtype=dout.dtype, device=dout.device) if ctx.bias_grad_is_zero else dout.sum(dim=0)
-        dy, sums = ops.norm_bwd(y, dh, ctx.group_rows, scale, shift, mean, rstd, ops.ACT_RELU)
+        if fused:
+            dy = ops.norm_bwd_apply(y, dz, ctx.group_rows, scale, shift, mean, rstd, sums)
+        else:
+            dy, sums = ops.norm_bwd(y, dh, ctx.group_rows, scale, shift, mean, rstd, ops.ACT_RELU)
         dg = sums[..., 1].sum(dim=0).float() if ctx.affine else None
         dbeta = sums[..., 0].sum(dim=0).float() if ctx.affine else None
         return dy, None, dg, dbeta, None, dW, db, None, None, (dout if ctx.has_res else None)
@@ -411,6 +423,7 @@ class _OverlapCross(torch.autograd.Function):
         wo, stats = ops.overlap_cross_train(S, ol)
         ctx.save_for_backward(S, fn, ol, wo, stats)
         ctx.B, ctx.N = B, N
+        ctx.engine, ctx.overflow = precision == "f16x3", overflow
         return wo
 
     @staticmethod
@@ -418,6 +431,13 @@ class _OverlapCross(torch.autograd.Function):
         S, fn, ol, wo, stats = ctx.saved_tensors
         B, N = ctx.B, ctx.N
         dS, g_ol = ops.overlap_cross_bwd(S, ol, wo, stats, g_wo)
+        D = fn.shape[1]
+        if ctx.engine and N % 64 == 0 and D % 64 == 0 and os.environ.get("OGMM_OVERLAP_BWD_LIB", "0") != "1":
+            # both products on the fp16x3 engine (round 4; two batched fp32 library GEMMs before: 2.2 ms of the 128-pair step): dS[b] fn_tgt[b] reads dS as
+            # it lies against a per-batch image of fn_tgt^T; dS[b]^T fn_src[b] is the weight gradient's dY^T X form with one row chunk per pair, un-summed
+            g_s = ops.batched_a_times_x(dS, fn[B * N:], ctx.overflow)
+            g_t = ops.weight_grad(dS.view(B * N, N), [fn[:B * N]], ctx.overflow, chunk_rows=N, keep_parts=True).view(B * N, D)
+            return torch.cat([g_s, g_t], dim=0), g_ol, None, None, None, None
         fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
         g_fn = torch.cat([torch.bmm(dS, ft), torch.bmm(dS.transpose(1, 2), fs)], dim=0).view(2 * B * N, -1)
         return g_fn, g_ol, None, None, None, None

@@ -138,7 +138,10 @@ def test_linear_forward_backward(precision, rows, k1, k2, cout, bias):
 
 
 @pytest.mark.parametrize("kind,rows,groups,k,cout,want_stats", [("bn", 1024, 2, 256, 512, True), ("bn", 2048, 2, 1024, 256, False),
-                                                               ("in", 1536, 3, 512, 256, False)])
+                                                               ("in", 1536, 3, 512, 256, False),
+                                                               # large enough for the LDS-DMA engine (>= 256 tiles of 256 x 256 in the dh GEMM): the normalisation
+                                                               # backward's reduction then rides in that GEMM's epilogue (struct ogmm_gemm.nb_*, round 4)
+                                                               ("bn", 32768, 2, 1024, 512, False), ("in", 16384 + 8192, 24, 1024, 512, False)])
 def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_stats):
     """_NormLinear (normalised map never written: GEMM a_scale read + ogmm_pack_frag_t a_scale) against the fp64 statement of
     normalise -> ReLU -> layer: output, column sums, running statistics, and the gradients of y, gamma, beta, W, b."""
@@ -161,6 +164,8 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
         nb = torch.zeros((), dtype=torch.long, device=DEV)
         n = rows // groups
         assert tag == "ref" or o._norm_linear_fusable(y, n, W)
+        if tag == "hip" and rows >= 16384:
+            assert __import__("ogmm_amd.ops", fromlist=["x"]).norm_bwd_fusable(rows, k, cout, n)          # (the case exists to exercise that path)
         st = None if tag == "ref" else __import__("ogmm_amd.ops", fromlist=["x"]).colstats(y.detach(), n)
         if kind == "bn":
             out = o.batchnorm_relu_linear(dbl(y), st, dbl(gamma), dbl(beta), rm, rv, nb, groups, dbl(W), dbl(b), want_stats=want_stats)
@@ -182,6 +187,34 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
 
 
 @pytest.mark.parametrize("rows,cols,n", [(3000, 512, 7), (1111, 6, 3), (64, 1024, 9), (500, 256, 2)])
+def test_norm_bwd_reduction_in_the_gemm_epilogue_equals_the_separate_pass(monkeypatch):
+    """struct ogmm_gemm.nb_*: dz and the two column sums out of the dh GEMM's epilogue against the separate reduction kernel on the same operands --
+    the same dz to the last bit (same product, same mask), the sums to fp32 partial-sum rounding (32-row partials in fp32, then fp64)."""
+    ops = __import__("ogmm_amd.ops", fromlist=["x"])
+    g = torch.Generator().manual_seed(5)
+    rows, k, cout, groups = 65536, 512, 1024, 64          # dh = dout [rows, k] W [cout, k]^T -> [rows, cout]: the mlp.3 / conv.6 backward shape
+    n = rows // groups
+    x = (torch.randn(rows, cout, generator=g) * 1.5 + 0.2).to(DEV)
+    dout = torch.randn(rows, k, generator=g).to(DEV)
+    W = (torch.randn(cout, k, generator=g) / k ** .5).to(DEV)
+    mean = x.view(groups, n, cout).mean(1).contiguous()
+    rstd = torch.rsqrt(x.view(groups, n, cout).var(1, unbiased=False) + 1e-5).contiguous()
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    scale = (rstd * gamma).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    assert ops.norm_bwd_fusable(rows, cout, k, n)
+    sp = ops.split_f16_training(W, cout, frag=True)
+    layer = {"W": W, "split": sp, "scale": sp["col_scale"]}
+    sums_f = torch.zeros((groups, cout, 2), dtype=torch.float64, device=DEV)
+    dz = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, col_stats=sums_f, group_rows=n, norm_bwd=(x, mean, rstd, scale, shift, ops.ACT_RELU))
+    dx_f = ops.norm_bwd_apply(x, dz, n, scale, shift, mean, rstd, sums_f)
+    dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True)
+    dx_u, sums_u = ops.norm_bwd(x, dh, n, scale, shift, mean, rstd, ops.ACT_RELU)
+    mask = (x * scale.repeat_interleave(n, 0) + shift.repeat_interleave(n, 0)) > 0
+    assert torch.equal(dz, dh * mask)
+    assert _rel(sums_f, sums_u) < 1e-6 and _rel(dx_f, dx_u) < 1e-6
+
+
 def test_fanout_adds_gradients_in_one_pass(rows, cols, n):
     """_Fanout / ogmm_add_n: n consumers of one map, some through column views of wider buffers; same sum, same order as autograd's"""
     from ogmm_amd import ops as O
@@ -275,7 +308,7 @@ def test_attention_forward_backward(C, N, M):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-@pytest.mark.parametrize("B,N,D", [(2, 512, 512), (3, 200, 128), (1, 1024, 512)])
+@pytest.mark.parametrize("B,N,D", [(2, 512, 512), (3, 200, 128), (1, 1024, 512), (40, 1024, 512)])          # (40 pairs: the large-shape engines in the backward's two products)
 def test_overlap_cross_forward_backward(precision, B, N, D):
     g = torch.Generator().manual_seed(B * N)
     fn = torch.nn.functional.normalize(torch.randn(2 * B * N, D, generator=g), dim=1).to(DEV).requires_grad_(True)
