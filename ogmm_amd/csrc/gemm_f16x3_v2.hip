@@ -242,7 +242,7 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
                      "ogmm_gemm_nt(f16x3 frag): InstanceNorm fusion needs group_rows %% 256 == 0, no pooling, aligned a_scale/a_shift");
     if (g.col_stats) {
         ogmm_gemm probe = g;
-        OGMM_REQUIRE(g.C && (g.N & 3) == 0 && (g.ldc & 3) == 0 && aligned16(g.C) && !g.Res, "ogmm_gemm_nt(f16x3 frag): col_stats needs the wide epilogue (N, ldc %% 4 == 0, no residual)");
+        OGMM_REQUIRE(g.C && (g.N & 3) == 0 && (g.ldc & 3) == 0 && aligned16(g.C) && (!g.Res || g.nb_mean), "ogmm_gemm_nt(f16x3 frag): col_stats needs the wide epilogue (N, ldc %% 4 == 0, no residual)");
         (void)probe;
     }
     if (g.pool_k > 0) return g.N <= 64 ? launch_v2<5, 1, 1, 2, true>(g, s) : launch_v2<5, 1, 1, 4, true>(g, s);

@@ -430,14 +430,21 @@ class _OverlapCross(torch.autograd.Function):
     def backward(ctx, g_wo):
         S, fn, ol, wo, stats = ctx.saved_tensors
         B, N = ctx.B, ctx.N
-        dS, g_ol = ops.overlap_cross_bwd(S, ol, wo, stats, g_wo)
         D = fn.shape[1]
         if ctx.engine and N % 64 == 0 and D % 64 == 0 and os.environ.get("OGMM_OVERLAP_BWD_LIB", "0") != "1":
             # both products on the fp16x3 engine (round 4; two batched fp32 library GEMMs before: 2.2 ms of the 128-pair step): dS[b] fn_tgt[b] reads dS as
-            # it lies against a per-batch image of fn_tgt^T; dS[b]^T fn_src[b] is the weight gradient's dY^T X form with one row chunk per pair, un-summed
-            g_s = ops.batched_a_times_x(dS, fn[B * N:], ctx.overflow)
-            g_t = ops.weight_grad(dS.view(B * N, N), [fn[:B * N]], ctx.overflow, chunk_rows=N, keep_parts=True).view(B * N, D)
-            return torch.cat([g_s, g_t], dim=0), g_ol, None, None, None, None
+            # it lies against a per-batch image of fn_tgt^T; dS[b]^T fn_src[b] is the weight gradient's dY^T X form with one row chunk per pair, un-summed.
+            # dS is the engine's fp32 operand here, split into binary16 terms on the fly, and its entries are softmax gradients of order |g| / N: far into
+            # binary16's subnormals unless scaled.  dS is linear in g_wo, so g_wo is multiplied by a power of two (|dS| <= 2 max|g_wo| -> at most 2^14; found on
+            # the device, no host round trip) and the products and the logit gradient are multiplied back by its inverse: exact either way.
+            k2 = torch.floor(13.0 - torch.log2(g_wo.detach().abs().amax().clamp_min(1e-30).float())).clamp_(-40.0, 40.0)
+            up, down = torch.exp2(k2), torch.exp2(-k2)
+            dS, g_ol = ops.overlap_cross_bwd(S, ol, wo, stats, g_wo * up)
+            inv = down.expand(D).contiguous()
+            g_s = ops.batched_a_times_x(dS, fn[B * N:], ctx.overflow, out_scale=inv)
+            g_t = ops.weight_grad(dS.view(B * N, N), [fn[:B * N]], ctx.overflow, chunk_rows=N, keep_parts=True, out_scale=inv).view(B * N, D)
+            return torch.cat([g_s, g_t], dim=0), g_ol * down, None, None, None, None
+        dS, g_ol = ops.overlap_cross_bwd(S, ol, wo, stats, g_wo)
         fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
         g_fn = torch.cat([torch.bmm(dS, ft), torch.bmm(dS.transpose(1, 2), fs)], dim=0).view(2 * B * N, -1)
         return g_fn, g_ol, None, None, None, None

@@ -186,7 +186,6 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
         assert _rel(a, r) < 2e-5, (i_, _rel(a, r))
 
 
-@pytest.mark.parametrize("rows,cols,n", [(3000, 512, 7), (1111, 6, 3), (64, 1024, 9), (500, 256, 2)])
 def test_norm_bwd_reduction_in_the_gemm_epilogue_equals_the_separate_pass(monkeypatch):
     """struct ogmm_gemm.nb_*: dz and the two column sums out of the dh GEMM's epilogue against the separate reduction kernel on the same operands --
     the same dz to the last bit (same product, same mask), the sums to fp32 partial-sum rounding (32-row partials in fp32, then fp64)."""
@@ -215,6 +214,7 @@ def test_norm_bwd_reduction_in_the_gemm_epilogue_equals_the_separate_pass(monkey
     assert _rel(sums_f, sums_u) < 1e-6 and _rel(dx_f, dx_u) < 1e-6
 
 
+@pytest.mark.parametrize("rows,cols,n", [(3000, 512, 7), (1111, 6, 3), (64, 1024, 9), (500, 256, 2)])
 def test_fanout_adds_gradients_in_one_pass(rows, cols, n):
     """_Fanout / ogmm_add_n: n consumers of one map, some through column views of wider buffers; same sum, same order as autograd's"""
     from ogmm_amd import ops as O
