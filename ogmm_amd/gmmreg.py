@@ -27,6 +27,7 @@ from ._lib import OgmmError
 from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
+_EM_SCHED = int(os.environ.get("OGMM_EM_SCHED", "0"))
 # Measured budget (DESIGN.md section 4 "Per-layer term budget").  Round 4: an entry stays only if the layer's rounding holds the 1e-5 bar on BOTH weight
 # families of the parity suite -- the closed-form default fill AND synth.fill_state_dict(profile="sharp") (peaked attention, saturated overlap scores).
 # Round 3's entries for conv2.0 / conv2.3 (weight rounded), the three Q projections and the attention's score product (both rounded) were measured on
@@ -476,21 +477,34 @@ class GMMReg(nn.Module):
                          terms=tb.get("overlap.3", 0))      # overlap.3 + overlap.6
 
         # ---- GMM E/M (needs only xyz and the overlap scores) on the side stream, next to self-attention 2 (gmmreg.py:92-101)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        def run_em():
             # thresh / group_size: the reference's Sinkhorn early exit (lib/utils.py:99-102), per call batch -- the B src clouds and the B tgt
             # clouds are separate wkeans_plus calls (models/gmmreg.py:100-101).  capture=True also records every sweep's residual and the
             # number of sweeps every E-step ran: see sinkhorn_exit_margin()
-            em = ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=self.sinkhorn_thresh, group_size=B,
-                            return_resid=capture, return_sweeps=capture, status=self._status)
-            gamma, pi, mu = em[:3]
-            em_done = torch.cuda.Event()
-            em_done.record(side)
-        o.record_stream(side)
-        for t_ in (gamma, pi, mu):
-            t_.record_stream(main)
+            return ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=self.sinkhorn_thresh, group_size=B,
+                              return_resid=capture, return_sweeps=capture, status=self._status)
+        em_sched = _EM_SCHED          # experiment switch (OGMM_EM_SCHED): 0 = beside the whole last transformer (default), 1 = serial behind it, 2 = high-priority stream
+        em_stream = side
+        if em_sched == 2:
+            if getattr(self, "_em_hi", None) is None or self._em_hi.device != dev:
+                self._em_hi = torch.cuda.Stream(device=dev, priority=-1)
+            em_stream = self._em_hi
+        if em_sched != 1:
+            em_stream.wait_stream(main)
+            with torch.cuda.stream(em_stream):
+                em = run_em()
+                gamma, pi, mu = em[:3]
+                em_done = torch.cuda.Event()
+                em_done.record(em_stream)
+            o.record_stream(em_stream)
+            for t_ in (gamma, pi, mu):
+                t_.record_stream(main)
         f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0), kv_terms=tb.get("sattn2.kv", 0), qk_terms=tb.get("sattn2.qk", 0))
-        main.wait_event(em_done)
+        if em_sched == 1:
+            em = run_em()
+            gamma, pi, mu = em[:3]
+        else:
+            main.wait_event(em_done)
 
         # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)
         muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)
