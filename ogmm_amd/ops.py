@@ -804,7 +804,7 @@ def maxpool_k_bwd(dout, arg, k):
     return dh
 
 
-def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=None, keep_parts=False, out_scale=None):
+def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=None, keep_parts=False, out_scale=None, parts_out=None):
     """dW = dY^T [x_0 | x_1 | ...] on the fp16x3 engine: dy [R, n], xs = list of [R, k_i] (last stride 1) -> [n, sum k_i].
     x_affine (one x only): (scale [G, k], shift [G, k], relu, group_rows) -- x is a pre-normalisation map, X = relu(x * scale + shift).
     colsum=True: -> (dW, db) with db = dy.sum(0) gathered while dY^T is written (fp64 partial sums), no extra pass over dy.
@@ -836,7 +836,8 @@ def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=N
         assert x_affine is None or (len(xs) == 1 and aff[0].shape[-1] == k and aff[0].is_contiguous() and aff[1].is_contiguous())
         _lib.call("ogmm_pack_frag_t", _p(_f32(x, "x")), x.stride(0), R, k, chunk, pitch, S, n_pad, _p(hi), _p(lo), _p(overflow), _p(aff[0]), _p(aff[1]),
                   1 if aff[2] else 0, aff[3], _stream())
-        part = torch.empty((S, n, k), dtype=torch.float32, device=dy.device)
+        part = torch.empty((S, n, k), dtype=torch.float32, device=dy.device) if parts_out is None else parts_out
+        assert tuple(part.shape) == (S, n, k) and part.is_contiguous()
         split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
         gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow,
                 scale=out_scale)          # (out_scale [k]: a per-column factor on the products, e.g. the inverse of a power of two dy was scaled by)
@@ -847,7 +848,7 @@ def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=N
     return (dW, csum.sum(dim=0).float()) if colsum else dW
 
 
-def batched_a_times_x(A, x, overflow=None, out_scale=None):
+def batched_a_times_x(A, x, overflow=None, out_scale=None, out=None):
     """A [B, N, N] (row-major), x [B*N, D] -> [B*N, D] with out[b] = A[b] x[b], on the fp16x3 engine: x[b]^T becomes a split fragment image per batch
     (ogmm_pack_frag_t with one chunk per batch: the weight gradient's operand packer), A is read as it lies.  N % 64 == 0."""
     B, N, _ = A.shape
@@ -858,7 +859,9 @@ def batched_a_times_x(A, x, overflow=None, out_scale=None):
     hi = torch.empty(B * n_pad * pitch, dtype=torch.float16, device=A.device)
     lo = torch.empty_like(hi)
     _lib.call("ogmm_pack_frag_t", _p(_f32(x, "x")), x.stride(0), B * N, D, N, pitch, B, n_pad, _p(hi), _p(lo), _p(overflow), _p(None), _p(None), 0, 0, _stream())
-    out = torch.empty((B * N, D), dtype=torch.float32, device=A.device)
+    if out is None:
+        out = torch.empty((B * N, D), dtype=torch.float32, device=A.device)
+    assert tuple(out.shape) == (B * N, D) and out.is_contiguous()
     split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
     gemm_nt(A, N, N, None, 0, N, D, C=out, ldc=D, batch=(B, 1), sA=(N * N, 0), sC=(N * D, 0), split=split, overflow=overflow, scale=out_scale)
     return out

@@ -441,9 +441,10 @@ class _OverlapCross(torch.autograd.Function):
             up, down = torch.exp2(k2), torch.exp2(-k2)
             dS, g_ol = ops.overlap_cross_bwd(S, ol, wo, stats, g_wo * up)
             inv = down.expand(D).contiguous()
-            g_s = ops.batched_a_times_x(dS, fn[B * N:], ctx.overflow, out_scale=inv)
-            g_t = ops.weight_grad(dS.view(B * N, N), [fn[:B * N]], ctx.overflow, chunk_rows=N, keep_parts=True, out_scale=inv).view(B * N, D)
-            return torch.cat([g_s, g_t], dim=0), g_ol * down, None, None, None, None
+            g_fn = torch.empty((2 * B * N, D), dtype=torch.float32, device=fn.device)          # both halves written in place: no concatenation pass
+            ops.batched_a_times_x(dS, fn[B * N:], ctx.overflow, out_scale=inv, out=g_fn[:B * N])
+            ops.weight_grad(dS.view(B * N, N), [fn[:B * N]], ctx.overflow, chunk_rows=N, keep_parts=True, out_scale=inv, parts_out=g_fn[B * N:].view(B, N, D))
+            return g_fn, g_ol * down, None, None, None, None
         dS, g_ol = ops.overlap_cross_bwd(S, ol, wo, stats, g_wo)
         fs, ft = fn[:B * N].view(B, N, -1), fn[B * N:].view(B, N, -1)
         g_fn = torch.cat([torch.bmm(dS, ft), torch.bmm(dS.transpose(1, 2), fs)], dim=0).view(2 * B * N, -1)
