@@ -186,6 +186,26 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
         assert _rel(a, r) < 2e-5, (i_, _rel(a, r))
 
 
+@pytest.mark.parametrize("B,N,D", [(3, 256, 128), (1, 1024, 512), (20, 512, 256), (36, 1024, 512)])
+def test_batched_products_of_the_overlap_backward_against_fp64(B, N, D):
+    """ops.batched_a_times_x (A[b] x[b]) and ops.weight_grad(chunk_rows = N, keep_parts = True) (A[b]^T x[b]) -- the two engine forms behind the overlap
+    block's backward -- against fp64 products, with and without the per-column output scale, on batches that take the small-tile and the large-shape engines."""
+    ops = __import__("ogmm_amd.ops", fromlist=["x"])
+    g = torch.Generator().manual_seed(B + N)
+    A = torch.randn(B, N, N, generator=g).to(DEV)
+    x = torch.randn(B * N, D, generator=g).to(DEV)
+    sc = torch.full((D,), 0.25, device=DEV)
+    want = torch.bmm(A.double(), x.double().view(B, N, D)).view(B * N, D)
+    want_t = torch.bmm(A.double().transpose(1, 2), x.double().view(B, N, D)).view(B * N, D)
+    got = ops.batched_a_times_x(A, x)
+    got_sc = ops.batched_a_times_x(A, x, out_scale=sc)
+    got_t = ops.weight_grad(A.view(B * N, N), [x], chunk_rows=N, keep_parts=True).view(B * N, D)
+    buf = torch.empty((B, N, D), device=DEV)
+    ops.weight_grad(A.view(B * N, N), [x], chunk_rows=N, keep_parts=True, out_scale=sc, parts_out=buf)
+    assert _rel(got, want) < 2e-6 and _rel(got_sc, 0.25 * want) < 2e-6
+    assert _rel(got_t, want_t) < 2e-6 and _rel(buf.view(B * N, D), 0.25 * want_t) < 2e-6
+
+
 def test_norm_bwd_reduction_in_the_gemm_epilogue_equals_the_separate_pass(monkeypatch):
     """struct ogmm_gemm.nb_*: dz and the two column sums out of the dh GEMM's epilogue against the separate reduction kernel on the same operands --
     the same dz to the last bit (same product, same mask), the sums to fp32 partial-sum rounding (32-row partials in fp32, then fp64)."""
