@@ -173,9 +173,9 @@ def fill_state_dict(state_dict, profile="default"):
     BN weight U(0.5,1.5), bias U(-0.2,0.2), running_mean U(-0.2,0.2), running_var U(0.5,1.5).
     profile="sharp": the same hash with wider BatchNorm ranges (weight U(0.4,2.0), bias U(-0.5,0.5), running_mean U(-0.5,0.5), running_var
     U(0.25,2.0)) and the per-tensor gains of SHARP_GAINS (peaked attention, saturated overlap scores)."""
-    if profile not in ("default", "sharp"):
+    if profile not in ("default", "sharp", "mid"):
         raise ValueError("unknown weight profile %r" % profile)
-    sharp = profile == "sharp"
+    sharp = profile in ("sharp", "mid")
     for name, t in state_dict.items():
         if name.endswith("num_batches_tracked"):
             t.zero_()
@@ -198,7 +198,10 @@ def fill_state_dict(state_dict, profile="default"):
         if sharp:
             g = SHARP_GAINS.get(name)
             if g is not None:
-                v = v * g[0] + g[1]
+                # "mid": the square root of every gain and a quarter of the offset -- half-way (in the logarithm) between the two families; the family of
+                # the TRAIN-mode fixture: with batch statistics the full gains saturate every overlap score to 0 / 1 and the reference's own train-mode
+                # forward is then only reproducible to 1e-4 ... 1e-3 (tests/golden/make_golden_train.py records that noise)
+                v = v * g[0] + g[1] if profile == "sharp" else v * (g[0] ** 0.5) + 0.25 * g[1]
         t.copy_(torch.from_numpy(np.ascontiguousarray(v)).to(t.dtype))
     return state_dict
 

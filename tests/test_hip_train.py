@@ -9,7 +9,7 @@ from ogmm_amd import losses, metric, synth
 from ogmm_amd.gmmreg import GMMReg
 from ogmm_amd.train_ops import TrainOps
 from train_ref import RefTrainOps
-from train_util import TRAIN_CASES, check_grads, load_train_case
+from train_util import TRAIN_CASES, check_grads, load_train_case, noise_of, profile_of
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -352,7 +352,7 @@ def test_training_step_matches_reference(name, precision):
     fx, cfg, (B, N, J, D, top_k) = load_train_case(name)
     cfg.precision = precision
     model = GMMReg(D, J, cfg)
-    synth.fill_state_dict(model.state_dict())
+    synth.fill_state_dict(model.state_dict(), profile=profile_of(fx))          # train_mid_*: a non-degenerate weight family (scores spanning (0, 1) in train mode, attention logits +-3 ... 6)
     model = model.to(DEV).train()
     src, tgt = torch.from_numpy(fx["src"]).to(DEV), torch.from_numpy(fx["tgt"]).to(DEV)
     out = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]))
@@ -369,12 +369,14 @@ def test_training_step_matches_reference(name, precision):
     worst = check_grads(fx, grads, report=errs)
     print("TRAIN-PARITY %s %s loss=%.8f (ref %.8f) %s worst_grad_err_over_allowed=%.2f" % (
         precision, name, loss.item(), float(fx["loss"]), " ".join("%s=%.2e" % kv for kv in rep.items()), worst))
-    assert abs(loss.item() - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    # bars: the base bar, or 3 x the reference's own train-mode noise on the fixture (1 / 8 host threads, fp64: recorded by make_golden_train.py; on the
+    # default fill that noise is below every base bar, on the non-degenerate family the overlap scores move by 5e-5 in the reference itself)
+    assert abs(loss.item() - float(fx["loss"])) <= max(1e-5 * abs(float(fx["loss"])), 3 * noise_of(fx, "loss"))
     for kpart in parts:
         # the Welsch term sums 2 - exp(-a) - exp(-b) with a, b ~ 1e-6: every summand carries the 6e-8 rounding of "1 - tiny",
         # so the fp32 value itself is only defined to ~1e-5 (it enters the loss with weight 0.01)
-        assert rep[kpart] <= (1e-4 if kpart == "welsch" else 1e-5) * max(1.0, abs(float(fx["loss_" + kpart]))), kpart
-    assert rep["R"] < 1e-5 and rep["t"] < 1e-5 and rep["o"] < 1e-5
+        assert rep[kpart] <= max((1e-4 if kpart == "welsch" else 1e-5) * max(1.0, abs(float(fx["loss_" + kpart]))), 3 * noise_of(fx, "loss")), kpart
+    assert rep["R"] < max(1e-5, 3 * noise_of(fx, "R")) and rep["t"] < max(1e-5, 3 * noise_of(fx, "t")) and rep["o"] < max(1e-5, 3 * noise_of(fx, "o"))
     sd = model.state_dict()
     for key in (f[len("stat/"):] for f in fx.files if f.startswith("stat/")):
         np.testing.assert_allclose(sd[key].cpu().numpy(), fx["stat/" + key], rtol=1e-5, atol=1e-6, err_msg=key)

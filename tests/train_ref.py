@@ -130,11 +130,11 @@ class RefTrainOps(TrainOps):
         return tuple(torch.cat(t) for t in zip(*outs))
 
 
-def params_from_fixture_spec(D, dtype=torch.float32):
+def params_from_fixture_spec(D, dtype=torch.float32, profile="default"):
     """closed-form weights (ogmm_amd/synth.py) as a name -> tensor dict with requires_grad on the parameters"""
     from ogmm_amd import gmmreg, synth
     P = {k: torch.zeros(s) if "num_batches" not in k else torch.zeros((), dtype=torch.long) for k, s in gmmreg.state_spec(D)}
-    synth.fill_state_dict(P)
+    synth.fill_state_dict(P, profile=profile)
     P = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in P.items()}
     for k, v in P.items():
         if v.is_floating_point() and "running" not in k:

@@ -8,7 +8,7 @@ import torch
 from ogmm_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TRAIN_CASES = ["train_b2_n512_j16", "train_b3_n320_j8_k12"]
+TRAIN_CASES = ["train_b2_n512_j16", "train_b3_n320_j8_k12", "train_mid_b2_n512_j16"]
 SAMPLE = 97
 
 
@@ -22,6 +22,17 @@ def load_train_case(name):
     B, N, J, k, M, D, H, top_k = (int(v) for v in fx["meta"])
     cfg = Namespace(gnn_k=k, num_heads=H, km_clusters=M, overlap_radius=0.035, n_clusters=J)
     return fx, cfg, (B, N, J, D, top_k)
+
+
+def profile_of(fx):
+    """the weight family a training fixture was generated with (synth.fill_state_dict(profile=...))"""
+    return str(fx["profile"]) if "profile" in fx.files else "default"
+
+
+def noise_of(fx, what):
+    """the reference's own train-mode distance between 1 / 8 host threads and against fp64 on this fixture (make_golden_train.py), 0 for old fixtures"""
+    key = "noise_" + what
+    return float(fx[key]) if key in fx.files else 0.0
 
 
 def filled_state(module_or_spec):
