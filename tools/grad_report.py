@@ -1,5 +1,10 @@
+"""Per-parameter gradient report of one training fixture on the GPU box: the HIP training step's gradients (both engines) against the fixture's fp64 truth,
+next to the reference's own fp32-vs-fp64 distance per parameter (tests/train_util.py check_grads, with the outlier allowance lifted so that every
+parameter is listed).  Used to pick / reject seeds for training fixtures (tests/golden/make_golden_train.py).   usage: grad_report.py <fixture name>"""
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from train_util import check_grads, load_train_case, profile_of
 from ogmm_amd import losses, synth
 from ogmm_amd.gmmreg import GMMReg
