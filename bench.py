@@ -108,6 +108,9 @@ def main():
                     help="cfg1 = BASELINE configs[1] (headline); cfg2 = configs[2] shape (N=2048, J=64, B=256); cfg3 = configs[3] shape per GPU "
                          "(room clouds, N=2048, J=64, B=64); train = configs[4]: full training step, N=1024, J=16, 128 pairs per GPU (global 1024 on 8)")
     ap.add_argument("--train-batch", type=int, default=128, help="pairs per GPU and step for --workload train")
+    ap.add_argument("--weights", choices=["default", "sharp"], default="default",
+                    help="weight family of the synthetic model (ogmm_amd/synth.py): sharp = peaked attention, overlap scores spanning (0, 1); for A/B runs -- the "
+                         "headline is quoted on the default family, the sharp family is a secondary leg")
     ap.add_argument("--secondary", type=int, default=1, help="1 (default): at N=1 the headline run also times short legs of cfg2 / cfg3 / train and attaches them as "
                                                              "`secondary`; 0: headline only")
     args = ap.parse_args()
@@ -132,7 +135,9 @@ def main():
     if args.workload == "train":
         result = train_leg(args, ctx, args.train_batch, args.steps, args.warmup, cpu_check=args.cpu_sample > 0)
     else:
-        result, keep = eval_leg(args, ctx, args.workload, args.steps, args.warmup)
+        result, keep = eval_leg(args, ctx, args.workload, args.steps, args.warmup, profile=args.weights)
+        if args.weights != "default":
+            result["config"]["workload"] += "; weight family: " + args.weights
         if rank == 0 and world == 1 and not stub:
             result["roofline"]["library_gemm_same_box"] = library_yardstick(dev, result["config"]["pairs_per_gpu_step"] * 2 * result["config"]["n_points"])
         if rank == 0 and world == 1 and args.cpu_sample > 0 and not stub:
@@ -148,7 +153,7 @@ def main():
         dist.destroy_process_group()
 
 
-def eval_leg(args, ctx, workload, steps, warmup, precision=None):
+def eval_leg(args, ctx, workload, steps, warmup, precision=None, profile="default"):
     """One eval workload: W untimed forwards, exactly K timed ones bracketed by barrier + synchronize, MAX over ranks -> the bench line's fields (dict)
     and what the CPU leg needs (model, inputs, last outputs)."""
     from ogmm_amd import dist as odist, ops, synth
@@ -158,7 +163,7 @@ def eval_leg(args, ctx, workload, steps, warmup, precision=None):
     cfg = make_cfg(J)
     rank, world, dist, dev, stub = ctx.rank, ctx.world, ctx.dist, ctx.dev, ctx.stub
     model = GMMReg(512, J, cfg)
-    synth.fill_state_dict(model.state_dict())
+    synth.fill_state_dict(model.state_dict(), profile=profile)          # "sharp": the second, non-degenerate weight family of the parity suite (secondary leg)
     params_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model.precision = precision
     if stub:
@@ -326,6 +331,19 @@ def secondary_legs(args, ctx):
             leg = {"workload": wl, "error": "%s: %s" % (type(e).__name__, e)}
         legs.append(leg)
         torch.cuda.empty_cache()
+    try:
+        # the headline workload once more on the SHARP weight family (peaked attention, overlap scores spanning (0, 1)): the same kernels, so the same
+        # throughput -- what the leg adds to the record is the parity of a timed forward on non-degenerate weights (16 of its 64 pairs against the oracle)
+        res, keep = eval_leg(args, ctx, "cfg1", 12, 3, profile="sharp")          # (12 steps: at 5, two of them carry the event brackets and the leg reads 8 % low)
+        legs.append({"workload": res["config"]["workload"].replace("closed-form weights", "closed-form weights of the SHARP family (synth.fill_state_dict(profile='sharp'))"),
+                     "metric": "pairs_per_sec", "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 12, "warmup": 3,
+                     "roofline": {k: res["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "kernel_share_of_step")},
+                     "parity": parity_sample(keep, tuple(range(0, 64, 4)), threads) if args.cpu_sample > 0 else None,
+                     "fp16_split_overflowed": bool(keep.model.fp16_overflowed())})
+        del keep
+    except Exception as e:          # noqa: BLE001
+        legs.append({"workload": "cfg1 on sharp weights", "error": "%s: %s" % (type(e).__name__, e)})
+    torch.cuda.empty_cache()
     try:
         res = train_leg(args, ctx, args.train_batch, 5, 2, cpu_check=args.cpu_sample > 0)
         legs.append({"workload": res["config"]["workload"], "metric": res["metric"], "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 5, "warmup": 2,

@@ -28,10 +28,11 @@ def test_committed_bench_line_has_the_contract_fields():
     # the arithmetic travels in strings (the driver's parsed record drops nested dicts): dtype names the split and the reduced-term layers
     assert isinstance(line["dtype"], str) and "f16x3" in line["dtype"] and "similarity=1" in line["dtype"]
     assert "arithmetic:" in line["config"]["workload"] and line["config"]["term_budget"] == {"similarity": 1}
-    # the other BASELINE configs, observed by the same command: configs[2] / [3] shapes and the configs[4] training step, each with a roofline fraction and a parity sample
+    # the other BASELINE configs, observed by the same command: configs[2] / [3] shapes, the headline workload on the sharp weight family and the configs[4]
+    # training step, each with a roofline fraction and a parity sample
     legs = line["secondary"]
-    assert len(legs) == 3 and all("error" not in leg for leg in legs)
-    for leg, tag in zip(legs, ("configs[2]", "configs[3]", "configs[4]")):
+    assert len(legs) == 4 and all("error" not in leg for leg in legs)
+    for leg, tag in zip(legs, ("configs[2]", "configs[3]", "SHARP family", "configs[4]")):
         assert tag in leg["workload"] and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1 and leg["parity"]["R_err_rad_max"] < 1e-5
 
 
