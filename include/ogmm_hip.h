@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 23
+#define OGMM_ABI_VERSION 24
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -150,6 +150,14 @@ typedef struct ogmm_gemm {
      * disappears; ogmm_norm_bwd_apply(x, dy = dz, act = NONE, sums = col_stats) finishes.  x = Res / ldr (same shape as C; no residual is added in this mode),
      * nb_* are [groups][N] float, group = row / group_rows (group_rows %% 256 == 0), nb_act in {RELU, LEAKY02}.  LDS-DMA engine (N >= 512, whole tiles) only. */
     const float* nb_mean; const float* nb_rstd; const float* nb_scale; const float* nb_shift; int32_t nb_act;
+    /* A read TRANSPOSED (training; round 4, ABI 24): the logical operand is A[m][k] = A_mem[k * lda + m] -- A_mem is a row-major [K][M] map, e.g. the
+     * upstream gradient dY [rows][Cout] of a weight gradient dW = dY^T X (M = Cout, K = rows, B = the fragment image of X^T, batch = row chunks with
+     * sA_o = chunk_rows * lda).  The LDS-DMA engine fetches 4 k-rows x 64 m per DMA instruction and reads its operand fragments with transposing
+     * ds_read2st64_b32; same products in the same order as the plain form on an explicitly transposed copy: bit-identical results, without the copy.
+     * One A piece (K2 = 0), M %% 4 == 0, lda %% 4 == 0, K1 %% 32 == 0, no a_scale / gather / overlap / nb_* forms.  ogmm_gemm_atrans_supported tells.
+     * a_colsum (optional, with a_trans): double [M], ADDED to: a_colsum[m] += sum over k (and over the batch) of A[m][k] -- the bias gradient dy.sum(0), gathered
+     * from the operand fragments the engine reads anyway (fp32 tree over 8 values, fp64 from there on); the caller zeroes it. */
+    int32_t a_trans; double* a_colsum;
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
@@ -161,6 +169,7 @@ int ogmm_gemm_rowdot_fusable(int M, int N, int K1, int K2);
 /* 1 if ogmm_gemm_nt takes gathered A rows (a_gather_ids) for an M x N layer with K input channels over `rows` source rows, else 0 */
 int ogmm_gemm_gather_fusable(int M, int N, int K, int64_t rows);
 int ogmm_gemm_normbwd_fusable(int M, int N, int K, int group_rows);          /* the normalisation-backward fusion (ogmm_gemm.nb_*): 1 / 0 */
+int ogmm_gemm_atrans_supported(int M, int N, int K, int64_t lda, int batch);  /* the transposed-A form (ogmm_gemm.a_trans) for `batch` products of M x N over K: 1 / 0 */
 /* second half of the fused overlap block: merges the (1, sum, dot) triples the similarity GEMM left (models/gmmreg.py:79-80):
  * wo_src[(b N + i) ldo] = softmax(S_b, dim = 1)[i] . o_tgt, wo_tgt[(b N + j) ldo] = softmax(S_b^T, dim = 1)[j] . o_src */
 int ogmm_overlap_finalize(const float* rowpart, const float* colpart, int B, int N, float* wo_src, float* wo_tgt, int64_t ldo, void* stream);

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -39,6 +39,7 @@ class GemmDesc(Structure):
         ("col_stats_slot_mask", c_int32), ("col_stats_slot_stride", c_int64),
         ("terms", c_int32),
         ("nb_mean", c_void_p), ("nb_rstd", c_void_p), ("nb_scale", c_void_p), ("nb_shift", c_void_p), ("nb_act", c_int32),
+        ("a_trans", c_int32), ("a_colsum", c_void_p),
     ]
 
 
@@ -53,6 +54,7 @@ PROTOTYPES = {
     "ogmm_gemm_overlap_fusable": [c_int, c_int, c_int],
     "ogmm_gemm_rowdot_fusable": [c_int, c_int, c_int, c_int],
     "ogmm_gemm_normbwd_fusable": [c_int, c_int, c_int, c_int],
+    "ogmm_gemm_atrans_supported": [c_int, c_int, c_int, c_int64, c_int],
     "ogmm_gemm_gather_fusable": [c_int, c_int, c_int, c_int64],
     "ogmm_overlap_finalize": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_row_rnorm": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p],

@@ -174,7 +174,7 @@ extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {
     OGMM_REQUIRE(g.col_stats_slot_mask >= 0 && ((g.col_stats_slot_mask + 1) & g.col_stats_slot_mask) == 0 &&
                  (g.col_stats_slot_mask == 0 || (g.col_stats && g.group_rows > 0 && g.col_stats_slot_stride >= (int64_t)((g.M + g.group_rows - 1) / g.group_rows) * g.N * 2)),
                  "ogmm_gemm_nt: col_stats_slot_mask must be 2^n - 1 and col_stats_slot_stride must hold one [groups][N][2] copy");
-    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart && !g.rd_out && !g.a_gather_ids && !g.nb_mean), "ogmm_gemm_nt: InstanceNorm / overlap-block / Cout = 1 head / row gather / normalisation-backward fusion is only available with OGMM_PREC_F16X3_FRAG");
+    OGMM_REQUIRE(frag || (!g.col_stats && !g.a_scale && !g.ovl_rowpart && !g.rd_out && !g.a_gather_ids && !g.nb_mean && !g.a_trans), "ogmm_gemm_nt: InstanceNorm / overlap-block / Cout = 1 head / row gather / normalisation-backward fusion is only available with OGMM_PREC_F16X3_FRAG");
     if (g.pool_k > 0)
         OGMM_REQUIRE(g.pool_out && g.act == OGMM_ACT_RELU && g.pool_k >= 4 && g.pool_k <= 160 && g.M % g.pool_k == 0 &&
                          g.batch_outer * g.batch_inner == 1,
@@ -224,6 +224,16 @@ extern "C" int ogmm_gemm_normbwd_fusable(int M, int N, int K, int group_rows) {
     g.A = dummy; g.lda = K; g.K1 = K; g.M = M; g.N = N; g.batch_outer = 1; g.batch_inner = 1; g.precision = OGMM_PREC_F16X3_FRAG;
     g.ldb_h = (K + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy; g.C = dummy; g.Res = dummy; g.col_stats = ddummy; g.group_rows = group_rows;
     g.nb_mean = dummy; g.nb_rstd = dummy; g.nb_scale = dummy; g.nb_shift = dummy; g.nb_act = OGMM_ACT_RELU;
+    return ogmm::gemm_f16x3_v10_applicable(g) ? 1 : 0;
+}
+
+// Would ogmm_gemm_nt take a transposed A operand (ogmm_gemm.a_trans) for `batch` products of M x N over K with row pitch lda of the [K][M] map?  (1 / 0)
+extern "C" int ogmm_gemm_atrans_supported(int M, int N, int K, int64_t lda, int batch) {
+    if (M <= 0 || N <= 0 || K <= 0 || lda < M || batch <= 0) return 0;
+    static float dummy[4];
+    ogmm_gemm g = {};
+    g.A = dummy; g.lda = lda; g.K1 = K; g.M = M; g.N = N; g.batch_outer = batch; g.batch_inner = 1; g.precision = OGMM_PREC_F16X3_FRAG;
+    g.ldb_h = (K + 63) / 64 * 64; g.B_hi = dummy; g.B_lo = dummy; g.C = dummy; g.a_trans = 1;
     return ogmm::gemm_f16x3_v10_applicable(g) ? 1 : 0;
 }
 

@@ -40,9 +40,18 @@ __device__ unsigned long long g_v10_probe[4];
 //   1  hi*hi: BOTH operands rounded to binary16 (11 significand bits); no lo term is formed at all.  Four matrix instructions per group: the raw
 //      activation fragments are read in gap 3 of a half step's first group, converted (v_cvt_pk_f16_f32 only) in gap 3 of its second and third.
 //      With a third of the matrix work the loop is bound by its operand DMA (48 KiB per step and CU).
-template <int ABL, bool AFF, bool OVL, int TERMS = 3, bool NBS = false>
+// TA: the A operand is read TRANSPOSED (struct ogmm_gemm.a_trans): A[m][k] = A_mem[k * lda + m], the weight gradient's dY^T without the transposed copy.
+//   A wave's stage is then [32 k][64 m] fp32 = the same 8 KiB from the same 8 DMA instructions, each fetching 4 k-rows x 256 B; lane l of instruction i
+//   fetches row 4 i + (l >> 4), 16-byte chunk (l & 15) ^ (8 * ((i >> 1) & 1)), so that element (k, m) lies at byte k * 256 + ((m / 4) ^ (8 * ((k >> 3) & 1))) * 16
+//   + (m % 4) * 4.  Lane (lr, lh) of the MFMA's A operand holds k = 16 s + 8 lh + e, e = 0..7, of row m = 32 rb + lr: eight dwords 256 B apart = four
+//   ds_read2st64_b32 (offsets 16 s + e, + 1 in units of 256 B) from lane base lh * 2048 + (((rb ^ lh) * 8 + lr / 4) * 16) + (lr % 4) * 4 -- the chunk swizzle
+//   puts the two lane halves on disjoint banks.  Same k order, same split, same products: bit-identical to the plain form on a transposed copy.
+//   TA = 2: the same, and the column sums of A_mem (sum over k of A[m][k] = the bias gradient dy.sum(0)) ride along: every lane adds the eight raw values of
+//   each fragment it reads (fp32 tree of 8, then fp64) in gaps the split leaves free; the n-tile-0 workgroups add them to a_colsum[m] (fp64 atomics).
+template <int ABL, bool AFF, bool OVL, int TERMS = 3, bool NBS = false, int TA = 0>
 __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
     static_assert(TERMS == 3 || ((TERMS == 2 || TERMS == 1) && !AFF), "TERMS < 3 has no InstanceNorm-on-A form (its transform pieces need the gaps of 12 MFMAs)");
+    static_assert(!TA || (!AFF && !OVL && !NBS && TERMS == 3), "the transposed-A form exists for the plain three-term product only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
 
     const int bid = blockIdx.x;
@@ -72,11 +81,19 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     // A rows gathered on the fly (ogmm_gemm.a_gather_ids): output row m = c S + s reads source row map(c) N + ids[map(c)][s]; the DMA's per-lane row
     // offsets then come from the index list, relative to A itself instead of the tile's first row
     const bool gathered = g.a_gather_ids != nullptr;
-    const float* __restrict__ A1p = g.A + zb * g.sA_o + (gathered ? 0 : (int64_t)m0 * g.lda);
+    const float* __restrict__ A1p = g.A + zb * g.sA_o + (TA ? (int64_t)m0 : (gathered ? 0 : (int64_t)m0 * g.lda));
     const float* __restrict__ A2p = g.A2 ? g.A2 + zb * g.sA2_o + (int64_t)m0 * g.lda2 : nullptr;
     const unsigned lds0 = (unsigned)(size_t)smem10;
     unsigned aoff[8];
     auto set_aoff = [&](int ld) {
+        if (TA) {          // k-row 4 i + (lane >> 4) of the stage, columns m0 + 64 wave + 4 chunk .. + 3 (clamped to the last whole quad of M: never stored)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int col = min(wave * 64 + (((lane & 15) ^ (((i >> 1) & 1) * 8)) << 2), g.M - 4 - m0);
+                aoff[i] = (unsigned)((i * 4 + (lane >> 4)) * ld + col) * 4u;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = wave * 64 + i * 8 + (lane >> 3);
@@ -99,7 +116,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     auto issue_a_piece = [&](int t, int i) {
         const bool second = t >= nk1;
         if (i == 0 && t == nk1 && nk2 > 0) set_aoff((int)g.lda2);          // stages are issued in order and piece 0 first: switch to the second A piece once
-        const float* Ap = second ? A2p + (t - nk1) * BK8 : A1p + t * BK8;
+        const float* Ap = TA ? A1p + (int64_t)t * BK8 * g.lda : (second ? A2p + (t - nk1) * BK8 : A1p + t * BK8);
         lds_dma16(aoff[i], Ap, lds0 + (t % A_STAGES) * A_STAGE + wave * 8192 + i * 1024);
     };
     auto issue_b_piece = [&](int t, int i) {
@@ -130,7 +147,17 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     f16x8 bh[2][2], bl[2][2];                      // [group parity][column block of the pair]
     f32x4 rsc[2], rsh[2];                          // AFF: the 8 scales / shifts of the fragment's k positions
     const float aff_lo = (AFF && g.a_relu) ? 0.0f : -__builtin_inff();
+    const int ta_rd = wave * 8192 + lh * 2048 + ((lr >> 2) << 4) + ((lr & 3) << 2);
     auto read_a = [&](int tau, int s, int rb) {          // raw fp32 fragment of row block rb, k16 block s of stage tau
+        if (TA) {
+            const unsigned char* As = smem10 + (tau % A_STAGES) * A_STAGE + ta_rd + ((rb ^ lh) << 7) + s * 4096;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ra[rb][0][e] = *reinterpret_cast<const float*>(As + e * 256);
+                ra[rb][1][e] = *reinterpret_cast<const float*>(As + (4 + e) * 256);
+            }
+            return;
+        }
         const unsigned char* As = smem10 + (tau % A_STAGES) * A_STAGE + a_rd + rb * 4096;
         ra[rb][0] = *reinterpret_cast<const f32x4*>(As + (a_c0 ^ (s * 64)));
         ra[rb][1] = *reinterpret_cast<const f32x4*>(As + (a_c1 ^ (s * 64)));
@@ -179,6 +206,15 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
             else piece_split(s, (pi - 16) & 3, (pi - 16) >> 2);
         } else piece_split(s, pi & 3, pi >> 2);
     };
+    // TA = 2: column sums of the raw fragments, in pieces of <= 3 vector instructions (gaps m = 8..11 of the groups whose gaps m = 4..7 hold the split)
+    constexpr bool CS = TA == 2;
+    float cs_a[4];
+    double cs_acc[2] = {0.0, 0.0};
+    auto cs_piece = [&](int gl, int j) {
+        if (gl == 1) { const f32x4 v = ra[j >> 1][j & 1]; cs_a[j] = (v[0] + v[1]) + (v[2] + v[3]); }
+        else if (gl == 2) { if (j < 2) cs_a[2 * j] += cs_a[2 * j + 1]; }
+        else if (j < 2) cs_acc[j] += (double)cs_a[2 * j];
+    };
     auto read_b = [&](int tau, int grp, int c) {          // MFMA group grp = k16 block grp >> 2, column blocks 2q, 2q+1 with q = grp & 3
         const unsigned char* Bs = smem10 + B_OFF + (tau % B_STAGES) * B_STAGE + b_rd;
         const int s = grp >> 2, q = grp & 3;
@@ -212,6 +248,12 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
     read_b(0, 0, 1);
 #pragma unroll
     for (int pi = 0; pi < (AFF ? 28 : (TERMS == 1 ? 4 : 12)); ++pi) piece(0, pi);
+    if (CS) {
+#pragma unroll
+        for (int gl = 1; gl < 4; ++gl)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs_piece(gl, j);
+    }
 
     // One K step = 8 MFMA groups of 12: k16 block s = grp >> 2 against the column-block pair q = grp & 3, for both row blocks; MFMA m of a group is
     // product m >> 2 (lo*hi, hi*lo, hi*hi), row block (m >> 1) & 1, column block m & 1 -- per accumulator the same order as v8.  What the wave issues
@@ -288,6 +330,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                         if (gl == 0 && m >= 8) piece(sn, m - 8);
                         if (gl > 0 && m >= 4) piece(sn, 4 + (gl - 1) * 8 + (m - 4));
                     } else if (gl > 0 && m >= 4 && m < 8) piece(sn, (gl - 1) * 4 + (m - 4));
+                    if (CS && gl > 0 && m >= 8) cs_piece(gl, m - 8);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -312,6 +355,17 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) { chk = fmaf(acc0[0][r], 0.0f, chk); chk = fmaf(acc1[0][r], 0.0f, chk); }
         if (chk != chk) atomicOr(g.overflow, 1);
+    }
+    if constexpr (CS) {
+        if (tile_n == 0) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                double v = cs_acc[rb];
+                v += __shfl_xor(v, 32, 64);
+                const int mcol = m0 + wave * 64 + rb * 32 + lr;
+                if (lh == 0 && mcol < g.M) atomicAdd(g.a_colsum + mcol, v);
+            }
+        }
     }
     __builtin_amdgcn_s_barrier();          // every wave is done with the last stage: LDS becomes the epilogue's scratch
     if (ABL & 8) {          // ablation: no output stores
@@ -440,21 +494,23 @@ bool gemm_f16x3_v10_applicable(const ogmm_gemm& g) {
     const bool nb_ok = !g.nb_mean || (whole_tiles && g.nb_rstd && g.nb_scale && g.nb_shift && g.col_stats && g.Res && g.C && !g.a_scale && !g.ovl_rowpart && !g.a_gather_ids &&
                                       g.group_rows > 0 && g.group_rows % BM == 0 && g.batch_outer * g.batch_inner == 1 && g.N >= 512 &&
                                       (g.nb_act == OGMM_ACT_RELU || g.nb_act == OGMM_ACT_LEAKY02));
-    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok && nb_ok &&
+    const bool ta_ok = !g.a_trans || (g.K2 == 0 && !g.a_scale && !g.a_gather_ids && !g.ovl_rowpart && !g.nb_mean && g.M % 4 == 0 && g.M >= 4 && (g.terms == 0 || g.terms == 3) &&
+                                      (int64_t)BK8 * g.lda * 4 + 1024 < (1ll << 31));
+    return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok && nb_ok && ta_ok &&
            (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
            (g.K2 == 0 || g.K1 % 64 == 0) && (g.K1 + 63) / 64 * 64 + (g.K2 + 63) / 64 * 64 <= g.ldb_h && (g.lda % 4) == 0 && (g.K2 == 0 || (g.lda2 % 4) == 0);
 }
 
-template <int ABL, bool AFF = false, bool OVL = false, int TERMS = 3, bool NBS = false>
+template <int ABL, bool AFF = false, bool OVL = false, int TERMS = 3, bool NBS = false, int TA = 0>
 static int launch_v10(const ogmm_gemm& g, hipStream_t s) {
     const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     static ogmm::PerDeviceOnce attr_once;          // per template instance and device
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS, TA>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (AFF ? 32768 : 0));
     if (m_tiles % 8 != 0 && m_tiles < 32)
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS, TA>), dim3((unsigned)(m_tiles * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, -m_tiles, n_tiles);
     else
-        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
+        hipLaunchKernelGGL((gemm_f16x3_v10_kernel<ABL, AFF, OVL, TERMS, NBS, TA>), dim3((unsigned)(m_tiles8 * n_tiles), 1, (unsigned)g.batch_outer), dim3(T), LDS_BYTES + (AFF ? 32768 : 0), s, g, m_tiles, n_tiles);
     return check_launch("ogmm_gemm_nt(f16x3 v10)");
 }
 
@@ -490,6 +546,7 @@ int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
         default:
             if (g.ovl_rowpart) return g.terms == 1 ? launch_v10<0, false, true, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, true, 2>(g, s) : launch_v10<0, false, true>(g, s);
             if (g.nb_mean) return launch_v10<0, false, false, 3, true>(g, s);          // normalisation-backward fusion (training): its own instantiation
+            if (g.a_trans) return g.a_colsum ? launch_v10<0, false, false, 3, false, 2>(g, s) : launch_v10<0, false, false, 3, false, 1>(g, s);   // transposed A (training: the weight gradient's dY^T read as dY lies)
             if (g.a_scale) return launch_v10<0, true>(g, s);          // (the InstanceNorm-on-A form has no reduced variant: terms is a permission, not an order)
             return g.terms == 1 ? launch_v10<0, false, false, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, false, 2>(g, s) : launch_v10<0>(g, s);
     }

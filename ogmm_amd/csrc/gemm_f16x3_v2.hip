@@ -265,6 +265,10 @@ int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s) {
         OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && g.N >= 512 && gemm_f16x3_v10_applicable(g), "ogmm_gemm_nt: gathered A rows need the fragment-major fp16x3 engine, N >= 512, one A piece (ogmm_gemm_gather_fusable)");
         return gemm_nt_f16x3_v10(g, s);
     }
+    if (g.a_trans) {
+        OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && gemm_f16x3_v10_applicable(g), "ogmm_gemm_nt: a transposed A operand (a_trans) needs the fragment-major fp16x3 engine: one A piece, K %% 32 == 0, M %% 4 == 0, N >= 256, >= 256 tiles (ogmm_gemm_atrans_supported)");
+        return gemm_nt_f16x3_v10(g, s);
+    }
     if (g.nb_mean) {
         OGMM_REQUIRE(g.precision == OGMM_PREC_F16X3_FRAG && g.N >= 512 && gemm_f16x3_v10_applicable(g), "ogmm_gemm_nt: the normalisation-backward fusion needs the fragment-major fp16x3 engine on whole 256 x 256 tiles, N >= 512, col_stats, Res = x, group_rows %% 256 == 0 (ogmm_gemm_normbwd_fusable)");
         return gemm_nt_f16x3_v10(g, s);

@@ -211,7 +211,7 @@ def split_f16_training(W, cout, **kw):
 def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scale=None, shift=None, row_affine=False,
             alpha=1.0, act=ACT_NONE, res=None, ldr=0, batch=(1, 1), sA=(0, 0), sA2=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
             pool_k=0, pool_out=None, ldp=0, store_c=True, split=None, overflow=None, col_stats=None, a_affine=None, group_rows=0,
-            overlap=None, row_rscale=None, head=None, a_gather=None, single_term=False, terms=0, norm_bwd=None):
+            overlap=None, row_rscale=None, head=None, a_gather=None, single_term=False, terms=0, norm_bwd=None, a_trans=False, a_colsum=None):
     """Raw descriptor call; A, B, ... are tensors (only their data_ptr is used) -- see `struct ogmm_gemm`.
     split = dict from split_f16(B) selects the fp16x3 engine (B itself may then be None)."""
     d = GemmDesc()
@@ -243,6 +243,10 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     d.act = act
     d.pool_k, d.pool_out, d.ldp, d.store_c = pool_k, (pool_out.data_ptr() if pool_out is not None else None), ldp, 1 if store_c else 0
     d.group_rows = group_rows
+    d.a_trans = 1 if a_trans else 0          # A_mem is [K][M] row-major (struct ogmm_gemm.a_trans): the weight gradient's dY read as it lies
+    if a_colsum is not None:                 # float64 [M], zeroed by the caller: += the column sums of A_mem (struct ogmm_gemm.a_colsum)
+        assert a_trans and a_colsum.dtype == torch.float64 and a_colsum.is_contiguous() and a_colsum.numel() == M
+        d.a_colsum = a_colsum.data_ptr()
     d.terms = terms          # per-layer term budget (struct ogmm_gemm.terms): 2 = the weight operand rounded to binary16 where the engine has the form
     if col_stats is not None:          # [G, N, 2] or, spread over 2^n copies that the caller sums, [2^n, G, N, 2] (struct ogmm_gemm.col_stats_slot_mask)
         d.col_stats = col_stats.data_ptr()
@@ -804,6 +808,9 @@ def maxpool_k_bwd(dout, arg, k):
     return dh
 
 
+DW_TRANSPOSED_A = os.environ.get("OGMM_DW_TRANSPOSED_A", "1") != "0"      # 0: materialise dY^T (ogmm_transpose_pad) as rounds 1-3 did (A/B timing, bit-identical)
+
+
 def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=None, keep_parts=False, out_scale=None, parts_out=None):
     """dW = dY^T [x_0 | x_1 | ...] on the fp16x3 engine: dy [R, n], xs = list of [R, k_i] (last stride 1) -> [n, sum k_i].
     x_affine (one x only): (scale [G, k], shift [G, k], relu, group_rows) -- x is a pre-normalisation map, X = relu(x * scale + shift).
@@ -822,9 +829,18 @@ def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=N
         chunk = chunk_rows
     S = (R + chunk - 1) // chunk
     pitch = chunk + 64
-    dyt = torch.empty((S, n, pitch), dtype=torch.float32, device=dy.device)
-    csum = torch.empty((16, n), dtype=torch.float64, device=dy.device) if colsum else None
-    _lib.call("ogmm_transpose_pad", _p(_f32(dy, "dy")), dy.stride(0), R, n, chunk, pitch, S, _p(dyt), _p(csum), 16, _stream())
+    # round 4: the engine reads dY as it lies (struct ogmm_gemm.a_trans: transposing fragment reads) where every chunk is whole and the shapes fit its
+    # 256 x 256 tiles; the bias gradient's column sums then ride on the engine's own operand fragments (struct ogmm_gemm.a_colsum) instead of the transposed copy
+    ldy = dy.stride(0)
+    direct = (DW_TRANSPOSED_A and R % chunk == 0 and chunk % 32 == 0 and ldy % 4 == 0 and dy.data_ptr() % 16 == 0 and
+              all(_lib.load().ogmm_gemm_atrans_supported(n, x.shape[1], chunk, ldy, S) for x in xs))
+    csum = None
+    if direct:
+        csum = torch.zeros(n, dtype=torch.float64, device=dy.device) if colsum else None
+    else:
+        dyt = torch.empty((S, n, pitch), dtype=torch.float32, device=dy.device)
+        csum = torch.empty((16, n), dtype=torch.float64, device=dy.device) if colsum else None
+        _lib.call("ogmm_transpose_pad", _p(_f32(dy, "dy")), dy.stride(0), R, n, chunk, pitch, S, _p(dyt), _p(csum), 16, _stream())
     outs = []
     for x in xs:
         assert x.stride(1) == 1 and x.shape[0] == R
@@ -839,13 +855,19 @@ def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=N
         part = torch.empty((S, n, k), dtype=torch.float32, device=dy.device) if parts_out is None else parts_out
         assert tuple(part.shape) == (S, n, k) and part.is_contiguous()
         split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
-        gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow,
-                scale=out_scale)          # (out_scale [k]: a per-column factor on the products, e.g. the inverse of a power of two dy was scaled by)
+        if direct:
+            gemm_nt(dy, ldy, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(chunk * ldy, 0), sC=(n * k, 0), split=split, overflow=overflow,
+                    scale=out_scale, a_trans=True, a_colsum=csum if x is xs[0] else None)
+        else:
+            gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow,
+                    scale=out_scale)          # (out_scale [k]: a per-column factor on the products, e.g. the inverse of a power of two dy was scaled by)
         if keep_parts:
             return part
         outs.append(part.sum(dim=0) if S > 1 else part[0])
     dW = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
-    return (dW, csum.sum(dim=0).float()) if colsum else dW
+    if colsum:
+        return dW, (csum.float() if direct else csum.sum(dim=0).float())
+    return dW
 
 
 def batched_a_times_x(A, x, overflow=None, out_scale=None, out=None):

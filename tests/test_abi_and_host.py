@@ -134,8 +134,11 @@ def test_hot_kernels_do_not_spill():
     rows = kr.main()
     # (the fused-head instantiation <0, false, true> spills in its four-way epilogue only -- behind the K loop -- and is not in this list)
     hot = ["gemm_f16x3_v8_kernel<0, false, false, 3>", "gemm_f16x3_v8_kernel<0, false, false, 2>", "gemm_f16x3_v8_kernel<0, true, false, 3>",
-           "gemm_f16x3_v10_kernel<0, false, false, 3, false>", "gemm_f16x3_v10_kernel<0, false, false, 2, false>", "gemm_f16x3_v10_kernel<0, true, false, 3, false>",
-           "gemm_f16x3_v10_kernel<0, false, false, 3, true>",          # (the normalisation-backward epilogue of the training step: its own instantiation)
+           "gemm_f16x3_v10_kernel<0, false, false, 3, false, 0>", "gemm_f16x3_v10_kernel<0, false, false, 2, false, 0>",
+           "gemm_f16x3_v10_kernel<0, true, false, 3, false, 0>",
+           "gemm_f16x3_v10_kernel<0, false, false, 3, true, 0>",          # (the normalisation-backward epilogue of the training step: its own instantiation)
+           "gemm_f16x3_v10_kernel<0, false, false, 3, false, 1>",         # (the transposed-A form of the weight gradient, and with the bias gradient's column sums)
+           "gemm_f16x3_v10_kernel<0, false, false, 3, false, 2>",
            "edgeconv_fused_kernel<20, false>",
            "attention_t_kernelILi4ELb1E",
            "knn_kernel<21>", "knn2_kernel<21>", "gmm_em_cached_kernel<16, true>"]

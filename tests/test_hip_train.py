@@ -186,6 +186,40 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
         assert _rel(a, r) < 2e-5, (i_, _rel(a, r))
 
 
+@pytest.mark.parametrize("R,n,k,ldy,affine", [(65536, 512, 512, 512, False), (32768, 1024, 256, 1024, False), (131072, 256, 1024, 256, False),
+                                              (65536, 512, 512, 1024, False), (65536, 1024, 512, 1024, True), (36864, 512, 768, 512, False)])
+def test_weight_gradient_reads_dy_as_it_lies_and_equals_the_transposed_copy_bit_for_bit(R, n, k, ldy, affine, monkeypatch):
+    """struct ogmm_gemm.a_trans (round 4): dW = dY^T X with the engine's transposing fragment reads on dY itself against the same products on the
+    materialised dY^T of rounds 1-3 -- same k order, same split, same accumulation: torch.equal -- and both against fp64; dy as a column slice of a wider
+    map (ldy > n), the affine + ReLU read of X, the bias gradient from the separate column-sum pass."""
+    ops = __import__("ogmm_amd.ops", fromlist=["x"])
+    from ogmm_amd import _lib
+    g = torch.Generator().manual_seed(R + n)
+    wide = torch.randn(R, ldy, generator=g).to(DEV)
+    dy = wide[:, ldy - n:] if ldy > n else wide
+    x = torch.randn(R, k, generator=g).to(DEV)
+    aff = None
+    X = x.double()
+    if affine:
+        G = R // 1024
+        sc, sh = (torch.rand(G, k, generator=g) + 0.5).to(DEV), (torch.rand(G, k, generator=g) - 0.5).to(DEV)
+        aff = (sc, sh, True, 1024)
+        X = torch.relu(x.double().view(G, 1024, k) * sc.double()[:, None] + sh.double()[:, None]).view(R, k)
+    monkeypatch.setattr(ops, "DW_TRANSPOSED_A", True)
+    tiles = (n // 256) * (k // 256)
+    S = max(1, min((512 + tiles - 1) // tiles, R // 256))
+    chunk = ((R + S - 1) // S + 63) // 64 * 64
+    if R % chunk == 0:          # (else the direct form must not be taken: the copy's zero padding is what makes a ragged last chunk legal)
+        assert _lib.load().ogmm_gemm_atrans_supported(n, k, chunk, ldy, R // chunk) == 1
+    dW, db = ops.weight_grad(dy, [x], x_affine=aff, colsum=True)
+    monkeypatch.setattr(ops, "DW_TRANSPOSED_A", False)
+    dW0, db0 = ops.weight_grad(dy, [x], x_affine=aff, colsum=True)
+    assert torch.equal(dW, dW0)
+    want = dy.double().t() @ X
+    assert _rel(dW, want) < 2e-6, _rel(dW, want)
+    assert _rel(db, dy.double().sum(0)) < 1e-6 and _rel(db0, dy.double().sum(0)) < 1e-6
+
+
 @pytest.mark.parametrize("B,N,D", [(3, 256, 128), (1, 1024, 512), (20, 512, 256), (36, 1024, 512)])
 def test_batched_products_of_the_overlap_backward_against_fp64(B, N, D):
     """ops.batched_a_times_x (A[b] x[b]) and ops.weight_grad(chunk_rows = N, keep_parts = True) (A[b]^T x[b]) -- the two engine forms behind the overlap
