@@ -362,7 +362,15 @@ int ogmm_icp_point_to_point_ws(const float* src, const float* tgt, int B, int N,
  *   ogmm_norm_bwd_reduce: sums[g][c] = {sum dz, sum dz * xhat}, dz = dy * act'(x*scale + shift), xhat = (x - mean) * rstd  (fp64, zeroed by the call)
  *   ogmm_norm_bwd_apply:  dx = scale * (dz - sums0/n - xhat * sums1/n),  n = group_rows
  * (the activation derivative is taken from the recomputed pre-activation, so the stored output is not re-read)
- * The host turns stats into mean / rstd / scale = gamma*rstd / shift = beta - mean*scale and sums into dgamma, dbeta. */
+ *   ogmm_norm_finalize:   stats -> mean = s0/n, var = max(s1/n - mean^2, 0), rstd = 1/sqrt(var + eps), scale = gamma*rstd, shift = beta - mean*scale
+ *                         (fp64, the float outputs rounded once; gamma / beta [cols] may be NULL; every output is [G][cols]) in one launch
+ * The host turns sums into dgamma, dbeta. */
+int ogmm_norm_finalize(const double* stats /*[G][cols][2]*/, int64_t groups, int cols, int64_t group_rows, double eps, const float* gamma, const float* beta,
+                       float* scale, float* shift, float* mean, float* rstd, double* mean64, double* var64, void* stream);
+/* BatchNorm running statistics after G sequential train-mode calls of the shared layer (torch.nn.BatchNorm1d: running = (1 - momentum) running + momentum batch,
+ * variance unbiased by n / (n - 1), n = group_rows; num_batches += G, may be NULL): mean64 / var64 [G][cols] as ogmm_norm_finalize leaves them */
+int ogmm_bn_update_running(const double* mean64, const double* var64, int groups, int cols, int64_t group_rows, float momentum, float* running_mean,
+                           float* running_var, int64_t* num_batches, void* stream);
 int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, double* stats /*[G][cols][2]*/, void* stream);
 int ogmm_affine_act(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, const float* scale /*[G][cols]*/,
                     const float* shift, int act, float* y, int64_t ldy, void* stream);
@@ -448,6 +456,13 @@ int ogmm_nearest_point(const float* xyz, const float* mu /*[C][J][3]*/, int C, i
  * inv_out[0 .. inv_len) = 2^-e (handed to ogmm_gemm_nt as its per-column `scale`).  The training step splits its weights every step
  * (train_ops._Linear): no host synchronisation, no cached exponent that could go stale. */
 int ogmm_pow2_scale(const float* W, int64_t count, int top, float* scale_out, float* inv_out, int inv_len, void* stream);
+/* The same scale (top = 10) AND the OGMM_PREC_F16X3_FRAG image of 2^e W in two launches (round 4: the step re-splits ~120 weights, each was 4-14 small launches):
+ * W [rows][cols] contiguous fp32 (ld == cols); transpose = 0: B = W (N = rows; K = cols as the two pieces k1 | cols - k1 of struct ogmm_gemm, each padded with zeros
+ * to a multiple of 64; k1 <= 0: one piece), transpose = 1: B = W^T (N = cols, K = rows: the operand of dX = dY W, without a transposed copy).  The image has n_pad
+ * (%% 32 == 0, >= N; rows beyond N are zero) rows and ldb_h = padded K columns.  scratch4: four floats, ZERO on entry; on exit [0] = 2^e and [2], [3] are zero again,
+ * so a pool of slots can be reused call after call.  inv_out[0 .. inv_len) = 2^-e. */
+int ogmm_split_weight(const float* W, int64_t ld, int rows, int cols, int transpose, int k1, float* scratch4, float* inv_out, int inv_len, void* hi, void* lo,
+                      int64_t ldb_h, int n_pad, void* stream);
 
 /* ---- T6: constants of the input that feed trainable thin layers, un-fused for training:
  *   ogmm_edge_features: out[(c*N+i)*k + j][0..5] = (x_j - x_i, x_i), j over idx[c][i][:]          (lib/utils.py:47-66)

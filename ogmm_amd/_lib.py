@@ -101,6 +101,8 @@ PROTOTYPES = {
     "ogmm_icp_point_to_point_ws": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_double, c_double,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     # training mode
+    "ogmm_norm_finalize": [c_void_p, c_int64, c_int, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogmm_bn_update_running": [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_colstats": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p],
     "ogmm_affine_act": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_norm_bwd_reduce": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int64,
@@ -125,6 +127,7 @@ PROTOTYPES = {
     "ogmm_debug_edgeconv_probe": [c_void_p],
     "ogmm_debug_edgeconv_pc_probe": [c_void_p],
     "ogmm_transpose_pad": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "ogmm_split_weight": [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "ogmm_pack_frag_t": [c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                          c_void_p],
 }

@@ -72,6 +72,8 @@ __global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __res
 
 }  // namespace
 
+extern "C" int ogmm_pow2_scale(const float* W, int64_t count, int top, float* scale_out, float* inv_out, int inv_len, void* stream);
+
 namespace {
 // Power-of-two scale of a weight for the binary16 split (ops.split_f16): 2^e with max|W| 2^e in [2^top, 2^(top+1)), e clamped to +-24; one workgroup scans
 // the weight (<= a few MB: ~10 us), writes 2^e and fills a vector with 2^-e that the GEMM takes as its per-column scale (struct ogmm_gemm.scale).  No
@@ -102,10 +104,74 @@ __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict
     int e = 0;
     if (mx > 0.0f && mx < __builtin_inff()) e = min(24, max(-24, top - (int)floorf(log2f(mx))));
     const float sc = exp2f((float)e), inv = exp2f((float)-e);
-    if (threadIdx.x == 0) scale_out[0] = sc;
+    if (threadIdx.x == 0) {
+        scale_out[0] = sc;
+        // leave the reduction's scratch as it was found (zero): a caller may hand the same four floats to the next call (ogmm_split_weight's slot pool)
+        __hip_atomic_store(reinterpret_cast<int*>(scale_out + 2), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<int*>(scale_out + 3), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int i = threadIdx.x; i < inv_len; i += 256) inv_out[i] = inv;
 }
+
+// The OGMM_PREC_F16X3_FRAG image of sc * W (or of sc * W^T) for a weight that changes every step, sc = *scale a device scalar (a power of two: the product
+// is exact).  Image entry ((nb * (Kp / 16) + kb) * 64 + lane) holds B[nb * 32 + (lane & 31)][kb * 16 + (lane >> 5) * 8 + j], j = 0..7, with
+// B[n][k] = W[n][src(k)] (TRANSPOSE: W[src(k)][n]); src maps the image's K axis -- piece one [0, k1) at 0, piece two [k1, K) at k1p, both padded with
+// zeros to multiples of 64 (struct ogmm_gemm: K1 | K2) -- onto the weight's columns; rows n >= N are zero.
+using f16x8w = __attribute__((ext_vector_type(8))) _Float16;
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int64_t ld, int N, int K, int k1, int k1p, int Kp, int64_t total,
+                                                           const float* __restrict__ scale, f16x8w* __restrict__ hi, f16x8w* __restrict__ lo) {
+    const int64_t gI = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gI >= total) return;
+    const float sc = *scale;
+    const int lane = (int)(gI & 63);
+    const int64_t blk = gI >> 6;
+    const int kb = (int)(blk % (Kp / 16)), nb = (int)(blk / (Kp / 16));
+    const int n = nb * 32 + (lane & 31), kk0 = kb * 16 + (lane >> 5) * 8;
+    f16x8w h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n < N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = kk0 + j;
+            const int k = kk < k1p ? (kk < k1 ? kk : -1) : (kk - k1p + k1 < K ? kk - k1p + k1 : -1);
+            float v = 0.0f;
+            if (k >= 0) v = TRANSPOSE ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k];
+            const float x = __builtin_amdgcn_fmed3f(v * sc, -65504.0f, 65504.0f);
+            const _Float16 hh = (_Float16)x;
+            h[j] = hh;
+            l[j] = (_Float16)(x - (float)hh);
+        }
+    }
+    hi[gI] = h;
+    lo[gI] = l;
+}
 }  // namespace
+
+// Power-of-two scale (as ogmm_pow2_scale, top = 10) and split fragment image of a per-step weight in two launches.  W [rows][ld] fp32; transpose = 0: the
+// image of W (N = rows, K = cols in the two-piece layout k1 | cols - k1, each padded to 64: Kp = ldb_h), 1: the image of W^T (N = cols, K = rows, one
+// piece).  n_pad (a multiple of 32) = rows of the image.  scratch4: four floats, ZERO on entry; on exit [0] = the scale, [2], [3] zero again.
+extern "C" int ogmm_split_weight(const float* W, int64_t ld, int rows, int cols, int transpose, int k1, float* scratch4, float* inv_out, int inv_len, void* hi,
+                                 void* lo, int64_t ldb_h, int n_pad, void* stream) {
+    OGMM_REQUIRE(W && scratch4 && inv_out && hi && lo && rows > 0 && cols > 0 && ld >= cols && inv_len > 0 && n_pad % 32 == 0 && ldb_h % 64 == 0,
+                 "ogmm_split_weight: null pointer, empty shape, or n_pad %% 32 / ldb_h %% 64 != 0");
+    OGMM_REQUIRE(ogmm::aligned16(hi) && ogmm::aligned16(lo), "ogmm_split_weight: images must be 16-byte aligned");
+    const int N = transpose ? cols : rows, K = transpose ? rows : cols;
+    if (transpose || k1 <= 0 || k1 > K) k1 = K;
+    const int k1p = (k1 + 63) / 64 * 64, k2p = (K - k1 + 63) / 64 * 64;
+    OGMM_REQUIRE(n_pad >= N && ldb_h == k1p + k2p, "ogmm_split_weight: n_pad < N or ldb_h != padded K (%d + %d)", k1p, k2p);
+    OGMM_REQUIRE(ld == cols, "ogmm_split_weight: the scale scan reads W as one contiguous block (ld == cols)");
+    int rc = ogmm_pow2_scale(W, (int64_t)rows * cols, 10, scratch4, inv_out, inv_len, stream);
+    if (rc) return rc;
+    const int64_t total = (int64_t)(n_pad / 32) * (ldb_h / 16) * 64;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (transpose)
+        hipLaunchKernelGGL(split_weight_kernel<true>, dim3(blocks), dim3(256), 0, ogmm::as_stream(stream), W, ld, N, K, k1, k1p, (int)ldb_h, total, scratch4,
+                           reinterpret_cast<f16x8w*>(hi), reinterpret_cast<f16x8w*>(lo));
+    else
+        hipLaunchKernelGGL(split_weight_kernel<false>, dim3(blocks), dim3(256), 0, ogmm::as_stream(stream), W, ld, N, K, k1, k1p, (int)ldb_h, total, scratch4,
+                           reinterpret_cast<f16x8w*>(hi), reinterpret_cast<f16x8w*>(lo));
+    return ogmm::check_launch("ogmm_split_weight");
+}
 
 extern "C" int ogmm_pow2_scale(const float* W, int64_t count, int top, float* scale_out, float* inv_out, int inv_len, void* stream) {
     OGMM_REQUIRE(W && scale_out && inv_out && count > 0 && inv_len > 0 && top >= 0 && top <= 14, "ogmm_pow2_scale: bad arguments");

@@ -401,6 +401,61 @@ static bool vec_ok(const void* p, int64_t ld, int cols) { return cols % 4 == 0 &
         default: { constexpr int CV = 64; CALL; } break; \
     }
 
+// stats -> the constants of one normalisation layer, in one launch (round 4: the host-side tensor expressions were ~17 small launches per layer and step):
+// mean = s0 / n, var = max(s1 / n - mean^2, 0) (biased), rstd = 1 / sqrt(var + eps), scale = rstd * gamma, shift = beta - mean * scale -- all in fp64, the
+// float outputs rounded once.
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const double* __restrict__ stats, int64_t total, int cols, double n, double eps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
+                                                            float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            double* __restrict__ mean64, double* __restrict__ var64) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cols);
+    const double m = stats[2 * i] / n;
+    const double v = fmax(stats[2 * i + 1] / n - m * m, 0.0);
+    const double r = 1.0 / sqrt(v + eps);
+    const double sc = gamma ? r * (double)gamma[c] : r;
+    const double sh = beta ? (double)beta[c] - m * sc : -m * sc;
+    scale[i] = (float)sc; shift[i] = (float)sh; mean[i] = (float)m; rstd[i] = (float)r;
+    mean64[i] = m; var64[i] = v;
+}
+
+int ogmm_norm_finalize(const double* stats, int64_t groups, int cols, int64_t group_rows, double eps, const float* gamma, const float* beta, float* scale,
+                       float* shift, float* mean, float* rstd, double* mean64, double* var64, void* stream) {
+    OGMM_REQUIRE(stats && scale && shift && mean && rstd && mean64 && var64 && groups > 0 && cols > 0 && group_rows > 0, "ogmm_norm_finalize: null pointer or empty shape");
+    const int64_t total = groups * cols;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), stats, total, cols, (double)group_rows, eps,
+                       gamma, beta, scale, shift, mean, rstd, mean64, var64);
+    return check_launch("ogmm_norm_finalize");
+}
+
+// BatchNorm's running statistics after a train-mode forward over G sequential calls of the shared layer (torch.nn.BatchNorm1d semantics, momentum 0.1:
+// running = (1 - momentum) running + momentum batch, the variance unbiased by n / (n - 1)), one launch for all groups and both buffers
+__global__ __launch_bounds__(256) void bn_update_running_kernel(const double* __restrict__ mean64, const double* __restrict__ var64, int groups, int cols, double unbias,
+                                                                float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                int64_t* __restrict__ num_batches) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += groups;
+    if (c >= cols) return;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int g = 0; g < groups; ++g) {
+        const float m = (float)mean64[(int64_t)g * cols + c], v = (float)(var64[(int64_t)g * cols + c] * unbias);
+        rm = add_rn(mul_rn(rm, 1.0f - momentum), mul_rn(momentum, m));
+        rv = add_rn(mul_rn(rv, 1.0f - momentum), mul_rn(momentum, v));
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+}
+
+int ogmm_bn_update_running(const double* mean64, const double* var64, int groups, int cols, int64_t group_rows, float momentum, float* running_mean,
+                           float* running_var, int64_t* num_batches, void* stream) {
+    OGMM_REQUIRE(mean64 && var64 && running_mean && running_var && groups > 0 && cols > 0 && group_rows > 0, "ogmm_bn_update_running: null pointer or empty shape");
+    const double unbias = (double)group_rows / (double)(group_rows > 1 ? group_rows - 1 : 1);
+    hipLaunchKernelGGL(bn_update_running_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, as_stream(stream), mean64, var64, groups, cols, unbias, momentum,
+                       running_mean, running_var, num_batches);
+    return check_launch("ogmm_bn_update_running");
+}
+
 int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, double* stats, void* stream) {
     OGMM_REQUIRE(rows >= 0 && cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_colstats: rows=%lld must be a multiple of group_rows=%lld",
                  (long long)rows, (long long)group_rows);

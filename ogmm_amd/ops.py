@@ -184,20 +184,48 @@ def split_f16(W, pad_to=8, frag=False, k1=None, exp=None, scale_t=None):
     return {"W_hi": hi.contiguous(), "W_lo": lo.contiguous(), "inv_scale": 2.0 ** (-e)}
 
 
-def split_f16_training(W, cout, **kw):
-    """split_f16(frag=True) for weights that change every step (the trainer re-splits ~120 of them per step, many as permuted / transposed temporaries):
-    the power-of-two scale is found on the DEVICE (ogmm_pow2_scale: one small launch, no host synchronisation, nothing cached that could go stale or
-    be keyed on a recycled address), leaving one binade of headroom.  The inverse scale cannot ride in the host-side `alpha`, so it comes back as
-    `col_scale` [cout], the GEMM's per-column scale (struct ogmm_gemm.scale); `inv_scale` is 1."""
+_SPLIT_SLOTS = {}          # device -> [pool float32 [4096, 4] (zero), next slot]: the scale kernel's scratch, left zero by every call (ogmm_split_weight)
+SPLIT_WEIGHT_FUSED = os.environ.get("OGMM_SPLIT_WEIGHT_FUSED", "1") != "0"      # 0: rounds 1-3's path (tensor expressions + ogmm_pack_frag), for A/B timing
+
+
+def _split_slot(device):
+    ent = _SPLIT_SLOTS.get(device)
+    if ent is None:
+        ent = _SPLIT_SLOTS[device] = [torch.zeros((4096, 4), dtype=torch.float32, device=device), 0]
+    slot = ent[0][ent[1] % 4096]
+    ent[1] += 1
+    return slot
+
+
+def split_f16_training(W, cout, transpose=False, **kw):
+    """split_f16(frag=True) for weights that change every step (the trainer re-splits ~120 of them per step): the power-of-two scale is found on the DEVICE
+    (no host synchronisation, nothing cached that could go stale or be keyed on a recycled address), leaving one binade of headroom, and the fragment image
+    is written straight from the weight -- two launches per split (ogmm_split_weight).  transpose=True: the image of W^T (the operand of dX = dY W) from W as it
+    lies; `cout` is then the number of the GEMM's output columns = W.shape[1] (rounded up by the caller if it pads).  The inverse scale cannot ride in the
+    host-side `alpha`, so it comes back as `col_scale` [cout], the GEMM's per-column scale (struct ogmm_gemm.scale); `inv_scale` is 1."""
     W = W.float().contiguous()
+    k1 = kw.get("k1")
+    if SPLIT_WEIGHT_FUSED and kw.get("frag"):
+        rows, cols = W.shape
+        N, K = (cols, rows) if transpose else (rows, cols)
+        k1 = K if (transpose or k1 is None) else k1
+        assert k1 == K or k1 % 64 == 0
+        ldb_h = (k1 + 63) // 64 * 64 + (K - k1 + 63) // 64 * 64
+        n_pad = (N + 255) // 256 * 256
+        hi = torch.empty(n_pad * ldb_h, dtype=torch.float16, device=W.device)
+        lo = torch.empty_like(hi)
+        inv = torch.empty(cout, dtype=torch.float32, device=W.device)
+        _lib.call("ogmm_split_weight", _p(W), cols, rows, cols, 1 if transpose else 0, k1, _p(_split_slot(W.device)), _p(inv), cout, _p(hi), _p(lo), ldb_h, n_pad,
+                  _stream())
+        return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": ldb_h, "col_scale": inv}
+    if transpose:
+        W = W.t().contiguous()
     sc = torch.zeros(4, dtype=torch.float32, device=W.device)          # [0] the scale; [2], [3] the grid-wide reduction's scratch (zero on entry)
     inv = torch.empty(cout, dtype=torch.float32, device=W.device)
     _lib.call("ogmm_pow2_scale", _p(W), W.numel(), 10, _p(sc), _p(inv), cout, _stream())
     N, K = W.shape
-    k1 = kw.get("k1")
     if kw.get("frag") and N % 256 == 0 and K % 64 == 0 and (k1 is None or k1 == K or k1 % 64 == 0):
         # whole tiles and no padding between the A pieces: the split fragment images straight from the scaled weight with the activation packer
-        # (ogmm_pack_frag: the same image; four launches per split instead of a dozen torch ones -- the training step is sensitive to host time)
         Ws = W * sc[0:1]
         hi = torch.empty(N * K, dtype=torch.float16, device=W.device)
         lo = torch.empty_like(hi)
@@ -733,6 +761,31 @@ def colstats(x, group_rows):
     st = torch.empty((rows // group_rows, cols, 2), dtype=torch.float64, device=x.device)
     _lib.call("ogmm_colstats", _p(_f32(x, "x")), x.stride(0), rows, cols, group_rows, _p(st), _stream())
     return st
+
+
+def norm_finalize(st, group_rows, weight, bias, eps):
+    """st float64 [G, cols, 2] = {sum, sum of squares} over group_rows rows -> (scale, shift, mean, rstd float32 [G, cols], mean64, var64 float64 [G, cols]):
+    the constants of one normalisation layer in one launch (scale = gamma rstd, shift = beta - mean scale; var biased, clamped at 0)"""
+    assert st.dtype == torch.float64 and st.dim() == 3 and st.shape[2] == 2
+    st = st.contiguous()
+    G, cols = st.shape[0], st.shape[1]
+    f32 = torch.empty((4, G, cols), dtype=torch.float32, device=st.device)
+    f64 = torch.empty((2, G, cols), dtype=torch.float64, device=st.device)
+    w = None if weight is None else _f32(weight.detach(), "weight").contiguous()
+    b = None if bias is None else _f32(bias.detach(), "bias").contiguous()
+    _lib.call("ogmm_norm_finalize", _p(st), G, cols, group_rows, float(eps), _p(w), _p(b), _p(f32[0]), _p(f32[1]), _p(f32[2]), _p(f32[3]), _p(f64[0]), _p(f64[1]),
+              _stream())
+    return f32[0], f32[1], f32[2], f32[3], f64[0], f64[1]
+
+
+def bn_update_running(mean64, var64, group_rows, momentum, running_mean, running_var, num_batches):
+    """torch.nn.BatchNorm1d's running-statistics update for the G sequential calls whose batch statistics are mean64 / var64 [G, cols] (biased variance), in
+    place, one launch; num_batches (int64 scalar tensor) += G"""
+    G, cols = mean64.shape
+    assert (mean64.dtype == torch.float64 and var64.dtype == torch.float64 and mean64.is_contiguous() and var64.is_contiguous() and
+            running_mean.dtype == torch.float32 and running_var.dtype == torch.float32 and running_mean.is_contiguous() and running_var.is_contiguous() and
+            running_mean.numel() == cols and running_var.numel() == cols and (num_batches is None or num_batches.dtype == torch.int64))
+    _lib.call("ogmm_bn_update_running", _p(mean64), _p(var64), G, cols, group_rows, float(momentum), _p(running_mean), _p(running_var), _p(num_batches), _stream())
 
 
 def affine_act(x, group_rows, scale, shift, act, out=None):

@@ -40,13 +40,7 @@ class _NormAct(torch.autograd.Function):
         y = y.contiguous()
         if st is None:                     # otherwise: column sums that the producing GEMM's epilogue already accumulated
             st = ops.colstats(y, group_rows)
-        mean64 = st[..., 0] / group_rows
-        var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
-        rstd64 = torch.rsqrt(var64 + BN_EPS)
-        scale64 = rstd64 if weight is None else rstd64 * weight.detach().double()
-        shift64 = -mean64 * scale64 if bias is None else bias.detach().double() - mean64 * scale64
-        scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
-        mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
+        scale, shift, mean, rstd, mean64, var64 = ops.norm_finalize(st, group_rows, weight, bias, BN_EPS)
         h = ops.affine_act(y, group_rows, scale, shift, act)
         ctx.save_for_backward(y, scale, shift, mean, rstd)
         ctx.group_rows, ctx.act, ctx.affine = group_rows, act, weight is not None
@@ -72,13 +66,7 @@ class _NormActPool(torch.autograd.Function):
         y = y.contiguous()
         if st is None:
             st = ops.colstats(y, group_rows)
-        mean64 = st[..., 0] / group_rows
-        var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
-        rstd64 = torch.rsqrt(var64 + BN_EPS)
-        scale64 = rstd64 if weight is None else rstd64 * weight.detach().double()
-        shift64 = -mean64 * scale64 if bias is None else bias.detach().double() - mean64 * scale64
-        scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
-        mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
+        scale, shift, mean, rstd, mean64, var64 = ops.norm_finalize(st, group_rows, weight, bias, BN_EPS)
         h, pooled, arg = ops.affine_act_pool(y, k, group_rows, scale, shift, act, want_y=want_h)
         ctx.save_for_backward(y, scale, shift, mean, rstd, arg)
         ctx.group_rows, ctx.act, ctx.affine, ctx.k = group_rows, act, weight is not None, k
@@ -145,6 +133,17 @@ class _ThinLinear(torch.autograd.Function):
         return dx, dW, db
 
 
+def _transposed_weight_layer(W):
+    """The packed layer of dX = dY W for the engine: the split fragment image of W^T [K, Cout] written straight from W (ops.split_f16_training(transpose=True):
+    two launches, no transposed copy); K is rounded up to a multiple of 4 (16-byte output rows), the extra output columns are zero.  `W` of the layer is a
+    shape-only stand-in: the fragment engines never read the fp32 operand."""
+    Wd = W.detach()
+    cout, k = Wd.shape
+    k4 = (k + 3) // 4 * 4
+    sp = ops.split_f16_training(Wd, k4, transpose=True, frag=True)
+    return {"W": Wd.new_empty(1).expand(k4, cout), "split": sp, "scale": sp["col_scale"]}
+
+
 class _Linear(torch.autograd.Function):
     """y = [x | x2] W^T + b.  Forward and dX = dY W on the GEMM engine (fp16x3 split of the CURRENT weights, or exact fp32
     forward + library dX with precision "f32"); dW = dY^T X runs on the engine as a split-K GEMM over transposed operands
@@ -204,11 +203,7 @@ class _Linear(torch.autograd.Function):
                 # dX = dY W on the engine: the weight operand is W^T [K, Cout], split per step.  Activation gradients sit far
                 # below binary16's normal range (max 1e-6 .. 0.2 per layer at loss scale 1); the trainer's power-of-two loss
                 # scale (exact in fp32) lifts them into it, the overflow flag reports a scale that is too large.
-                Wt = W.detach().t().contiguous()
-                if Wt.shape[0] % 4:
-                    Wt = torch.cat([Wt, Wt.new_zeros(4 - Wt.shape[0] % 4, Wt.shape[1])], dim=0)
-                sp = ops.split_f16_training(Wt, Wt.shape[0], frag=True)
-                layer = {"W": Wt, "split": sp, "scale": sp["col_scale"]}
+                layer = _transposed_weight_layer(W)
                 dall = ops.conv1x1(_rm(dy), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
             else:
                 dall = dy @ W
@@ -256,13 +251,7 @@ class _NormLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, st, nweight, nbias, group_rows, W, b, overflow, stats_rows, res=None):
         y = y.contiguous()
-        mean64 = st[..., 0] / group_rows
-        var64 = (st[..., 1] / group_rows - mean64 * mean64).clamp_min_(0.0)
-        rstd64 = torch.rsqrt(var64 + BN_EPS)
-        scale64 = rstd64 if nweight is None else rstd64 * nweight.detach().double()
-        shift64 = -mean64 * scale64 if nbias is None else nbias.detach().double() - mean64 * scale64
-        scale, shift = scale64.float().contiguous(), shift64.float().contiguous()
-        mean, rstd = mean64.float().contiguous(), rstd64.float().contiguous()
+        scale, shift, mean, rstd, mean64, var64 = ops.norm_finalize(st, group_rows, nweight, nbias, BN_EPS)
         Wd = W.detach().contiguous()
         sp = ops.split_f16_training(Wd, Wd.shape[0], frag=True, k1=Wd.shape[1])
         layer = {"W": Wd, "split": sp, "scale": sp["col_scale"]}
@@ -290,9 +279,7 @@ class _NormLinear(torch.autograd.Function):
     def backward(ctx, dout, _dm, _dv, _dst=None):
         y, scale, shift, mean, rstd, W = ctx.saved_tensors
         dout = _rm(dout)
-        Wt = W.detach().t().contiguous()
-        sp = ops.split_f16_training(Wt, Wt.shape[0], frag=True)
-        layer = {"W": Wt, "split": sp, "scale": sp["col_scale"]}
+        layer = _transposed_weight_layer(W)
         rows, cin = y.shape
         fused = ops.norm_bwd_fusable(rows, cin, dout.shape[1], ctx.group_rows)
         if fused:
@@ -550,12 +537,7 @@ class TrainOps:
         shared layer), then ReLU or LeakyReLU(0.2).  Running statistics are updated in place, block 0 first."""
         n = y.shape[0] // groups
         h, mean64, var64 = _NormAct.apply(y, weight, bias, n, _ACT[act], stats)
-        with torch.no_grad():
-            unbiased = var64 * (n / max(n - 1, 1))
-            for g in range(groups):
-                running_mean.mul_(1 - BN_MOMENTUM).add_(mean64[g].to(running_mean.dtype), alpha=BN_MOMENTUM)
-                running_var.mul_(1 - BN_MOMENTUM).add_(unbiased[g].to(running_var.dtype), alpha=BN_MOMENTUM)
-            num_batches += groups
+        self._update_running(running_mean, running_var, num_batches, mean64, var64, n, groups)
         return h
 
     def batchnorm_act_pool(self, y, weight, bias, running_mean, running_var, num_batches, groups, act, k, want_h, stats=None):
@@ -565,12 +547,7 @@ class TrainOps:
             h = self.batchnorm_act(y, weight, bias, running_mean, running_var, num_batches, groups, act, stats)
             return (h if want_h else None), self.maxpool_k(h, k)
         h, pooled, mean64, var64 = _NormActPool.apply(y, weight, bias, n, _ACT[act], k, want_h, stats)
-        with torch.no_grad():
-            unbiased = var64 * (n / max(n - 1, 1))
-            for g in range(groups):
-                running_mean.mul_(1 - BN_MOMENTUM).add_(mean64[g].to(running_mean.dtype), alpha=BN_MOMENTUM)
-                running_var.mul_(1 - BN_MOMENTUM).add_(unbiased[g].to(running_var.dtype), alpha=BN_MOMENTUM)
-            num_batches += groups
+        self._update_running(running_mean, running_var, num_batches, mean64, var64, n, groups)
         return (h if want_h else None), pooled
 
     def _norm_linear_fusable(self, y, group_rows, W):
@@ -579,7 +556,13 @@ class TrainOps:
                 and Cout % 4 == 0)
 
     def _update_running(self, running_mean, running_var, num_batches, mean64, var64, n, groups):
+        """torch.nn.BatchNorm1d's buffer update for the `groups` sequential calls of the shared layer (models/dgcnn.py:126-130): one launch"""
+        assert mean64.shape[0] == groups
         with torch.no_grad():
+            if (running_mean.dtype == torch.float32 and running_mean.is_contiguous() and running_var.is_contiguous() and mean64.is_contiguous()
+                    and var64.is_contiguous() and num_batches.dtype == torch.int64):
+                ops.bn_update_running(mean64, var64, n, BN_MOMENTUM, running_mean, running_var, num_batches)
+                return
             unbiased = var64 * (n / max(n - 1, 1))
             for g in range(groups):
                 running_mean.mul_(1 - BN_MOMENTUM).add_(mean64[g].to(running_mean.dtype), alpha=BN_MOMENTUM)

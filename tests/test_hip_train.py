@@ -186,6 +186,57 @@ def test_norm_linear_fused_forward_backward(kind, rows, groups, k, cout, want_st
         assert _rel(a, r) < 2e-5, (i_, _rel(a, r))
 
 
+@pytest.mark.parametrize("cout,k,k1", [(512, 512, None), (1024, 516, 512), (256, 1024, None), (64, 6, None), (128, 64, None), (516, 1024, None), (1, 256, None)])
+def test_per_step_weight_split_in_two_launches_equals_the_tensor_expressions(cout, k, k1, monkeypatch):
+    """ogmm_split_weight (round 4): scale + fragment image of W, and of W^T straight from W, against rounds 1-3's path (ogmm_pow2_scale + tensor expressions /
+    ogmm_pack_frag on a materialised transpose): the same images bit for bit, the same per-column inverse scale; the slot pool's scratch is zero again afterwards."""
+    ops = __import__("ogmm_amd.ops", fromlist=["x"])
+    g = torch.Generator().manual_seed(cout + k)
+    W = (torch.randn(cout, k, generator=g) * 0.05).to(DEV)
+    for transpose in (False, True):
+        if transpose and k1 is not None:
+            continue
+        n_out = (k + 3) // 4 * 4 if transpose else cout
+        kw = dict(frag=True) if transpose or k1 is None else dict(frag=True, k1=k1)
+        monkeypatch.setattr(ops, "SPLIT_WEIGHT_FUSED", True)
+        a = ops.split_f16_training(W, n_out, transpose=transpose, **kw)
+        monkeypatch.setattr(ops, "SPLIT_WEIGHT_FUSED", False)
+        b = ops.split_f16_training(W, n_out, transpose=transpose, **kw)
+        assert a["ldb_h"] == b["ldb_h"] and a["variant"] == b["variant"] and torch.equal(a["col_scale"], b["col_scale"])
+        assert torch.equal(a["W_hi"].reshape(-1), b["W_hi"].reshape(-1)) and torch.equal(a["W_lo"].reshape(-1), b["W_lo"].reshape(-1)), (transpose,)
+    pool = ops._SPLIT_SLOTS[W.device][0]
+    assert float(pool[:, 2:].abs().max()) == 0.0
+
+
+def test_norm_constants_and_running_statistics_in_one_launch_each():
+    """ogmm_norm_finalize / ogmm_bn_update_running against the tensor expressions they replace (fp64 throughout, float outputs rounded once; BatchNorm1d's
+    momentum update applied group after group)."""
+    ops = __import__("ogmm_amd.ops", fromlist=["x"])
+    g = torch.Generator().manual_seed(11)
+    G, cols, n = 2, 300, 4096
+    x = (torch.randn(G * n, cols, generator=g) * 3 + 1).to(DEV)
+    st = ops.colstats(x, n)
+    w, b = (torch.rand(cols, generator=g) + 0.5).to(DEV), (torch.rand(cols, generator=g) - 0.5).to(DEV)
+    for weight, bias in ((w, b), (None, None)):
+        scale, shift, mean, rstd, mean64, var64 = ops.norm_finalize(st, n, weight, bias, 1e-5)
+        m = st[..., 0] / n
+        v = (st[..., 1] / n - m * m).clamp_min(0.0)
+        r = torch.rsqrt(v + 1e-5)
+        sc = r if weight is None else r * weight.double()
+        sh = -m * sc if bias is None else bias.double() - m * sc
+        assert torch.equal(mean64, m) and torch.equal(var64, v)
+        for got, want in ((scale, sc), (shift, sh), (mean, m), (rstd, r)):
+            assert float((got.double() - want).abs().max() / want.abs().max()) < 1.5e-7
+    rm, rv, nb = torch.zeros(cols, device=DEV), torch.ones(cols, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    rm2, rv2 = rm.clone(), rv.clone()
+    ops.bn_update_running(mean64, var64, n, 0.1, rm, rv, nb)
+    unb = var64 * (n / (n - 1))
+    for gi in range(G):
+        rm2.mul_(0.9).add_(mean64[gi].float(), alpha=0.1)
+        rv2.mul_(0.9).add_(unb[gi].float(), alpha=0.1)
+    assert int(nb) == G and torch.allclose(rm, rm2, rtol=3e-7, atol=1e-8) and torch.allclose(rv, rv2, rtol=3e-7, atol=1e-8)
+
+
 @pytest.mark.parametrize("R,n,k,ldy,affine", [(65536, 512, 512, 512, False), (32768, 1024, 256, 1024, False), (131072, 256, 1024, 256, False),
                                               (65536, 512, 512, 1024, False), (65536, 1024, 512, 1024, True), (36864, 512, 768, 512, False)])
 def test_weight_gradient_reads_dy_as_it_lies_and_equals_the_transposed_copy_bit_for_bit(R, n, k, ldy, affine, monkeypatch):
