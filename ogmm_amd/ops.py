@@ -861,6 +861,7 @@ def maxpool_k_bwd(dout, arg, k):
     return dh
 
 
+DW_MIN_TILES = int(os.environ.get("OGMM_DW_MIN_TILES", "0"))          # 0: 256 / 512 by shape (weight_grad); a number: that many tiles at least (A/B timing)
 DW_TRANSPOSED_A = os.environ.get("OGMM_DW_TRANSPOSED_A", "1") != "0"      # 0: materialise dY^T (ogmm_transpose_pad) as rounds 1-3 did (A/B timing, bit-identical)
 
 
@@ -875,7 +876,10 @@ def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=N
     R, n = dy.shape
     assert dy.stride(1) == 1
     tiles_mn = ((n + 255) // 256) * max((max(x.shape[1] for x in xs) + 255) // 256, 1)
-    S = max(1, min((512 + tiles_mn - 1) // tiles_mn, (R + 255) // 256))        # >= 512 tiles: the large-shape engine's threshold
+    # row chunks (split K): exactly one 256 x 256 tile per CU where the tile count of dW divides 256 (longer K loops per tile, half the partial products to sum:
+    # 115.7 against 117.5 ms per training step), else >= 512 tiles so that a ragged second round costs little (384: 125 ms)
+    want_tiles = DW_MIN_TILES if DW_MIN_TILES else (256 if 256 % tiles_mn == 0 else 512)
+    S = max(1, min((want_tiles + tiles_mn - 1) // tiles_mn, (R + 255) // 256))
     chunk = ((R + S - 1) // S + 63) // 64 * 64
     if chunk_rows is not None:
         assert chunk_rows % 64 == 0 and R % chunk_rows == 0 and len(xs) == 1 and not colsum

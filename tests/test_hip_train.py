@@ -258,7 +258,7 @@ def test_weight_gradient_reads_dy_as_it_lies_and_equals_the_transposed_copy_bit_
         X = torch.relu(x.double().view(G, 1024, k) * sc.double()[:, None] + sh.double()[:, None]).view(R, k)
     monkeypatch.setattr(ops, "DW_TRANSPOSED_A", True)
     tiles = (n // 256) * (k // 256)
-    S = max(1, min((512 + tiles - 1) // tiles, R // 256))
+    S = max(1, min(((256 if 256 % tiles == 0 else 512) + tiles - 1) // tiles, R // 256))
     chunk = ((R + S - 1) // S + 63) // 64 * 64
     if R % chunk == 0:          # (else the direct form must not be taken: the copy's zero padding is what makes a ragged last chunk legal)
         assert _lib.load().ogmm_gemm_atrans_supported(n, k, chunk, ldy, R // chunk) == 1
