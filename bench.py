@@ -334,9 +334,9 @@ def secondary_legs(args, ctx):
     try:
         # the headline workload once more on the SHARP weight family (peaked attention, overlap scores spanning (0, 1)): the same kernels, so the same
         # throughput -- what the leg adds to the record is the parity of a timed forward on non-degenerate weights (16 of its 64 pairs against the oracle)
-        res, keep = eval_leg(args, ctx, "cfg1", 12, 3, profile="sharp")          # (12 steps: at 5, two of them carry the event brackets and the leg reads 8 % low)
+        res, keep = eval_leg(args, ctx, "cfg1", 20, 5, profile="sharp")          # (the headline's own step count: short legs read low -- two steps carry the event brackets)
         legs.append({"workload": res["config"]["workload"].replace("closed-form weights", "closed-form weights of the SHARP family (synth.fill_state_dict(profile='sharp'))"),
-                     "metric": "pairs_per_sec", "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 12, "warmup": 3,
+                     "metric": "pairs_per_sec", "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 20, "warmup": 5,
                      "roofline": {k: res["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "kernel_share_of_step")},
                      "parity": parity_sample(keep, tuple(range(0, 64, 4)), threads) if args.cpu_sample > 0 else None,
                      "fp16_split_overflowed": bool(keep.model.fp16_overflowed())})
