@@ -41,6 +41,10 @@ const char* ogmm_last_error(void);
  * heap-select / introselect is re-stated for such rows); the set is written in (distance, index) order
  * (torch's order among equal distances is unspecified and no caller depends on it).  1 <= k <= 32, k <= N. */
 int ogmm_knn(const float* xyz /*[C][N][3]*/, int C, int N, int k, int32_t* idx /*[C][N][k]*/, void* stream);
+/* torch.topk(v, k, dim = -1, largest)[1] of a row-major [rows][n] map (row stride ldv) with the reference CPU kernel's choice among TIED values (the same
+ * re-statement of ATen's selection as ogmm_knn's tie resolution): the Welsch term of the training loss (lib/loss.py:92, :95) takes the top_k points of the 0 / 1
+ * ground-truth overlap labels, so with more than top_k ones the kept set -- and the loss -- depends on it.  idx [rows][k] in (value, index) order. */
+int ogmm_topk_rows(const float* v, int64_t ldv, int rows, int n, int k, int largest, int32_t* idx, void* stream);
 
 /* ---- K5: farthest point sampling.  lib/utils.py:170-198 (farthest_point_sample).
  * start != NULL: is_center=False with the torch.randint draw (:190) as an explicit input [C].

@@ -47,6 +47,7 @@ class GemmDesc(Structure):
 PROTOTYPES = {
     "ogmm_abi_version": [],
     "ogmm_last_error": [],
+    "ogmm_topk_rows": [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_knn": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_fps": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_gather_rows": [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],

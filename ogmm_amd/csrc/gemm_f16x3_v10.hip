@@ -51,7 +51,7 @@ __device__ unsigned long long g_v10_probe[4];
 template <int ABL, bool AFF, bool OVL, int TERMS = 3, bool NBS = false, int TA = 0>
 __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
     static_assert(TERMS == 3 || ((TERMS == 2 || TERMS == 1) && !AFF), "TERMS < 3 has no InstanceNorm-on-A form (its transform pieces need the gaps of 12 MFMAs)");
-    static_assert(!TA || (!AFF && !OVL && !NBS && TERMS == 3), "the transposed-A form exists for the plain three-term product only");
+    static_assert(!TA || (!AFF && !OVL && !NBS && TERMS >= 2), "the transposed-A form exists for the plain product with three or two terms");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
 
     const int bid = blockIdx.x;
@@ -330,7 +330,8 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
                         if (gl == 0 && m >= 8) piece(sn, m - 8);
                         if (gl > 0 && m >= 4) piece(sn, 4 + (gl - 1) * 8 + (m - 4));
                     } else if (gl > 0 && m >= 4 && m < 8) piece(sn, (gl - 1) * 4 + (m - 4));
-                    if (CS && gl > 0 && m >= 8) cs_piece(gl, m - 8);
+                    // (three terms: the gaps m = 8..11 are free; two terms: a group has eight gaps, the sums share m = 4..7 with the split: <= 5 instructions per gap)
+                    if (CS && gl > 0 && m >= (TERMS == 3 ? 8 : 4) && m < (TERMS == 3 ? 12 : 8)) cs_piece(gl, m - (TERMS == 3 ? 8 : 4));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -494,7 +495,7 @@ bool gemm_f16x3_v10_applicable(const ogmm_gemm& g) {
     const bool nb_ok = !g.nb_mean || (whole_tiles && g.nb_rstd && g.nb_scale && g.nb_shift && g.col_stats && g.Res && g.C && !g.a_scale && !g.ovl_rowpart && !g.a_gather_ids &&
                                       g.group_rows > 0 && g.group_rows % BM == 0 && g.batch_outer * g.batch_inner == 1 && g.N >= 512 &&
                                       (g.nb_act == OGMM_ACT_RELU || g.nb_act == OGMM_ACT_LEAKY02));
-    const bool ta_ok = !g.a_trans || (g.K2 == 0 && !g.a_scale && !g.a_gather_ids && !g.ovl_rowpart && !g.nb_mean && g.M % 4 == 0 && g.M >= 4 && (g.terms == 0 || g.terms == 3) &&
+    const bool ta_ok = !g.a_trans || (g.K2 == 0 && !g.a_scale && !g.a_gather_ids && !g.ovl_rowpart && !g.nb_mean && g.M % 4 == 0 && g.M >= 4 && g.terms != 1 &&
                                       (int64_t)BK8 * g.lda * 4 + 1024 < (1ll << 31));
     return enabled && g.pool_k == 0 && (!g.col_stats || whole_tiles) && ovl_ok && gather_ok && nb_ok && ta_ok &&
            (!g.a_scale || (g.a_shift && g.group_rows > 0 && g.group_rows % BM == 0 && g.K1 + g.K2 <= AFF_MAX_K && (g.K1 + g.K2) % 4 == 0)) && g.N >= 256 && tiles >= min_tiles && g.K1 % BK8 == 0 && g.K2 % BK8 == 0 && g.ldb_h % 64 == 0 &&
@@ -546,7 +547,10 @@ int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
         default:
             if (g.ovl_rowpart) return g.terms == 1 ? launch_v10<0, false, true, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, true, 2>(g, s) : launch_v10<0, false, true>(g, s);
             if (g.nb_mean) return launch_v10<0, false, false, 3, true>(g, s);          // normalisation-backward fusion (training): its own instantiation
-            if (g.a_trans) return g.a_colsum ? launch_v10<0, false, false, 3, false, 2>(g, s) : launch_v10<0, false, false, 3, false, 1>(g, s);   // transposed A (training: the weight gradient's dY^T read as dY lies)
+            if (g.a_trans) {
+                if (g.terms == 2) return g.a_colsum ? launch_v10<0, false, false, 2, false, 2>(g, s) : launch_v10<0, false, false, 2, false, 1>(g, s);
+                return g.a_colsum ? launch_v10<0, false, false, 3, false, 2>(g, s) : launch_v10<0, false, false, 3, false, 1>(g, s);
+            }   // transposed A (training: the weight gradient's dY^T read as dY lies)
             if (g.a_scale) return launch_v10<0, true>(g, s);          // (the InstanceNorm-on-A form has no reduced variant: terms is a permission, not an order)
             return g.terms == 1 ? launch_v10<0, false, false, 1>(g, s) : g.terms == 2 ? launch_v10<0, false, false, 2>(g, s) : launch_v10<0>(g, s);
     }

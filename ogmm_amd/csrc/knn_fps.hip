@@ -450,6 +450,47 @@ __global__ __launch_bounds__(256) void knn_resolve_ties_kernel(const float* __re
     }
 }
 
+// torch.topk(v, k, dim = -1, largest) of a [rows][n] map with the CPU kernel's choice among TIED values (torch_topk_select.h: the selection algorithms of
+// ATen's TopKImpl.h on GNU libstdc++, move for move) -- the Welsch term of the training loss takes the top_k points of the 0 / 1 ground-truth overlap
+// labels (lib/loss.py:92, :95): with more than top_k ones the kept SET is decided by those moves, and the loss's value with it.  One workgroup per row;
+// "largest" runs the smallest-selection on the negated values (the comparator a > b is -a < -b; a NaN counts as the largest value, as in ATen).  The kept
+// set is written in (value, index) order (torch leaves the order among equal values unspecified).
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ v, int64_t ldv, int n, int k, int largest, int32_t* __restrict__ idx,
+                                                        int have_lists) {
+    extern __shared__ __attribute__((aligned(16))) ogmm_select::Cand cand_t[];   // [n], then int Lpos[n], Rpos[n]
+    int* Lpos = reinterpret_cast<int*>(cand_t + n);
+    int* Rpos = Lpos + n;
+    __shared__ int wave_tot_t[4];
+    const int tid = threadIdx.x;
+    const float* __restrict__ row = v + (int64_t)blockIdx.x * ldv;
+    for (int j = tid; j < n; j += 256) {
+        float x = row[j];
+        if (largest) x = x != x ? -__builtin_inff() : -x;
+        else if (x != x) x = __builtin_inff();
+        cand_t[j].v = x;
+        cand_t[j].i = j;
+    }
+    __syncthreads();
+    if ((long long)k * 64 <= n) {
+        if (tid == 0) ogmm_select::heap_select(cand_t, k, n);
+    } else if (have_lists) {
+        block_introselect(cand_t, k - 1, n, Lpos, Rpos, wave_tot_t, nullptr);
+    } else {
+        if (tid == 0) ogmm_select::introselect(cand_t, k - 1, n);
+    }
+    __syncthreads();
+    // order the kept set by (value, index): rank of every element among the k (k <= a few thousand: k^2 / 256 comparisons per thread)
+    for (int a = tid; a < k; a += 256) {
+        const ogmm_select::Cand c = cand_t[a];
+        int rank = 0;
+        for (int b = 0; b < k; ++b) {
+            const ogmm_select::Cand o = cand_t[b];
+            rank += (o.v < c.v || (o.v == c.v && o.i < c.i)) ? 1 : 0;
+        }
+        idx[(int64_t)blockIdx.x * k + rank] = c.i;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // FPS: one workgroup per (sampling, cloud); points and the running-min array live in registers
 // (PPT points per thread, interleaved so loads coalesce), a copy of the cloud in LDS serves the
@@ -550,6 +591,18 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 }  // namespace
+
+extern "C" int ogmm_topk_rows(const float* v, int64_t ldv, int rows, int n, int k, int largest, int32_t* idx, void* stream) {
+    OGMM_REQUIRE(v && idx && rows > 0 && n > 0 && k >= 1 && k <= n && ldv >= n, "ogmm_topk_rows: null pointer or bad shape (rows=%d n=%d k=%d)", rows, n, k);
+    const size_t with_lists = (size_t)n * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)), without = (size_t)n * sizeof(ogmm_select::Cand);
+    OGMM_REQUIRE(without <= 158 * 1024, "ogmm_topk_rows: n=%d does not fit the LDS-resident candidate list (max 20224)", n);
+    const int have_lists = with_lists <= 158 * 1024 ? 1 : 0;
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)rows), dim3(256), have_lists ? with_lists : without, ogmm::as_stream(stream), v, ldv, n, k, largest, idx,
+                       have_lists);
+    return ogmm::check_launch("ogmm_topk_rows");
+}
 
 extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, void* stream) {
     OGMM_REQUIRE(xyz && idx && C > 0 && N > 0, "ogmm_knn: null pointer or empty input");

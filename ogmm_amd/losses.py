@@ -48,8 +48,14 @@ def welsch_loss(src, tgt, R, t, src_overlap, tgt_overlap, alpha=10.0, top_k=512)
     """`WelschLoss.forward` (lib/loss.py:83-106) with the predicted motion given as (R, t) instead of the 4x4 the
     reference packs first (lib/se3.py:29-52).  src, tgt [B,N,3]."""
     moved = torch.bmm(src, R.transpose(1, 2)) + t.reshape(-1, 1, 3)
-    s_ids = torch.topk(src_overlap, k=top_k, dim=-1)[1]
-    t_ids = torch.topk(tgt_overlap, k=top_k, dim=-1)[1]
+    if moved.is_cuda:
+        # the labels are 0 / 1: with more than top_k ones WHICH of them torch.topk keeps is decided by the CPU kernel's selection moves (the reference's loss is
+        # computed from them); the device library's own top-k breaks those ties differently -- 5e-4 in the Welsch term at N = 1024, top_k = 512
+        from . import ops
+        s_ids, t_ids = ops.topk_rows(src_overlap.float().contiguous(), top_k), ops.topk_rows(tgt_overlap.float().contiguous(), top_k)
+    else:
+        s_ids = torch.topk(src_overlap, k=top_k, dim=-1)[1]
+        t_ids = torch.topk(tgt_overlap, k=top_k, dim=-1)[1]
     take = lambda p, ids: torch.gather(p, 1, ids[:, :, None].expand(-1, -1, 3))          # noqa: E731
     if moved.is_cuda:
         # min over a [B, top_k, N] distance tensor (268 MB per term at 128 x 512 x 1024, plus its backward) = the distance to the NEAREST point: the

@@ -865,7 +865,7 @@ DW_MIN_TILES = int(os.environ.get("OGMM_DW_MIN_TILES", "0"))          # 0: 256 /
 DW_TRANSPOSED_A = os.environ.get("OGMM_DW_TRANSPOSED_A", "1") != "0"      # 0: materialise dY^T (ogmm_transpose_pad) as rounds 1-3 did (A/B timing, bit-identical)
 
 
-def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=None, keep_parts=False, out_scale=None, parts_out=None):
+def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=None, keep_parts=False, out_scale=None, parts_out=None, terms=0):
     """dW = dY^T [x_0 | x_1 | ...] on the fp16x3 engine: dy [R, n], xs = list of [R, k_i] (last stride 1) -> [n, sum k_i].
     x_affine (one x only): (scale [G, k], shift [G, k], relu, group_rows) -- x is a pre-normalisation map, X = relu(x * scale + shift).
     colsum=True: -> (dW, db) with db = dy.sum(0) gathered while dY^T is written (fp64 partial sums), no extra pass over dy.
@@ -914,10 +914,10 @@ def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=N
         split = {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": pitch, "sB": n_pad * pitch}
         if direct:
             gemm_nt(dy, ldy, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(chunk * ldy, 0), sC=(n * k, 0), split=split, overflow=overflow,
-                    scale=out_scale, a_trans=True, a_colsum=csum if x is xs[0] else None)
+                    scale=out_scale, a_trans=True, a_colsum=csum if x is xs[0] else None, terms=terms)
         else:
             gemm_nt(dyt, pitch, chunk, None, 0, n, k, C=part, ldc=k, batch=(S, 1), sA=(n * pitch, 0), sC=(n * k, 0), split=split, overflow=overflow,
-                    scale=out_scale)          # (out_scale [k]: a per-column factor on the products, e.g. the inverse of a power of two dy was scaled by)
+                    scale=out_scale, terms=terms)          # (out_scale [k]: a per-column factor on the products, e.g. the inverse of a power of two dy was scaled by)
         if keep_parts:
             return part
         outs.append(part.sum(dim=0) if S > 1 else part[0])
@@ -956,6 +956,15 @@ def kabsch_bwd(src, corr, w, gR, gt):
     gtc = None if gt is None else _f32(gt, "gt").contiguous()
     _lib.call("ogmm_kabsch_bwd", _p(src), _p(corr), _p(w), B, J, _p(gRc), _p(gtc), _p(g_src), _p(g_corr), _p(g_w), _stream())
     return g_src, g_corr, g_w
+
+
+def topk_rows(v, k, largest=True):
+    """torch.topk(v, k, dim=-1, largest)[1] for v [rows, n] with the reference CPU kernel's choice among tied values (ogmm_topk_rows) -> int64 [rows, k]"""
+    assert v.dim() == 2 and v.stride(1) == 1
+    rows, n = v.shape
+    idx = torch.empty((rows, k), dtype=torch.int32, device=v.device)
+    _lib.call("ogmm_topk_rows", _p(_f32(v, "v")), v.stride(0), rows, n, k, 1 if largest else 0, _p(idx), _stream())
+    return idx.long()
 
 
 def nearest_point(xyz, mu):

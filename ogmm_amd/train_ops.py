@@ -204,7 +204,7 @@ class _Linear(torch.autograd.Function):
                 # below binary16's normal range (max 1e-6 .. 0.2 per layer at loss scale 1); the trainer's power-of-two loss
                 # scale (exact in fp32) lifts them into it, the overflow flag reports a scale that is too large.
                 layer = _transposed_weight_layer(W)
-                dall = ops.conv1x1(_rm(dy), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
+                dall = ops.conv1x1(_rm(dy), layer, ops.ACT_NONE, split=True, overflow=ctx.overflow, terms=BWD_TERMS_DX)
             else:
                 dall = dy @ W
             dx = dall[:, :K1]
@@ -219,7 +219,7 @@ class _Linear(torch.autograd.Function):
             parts = [None] * len(pieces)
             want_db = ctx.has_bias and ctx.needs_input_grad[3] and not ctx.bias_grad_is_zero
             if any(wide):
-                got = ops.weight_grad(_rm(dy), [_rm(p_) for p_, w_ in zip(pieces, wide) if w_], ctx.overflow, colsum=want_db)
+                got = ops.weight_grad(_rm(dy), [_rm(p_) for p_, w_ in zip(pieces, wide) if w_], ctx.overflow, colsum=want_db, terms=BWD_TERMS_DW)
                 if want_db:
                     got, db = got
                 off = 0
@@ -238,6 +238,11 @@ class _Linear(torch.autograd.Function):
         return dx, dx2, dW, db, None, None, None
 
 
+# experiment switches (measured, NOT the default: tools/bwd_terms_check.py): 2 = the B operand of a backward GEMM rounded to binary16 (two matrix
+# instructions per product instead of three) -- W^T in dX = dY W (BWD_TERMS_DX), the image of X^T in dW = dY^T X (BWD_TERMS_DW); OGMM_BWD_TERMS sets both
+BWD_TERMS = int(os.environ.get("OGMM_BWD_TERMS", "0"))
+BWD_TERMS_DX = int(os.environ.get("OGMM_BWD_TERMS_DX", str(BWD_TERMS)))
+BWD_TERMS_DW = int(os.environ.get("OGMM_BWD_TERMS_DW", str(BWD_TERMS)))
 FUSE_NORM_LINEAR = os.environ.get("OGMM_FUSE_NORM_LINEAR", "1") != "0"      # 0: write the normalised maps (A/B timing)
 
 
@@ -289,11 +294,11 @@ class _NormLinear(torch.autograd.Function):
             dz = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow, col_stats=sums, group_rows=ctx.group_rows,
                              norm_bwd=(y, mean, rstd, scale, shift, ops.ACT_RELU))
         else:
-            dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow)
+            dh = ops.conv1x1(dout, layer, ops.ACT_NONE, split=True, overflow=ctx.overflow, terms=BWD_TERMS_DX)
         dW = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[6] and not ctx.bias_grad_is_zero
         if ctx.needs_input_grad[5]:
-            dW = ops.weight_grad(dout, [y], ctx.overflow, x_affine=(scale, shift, True, ctx.group_rows), colsum=want_db)
+            dW = ops.weight_grad(dout, [y], ctx.overflow, x_affine=(scale, shift, True, ctx.group_rows), colsum=want_db, terms=BWD_TERMS_DW)
             if want_db:
                 dW, db = dW
         if ctx.has_bias and ctx.needs_input_grad[6] and db is None:

@@ -42,6 +42,10 @@ CASES = {
     # parameters shift together, median 1.2e-3, while the split engine on the same fixture sits at 4.9e-4), 720.. (B = 3, N = 320) 10 / 10.  The
     # committed fixture is the one on which the bar means something for both engines.
     "train_mid_b2_n512_j16": (2, 512, 16, "partial", 640, 20, 128, 512, "mid"),
+    # round 4: the shape of BASELINE configs[4] per cloud (N = 1024, J = 16, k = 20) at the smallest batch on which the LDS-DMA engines take the step's wide
+    # GEMMs (8192 stacked rows: 32 row tiles; the weight gradient's transposed-A form with 256-row chunks) -- the fixtures above run on the small-tile engine
+    "train_b4_n1024_j16": (4, 1024, 16, "partial", 900, 20, 128, 512),
+    "train_mid_b4_n1024_j16": (4, 1024, 16, "partial", 840, 20, 128, 512, "mid"),
 }
 SAMPLE = 97      # gradient entries stored per parameter (strided over the flattened tensor)
 
@@ -161,8 +165,16 @@ def main():
         fx["noise_t"] = np.float64(max(d(out1[1], trans.detach()), d(out64[1].detach(), trans.detach())))
         fx["noise_o"] = np.float64(max(d(out1[2], so.detach()), d(out1[3], to.detach()), d(out64[2].detach(), so.detach()), d(out64[3].detach(), to.detach())))
         fx["noise_clu"] = np.float64(max(d(out1[4], clu.detach()), d(out64[4].detach(), clu.detach())))
-        print("   reference's own train-mode noise (1 thread / fp64 against the fixture): loss %.2e  R %.2e  t %.2e  scores %.2e  clu %.2e" % (
-            fx["noise_loss"], fx["noise_R"], fx["noise_t"], fx["noise_o"], fx["noise_clu"]))
+
+        def welsch_of(o, s_, t_, dt):          # the Welsch term alone (it enters the loss with weight 0.01, so the loss's noise does not bound it)
+            Tp = torch.eye(4, dtype=dt)[None].repeat(B, 1, 1)
+            Tp[:, :3, :3] = o[0].detach().to(dt)
+            Tp[:, :3, 3:4] = o[1].detach().to(dt).view(-1, 3, 1)
+            return float(O.welsch_loss(s_.transpose(1, 2), t_.transpose(1, 2), Tp, so_gt.to(dt), to_gt.to(dt), 10.0, top_k))
+        wref = float(parts["welsch"])
+        fx["noise_welsch"] = np.float64(max(abs(welsch_of(out1, src, tgt, torch.float32) - wref), abs(welsch_of(out64, src.double(), tgt.double(), torch.float64) - wref)))
+        print("   reference's own train-mode noise (1 thread / fp64 against the fixture): loss %.2e  R %.2e  t %.2e  scores %.2e  clu %.2e  welsch %.2e (of %.3f)" % (
+            fx["noise_loss"], fx["noise_R"], fx["noise_t"], fx["noise_o"], fx["noise_clu"], fx["noise_welsch"], wref))
         fx["gnorm_total"] = np.float64(total)
         fx["loss64"] = np.float64(loss64.item())
         for kpart, v in parts.items():

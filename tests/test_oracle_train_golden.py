@@ -6,10 +6,10 @@ import torch
 
 from ogmm_amd import gmmreg, synth
 from oracle import ogmm_oracle as O
-from train_util import TRAIN_CASES, check_grads, load_train_case, noise_of, profile_of
+from train_util import TRAIN_CASES, TRAIN_CASES_ENGINE, check_grads, load_train_case, noise_of, profile_of
 
 
-@pytest.mark.parametrize("name", TRAIN_CASES)
+@pytest.mark.parametrize("name", TRAIN_CASES + TRAIN_CASES_ENGINE)
 def test_oracle_training_step_matches_reference(name):
     torch.set_num_threads(8)
     fx, cfg, (B, N, J, D, top_k) = load_train_case(name)

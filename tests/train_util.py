@@ -9,6 +9,9 @@ from ogmm_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAIN_CASES = ["train_b2_n512_j16", "train_b3_n320_j8_k12", "train_mid_b2_n512_j16"]
+# round 4: configs[4]'s per-cloud shape (N = 1024, J = 16, k = 20) at the smallest batch whose wide GEMMs run on the LDS-DMA engines (the weight gradient's
+# transposed-A form included) -- both weight families; checked on the GPU and against the oracle, not by the (slow) CPU graph test
+TRAIN_CASES_ENGINE = ["train_b4_n1024_j16", "train_mid_b4_n1024_j16"]
 SAMPLE = 97
 
 
