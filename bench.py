@@ -481,7 +481,7 @@ def cpu_leg(args, keep):
 def train_leg(args, ctx, B, steps, warmup, cpu_check=True):
     """BASELINE configs[4]: one step = forward (train-mode BatchNorm) + the loss of train.py:54-72 + backward + one flat
     gradient all-reduce (RCCL; skipped at N=1) + Adam + BatchNorm-buffer broadcast, on 128 synthetic pairs per GPU."""
-    from ogmm_amd import dist as odist, ops, synth
+    from ogmm_amd import dist as odist, ops, synth, train_ops
     from ogmm_amd.gmmreg import GMMReg
     from ogmm_amd.trainer import Trainer
     N, J_ = 1024, 16
@@ -526,7 +526,8 @@ def train_leg(args, ctx, B, steps, warmup, cpu_check=True):
     result = {
         "metric": "train_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if model.precision == "f32" else "f32 (f16x3 split, 3 terms everywhere; loss scale 2^16)", "data": "synthetic", "engine": model.precision,
+        "dtype": "f32" if model.precision == "f32" else "f32 (f16x3 split: forward and dX three terms, dW %s; loss scale 2^16)" % (
+            "two terms (activation operand rounded to binary16)" if train_ops.BWD_TERMS_DW == 2 else "three terms"), "data": "synthetic", "engine": model.precision,
         "config": {"workload": "BASELINE configs[4]: end-to-end training step (forward in train mode, loss of train.py, backward, gradient "
                                "all-reduce, Adam), ModelNet40-shaped partial-overlap pairs, N=1024, J=16, %d pairs per GPU" % B,
                    "pairs_per_gpu_step": B, "n_points": N, "n_clusters": J_,

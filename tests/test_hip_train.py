@@ -484,6 +484,40 @@ def test_training_step_matches_reference(name, precision):
     assert not model.fp16_overflowed()
 
 
+@pytest.mark.parametrize("name", TRAIN_CASES_ENGINE)
+def test_two_term_weight_gradient_stays_at_the_three_term_distance_from_the_truth(name, monkeypatch):
+    """train_ops.BWD_TERMS_DW = 2 (an opt-in switch: the activation operand of dW = dY^T X rounded to binary16) on the reference-generated fixtures whose wide GEMMs run
+    on the LDS-DMA engines: per live parameter the distance to the fixture's fp64 truth is the three-term distance to within 10 % (or a quarter of the
+    reference's own fp32-vs-fp64 distance), and the two gradients are within 2e-4 of each other."""
+    from ogmm_amd import train_ops
+    fx, cfg, (B, N, J, D, top_k) = load_train_case(name)
+    cfg.precision = "f16x3"
+    grads, errs = {}, {}
+    for terms in (0, 2):
+        monkeypatch.setattr(train_ops, "BWD_TERMS_DW", terms)
+        model = GMMReg(D, J, cfg)
+        synth.fill_state_dict(model.state_dict(), profile=profile_of(fx))
+        model = model.to(DEV).train()
+        src, tgt = torch.from_numpy(fx["src"]).to(DEV), torch.from_numpy(fx["tgt"]).to(DEV)
+        out = model(src, tgt, fps_starts=torch.from_numpy(fx["fps_starts"]))
+        loss, _ = losses.training_loss(out, src, tgt, torch.from_numpy(fx["T_gt"]).to(DEV), torch.from_numpy(fx["src_overlap"]).to(DEV),
+                                       torch.from_numpy(fx["tgt_overlap"]).to(DEV), 10.0, top_k)
+        (loss * 65536.0).backward()
+        grads[terms] = {k: p.grad / 65536.0 for k, p in model.named_parameters() if p.grad is not None}
+        rep = {}
+        check_grads(fx, grads[terms], report=rep, max_outlier_frac=1.0)
+        errs[terms] = rep
+    moved = 0
+    for k, (e3, allowed) in errs[0].items():
+        e2 = errs[2][k][0]
+        ref = float(fx["gerr/" + k])
+        assert e2 <= max(1.1 * e3, e3 + 0.25 * ref), (k, e2, e3, ref)
+        d = float((grads[2][k] - grads[0][k]).norm() / grads[0][k].norm().clamp_min(1e-30))
+        assert d < 2e-4, (k, d)
+        moved += d > 1e-6
+    assert moved >= 4          # (the two-term form was really taken: the wide layers' weight gradients differ in their last bits)
+
+
 @pytest.mark.parametrize("B,N,J,k,M,topk", [(1, 512, 16, 20, 128, 256), (5, 300, 8, 12, 32, 128), (2, 717, 16, 20, 128, 512)])
 def test_trainer_steps_on_ragged_shapes(B, N, J, k, M, topk):
     """Three optimiser steps on the same batch: single-pair batches (BatchNorm groups of one cloud), row counts that are no multiple of

@@ -1,5 +1,5 @@
 """What rounding the B operand of the BACKWARD GEMMs to binary16 (two matrix instructions per product instead of three: W^T in dX = dY W, X^T in dW = dY^T X;
-train_ops.BWD_TERMS = 2) does to the gradients at a size on which the LDS-DMA engines actually run (the reference-generated training fixtures are too small for
+train_ops.BWD_TERMS_DX / BWD_TERMS_DW = 2; BWD_WHICH=dx|dw|both picks which) does to the gradients at a size on which the LDS-DMA engines actually run (the reference-generated training fixtures are too small for
 them): per parameter the relative distance between the two-term and the three-term gradients, next to the distance between the three-term gradients and the
 exact-fp32 engine's -- the engine's own fp32-class noise on the same step -- and, where a fixture of the family exists, the reference's own fp32-vs-fp64
 distance as the scale the parity tests use.
