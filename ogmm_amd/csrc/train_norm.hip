@@ -98,10 +98,17 @@ __global__ __launch_bounds__(256) void affine_act_v4_kernel(const float* __restr
     const int col = (blockIdx.y * CV + cl) * 4;
     if (col >= cols) return;
     const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = min(r0 + 64, rows);
+    const int64_t g0 = r0 / group_rows;
+    const bool one_group = (r1 - 1) / group_rows == g0;          // (group_rows %% 64 == 0: the constants are loaded once per thread, see norm_bwd_apply_v4_kernel)
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+    if (one_group) { sc = *reinterpret_cast<const float4*>(scale + g0 * cols + col); sh = *reinterpret_cast<const float4*>(shift + g0 * cols + col); }
+#pragma unroll 4
     for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
-        const int64_t gc = (r / group_rows) * cols + col;
+        if (!one_group) {
+            const int64_t gc = (r / group_rows) * cols + col;
+            sc = *reinterpret_cast<const float4*>(scale + gc); sh = *reinterpret_cast<const float4*>(shift + gc);
+        }
         const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + col);
-        const float4 sc = *reinterpret_cast<const float4*>(scale + gc), sh = *reinterpret_cast<const float4*>(shift + gc);
         float4 o;
         o.x = act_fwd(fmaf(v.x, sc.x, sh.x), act); o.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
         o.z = act_fwd(fmaf(v.z, sc.z, sh.z), act); o.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
@@ -235,23 +242,41 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_v4_kernel(const float* __r
     if (col >= cols) return;
     const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = min(r0 + 64, rows);
     const double inv_n = 1.0 / (double)group_rows;
-    for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
-        const int64_t gc = (r / group_rows) * cols + col;
+    // the per-(group, column) constants of one row: 4 float4 + 8 doubles = 128 bytes beside the 32 bytes of x and dz -- re-read per row they made the kernel
+    // bound by the CU's vector-memory path (3.9 TB/s of HBM traffic); a workgroup's 64 rows lie in one group whenever group_rows %% 64 == 0 (every
+    // normalisation of the model), so they are loaded once per thread (round 4; same arithmetic, same results)
+    float scv[4], shv[4], mv[4], rv[4], m1[4], m2[4];
+    auto load_consts = [&](int64_t gc) {
         const float4 sc = *reinterpret_cast<const float4*>(scale + gc), sh = *reinterpret_cast<const float4*>(shift + gc);
         const float4 m = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc);
-        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, mv[4] = {m.x, m.y, m.z, m.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+        scv[0] = sc.x; scv[1] = sc.y; scv[2] = sc.z; scv[3] = sc.w; shv[0] = sh.x; shv[1] = sh.y; shv[2] = sh.z; shv[3] = sh.w;
+        mv[0] = m.x; mv[1] = m.y; mv[2] = m.z; mv[3] = m.w; rv[0] = rs.x; rv[1] = rs.y; rv[2] = rs.z; rv[3] = rs.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { m1[e] = (float)(sums[(gc + e) * 2] * inv_n); m2[e] = (float)(sums[(gc + e) * 2 + 1] * inv_n); }
+    };
+    auto row = [&](int64_t r) {
         const float4 xv4 = *reinterpret_cast<const float4*>(x + r * ldx + col);
         const float4 dv4 = routed_load4(up, r, col);
         const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float m1 = (float)(sums[(gc + e) * 2] * inv_n), m2 = (float)(sums[(gc + e) * 2 + 1] * inv_n);
             const float dz = dv[e] * act_grad(fmaf(xv[e], scv[e], shv[e]), act);
             const float xh = (xv[e] - mv[e]) * rv[e];
-            o[e] = scv[e] * (dz - m1 - xh * m2);
+            o[e] = scv[e] * (dz - m1[e] - xh * m2[e]);
         }
         *reinterpret_cast<float4*>(dx + r * lddx + col) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+    const int64_t g0 = r0 / group_rows;
+    if ((r1 - 1) / group_rows == g0) {
+        load_consts(g0 * cols + col);
+#pragma unroll 4
+        for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) row(r);
+    } else {
+        for (int64_t r = r0 + rl; r < r1; r += Map<CV>::rows_per_pass) {
+            load_consts((r / group_rows) * cols + col);
+            row(r);
+        }
     }
 }
 
