@@ -295,7 +295,7 @@ class GMMReg(nn.Module):
             self._packed_fp = self._fingerprint(list(sd.values()))
         return self._packed
 
-    def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0, kv_terms=0, qk_terms=0):
+    def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0, kv_terms=0, qk_terms=0, after_attention=None):
         """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D]; the anchors [C, M, D] are rows
         anchor_ids [C, M] of anchor_feats [C*N, D] (of the cloud cloud_map[c], if given): lib/utils.py:111-127."""
         D, H = self.emb_dims, self.config.num_heads
@@ -305,6 +305,8 @@ class GMMReg(nn.Module):
         if ops.attention_supported(M, dh):
             kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map, eng=eng, terms=kv_terms)      # keys | values in one GEMM, rows gathered by its DMA
             o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H, qk_terms=qk_terms if eng.split else 0)
+            if after_attention is not None:
+                after_attention()          # (scheduling experiment OGMM_EM_SCHED=3: side-stream work queued behind the attention kernel instead of beside it)
             if self.fold_merge:
                 mlp0, msg = L["mlp0_folded"], o                       # merge conv folded into mlp0's weights
             else:
@@ -483,23 +485,32 @@ class GMMReg(nn.Module):
             # number of sweeps every E-step ran: see sinkhorn_exit_margin()
             return ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=self.sinkhorn_thresh, group_size=B,
                               return_resid=capture, return_sweeps=capture, status=self._status)
-        em_sched = _EM_SCHED          # experiment switch (OGMM_EM_SCHED): 0 = beside the whole last transformer (default), 1 = serial behind it, 2 = high-priority stream
+        em_sched = _EM_SCHED          # experiment switch (OGMM_EM_SCHED): 0 = beside the whole last transformer (default), 1 = serial behind it, 2 = high-priority stream, 3 = queued behind its attention kernel
         em_stream = side
         if em_sched == 2:
             if getattr(self, "_em_hi", None) is None or self._em_hi.device != dev:
                 self._em_hi = torch.cuda.Stream(device=dev, priority=-1)
             em_stream = self._em_hi
-        if em_sched != 1:
+        em_box = {}
+
+        def launch_em():
             em_stream.wait_stream(main)
             with torch.cuda.stream(em_stream):
-                em = run_em()
-                gamma, pi, mu = em[:3]
-                em_done = torch.cuda.Event()
-                em_done.record(em_stream)
+                em_box["em"] = run_em()
+                em_box["done"] = torch.cuda.Event()
+                em_box["done"].record(em_stream)
             o.record_stream(em_stream)
-            for t_ in (gamma, pi, mu):
+            for t_ in em_box["em"][:3]:
                 t_.record_stream(main)
-        f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0), kv_terms=tb.get("sattn2.kv", 0), qk_terms=tb.get("sattn2.qk", 0))
+        if em_sched in (0, 2):
+            launch_em()
+        f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0), kv_terms=tb.get("sattn2.kv", 0), qk_terms=tb.get("sattn2.qk", 0),
+                               after_attention=launch_em if em_sched == 3 else None)
+        if em_sched != 1:
+            if "em" not in em_box:          # (the transformer took a path without the fused attention: nothing called back)
+                launch_em()
+            em, em_done = em_box["em"], em_box["done"]
+            gamma, pi, mu = em[:3]
         if em_sched == 1:
             em = run_em()
             gamma, pi, mu = em[:3]
