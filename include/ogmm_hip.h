@@ -371,6 +371,8 @@ int ogmm_icp_point_to_point_ws(const float* src, const float* tgt, int B, int N,
  * The host turns sums into dgamma, dbeta. */
 int ogmm_norm_finalize(const double* stats /*[G][cols][2]*/, int64_t groups, int cols, int64_t group_rows, double eps, const float* gamma, const float* beta,
                        float* scale, float* shift, float* mean, float* rstd, double* mean64, double* var64, void* stream);
+/* dgamma[c] = sum over groups of sums[g][c][1], dbeta[c] = ... [0]: the affine parameters' gradients from ogmm_norm_bwd_reduce's (or the GEMM epilogue's) sums, one launch */
+int ogmm_norm_param_grads(const double* sums /*[G][cols][2]*/, int groups, int cols, float* dgamma, float* dbeta, void* stream);
 /* BatchNorm running statistics after G sequential train-mode calls of the shared layer (torch.nn.BatchNorm1d: running = (1 - momentum) running + momentum batch,
  * variance unbiased by n / (n - 1), n = group_rows; num_batches += G, may be NULL): mean64 / var64 [G][cols] as ogmm_norm_finalize leaves them */
 int ogmm_bn_update_running(const double* mean64, const double* var64, int groups, int cols, int64_t group_rows, float momentum, float* running_mean,

@@ -103,6 +103,7 @@ PROTOTYPES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     # training mode
     "ogmm_norm_finalize": [c_void_p, c_int64, c_int, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogmm_norm_param_grads": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_bn_update_running": [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_colstats": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p],
     "ogmm_affine_act": [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],

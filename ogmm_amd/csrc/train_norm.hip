@@ -481,6 +481,22 @@ int ogmm_bn_update_running(const double* mean64, const double* var64, int groups
     return check_launch("ogmm_bn_update_running");
 }
 
+// gradients of a normalisation layer's affine parameters from the backward sums: dgamma[c] = sum_g sums[g][c][1], dbeta[c] = sum_g sums[g][c][0] (fp64, rounded once)
+__global__ __launch_bounds__(256) void norm_param_grads_kernel(const double* __restrict__ sums, int groups, int cols, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < groups; ++g) { b += sums[((int64_t)g * cols + c) * 2]; a += sums[((int64_t)g * cols + c) * 2 + 1]; }
+    dgamma[c] = (float)a;
+    dbeta[c] = (float)b;
+}
+
+int ogmm_norm_param_grads(const double* sums, int groups, int cols, float* dgamma, float* dbeta, void* stream) {
+    OGMM_REQUIRE(sums && dgamma && dbeta && groups > 0 && cols > 0, "ogmm_norm_param_grads: null pointer or empty shape");
+    hipLaunchKernelGGL(norm_param_grads_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, as_stream(stream), sums, groups, cols, dgamma, dbeta);
+    return check_launch("ogmm_norm_param_grads");
+}
+
 int ogmm_colstats(const float* x, int64_t ldx, int64_t rows, int cols, int64_t group_rows, double* stats, void* stream) {
     OGMM_REQUIRE(rows >= 0 && cols > 0 && group_rows > 0 && rows % group_rows == 0, "ogmm_colstats: rows=%lld must be a multiple of group_rows=%lld",
                  (long long)rows, (long long)group_rows);

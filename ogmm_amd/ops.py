@@ -778,6 +778,15 @@ def norm_finalize(st, group_rows, weight, bias, eps):
     return f32[0], f32[1], f32[2], f32[3], f64[0], f64[1]
 
 
+def norm_param_grads(sums):
+    """sums float64 [G, cols, 2] = {sum dz, sum dz xhat} -> (dgamma, dbeta) float32 [cols]: the sums over the groups, one launch"""
+    sums = sums.contiguous()
+    G, cols = sums.shape[0], sums.shape[1]
+    out = torch.empty((2, cols), dtype=torch.float32, device=sums.device)
+    _lib.call("ogmm_norm_param_grads", _p(sums), G, cols, _p(out[0]), _p(out[1]), _stream())
+    return out[0], out[1]
+
+
 def bn_update_running(mean64, var64, group_rows, momentum, running_mean, running_var, num_batches):
     """torch.nn.BatchNorm1d's running-statistics update for the G sequential calls whose batch statistics are mean64 / var64 [G, cols] (biased variance), in
     place, one launch; num_batches (int64 scalar tensor) += G"""

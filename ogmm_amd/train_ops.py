@@ -53,7 +53,8 @@ class _NormAct(torch.autograd.Function):
         dy, sums = ops.norm_bwd(y, _rm(dh), ctx.group_rows, scale, shift, mean, rstd, ctx.act)
         if not ctx.affine:
             return dy, None, None, None, None, None
-        return dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float(), None, None, None
+        dg, dbeta = ops.norm_param_grads(sums)
+        return dy, dg, dbeta, None, None, None
 
 
 class _NormActPool(torch.autograd.Function):
@@ -87,7 +88,7 @@ class _NormActPool(torch.autograd.Function):
                                 dpool=None if dpooled is None else dpooled.contiguous(), arg=arg, k=ctx.k)
         if not ctx.affine:
             return (dy,) + (None,) * 7
-        return (dy, sums[..., 1].sum(dim=0).float(), sums[..., 0].sum(dim=0).float()) + (None,) * 5
+        return (dy,) + ops.norm_param_grads(sums) + (None,) * 5
 
 
 class _MaxPoolK(torch.autograd.Function):
@@ -317,8 +318,7 @@ class _NormLinear(torch.autograd.Function):
             dy = ops.norm_bwd_apply(y, dz, ctx.group_rows, scale, shift, mean, rstd, sums)
         else:
             dy, sums = ops.norm_bwd(y, dh, ctx.group_rows, scale, shift, mean, rstd, ops.ACT_RELU)
-        dg = sums[..., 1].sum(dim=0).float() if ctx.affine else None
-        dbeta = sums[..., 0].sum(dim=0).float() if ctx.affine else None
+        dg, dbeta = ops.norm_param_grads(sums) if ctx.affine else (None, None)
         return dy, None, dg, dbeta, None, dW, db, None, None, (dout if ctx.has_res else None)
 
 
