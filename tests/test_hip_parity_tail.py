@@ -104,3 +104,8 @@ def test_trained_weights_every_pair_against_the_oracle():
     r, t, o, inputs = distribution(model, P, cfg, 0, 64, 1024, "partial", label=label)
     assert not model.fp16_overflowed()
     check_tail(label, r, t, inputs, P, cfg, 0, 60)
+    # the same weights at the shape they were trained on (717 points: no multiple of any tile), 32 pairs
+    label = "trained weights (500 steps), N=717 J=16, pairs 300..331"
+    r, t, o, inputs = distribution(model, P, cfg, 300, 32, 717, "partial", label=label)
+    assert not model.fp16_overflowed()
+    check_tail(label, r, t, inputs, P, cfg, 300, 28)
