@@ -106,6 +106,25 @@ def test_forward_matches_oracle_live_batch():
     assert (so1.cpu() - so[3:4].cpu()).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("D,heads", [(256, 4), (1024, 4), (512, 8), (256, 2)])
+def test_other_embedding_sizes_and_head_counts_match_the_oracle(D, heads):
+    """emb_dims / num_heads away from the reference's defaults (512 / 4): the fused attention is built for 128-wide heads and several fusions for 512 channels;
+    every other configuration takes the general kernels and must land on the same results."""
+    cfg = Namespace(gnn_k=20, num_heads=heads, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    m = GMMReg(D, 16, cfg)
+    synth.fill_state_dict(m.state_dict())
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    src, tgt, _, _ = synth.make_batch(0, 3, 512, "partial")
+    starts = synth.fps_starts_for(0, 3, 512)
+    with torch.no_grad():
+        R, t, so, to, loss = m(src.cuda(), tgt.cuda(), fps_starts=starts)
+        Ro, to_, soo, too, losso = O.forward(P, cfg, src, tgt, starts)
+    assert O.rotation_error_rad(R.cpu(), Ro).max().item() < R_TOL and O.translation_error(t.cpu(), to_).max().item() < T_TOL
+    assert (so.cpu() - soo).abs().max().item() < O_TOL and (to.cpu() - too).abs().max().item() < O_TOL and abs(loss.item() - losso.item()) < LOSS_TOL
+    assert not m.fp16_overflowed()
+
+
 def test_forward_draws_fps_starts_like_the_reference():
     """With fps_starts=None the six draws come from torch's global CPU generator in the reference's order."""
     cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=64, overlap_radius=0.035, n_clusters=16)
