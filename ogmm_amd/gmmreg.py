@@ -359,6 +359,10 @@ class GMMReg(nn.Module):
         C, D, H, k, M, J = 2 * B, self.emb_dims, cfg.num_heads, cfg.gnn_k, cfg.km_clusters, self.n_clusters
         if M % 4 != 0 or M > N or J > N or k > N:
             raise OgmmError("km_clusters must be a multiple of 4 and km_clusters, n_clusters, gnn_k <= N")
+        if not (4 <= k <= 32) or J > 128:
+            # the kernels' documented ceilings, stated here instead of surfacing as a launch error from deep inside the forward: the kNN lists and the per-edge
+            # pooling are built for 4 ... 32 neighbours (the reference uses 20), the matching kernel for at most 128 components per cloud (the reference 16 ... 128)
+            raise OgmmError("this build supports 4 <= gnn_k <= 32 and n_clusters <= 128 (got gnn_k=%d, n_clusters=%d)" % (k, J))
         dev = src.device
         if self.precision not in ("f16x3", "f32", "f16"):
             raise OgmmError("precision must be 'f16x3', 'f32' or 'f16' (reduced: single binary16 term in the large GEMMs)")

@@ -316,6 +316,12 @@ def test_largest_supported_cloud_and_input_validation():
                 (torch.zeros(2, 4, 64, device="cuda:0"),) * 2):
         with pytest.raises(OgmmError):
             model(*bad)
+    # the kernels' ceilings are argument errors of the forward, not launch errors from inside it
+    y = torch.zeros(1, 3, 512, device="cuda:0")
+    for k_, J_ in ((1, 16), (40, 16), (20, 200)):
+        cfg_ = Namespace(gnn_k=k_, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J_)
+        with pytest.raises(OgmmError, match="gnn_k"):
+            GMMReg(512, J_, cfg_).to("cuda:0").eval()(y, y)
 
 
 @pytest.mark.gpu
