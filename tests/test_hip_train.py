@@ -254,7 +254,9 @@ def test_norm_constants_and_running_statistics_in_one_launch_each():
 
 
 @pytest.mark.parametrize("R,n,k,ldy,affine", [(65536, 512, 512, 512, False), (32768, 1024, 256, 1024, False), (131072, 256, 1024, 256, False),
-                                              (65536, 512, 512, 1024, False), (65536, 1024, 512, 1024, True), (36864, 512, 768, 512, False)])
+                                              (65536, 512, 512, 1024, False), (65536, 1024, 512, 1024, True), (36864, 512, 768, 512, False),
+                                              # output shapes that are no whole number of 256 x 256 tiles: clamped operand columns, the partial-tile epilogue
+                                              (65536, 320, 512, 320, False), (65536, 512, 384, 512, False), (32768, 260, 640, 264, False)])
 def test_weight_gradient_reads_dy_as_it_lies_and_equals_the_transposed_copy_bit_for_bit(R, n, k, ldy, affine, monkeypatch):
     """struct ogmm_gemm.a_trans (round 4): dW = dY^T X with the engine's transposing fragment reads on dY itself against the same products on the
     materialised dY^T of rounds 1-3 -- same k order, same split, same accumulation: torch.equal -- and both against fp64; dy as a column slice of a wider
@@ -273,7 +275,7 @@ def test_weight_gradient_reads_dy_as_it_lies_and_equals_the_transposed_copy_bit_
         aff = (sc, sh, True, 1024)
         X = torch.relu(x.double().view(G, 1024, k) * sc.double()[:, None] + sh.double()[:, None]).view(R, k)
     monkeypatch.setattr(ops, "DW_TRANSPOSED_A", True)
-    tiles = (n // 256) * (k // 256)
+    tiles = ((n + 255) // 256) * ((k + 255) // 256)
     S = max(1, min(((256 if 256 % tiles == 0 else 512) + tiles - 1) // tiles, R // 256))
     chunk = ((R + S - 1) // S + 63) // 64 * 64
     if R % chunk == 0:          # (else the direct form must not be taken: the copy's zero padding is what makes a ragged last chunk legal)
