@@ -100,16 +100,22 @@ __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict
     }
     __syncthreads();
     if (!s_last) return;
-    const float mx = __int_as_float(__hip_atomic_load(reinterpret_cast<int*>(scale_out + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    int e = 0;
-    if (mx > 0.0f && mx < __builtin_inff()) e = min(24, max(-24, top - (int)floorf(log2f(mx))));
-    const float sc = exp2f((float)e), inv = exp2f((float)-e);
+    // Only thread 0 reads the maximum, and it resets the scratch AFTER having read it: with every thread loading scale_out[2] and thread 0 storing 0 there,
+    // a wave that issued its load after wave 0's store saw mx == 0 and filled its share of inv_out with 1.0.  The scale travels to the
+    // other waves through LDS behind a barrier.
+    __shared__ float s_inv;
     if (threadIdx.x == 0) {
-        scale_out[0] = sc;
+        const float mx = __int_as_float(__hip_atomic_load(reinterpret_cast<int*>(scale_out + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        int e = 0;
+        if (mx > 0.0f && mx < __builtin_inff()) e = min(24, max(-24, top - (int)floorf(log2f(mx))));
+        scale_out[0] = exp2f((float)e);
+        s_inv = exp2f((float)-e);
         // leave the reduction's scratch as it was found (zero): a caller may hand the same four floats to the next call (ogmm_split_weight's slot pool)
         __hip_atomic_store(reinterpret_cast<int*>(scale_out + 2), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<int*>(scale_out + 3), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    const float inv = s_inv;
     for (int i = threadIdx.x; i < inv_len; i += 256) inv_out[i] = inv;
 }
 

@@ -613,7 +613,7 @@ class GMMReg(nn.Module):
         cap = {} if capture else None
         if self.precision not in ("f16x3", "f32"):
             raise OgmmError("training runs with precision 'f16x3' or 'f32' (the reduced 'f16' mode is inference only)")
-        backend = self._train_ops if self._train_ops is not None else train_ops.TrainOps(self.precision, self._overflow)
+        backend = self._train_ops if self._train_ops is not None else train_ops.TrainOps(self.precision, self._overflow, self._status)
         out = train_graph.forward_train(backend, P, self.config, self.n_clusters, src, tgt, fps_starts.to(src.device), cap)
         if capture:
             self.last_intermediates = cap

@@ -495,10 +495,10 @@ class _RotationFromCov(torch.autograd.Function):
 class TrainOps:
     """precision: "f16x3" (dense forward layers on the split-binary16 matrix-core engine) or "f32" (exact-fp32 engine)."""
 
-    def __init__(self, precision="f16x3", overflow=None):
+    def __init__(self, precision="f16x3", overflow=None, status=None):
         if precision not in ("f16x3", "f32"):
             raise ValueError("precision must be 'f16x3' or 'f32'")
-        self.precision, self.overflow = precision, overflow
+        self.precision, self.overflow, self.status = precision, overflow, status          # status: the model's protocol-error word (gmmreg._flags[1])
 
     # ------------------------------------------------------------------ selections (no gradient)
     def knn(self, xyz, k):
@@ -512,7 +512,7 @@ class TrainOps:
     def gmm_em(self, xyz, o, ids_j):
         # (src clouds | tgt clouds: two wkeans_plus calls in the reference, i.e. two call groups of the Sinkhorn early exit)
         return ops.gmm_em(xyz, o.contiguous(), ids_j.to(torch.int32).contiguous(), iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=1e-2,
-                          group_size=xyz.shape[0] // 2)
+                          group_size=xyz.shape[0] // 2, status=self.status)
 
     def nearest_point(self, xyz, mu):
         """index of the point nearest to each mu (lib/utils.py:244-254) -> [C,J] int64"""

@@ -102,7 +102,12 @@ class Trainer:
         both = torch.cat([fwd, bwd]).to(torch.float32)
         if self.dist is not None:
             self.dist.all_reduce(both, op=self.dist.ReduceOp.MAX)
-        f, b = both.tolist()
+        f, b, *st = both.tolist()
+        if st and st[0] > 0:
+            # the model's protocol status word (gmmreg._flags[1]: a bounded wait of the EdgeConv hand-over or of the E/M's early-exit group ran into its
+            # limit): that step's pi / mu are NaN-poisoned and training_loss's nan_to_num would turn them into a silent zero-loss step -- raise instead
+            raise FloatingPointError("kernel protocol error in a training step (status word %d: 2 = EdgeConv hand-over, 4 = E/M early-exit group wait); "
+                                     "the step's outputs are NaN-poisoned" % int(st[0]))
         return f > 0, b > 0
 
     def _forward(self, src, tgt, fps_starts):
@@ -129,8 +134,9 @@ class Trainer:
         # The engine's overflow flag (device int32[1]) is shared by forward activations and backward gradients.  It is snapshotted with device ops
         # after the forward and after the backward and read ONCE, behind the backward: no extra host round trip between the two.
         flag = self.model.overflow_flag(src.device) if hasattr(self.model, "overflow_flag") and src.is_cuda else None
+        flags = getattr(self.model, "_flags", None) if flag is not None else None          # [range flag, protocol status word]: both travel in the one read
         if flag is not None:
-            flag.zero_()
+            (flags if flags is not None else flag).zero_()
         out = self._forward(src, tgt, fps_starts)
         fwd_flag = None
         if flag is not None:
@@ -142,7 +148,7 @@ class Trainer:
         # previous step's outputs -- and through their grad_fn its graph -- still alive, ending the capture of a recorded step crashed inside the HIP
         # runtime on this ROCm; tools/train_capture_debug.py reproduces it.)
         return (tuple(o.detach() for o in out), loss.detach(), {k: v.detach() for k, v in parts.items()}, fwd_flag,
-                (flag.clone() if flag is not None else None))
+                ((flags if flags is not None else flag).clone() if flag is not None else None))
 
     def _replay(self, src, tgt, transform_gt, src_overlap, tgt_overlap, fps_starts):
         """graph=True: the recorded step on this batch (captured on first use per shape)"""

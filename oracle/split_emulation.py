@@ -8,6 +8,9 @@ The HIP path's GEMM engine multiplies fp32 operands as sums of binary16 terms on
     "x1"   a b ~ hi hi                          both rounded (precision = "f16", the labelled reduced mode): 1 MFMA
     "bf16" both operands rounded to bfloat16    what BASELINE configs[2] literally names; shown for comparison
     "f32" / None  exact fp32 (the reference's arithmetic)
+    "ulp:<seed>"  NOT an engine mode -- a conditioning probe (round 5): exact fp32 arithmetic on operands whose activation side was moved by ONE UNIT IN THE
+                  LAST PLACE with a random sign per element (x (1 +- 2^-24), seeded per layer): the classical stochastic-arithmetic estimate (CESTAC / CADNA)
+                  of how far a result is defined.  A pair whose (R, t) moves by >= 5e-6 under it is ill-conditioned whatever host evaluates the reference.
 This module restates those roundings on the CPU so that the oracle can answer, per layer, "what does rounding THIS layer's operands do to
 (R, t)?" -- the measurement behind the engine's per-layer term budget (tools/term_budget.py) and behind the stated tolerance of the reduced
 precision mode (tests/test_hip_forward.py::test_reduced_precision_mode_against_the_emulating_oracle).  It emulates the operand roundings, not
@@ -43,6 +46,8 @@ def mode_of(name):
     if _POLICY is None:
         return None
     m = _POLICY(name)
+    if m is not None and m.startswith("ulp:"):
+        return m
     if m is not None and m not in MODES:
         raise ValueError("unknown emulation mode %r for %s" % (m, name))
     return None if m == "f32" else m
@@ -67,8 +72,17 @@ def split16(x, scale_pow2=False):
     return hi, rn16(x - hi), inv
 
 
+def _jitter(a, mode, salt):
+    """a moved by one unit in the last place, random sign per element; deterministic in (seed of the mode, salt = the operand's shape)"""
+    g = torch.Generator().manual_seed((int(mode[4:]) * 1000003 + salt) % (2 ** 31))
+    sign = torch.randint(0, 2, a.shape, generator=g, dtype=torch.int8).to(a.dtype) * 2 - 1
+    return a * (1.0 + sign * 2.0 ** -24) if a.dtype == torch.float32 else a
+
+
 def _terms(a, w, mode, contract):
     """a: activation-side operand, w: weight-side operand, contract(a', w') -> the fp32 contraction"""
+    if mode.startswith("ulp:"):
+        return contract(_jitter(a, mode, a.numel() + 7 * w.numel()), w)
     if mode == "bf16":
         return contract(a.bfloat16().float(), w.bfloat16().float())
     ah, al, _ = split16(a)
@@ -94,6 +108,8 @@ def einsum(eq, a, b, mode):
     """weight-free contraction (similarity, attention scores / values): both operands are activations, `b` plays the B-operand role"""
     if mode == "bf16":
         return torch.einsum(eq, a.bfloat16().float(), b.bfloat16().float())
+    if mode.startswith("ulp:"):
+        return torch.einsum(eq, _jitter(a, mode, a.numel() + 7 * b.numel()), b)
     ah, al, _ = split16(a)
     bh, bl, _ = split16(b)
     y = torch.einsum(eq, ah, bh)

@@ -49,6 +49,8 @@ CASES = {
     "sharp_partial_b2_n1024_j16": (2, 1024, 16, "partial", 0, 20, 128, 1.0, "sharp"),      # BASELINE configs[1]
     "sharp_partial_b1_n2048_j64": (1, 2048, 64, "partial", 2000, 20, 128, 1.0, "sharp"),   # BASELINE configs[2] shape
     "sharp_partial_b1_n717_j128": (1, 717, 128, "partial", 300, 20, 128, 1.0, "sharp"),    # the repo's own defaults
+    # round 5: room planes (exact kNN ties, the hardest discrete case) at BASELINE configs[3]'s per-cloud shape on the sharp family
+    "sharp_room_b1_n2048_j64": (1, 2048, 64, "room", 3002, 20, 128, 1.0, "sharp"),
 }
 
 

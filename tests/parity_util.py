@@ -13,10 +13,17 @@ import os
 import torch
 
 from oracle import ogmm_oracle as O
+from oracle import split_emulation as E
 from ogmm_amd import synth
 
 SPREAD_THREADS = (1, 4, 16)          # MKL's 1-thread GEMM sums in another order than its threaded one; threaded runs differ among themselves by less
-TAIL_FACTOR = 4.0                    # a tail pair's HIP distance may be at most this multiple of the reference's own spread on that pair
+# Round 5: the thread probes are a property of the HOST (sharp configs[1] pair 75: 4e-6 between 1 / 4 / 16 threads on the GPU box's CPU, 1.6e-5 between 1 / 8
+# threads on the build container's), so a pair could pass or fail the "ill-conditioned" test by where it ran.  Added: three evaluations of the reference's
+# algorithm in its own fp32 arithmetic with every GEMM's activation operand moved by ONE UNIT IN THE LAST PLACE, random sign per element
+# (oracle/split_emulation.py "ulp:<seed>": the stochastic-arithmetic conditioning estimate of CESTAC / CADNA) -- deterministic and host-independent.
+# Ordinary pairs move by 0.3e-6 ... 1.7e-6 under it on both weight families; pair 75 by 1.0e-5, pair 84 by 2.7e-5, pair 112 by 1.9e-4.
+JITTER_SEEDS = (1, 2, 3)
+TAIL_FACTOR = 3.0                    # a tail pair's HIP distance may be at most this multiple of the reference's own spread on that pair (round 4: 4, with fewer probes)
 ILL_CONDITIONED = 5e-6               # ... and the pair must be visibly ill-conditioned: ordinary pairs spread by 0.3e-6 ... 3e-6
 
 
@@ -71,6 +78,9 @@ def reference_spread(P, cfg, src1, tgt1, starts1, threads=SPREAD_THREADS):
         inj = {k: cap[k] for k in ("knn_idx_src", "knn_idx_tgt")}
         with torch.no_grad():
             outs["f64"] = O.forward(P64, cfg, src1.double(), tgt1.double(), starts1, inject=inj)[:2]
+            for seed in JITTER_SEEDS:
+                with E.policy(lambda name, seed=seed: "ulp:%d" % seed):
+                    outs["ulp%d" % seed] = O.forward(P, cfg, src1, tgt1, starts1)[:2]
     finally:
         torch.set_num_threads(old)
     dr = {(a, b): O.rotation_error_rad(outs[a][0].double(), outs[b][0].double()).max().item() for a, b in itertools.combinations(outs, 2)}
@@ -90,8 +100,8 @@ def check_tail(label, r, t, inputs, P, cfg, first, min_within, bar=1e-5):
     for i in bad:
         sr, st, probes = reference_spread(P, cfg, src[i:i + 1], tgt[i:i + 1], starts[:, i:i + 1])
         rows.append((first + i, r[i].item(), t[i].item(), sr, st, probes))
-        print("PARITY-TAIL %s pair %d: HIP R %.2e t %.2e | reference's own spread R %.2e t %.2e (%s)" % (
-            label, first + i, r[i].item(), t[i].item(), sr, st, " ".join("%s %.1e" % kv for kv in probes.items())))
+        print("PARITY-TAIL %s pair %d: HIP R %.2e t %.2e | reference's own spread R %.2e t %.2e, HIP / spread %.2f (%s)" % (
+            label, first + i, r[i].item(), t[i].item(), sr, st, r[i].item() / max(sr, 1e-12), " ".join("%s %.1e" % kv for kv in probes.items())))
     within = n - len(bad)
     print("PARITY-TAIL %s: %d of %d pairs within %.0e; %d beyond, all characterised" % (label, within, n, bar, len(bad)))
     assert within >= min_within, "%s: only %d of %d pairs within %.0e (stated floor: %d)" % (label, within, n, bar, min_within)

@@ -82,7 +82,7 @@ def test_forward_matches_reference_golden(golden, name, precision):
     assert rep["R"] < R_TOL and rep["t"] < T_TOL, rep
     # sharp family: the head's gain makes the reference's OWN scores move by 2e-5 between 1 and 8 host threads (recorded with the fixture by
     # make_golden.py); the bar on the scores is then 3 x that, the bar on (R, t) stays the north star's 1e-5
-    o_tol = max(O_TOL, 3.0 * float(fx["ref_thread_noise_o"])) if "profile" in fx else O_TOL
+    o_tol = max(O_TOL, min(3.0 * float(fx["ref_thread_noise_o"]), 7.5e-5)) if "profile" in fx else O_TOL          # (capped: a regenerated fixture cannot loosen it further)
     assert rep["o"] < o_tol and rep["loss"] < LOSS_TOL, rep
 
 

@@ -38,6 +38,20 @@ def noise_of(fx, what):
     return float(fx[key]) if key in fx.files else 0.0
 
 
+# a tolerance of max(bar, 3 x the noise the fixture recorded) has no ceiling -- a regenerated fixture with larger recorded noise would loosen the
+# suite silently.  So (i) the noise a fixture may carry is bounded here (loading one beyond it fails: regenerate on another seed, as make_golden_train.py
+# does for its own criteria), and (ii) the noise-derived part of a tolerance is capped.  Units: R rad, t cloud units, o score units, loss absolute.
+NOISE_MAX = {"R": 4e-5, "t": 1e-5, "o": 1.5e-4, "loss": 2e-5}
+TOL_CAP = {"R": 5e-5, "t": 2e-5, "o": 2e-4, "loss": 3.5e-5}
+
+
+def noise_tol(fx, what, bar):
+    """max(bar, 3 x the reference's own recorded noise), the second part capped at TOL_CAP[what]; a fixture whose noise exceeds NOISE_MAX[what] is refused"""
+    n = noise_of(fx, what)
+    assert n <= NOISE_MAX[what], "fixture records %s noise %.2e > %.2e: not a case where 'close to the reference' means anything -- regenerate" % (what, n, NOISE_MAX[what])
+    return max(bar, min(3.0 * n, TOL_CAP[what]))
+
+
 def filled_state(module_or_spec):
     """closed-form weights of ogmm_amd/synth.py as a fresh dict of tensors"""
     return synth.fill_state_dict(module_or_spec)
