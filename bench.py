@@ -18,9 +18,10 @@ actually issued (3 per product; 1 on the layers of the term budget).  `path_frac
 same peak.  `roofline_other`: the runner-up kernels (EdgeConv: MFMA; attention: HBM), same brackets.
 cpu_baseline: the CPU oracle (a plain-PyTorch port of the reference, bit-identical to it) timed on this host's cores (thread sweep, B = 1 and 8; rank 0,
 N=1 only); the parity block checks EVERY pair of the timed batch against it.
-secondary (N=1 only, behind the headline's timed region): short legs of the other BASELINE configs -- configs[2] shape (B=256, N=2048, J=64), configs[3]
-shape per GPU (room clouds) and configs[4] (the training step, 128 pairs per GPU) -- each with its throughput, its engine roofline fraction and a parity
-sample against the oracle, so that the driver's record observes them too.
+secondary (N=1 only, behind the headline's timed region): the headline workload on the SHARP weight family (directly behind the headline, with a repeat of the
+default family behind it: an A/B in the record), the headline workload with --precision f32 (the strict same-arithmetic figure), and short legs of the other
+BASELINE configs -- configs[2] shape (B=256, N=2048, J=64), configs[3] shape per GPU (room clouds) and configs[4] (the training step, 128 pairs per GPU) -- each
+with its throughput, its engine roofline fraction and a parity sample against the oracle, so that the driver's record observes them too.
 """
 import argparse
 import json
@@ -146,7 +147,7 @@ def main():
         del keep
         if args.workload == "cfg1" and world == 1 and not stub and args.secondary:
             torch.cuda.empty_cache()
-            result["secondary"] = secondary_legs(args, ctx)
+            result["secondary"] = secondary_legs(args, ctx, result["value"])
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
@@ -313,17 +314,49 @@ def parity_sample(keep, ids, threads):
             "of": "pairs %s of the leg's last timed forward" % list(ids), "against": "CPU oracle"}
 
 
-def secondary_legs(args, ctx):
+def secondary_legs(args, ctx, headline_value=None):
     """BASELINE configs[2], [3] (shapes per GPU) and [4] (training step) as short legs behind the headline's timed region: the same code paths as
     `--workload cfg2 | cfg3 | train`, fewer steps; each with a parity sample.  A leg that fails reports its error instead of taking the headline down."""
     legs = []
     threads = min(16, os.cpu_count() or 1)
+    roof_keys = ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "kernel_share_of_step")
+    try:
+        # the headline workload once more on the SHARP weight family (peaked attention, overlap scores spanning (0, 1)): the same kernels, so the same
+        # throughput -- what the leg adds to the record is the parity of a timed forward on non-degenerate weights (16 of its 64 pairs against the oracle).
+        # Run DIRECTLY behind the headline (round 4's record had it behind cfg2 + cfg3 and 5.5 % low: leg order / clocks, or data dependence?), and followed by
+        # a repeat of the default family: `ab_with_headline` = default (headline) -> sharp -> default again, same box, same minute.
+        res, keep = eval_leg(args, ctx, "cfg1", 20, 5, profile="sharp")          # (the headline's own step count: short legs read low -- two steps carry the event brackets)
+        leg = {"workload": res["config"]["workload"].replace("closed-form weights", "closed-form weights of the SHARP family (synth.fill_state_dict(profile='sharp'))"),
+               "metric": "pairs_per_sec", "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 20, "warmup": 5,
+               "roofline": {k: res["roofline"][k] for k in roof_keys},
+               "parity": parity_sample(keep, tuple(range(0, 64, 4)), threads) if args.cpu_sample > 0 else None,
+               "fp16_split_overflowed": bool(keep.model.fp16_overflowed())}
+        del keep
+        torch.cuda.empty_cache()
+        res2, keep = eval_leg(args, ctx, "cfg1", 20, 5)
+        del keep
+        leg["ab_with_headline"] = {"default_before_pairs_per_s": headline_value, "sharp_pairs_per_s": res["value"], "default_after_pairs_per_s": res2["value"],
+                                   "note": "three consecutive legs of 20 timed steps on one box: the headline, this leg, the headline's workload again"}
+        legs.append(leg)
+    except Exception as e:          # noqa: BLE001
+        legs.append({"workload": "cfg1 on sharp weights", "error": "%s: %s" % (type(e).__name__, e)})
+    torch.cuda.empty_cache()
+    try:
+        # the strict same-arithmetic figure: every GEMM on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s peak)
+        res, keep = eval_leg(args, ctx, "cfg1", 5, 2, precision="f32")
+        legs.append({"workload": res["config"]["workload"], "metric": "pairs_per_sec", "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 5, "warmup": 2,
+                     "dtype": res["dtype"], "roofline": {k: res["roofline"][k] for k in roof_keys},
+                     "parity": parity_sample(keep, (0, 21, 42, 63), threads) if args.cpu_sample > 0 else None})
+        del keep
+    except Exception as e:          # noqa: BLE001
+        legs.append({"workload": "cfg1 --precision f32", "error": "%s: %s" % (type(e).__name__, e)})
+    torch.cuda.empty_cache()
     for wl in ("cfg2", "cfg3"):
         try:
             res, keep = eval_leg(args, ctx, wl, 5, 2)
             b = res["config"]["pairs_per_gpu_step"]
             leg = {"workload": res["config"]["workload"], "metric": "pairs_per_sec", "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 5, "warmup": 2,
-                   "roofline": {k: res["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "kernel_share_of_step")},
+                   "roofline": {k: res["roofline"][k] for k in roof_keys},
                    "parity": parity_sample(keep, (0, b // 2, b - 1), threads) if args.cpu_sample > 0 else None,
                    "fp16_split_overflowed": bool(keep.model.fp16_overflowed())}
             del keep
@@ -331,18 +364,6 @@ def secondary_legs(args, ctx):
             leg = {"workload": wl, "error": "%s: %s" % (type(e).__name__, e)}
         legs.append(leg)
         torch.cuda.empty_cache()
-    try:
-        # the headline workload once more on the SHARP weight family (peaked attention, overlap scores spanning (0, 1)): the same kernels, so the same
-        # throughput -- what the leg adds to the record is the parity of a timed forward on non-degenerate weights (16 of its 64 pairs against the oracle)
-        res, keep = eval_leg(args, ctx, "cfg1", 20, 5, profile="sharp")          # (the headline's own step count: short legs read low -- two steps carry the event brackets)
-        legs.append({"workload": res["config"]["workload"].replace("closed-form weights", "closed-form weights of the SHARP family (synth.fill_state_dict(profile='sharp'))"),
-                     "metric": "pairs_per_sec", "value": res["value"], "unit": "pairs/s", "ms_per_step": res["ms_per_step"], "steps": 20, "warmup": 5,
-                     "roofline": {k: res["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "kernel_share_of_step")},
-                     "parity": parity_sample(keep, tuple(range(0, 64, 4)), threads) if args.cpu_sample > 0 else None,
-                     "fp16_split_overflowed": bool(keep.model.fp16_overflowed())})
-        del keep
-    except Exception as e:          # noqa: BLE001
-        legs.append({"workload": "cfg1 on sharp weights", "error": "%s: %s" % (type(e).__name__, e)})
     torch.cuda.empty_cache()
     try:
         res = train_leg(args, ctx, args.train_batch, 5, 2, cpu_check=args.cpu_sample > 0)
@@ -415,6 +436,20 @@ class _StubForward:
         return False
 
 
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo; None when the file does not say"""
+    try:
+        seen, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":")[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_leg(args, keep):
     """cpu_baseline (the CPU oracle -- a plain-PyTorch port of the reference, bit-identical to it on the generating machine -- on this host's
     cores, B = 1 and B = 8, thread sweep, 3 warm-up + >= 10 timed at the best setting) and the parity of the TIMED forward (every pair of its batch)."""
@@ -467,9 +502,12 @@ def cpu_leg(args, keep):
     r_all, t_all, o_all = torch.cat(r_all), torch.cat(t_all), torch.cat(o_all)
     return {
         "cpu_baseline": {"value": best, "unit": "pairs/s", "cores": best_nt, "kind": "port", "host_threads": host,
+                         "cores_semantics": "threads used by the best setting of the sweep {1, 8, 16} -- NOT the host's core count (physical_cores); larger OpenMP teams "
+                                            "were slower on this pool's containers (see the comment in cpu_leg)",
+                         "physical_cores": physical_cores(),
                          "one_thread_pairs_per_s": sweep.get(1, {}).get("B1"),
                          "sweep_pairs_per_s": {str(nt): {k: round(v, 3) for k, v in d.items()} for nt, d in sweep.items()},
-                         "sample": "CPU oracle forward on pairs of the same batch: thread sweep {1, 8, 16} at B = 1 and B = 8 (1 warm-up + 2-3 timed each), "
+                         "sample": "best of sweep: CPU oracle forward on pairs of the same batch, thread sweep {1, 8, 16} at B = 1 and B = 8 (1 warm-up + 2-3 timed each), "
                                    "then the best setting (%d threads, %s) with 3 warm-up + 10 timed forwards, median" % (best_nt, best_b)},
         "parity": {"R_err_rad_max": r_all.max().item(), "R_err_rad_median": r_all.median().item(), "t_err_max": t_all.max().item(),
                    "overlap_err_max": o_all.max().item(), "pairs_checked": n, "pairs_over_1e-5": int(((r_all >= 1e-5) | (t_all >= 1e-5)).sum()),
@@ -487,25 +525,36 @@ def train_leg(args, ctx, B, steps, warmup, cpu_check=True):
     N, J_ = 1024, 16
     cfg = make_cfg(J_)
     rank, world, dist, dev = ctx.rank, ctx.world, ctx.dist, ctx.dev
+    stub = getattr(ctx, "stub", False)
+    if stub:
+        # Test seam (tests/test_train_dist_gloo.py::test_bench_train_leg_under_two_ranks): THIS function's control flow -- the sharding of the global pair
+        # ids, the Trainer's all-reduce / buffer broadcast, the barriers, the max over ranks, the result's fields -- on CPU over gloo, with the training graph on
+        # the plain-PyTorch operation set of tests/train_ref.py at a toy size.  Never set on a GPU box.
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from train_ref import RefTrainOps
+        N, J_, B = 96, 8, 1
+        cfg = Namespace(gnn_k=8, num_heads=4, km_clusters=16, overlap_radius=0.035, n_clusters=J_)
     model = GMMReg(512, J_, cfg)
     synth.fill_state_dict(model.state_dict())
     params_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     model.precision = args.precision if args.precision != "f16" else "f16x3"
+    if stub:
+        model._train_ops = RefTrainOps()
     first, _ = odist.shard_pairs(rank, world, B)
     batch = [t.to(dev) for t in synth.make_train_batch(first, B, N, "partial")]
     starts = synth.fps_starts_for(first, B, N)
     # forward + loss + backward replayed from a HIP graph (Trainer(graph=True): ~2500 launches per step, whose enqueueing takes the host as long as the GPU
     # needs to run them); OGMM_TRAIN_GRAPH=0 times the eager step.  The first steps are eager, the next one records: all inside the warm-up.
-    use_graph = os.environ.get("OGMM_TRAIN_GRAPH", "1") != "0"
-    trainer = Trainer(model, dist=dist, world=world, graph=use_graph)
+    use_graph = os.environ.get("OGMM_TRAIN_GRAPH", "1") != "0" and not stub
+    trainer = Trainer(model, dist=dist, world=world, graph=use_graph, **({"welsch_top_k": 48} if stub else {}))
     for _ in range(max(warmup, trainer.graph_warmup + 2) if use_graph else warmup):
         info = trainer.step(*batch, fps_starts=starts)
-    odist.barrier(dist)
+    odist.barrier(dist, cuda=not stub)
     t0 = time.perf_counter()
     for i in range(steps):
         info = trainer.step(*batch, fps_starts=starts)
-    odist.barrier(dist)
+    odist.barrier(dist, cuda=not stub)
     elapsed = time.perf_counter() - t0
     final_loss, loss_parts = float(info["loss"]), {k: float(v) for k, v in info["parts"].items()}
     # the engine's launches are bracketed in separate EAGER steps behind the timed region (events cannot sit inside a replayed graph, and they cost GPU time)
@@ -514,7 +563,8 @@ def train_leg(args, ctx, B, steps, warmup, cpu_check=True):
     sampled = [True] * (1 if use_graph else max(1, steps // EVENT_EVERY))
     for _ in sampled:
         trainer.step(*batch, fps_starts=starts)
-    torch.cuda.synchronize(dev)
+    if not stub:
+        torch.cuda.synchronize(dev)
     timeline, ops.GEMM_TIMELINE, ops.GEMM_TIMELINE_ONLY = ops.GEMM_TIMELINE, None, None
     n_sampled = sum(sampled)
     elapsed = odist.max_over_ranks(dist, elapsed, dev)
@@ -539,7 +589,7 @@ def train_leg(args, ctx, B, steps, warmup, cpu_check=True):
         "step_launch": "HIP graph replay of forward + loss + backward; all-reduce, un-scaling and Adam eager" if use_graph else "eager",
         "final_loss": final_loss, "loss_parts": loss_parts,
     }
-    if rank == 0 and world == 1 and cpu_check:
+    if rank == 0 and world == 1 and cpu_check and not stub:
         # parity sample + CPU baseline of the training step: the first 2 pairs as their own training batch (train-mode BatchNorm statistics are per batch, so
         # a sub-batch of the timed one is a different computation) through a fresh HIP model and through the oracle: loss parts, and the oracle's time
         from oracle import ogmm_oracle as O
@@ -571,6 +621,14 @@ def train_leg(args, ctx, B, steps, warmup, cpu_check=True):
                             "of": "a train-mode forward + loss of the first %d pairs as their own batch" % n, "against": "CPU oracle, train mode"}
         del m2, out_h, loss_h
     result["fp16_split_overflowed"] = bool(model.fp16_overflowed())
+    if stub:
+        # every rank must leave the steps with the same parameters and BatchNorm buffers (gradient all-reduce + rank-0 buffer broadcast)
+        chk = torch.stack([v.double().abs().sum() for v in model.state_dict().values() if v.is_floating_point()]).sum().reshape(1)
+        if dist is not None:
+            got = [torch.zeros_like(chk) for _ in range(world)]
+            dist.all_gather(got, chk)
+            result["stub_ranks_agree"] = bool(all(torch.equal(g, got[0]) for g in got))
+        result["stub_state_checksum"] = float(chk)
     return result
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 24
+#define OGMM_ABI_VERSION 25
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -238,8 +238,9 @@ int ogmm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream
  * (cloud, channel).  models/attn.py:24-25.  x [C][N][ld], D channels. */
 int ogmm_instnorm_relu(float* x, int64_t ld, int C, int N, int D, float eps, void* stream);
 
-/* statistics -> affine: mean = s1/rows, var = s2/rows - mean^2 (biased); scale = 1/sqrt(var+eps), shift = -mean*scale. */
-int ogmm_instnorm_finalize(const double* col_stats, int64_t n_entries, int rows, float eps, float* scale, float* shift, void* stream);
+/* statistics -> affine: mean = s1/rows, var = s2/rows - mean^2 (biased); scale = 1/sqrt(var+eps), shift = -mean*scale (models/attn.py:24).
+ * clear != 0 (ABI 25): every entry is zeroed behind its read, so the buffer is ready for the next accumulation without a fill by the caller. */
+int ogmm_instnorm_finalize(double* col_stats, int64_t n_entries, int rows, float eps, float* scale, float* shift, int clear, void* stream);
 
 /* activation rows x [rows][ld] (fp32) -> split fragment-major image (OGMM_PREC_F16X3_FRAG B operand: [ceil(rows/32)][K/16][64][8]
  * binary16, hi and lo), so that an activation can be the B side of ogmm_gemm_nt (the similarity of models/gmmreg.py:75).
@@ -252,6 +253,10 @@ int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* ou
 /* F.normalize(dim = channels) of x [rows][ld] written straight as the split fragment-major B image of ogmm_pack_frag (rows padded to a
  * multiple of 32 with zeros): the tgt side of the N x N similarity (models/gmmreg.py:74-75) never exists as an fp32 map. */
 int ogmm_l2norm_pack_frag(const float* x, int64_t ld, int64_t rows, int K, void* hi, void* lo, void* stream);
+/* (ABI 25) the same launch with a second job: rnorm_out[row] = 1 / max(|x_rn[row, 0:K]|_2, 1e-12) for the rows of ANOTHER map (ogmm_row_rnorm's result) --
+ * both operands of the similarity GEMM of models/gmmreg.py:74-75 (tgt half as image, src half's row scale) are prepared by one kernel. */
+int ogmm_l2norm_pack_frag_rnorm(const float* x, int64_t ld, int64_t rows, int K, void* hi, void* lo, const float* x_rn, int64_t ld_rn, int64_t rows_rn,
+                                float* rnorm_out, void* stream);
 /* Cout = 1 convolutions (proj.net.3, overlap.net.6): y[m] = act(dot(x[m][:], w) + b). */
 int ogmm_rowdot(const float* x, int64_t ldx, int64_t rows, int D, const float* w, const float* b /*device [1]*/,
                 int act, float* y, int64_t ldy, void* stream);

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -74,8 +74,9 @@ PROTOTYPES = {
                            c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],
     "ogmm_instnorm_relu": [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p],
-    "ogmm_instnorm_finalize": [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "ogmm_instnorm_finalize": [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p],
     "ogmm_l2norm_pack_frag": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p],
+    "ogmm_l2norm_pack_frag_rnorm": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p],
     "ogmm_pack_frag": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_l2norm_rows": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p],
     "ogmm_rowdot": [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],

@@ -77,15 +77,19 @@ __global__ __launch_bounds__(256) void instnorm_relu_kernel(float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- fused-InstanceNorm statistics -> affine (see ogmm_gemm.col_stats)
-__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const double* __restrict__ st, int64_t n, int rows, float eps,
-                                                                float* __restrict__ scale, float* __restrict__ shift) {
+// clear: the entry is zeroed behind the read -- every entry has exactly one reader, so the accumulating GEMM of the NEXT forward finds the buffer as it
+// needs it and the caller's per-forward fill of it (a launch, and for the whole-forward buffer a 6 MB pass) goes away (round 5).
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(double* __restrict__ st, int64_t n, int rows, float eps,
+                                                                float* __restrict__ scale, float* __restrict__ shift, int clear) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double mean = st[2 * i] / rows;
-    const double var = fmax(st[2 * i + 1] / rows - mean * mean, 0.0);
+    const double2 s12 = *reinterpret_cast<const double2*>(st + 2 * i);
+    const double mean = s12.x / rows;
+    const double var = fmax(s12.y / rows - mean * mean, 0.0);
     const double inv = 1.0 / sqrt(var + (double)eps);
     scale[i] = (float)inv;
     shift[i] = (float)(-mean * inv);
+    if (clear) *reinterpret_cast<double2*>(st + 2 * i) = double2{0.0, 0.0};
 }
 
 // ---------------------------------------------------------------- activation rows -> split fragment-major B image
@@ -125,10 +129,29 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict_
 // The tgt half of the normalised map is only ever the B operand of the similarity GEMM: a workgroup takes 32 rows, computes their norms
 // (one wave per row, as l2norm_rows_kernel: same sums, same division) and then writes the rows' slice of the hi/lo images directly
 // (pack_frag_kernel's layout; the second read of the rows comes from L2).  Saves writing and re-reading the fp32 map (2 x 134 MB at B = 64).
+// Second job of the same launch (round 5; x_rn != nullptr): workgroups beyond the image's take 32 rows each of ANOTHER map and write 1 / max(|row|, 1e-12)
+// (row_rnorm_kernel's sums and division) -- the src half's row scale of the similarity GEMM, which used to be a launch of its own behind this one.
 __global__ __launch_bounds__(256) void l2norm_pack_frag_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, f16x8p* __restrict__ hi,
-                                                               f16x8p* __restrict__ lo) {
+                                                               f16x8p* __restrict__ lo, int64_t pack_blocks, const float* __restrict__ x_rn, int64_t ld_rn,
+                                                               int64_t rows_rn, float* __restrict__ rnorm_out) {
     __shared__ float nrm_s[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int64_t)blockIdx.x >= pack_blocks) {
+        const int64_t r0 = ((int64_t)blockIdx.x - pack_blocks) * 32;
+        for (int r = wave; r < 32; r += 4) {
+            const int64_t row = r0 + r;
+            if (row >= rows_rn) break;
+            const float* __restrict__ p = x_rn + row * ld_rn;
+            float ss = 0.0f;
+            for (int d = lane * 4; d < K; d += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(p + d);
+                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+            const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+            if (lane == 0) rnorm_out[row] = 1.0f / nrm;
+        }
+        return;
+    }
     const int64_t nb = blockIdx.x, row0 = nb * 32;
     for (int r = wave; r < 32; r += 4) {
         const int64_t row = row0 + r;
@@ -382,10 +405,10 @@ extern "C" int ogmm_instnorm_relu(float* x, int64_t ld, int C, int N, int D, flo
     return ogmm::check_launch("ogmm_instnorm_relu");
 }
 
-extern "C" int ogmm_instnorm_finalize(const double* col_stats, int64_t n_entries, int rows, float eps, float* scale, float* shift, void* stream) {
-    OGMM_REQUIRE(col_stats && scale && shift && n_entries > 0 && rows > 0, "ogmm_instnorm_finalize: null pointer or empty input");
+extern "C" int ogmm_instnorm_finalize(double* col_stats, int64_t n_entries, int rows, float eps, float* scale, float* shift, int clear, void* stream) {
+    OGMM_REQUIRE(col_stats && scale && shift && n_entries > 0 && rows > 0 && ogmm::aligned16(col_stats), "ogmm_instnorm_finalize: null / unaligned pointer or empty input");
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, ogmm::as_stream(stream), col_stats,
-                       n_entries, rows, eps, scale, shift);
+                       n_entries, rows, eps, scale, shift, clear);
     return ogmm::check_launch("ogmm_instnorm_finalize");
 }
 
@@ -406,8 +429,20 @@ extern "C" int ogmm_l2norm_pack_frag(const float* x, int64_t ld, int64_t rows, i
     const int64_t blocks = (rows + 31) / 32;
     OGMM_REQUIRE(blocks <= 2147483647LL, "ogmm_l2norm_pack_frag: too many rows");
     hipLaunchKernelGGL(l2norm_pack_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, ogmm::as_stream(stream), x, ld, rows, K,
-                       reinterpret_cast<f16x8p*>(hi), reinterpret_cast<f16x8p*>(lo));
+                       reinterpret_cast<f16x8p*>(hi), reinterpret_cast<f16x8p*>(lo), blocks, (const float*)nullptr, (int64_t)0, (int64_t)0, (float*)nullptr);
     return ogmm::check_launch("ogmm_l2norm_pack_frag");
+}
+
+extern "C" int ogmm_l2norm_pack_frag_rnorm(const float* x, int64_t ld, int64_t rows, int K, void* hi, void* lo, const float* x_rn, int64_t ld_rn, int64_t rows_rn,
+                                           float* rnorm_out, void* stream) {
+    OGMM_REQUIRE(x && hi && lo && x_rn && rnorm_out && rows > 0 && rows_rn > 0 && K > 0 && K % 16 == 0 && ld % 4 == 0 && ld_rn % 4 == 0 && ogmm::aligned16(x) &&
+                 ogmm::aligned16(x_rn) && ogmm::aligned16(hi) && ogmm::aligned16(lo),
+                 "ogmm_l2norm_pack_frag_rnorm: K %% 16 == 0, ld %% 4 == 0 and 16-byte aligned pointers required");
+    const int64_t blocks = (rows + 31) / 32, blocks_rn = (rows_rn + 31) / 32;
+    OGMM_REQUIRE(blocks + blocks_rn <= 2147483647LL, "ogmm_l2norm_pack_frag_rnorm: too many rows");
+    hipLaunchKernelGGL(l2norm_pack_frag_kernel, dim3((unsigned)(blocks + blocks_rn)), dim3(256), 0, ogmm::as_stream(stream), x, ld, rows, K,
+                       reinterpret_cast<f16x8p*>(hi), reinterpret_cast<f16x8p*>(lo), blocks, x_rn, ld_rn, rows_rn, rnorm_out);
+    return ogmm::check_launch("ogmm_l2norm_pack_frag_rnorm");
 }
 
 extern "C" int ogmm_l2norm_rows(const float* x, int64_t ldx, int64_t rows, int D, float* out, int64_t ldo, void* stream) {

@@ -251,6 +251,7 @@ class GMMReg(nn.Module):
         self.overflow_policy = "deferred"          # what an fp16 range overflow in an eval forward does: _post_overflow_check
         self._side = None
         self._side2 = None
+        self._ws = None             # persistent zero-initialised buffers of the eval forward (_workspace)
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved.  (data_ptr, _version) catches optimizer steps,
@@ -295,6 +296,25 @@ class GMMReg(nn.Module):
             self._packed_fp = self._fingerprint(list(sd.values()))
         return self._packed
 
+    def _workspace(self, dev, stream, C, N, D, XW):
+        """Persistent zero-initialised buffers of the eval forward, one set per (stream, shape) -- a model that is driven from two streams at once gets
+        two sets -- at most four sets are kept.  `clean` is False while a forward is between its first accumulation and its last finalize: a forward that
+        raised in between leaves statistics behind, and the next one re-zeroes them."""
+        key = (str(dev), stream.cuda_stream, C, N, D, XW)
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 4:
+                self._ws.pop(next(iter(self._ws)))
+            ws = self._ws[key] = {"stats3": torch.zeros((3, C, 2 * D, 2), dtype=torch.float64, device=dev),
+                                  "extra": torch.zeros((C * N, XW), dtype=torch.float32, device=dev), "clean": True}
+        elif not ws["clean"]:
+            ws["stats3"].zero_()
+            ws["extra"][:, 2:].zero_()
+        ws["clean"] = False
+        return ws
+
     def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0, kv_terms=0, qk_terms=0, after_attention=None):
         """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D]; the anchors [C, M, D] are rows
         anchor_ids [C, M] of anchor_feats [C*N, D] (of the cloud cloud_map[c], if given): lib/utils.py:111-127."""
@@ -313,10 +333,11 @@ class GMMReg(nn.Module):
                 mlp0, msg = L["mlp0"], ops.conv1x1(o, L["merge"], eng=eng)
             if eng.split and ops.instnorm_fusable(mlp0.get("split"), N):
                 # InstanceNorm fused: statistics in mlp0's epilogue, normalise + ReLU while mlp3 stages its A operand
-                if stats is None:          # (the forward hands in a slice of a buffer zeroed on the side stream during the front end)
+                own = stats is None          # (the forward hands in a slice of its persistent, self-cleaning workspace: _workspace)
+                if own:
                     stats = torch.zeros((C, 2 * D, 2), dtype=torch.float64, device=dev)
                 z = ops.conv1x1(x, mlp0, x2=msg, col_stats=stats, group_rows=N, eng=eng)
-                a_sc, a_sh = ops.instnorm_finalize(stats, N, BN_EPS)
+                a_sc, a_sh = ops.instnorm_finalize(stats, N, BN_EPS, clear=not own)
                 return ops.conv1x1(z, L["mlp3"], res=res, a_affine=(a_sc, a_sh, True), group_rows=N, eng=eng)
             z = ops.conv1x1(x, mlp0, x2=msg, eng=eng)
             ops.instnorm_relu_(z, C, N, BN_EPS)
@@ -402,15 +423,15 @@ class GMMReg(nn.Module):
         # end) and the FPS chains take ~0.4 ms; side by side they are through in time.
         R = C * N
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
-        stats3 = torch.empty((3, C, 2 * D, 2), dtype=torch.float64, device=dev)
-        extra = torch.empty((R, XW), dtype=torch.float32, device=dev)
+        # the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0: persistent per (stream, shape), zeroed when created.
+        # Round 4 re-allocated and re-zeroed both per forward: the 16.8 MB fill of `extra` (30 of its 32 columns are constant zero) ran for 660 us beside
+        # the EdgeConv kernel.  Now `extra`'s pad columns are zeroed once (the forward writes columns 0 and 1 only) and ogmm_instnorm_finalize zeroes the
+        # statistics behind its read.
+        ws = self._workspace(dev, main, C, N, D, XW)
+        stats3, extra = ws["stats3"], ws["extra"]
         with torch.cuda.stream(side):
             idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
             hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
-            # zero-initialised buffers of the main chain, filled here instead of between its GEMMs (a 4 us fill costs the main stream ~10 us with its
-            # launch gap): the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0
-            stats3.zero_()
-            extra.zero_()
         with torch.cuda.stream(side2):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
             ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
@@ -421,8 +442,6 @@ class GMMReg(nn.Module):
         xyz.record_stream(side)
         for t_ in (ids_a, ids_j, idx5, hd, ha):
             t_.record_stream(main)
-        stats3.record_stream(side)
-        extra.record_stream(side)
         idx = ops.knn(xyz, k)
 
         # ---- DGCNN (models/dgcnn.py:133-154)
@@ -456,7 +475,7 @@ class GMMReg(nn.Module):
                          terms=tb.get("proj.0", 0))      # proj.0 + proj.3
         if self.fuse_overlap and D % 64 == 0 and ops.overlap_fusable(B, N, D, eng):
             # the N x N similarity never leaves the GEMM's accumulators: its epilogue forms the partial softmax-dots (struct ogmm_gemm.ovl_rowpart)
-            tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N)        # B operand: the tgt half, normalised and split in one pass
+            tgt_img = ops.l2norm_pack_frag_batched(f[B * N:], B, N, rnorm_of=f[:B * N])        # B operand: the tgt half, normalised and split in one pass; the same launch leaves the src half's 1 / |row|
             ops.overlap_fused(f[:B * N], tgt_img, B, N, D, extra[:B * N, 1], extra[B * N:, 1], XW, extra[:B * N, 0], extra[B * N:, 0], XW,
                               overflow=self._overflow, terms=tb.get("similarity", 0))
         else:
@@ -542,6 +561,7 @@ class GMMReg(nn.Module):
             cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0], o_logit=extra[:, 1],
                        o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss, sinkhorn_resid=em[3], sinkhorn_sweeps=em[4])
             self.last_intermediates = cap
+        ws["clean"] = True
         if is_test:
             # models/gmmreg.py:115-117: point-to-point ICP from the network's motion, correspondence radius 2 * overlap_radius
             # (lib/o3dutils.py:176).  The reference hands every pair to open3d on the CPU; here the whole batch stays on the GPU.

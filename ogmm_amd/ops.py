@@ -329,12 +329,14 @@ def instnorm_fusable(layer_split, N):
     return layer_split is not None and layer_split.get("variant") == PREC_F16X3_FRAG and N % 256 == 0
 
 
-def instnorm_finalize(col_stats, rows, eps=1e-5):
-    """col_stats [G, cols, 2] float64 -> (scale, shift) float32 [G, cols]."""
+def instnorm_finalize(col_stats, rows, eps=1e-5, clear=False):
+    """col_stats [G, cols, 2] float64 -> (scale, shift) float32 [G, cols].  clear: the statistics are zeroed behind the read (a persistent buffer is then
+    ready for the next forward's accumulation without a fill)."""
     G, cols, _ = col_stats.shape
+    assert col_stats.is_contiguous() and col_stats.dtype == torch.float64
     scale = torch.empty((G, cols), dtype=torch.float32, device=col_stats.device)
     shift = torch.empty_like(scale)
-    _lib.call("ogmm_instnorm_finalize", _p(col_stats), G * cols, rows, eps, _p(scale), _p(shift), _stream())
+    _lib.call("ogmm_instnorm_finalize", _p(col_stats), G * cols, rows, eps, _p(scale), _p(shift), 1 if clear else 0, _stream())
     return scale, shift
 
 
@@ -442,8 +444,10 @@ def pack_frag_batched(x, batch, rows):
     return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K}
 
 
-def l2norm_pack_frag_batched(x, batch, rows):
-    """pack_frag_batched(l2norm_rows(x), batch, rows) in one kernel per image set: the normalised rows exist only as split images."""
+def l2norm_pack_frag_batched(x, batch, rows, rnorm_of=None):
+    """pack_frag_batched(l2norm_rows(x), batch, rows) in one kernel per image set: the normalised rows exist only as split images.
+    rnorm_of [rows', K] (optional): the same launch also computes row_rnorm(rnorm_of) (the src half's row scale of the similarity GEMM), returned as
+    the image dict's "rnorm" entry."""
     K = x.shape[1]
     assert x.stride(1) == 1 and x.shape[0] == batch * rows and K % 64 == 0
     rp = (rows + 255) // 256 * 256
@@ -451,9 +455,16 @@ def l2norm_pack_frag_batched(x, batch, rows):
     lo = torch.zeros_like(hi) if rp != rows else torch.empty_like(hi)
     for b in range(batch) if rp != rows else ():
         _lib.call("ogmm_l2norm_pack_frag", _p(x[b * rows:]), x.stride(0), rows, K, _p(hi[b]), _p(lo[b]), _stream())
-    if rp == rows:
+    rnorm = None
+    if rp == rows and rnorm_of is not None and rnorm_of.shape[1] == K and rnorm_of.stride(1) == 1:
+        rnorm = torch.empty((rnorm_of.shape[0],), dtype=torch.float32, device=x.device)
+        _lib.call("ogmm_l2norm_pack_frag_rnorm", _p(x), x.stride(0), batch * rows, K, _p(hi), _p(lo), _p(_f32(rnorm_of, "rnorm_of")), rnorm_of.stride(0),
+                  rnorm_of.shape[0], _p(rnorm), _stream())
+    elif rp == rows:
         _lib.call("ogmm_l2norm_pack_frag", _p(x), x.stride(0), batch * rows, K, _p(hi), _p(lo), _stream())
-    return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K}
+    if rnorm is None and rnorm_of is not None:
+        rnorm = row_rnorm(rnorm_of)
+    return {"W_hi": hi, "W_lo": lo, "inv_scale": 1.0, "variant": PREC_F16X3_FRAG, "ldb_h": K, "sB": rp * K, "rnorm": rnorm}
 
 
 def attention(q, k, v, C, N, M, H, out=None, use_workspace=True, qk_terms=0):
@@ -598,7 +609,9 @@ def overlap_fused(f_src, tgt_img, B, N, D, o_src, o_tgt, ldo_in, wo_src, wo_tgt,
     nt = N // 256
     rowpart = torch.empty((B, nt, N, 3), dtype=torch.float32, device=f_src.device)
     colpart = torch.empty((B, nt, N, 3), dtype=torch.float32, device=f_src.device)
-    rinv = row_rnorm(f_src)
+    rinv = tgt_img.get("rnorm")          # (l2norm_pack_frag_batched(..., rnorm_of=f_src): computed by the launch that made the image)
+    if rinv is None:
+        rinv = row_rnorm(f_src)
     gemm_nt(f_src, f_src.stride(0), D, None, D, N, N, batch=(B, 1), sA=(N * f_src.stride(0), 0), split=tgt_img, overflow=overflow,
             overlap=(o_tgt, o_src, ldo_in, rowpart, colpart), row_rscale=rinv, terms=terms)          # the reference weights the ROW softmax with src_o, indexed by column
     _lib.call("ogmm_overlap_finalize", _p(rowpart), _p(colpart), B, N, _p(wo_src), _p(wo_tgt), ldo, _stream())

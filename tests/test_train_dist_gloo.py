@@ -91,3 +91,36 @@ def test_two_rank_training_step(tmp_path):
     fresh, _, _ = _make((900, 901))
     moved = sum(float((got[0]["state"][k] - v).abs().sum()) for k, v in fresh.state_dict().items() if v.is_floating_point() and "running" not in k)
     assert moved > 0
+
+
+def _bench_train_worker(rank, world, port, out_dir):
+    """bench.py's train leg (`--workload train`) under torch.distributed (gloo, CPU) through its OGMM_BENCH_STUB seam: the code `python bench.py --gpus 8
+    --workload train` runs around the model, with the training graph on tests/train_ref.py's operation set at a toy size"""
+    import contextlib
+    import io
+    torch.set_num_threads(3)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OGMM_BENCH_STUB="1")
+    sys.argv = ["bench.py", "--gpus", str(world), "--workload", "train", "--steps", "2", "--warmup", "1"]
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    with open(os.path.join(out_dir, "train_out%d.txt" % rank), "w") as f:
+        f.write(buf.getvalue())
+
+
+def test_bench_train_leg_under_two_ranks(tmp_path):
+    """`bench.train_leg` had never run at world > 1.  Two ranks, gloo: one JSON line from rank 0, the whole-job value (pairs of
+    both ranks / the slowest rank's time), a data-parallel label, and both ranks end with identical parameters and buffers."""
+    import json
+    world = 2
+    mp.spawn(_bench_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out0 = open(os.path.join(str(tmp_path), "train_out0.txt")).read().strip().splitlines()
+    out1 = open(os.path.join(str(tmp_path), "train_out1.txt")).read().strip()
+    assert len(out0) == 1 and out1 == "", "exactly ONE JSON line, printed by rank 0"
+    line = json.loads(out0[0])
+    assert line["metric"] == "train_pairs_per_sec" and line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert abs(line["value"] - 2 * 1 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]          # pairs of ALL ranks / the max-over-ranks time
+    assert "data parallel x2" in line["config"]["parallelism"]
+    assert line["stub_ranks_agree"] is True and line["final_loss"] == line["final_loss"] and line["final_loss"] > 0
