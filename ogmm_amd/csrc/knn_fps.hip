@@ -277,6 +277,202 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ xyz
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 5: the same two scans with the candidates in SCALAR registers and the distances in packed fp32.
+// knn2_kernel reads every candidate with one broadcast ds_read_b128 per wave: 2 scans x N reads of 8 LDS cycles each are 262 k LDS cycles per CU at
+// N = 1024 (4 workgroups of 4 waves) -- more than the kernel's vector instructions need, and the reason it sat at 221 us.  A candidate is the same for
+// every lane, i.e. wave-uniform data: here it arrives by s_load_dwordx16 from a PAIR-MAJOR copy of the cloud (ogmm_pack_clouds: entry j / 2 holds
+// x_j, x_j+1, y_j, y_j+1, z_j, z_j+1, |p_j|^2, |p_j+1|^2), and an SGPR pair is directly the second operand of v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32 -- two candidates per instruction, each half an ordinary IEEE fp32 mul / fma / add, so the distance VALUES are the same bits as
+// knn_dist_raw's (same operation sequence per candidate; -ffp-contract=off).  The list is padded to a multiple of 32 candidates with |p|^2 = +inf
+// entries (distance +inf: never below any threshold), which removes the scalar tail loops.  The LDS copy of the cloud stays for what needs random
+// access: the insertions (a handful per chunk), the short-list ladder and the folded tie resolution.
+typedef float f32x2k __attribute__((ext_vector_type(2)));
+typedef float f32x16k __attribute__((ext_vector_type(16)));
+
+template <int KL>
+__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz4p, int N, int NP, int k, int32_t* __restrict__ idx, int fold_ties) {
+    extern __shared__ __attribute__((aligned(16))) float4 pts[];   // [N], then the candidate lists [2 (KL-1)][256] int16
+    short* __restrict__ buf = reinterpret_cast<short*>(pts + N) + threadIdx.x;          // entry i of this thread at buf[i * 256]
+    const int c = blockIdx.y;
+    const float* __restrict__ cloud = xyz4p + (int64_t)c * NP * 4;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const float* __restrict__ e = cloud + (j >> 1) * 8 + (j & 1);
+        pts[j] = make_float4(e[0], e[2], e[4], e[6]);
+    }
+    __syncthreads();
+    const int q_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q_raw >= N && !fold_ties) return;
+    const bool live = q_raw < N;
+    const int q = live ? q_raw : N - 1;
+    const float4 pq = pts[q];
+    const f32x2k qx = {pq.x, pq.x}, qy = {pq.y, pq.y}, qz = {pq.z, pq.z}, qw = {pq.w, pq.w}, m2 = {-2.0f, -2.0f};
+    const f32x16k* __restrict__ cp = reinterpret_cast<const f32x16k*>(cloud);          // one entry = 2 pairs = 4 candidates
+    auto dist2 = [&](const f32x16k v, int p) -> f32x2k {          // raw distances of candidates 2p, 2p + 1 of the entry (knn_dist_raw, two at a time)
+        const f32x2k xj = {v[8 * p + 0], v[8 * p + 1]}, yj = {v[8 * p + 2], v[8 * p + 3]}, zj = {v[8 * p + 4], v[8 * p + 5]}, wj = {v[8 * p + 6], v[8 * p + 7]};
+        f32x2k dot = qx * xj;
+        dot = __builtin_elementwise_fma(qy, yj, dot);
+        dot = __builtin_elementwise_fma(qz, zj, dot);
+        return __builtin_elementwise_fma(m2, dot, qw) + wj;
+    };
+    const int n_chunks = NP / 32;
+    // ---- scan A: the k+1 smallest distances
+    float dk[KL];
+#pragma unroll
+    for (int p = 0; p < KL; ++p) dk[p] = __builtin_inff();
+    auto insert_d = [&](float d) {
+#pragma unroll
+        for (int p = KL - 1; p > 0; --p) dk[p] = __builtin_amdgcn_fmed3f(dk[p - 1], d, dk[p]);
+        dk[0] = fminf(dk[0], d);
+    };
+    {
+        f32x16k c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];          // half a chunk (16 candidates) in 64 SGPRs, the other half requested behind it
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int j = ch * 32;
+            const float worst = dk[KL - 1];
+            unsigned mask = 0u;
+            const f32x16k d0 = cp[ch * 8 + 4], d1 = cp[ch * 8 + 5], d2 = cp[ch * 8 + 6], d3 = cp[ch * 8 + 7];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x16k v = e == 0 ? c0 : (e == 1 ? c1 : (e == 2 ? c2 : c3));
+#pragma unroll
+                for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
+            }
+            const int nx = ch + 1 < n_chunks ? ch + 1 : ch;          // (the last chunk re-requests itself: no branch around the loads)
+            c0 = cp[nx * 8]; c1 = cp[nx * 8 + 1]; c2 = cp[nx * 8 + 2]; c3 = cp[nx * 8 + 3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x16k v = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
+#pragma unroll
+                for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
+            }
+            while (__any(mask != 0u)) {
+                const bool mine = mask != 0u;
+                const int t = mine ? __clz(mask) : 0;
+                insert_d(mine ? knn_dist(pq, pts[j + t]) : __builtin_inff());
+                mask &= ~(0x80000000u >> t);
+            }
+        }
+    }
+    float tau = 0.0f, d_next = -1.0f;
+#pragma unroll
+    for (int p = 0; p < KL; ++p) {
+        if (p == k - 1) tau = dk[p];
+        if (p == k) d_next = dk[p];
+    }
+    const bool boundary_tie = k < N && tau == d_next;
+    // ---- scan B: the candidates that can be among the first k, in index order (clamped distances, as knn2_kernel)
+    int cnt = 0, ties = 0;
+    auto append = [&](int jj, bool less) {
+        if (less || ties < k) {
+            buf[cnt * 256] = (short)jj;
+            ++cnt;
+            ties += less ? 0 : 1;
+        }
+    };
+    {
+        f32x16k c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int j = ch * 32;
+            unsigned lt = 0u, le = 0u;
+            const f32x16k d0 = cp[ch * 8 + 4], d1 = cp[ch * 8 + 5], d2 = cp[ch * 8 + 6], d3 = cp[ch * 8 + 7];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x16k v = e == 0 ? c0 : (e == 1 ? c1 : (e == 2 ? c2 : c3));
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f32x2k d = dist2(v, p);
+                    const float da = fmaxf(d[0], 1e-12f), db = fmaxf(d[1], 1e-12f);
+                    mark_lt(lt, da, tau); mark_le(le, da, tau);
+                    mark_lt(lt, db, tau); mark_le(le, db, tau);
+                }
+            }
+            const int nx = ch + 1 < n_chunks ? ch + 1 : ch;
+            c0 = cp[nx * 8]; c1 = cp[nx * 8 + 1]; c2 = cp[nx * 8 + 2]; c3 = cp[nx * 8 + 3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x16k v = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f32x2k d = dist2(v, p);
+                    const float da = fmaxf(d[0], 1e-12f), db = fmaxf(d[1], 1e-12f);
+                    mark_lt(lt, da, tau); mark_le(le, da, tau);
+                    mark_lt(lt, db, tau); mark_le(le, db, tau);
+                }
+            }
+            while (le != 0u) {
+                const int t = __clz(le);
+                const unsigned bit = 0x80000000u >> t;
+                append(j + t, (lt & bit) != 0u);
+                le &= ~bit;
+            }
+        }
+    }
+    // ---- the full ladder over the short list (strict '<': equal distances keep their index order)
+    float dl[KL];
+    int ik[KL];
+#pragma unroll
+    for (int p = 0; p < KL; ++p) { dl[p] = __builtin_inff(); ik[p] = 0; }
+    for (int i = 0; __any(i < cnt); ++i) {
+        const bool mine = i < cnt;
+        const int jj = mine ? (int)buf[i * 256] : 0;
+        const float d = mine ? knn_dist(pq, pts[jj]) : __builtin_inff();
+        if (d < dl[KL - 1]) {
+#pragma unroll
+            for (int p = KL - 1; p > 0; --p) {
+                const bool shift = d < dl[p - 1];
+                const bool here = !shift && d < dl[p];
+                dl[p] = shift ? dl[p - 1] : (here ? d : dl[p]);
+                ik[p] = shift ? ik[p - 1] : (here ? jj : ik[p]);
+            }
+            const bool first = d < dl[0];
+            dl[0] = first ? d : dl[0];
+            ik[0] = first ? jj : ik[0];
+        }
+    }
+    int32_t* out = idx + ((int64_t)c * N + q) * k;
+    if (live) {
+#pragma unroll
+        for (int p = 0; p < KL - 1; ++p)
+            if (p < k) out[p] = (p == 0 && boundary_tie) ? ~ik[0] : ik[p];
+    }
+    if (!fold_ties) return;
+    if (!__syncthreads_or(live && boundary_tie)) return;
+    __shared__ int tie_rows[256];
+    __shared__ int n_tie;
+    if (threadIdx.x == 0) n_tie = 0;
+    __syncthreads();
+    if (live && boundary_tie) tie_rows[atomicAdd(&n_tie, 1)] = q;
+    __syncthreads();
+    const int nt = n_tie;
+    int prev = -1;
+    for (int f = 0; f < nt; ++f) {
+        int row = 0x7fffffff;
+        for (int g = 0; g < nt; ++g) { const int r = tie_rows[g]; if (r > prev && r < row) row = r; }
+        prev = row;
+        resolve_ties_in_block(pts, N, k, row, idx + (int64_t)c * N * k, reinterpret_cast<void*>(pts + N), fold_ties == 2);
+    }
+}
+
+// src, tgt [B][3][N] (the model's input layout, models/gmmreg.py:50) -> xyz [2B][N][3] (src clouds, then tgt clouds: what torch.cat + transpose + contiguous
+// made in two launches) and the pair-major candidate copy xyz4p [2B][NP / 2][8] of knn3_kernel (NP = N rounded up to 32; padding: 0, 0, 0, |p|^2 = +inf).
+__global__ __launch_bounds__(256) void pack_clouds_kernel(const float* __restrict__ src, const float* __restrict__ tgt, int B, int N, int NP,
+                                                          float* __restrict__ xyz, float* __restrict__ xyz4p) {
+    const int c = blockIdx.y;
+    const float* __restrict__ in = (c < B ? src + (int64_t)c * 3 * N : tgt + (int64_t)(c - B) * 3 * N);
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= NP) return;
+    float x = 0.0f, y = 0.0f, z = 0.0f, w = __builtin_inff();
+    if (j < N) {
+        x = in[j]; y = in[N + j]; z = in[2 * N + j];
+        w = sqnorm3(x, y, z);
+        float* __restrict__ o = xyz + ((int64_t)c * N + j) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+    float* __restrict__ e = xyz4p + (int64_t)c * NP * 4 + (j >> 1) * 8 + (j & 1);
+    e[0] = x; e[2] = y; e[4] = z; e[6] = w;
+}
+
 // ---- std::nth_element's partition, by the whole workgroup, with the element moves of the sequential loop
 //     for (;;) { while (q[first] < pivot) ++first;  --last;  while (pivot < q[last]) --last;
 //                if (!(first < last)) return first;  swap(q[first], q[last]);  ++first; }
@@ -648,6 +844,50 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     const size_t ties_lds = (size_t)N * (sizeof(ogmm_select::Cand) + (lists ? 2 * sizeof(int) : 0));
     hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), ties_lds, s, xyz, N, k, rows, idx, lists ? 1 : 0);
     return ogmm::check_launch("ogmm_knn(resolve ties)");
+}
+
+extern "C" int ogmm_pack_clouds(const float* src, const float* tgt, int B, int N, float* xyz, float* xyz4p, void* stream) {
+    OGMM_REQUIRE(src && tgt && xyz && xyz4p && B > 0 && N > 0 && ogmm::aligned16(xyz4p), "ogmm_pack_clouds: null / unaligned pointer or empty input");
+    const int NP = (N + 31) / 32 * 32;
+    hipLaunchKernelGGL(pack_clouds_kernel, dim3((unsigned)((NP + 255) / 256), (unsigned)(2 * B)), dim3(256), 0, ogmm::as_stream(stream), src, tgt, B, N, NP, xyz, xyz4p);
+    return ogmm::check_launch("ogmm_pack_clouds");
+}
+
+extern "C" int ogmm_knn_packed_supported(int N, int k) {
+    if (N <= 0 || k < 1 || k > 32 || k > N) return 0;
+    const int KLsel = k <= 8 ? 9 : (k <= 20 ? 21 : 33);
+    return (size_t)N * sizeof(float4) + (size_t)2 * (KLsel - 1) * 256 * sizeof(short) <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" int ogmm_knn_packed(const float* xyz, const float* xyz4p, int C, int N, int k, int32_t* idx, void* stream) {
+    OGMM_REQUIRE(xyz && xyz4p && idx && C > 0 && N > 0 && ogmm::aligned16(xyz4p), "ogmm_knn_packed: null / unaligned pointer or empty input");
+    OGMM_REQUIRE(k >= 1 && k <= 32 && k <= N, "ogmm_knn_packed: need 1 <= k <= min(32, N), got k=%d N=%d", k, N);
+    OGMM_REQUIRE(ogmm_knn_packed_supported(N, k), "ogmm_knn_packed: N=%d with k=%d does not fit 64 KiB of LDS (cloud + candidate lists); use ogmm_knn", N, k);
+    const int NP = (N + 31) / 32 * 32;
+    const int KLsel = k <= 8 ? 9 : (k <= 20 ? 21 : 33);
+    const size_t lds = (size_t)N * sizeof(float4), lds2 = lds + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
+    static const int fold_env = [] { const char* e = getenv("OGMM_KNN_FOLD_TIES"); return e ? atoi(e) : 1; }();
+    int fold = 0;
+    if (fold_env) {          // (as ogmm_knn: the tie scratch in the LDS of the candidate lists, which are dead by then)
+        const size_t lists_bytes = lds2 - lds;
+        const bool heap = (long long)k * 64 <= N;
+        if (!heap && (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)) <= lists_bytes) fold = 2;
+        else if (heap && (size_t)N * sizeof(ogmm_select::Cand) <= lists_bytes) fold = 1;
+    }
+    hipStream_t s = ogmm::as_stream(stream);
+    dim3 grid((N + 255) / 256, C);
+    if (k <= 8) hipLaunchKernelGGL(knn3_kernel<9>, grid, dim3(256), lds2, s, xyz4p, N, NP, k, idx, fold);
+    else if (k <= 20) hipLaunchKernelGGL(knn3_kernel<21>, grid, dim3(256), lds2, s, xyz4p, N, NP, k, idx, fold);
+    else hipLaunchKernelGGL(knn3_kernel<33>, grid, dim3(256), lds2, s, xyz4p, N, NP, k, idx, fold);
+    if (int rc = ogmm::check_launch("ogmm_knn_packed")) return rc;
+    if (fold) return 0;
+    static ogmm::PerDeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_resolve_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    const int64_t rows = (int64_t)C * N;
+    const bool lists = (long long)k * 64 > N && (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)) <= 156 * 1024;
+    const size_t ties_lds = (size_t)N * (sizeof(ogmm_select::Cand) + (lists ? 2 * sizeof(int) : 0));
+    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), ties_lds, s, xyz, N, k, rows, idx, lists ? 1 : 0);
+    return ogmm::check_launch("ogmm_knn_packed(resolve ties)");
 }
 
 extern "C" int ogmm_fps(const float* xyz, int C, int N, int npoint, int n_sets, const int32_t* start, int32_t* ids, void* stream) {

@@ -403,7 +403,8 @@ class GMMReg(nn.Module):
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
         fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()   # [stage][src clouds | tgt clouds]
 
-        xyz = torch.cat([src, tgt], dim=0).transpose(1, 2).contiguous()         # [C,N,3]
+        # [C,N,3] (src clouds, then tgt clouds) and the pair-major candidate copy the kNN kernels read through the scalar cache: one launch
+        xyz, xyz4p = ops.pack_clouds(src, tgt)
         swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
         # Latency-bound selection kernels (one workgroup per cloud: FPS chains, the k=5 graph, later the E/M loop) run on a
         # side stream next to the GEMM-bound main stream: they occupy <= C of the 256 CUs.  Every tensor they touch stays
@@ -430,7 +431,7 @@ class GMMReg(nn.Module):
         ws = self._workspace(dev, main, C, N, D, XW)
         stats3, extra = ws["stats3"], ws["extra"]
         with torch.cuda.stream(side):
-            idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
+            idx5 = ops.knn(xyz, 5, packed=xyz4p)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
             hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
         with torch.cuda.stream(side2):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
@@ -440,9 +441,10 @@ class GMMReg(nn.Module):
         sel_done.record(side)
         xyz.record_stream(side2)
         xyz.record_stream(side)
+        xyz4p.record_stream(side)
         for t_ in (ids_a, ids_j, idx5, hd, ha):
             t_.record_stream(main)
-        idx = ops.knn(xyz, k)
+        idx = ops.knn(xyz, k, packed=xyz4p)
 
         # ---- DGCNN (models/dgcnn.py:133-154)
         R = C * N

@@ -88,12 +88,32 @@ def _p(t):
 
 
 # ---------------------------------------------------------------------------------------------- selection
-def knn(xyz, k):
-    """xyz [C,N,3] -> idx [C,N,k] int32   (lib/utils.py:37-44)."""
+KNN_PACKED = os.environ.get("OGMM_KNN_PACKED", "1") != "0"          # A/B switch: 0 = the LDS-broadcast kernels (ogmm_knn) everywhere
+
+
+def pack_clouds(src, tgt):
+    """src, tgt [B,3,N] (models/gmmreg.py:50) -> xyz [2B,N,3] (src clouds, then tgt clouds) and the pair-major candidate copy [2B, NP/2, 8] that knn(...,
+    packed=) reads through the scalar cache (include/ogmm_hip.h: ogmm_pack_clouds): one launch instead of torch's cat + transpose copy."""
+    B, _, N = src.shape
+    src, tgt = _f32(src, "src").contiguous(), _f32(tgt, "tgt").contiguous()
+    NP = (N + 31) // 32 * 32
+    xyz = torch.empty((2 * B, N, 3), dtype=torch.float32, device=src.device)
+    xyz4p = torch.empty((2 * B, NP // 2, 8), dtype=torch.float32, device=src.device)
+    _lib.call("ogmm_pack_clouds", _p(src), _p(tgt), B, N, _p(xyz), _p(xyz4p), _stream())
+    return xyz, xyz4p
+
+
+def knn(xyz, k, packed=None):
+    """xyz [C,N,3] -> idx [C,N,k] int32   (lib/utils.py:37-44).  packed: pack_clouds' second output for the same clouds -- the scalar-load kernel takes it
+    where it applies (same neighbour sets; tests/test_hip_ops.py compares the two kernels' outputs for identity)."""
     xyz = _f32(xyz, "xyz")
     assert xyz.is_contiguous() and xyz.dim() == 3 and xyz.shape[2] == 3
     C, N, _ = xyz.shape
     idx = torch.empty((C, N, k), dtype=torch.int32, device=xyz.device)
+    if packed is not None and KNN_PACKED and _lib.load().ogmm_knn_packed_supported(N, k) == 1:
+        assert packed.is_contiguous() and packed.shape == (C, (N + 31) // 32 * 16, 8)
+        _lib.call("ogmm_knn_packed", _p(xyz), _p(packed), C, N, k, _p(idx), _stream())
+        return idx
     _lib.call("ogmm_knn", _p(xyz), C, N, k, _p(idx), _stream())
     return idx
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def ops():
+def raw_ops():
     assert torch.cuda.is_available()
     from ogmm_amd import ops as _ops
     return _ops
@@ -30,7 +30,39 @@ def clouds(C, N, seed=0, kind="partial"):
 
 
 # ------------------------------------------------------------------------------------------------ K1
-@pytest.mark.parametrize("C,N,k", [(4, 1024, 20), (3, 200, 12), (2, 2048, 5), (2, 717, 20), (1, 64, 32), (2, 33, 1)])
+class _KnnBoth:
+    """ops.knn through BOTH kernels: the LDS-broadcast one (ogmm_knn) and, where it applies, the scalar-load / packed-fp32 one (ogmm_knn_packed, round 5) on
+    ogmm_pack_clouds' pair-major copy.  The two index tensors must be IDENTICAL (same distance bits, same insertion order, same tie resolution), so every
+    kNN test below pins both; pack_clouds' point-major output must be the clouds themselves."""
+
+    def __init__(self, ops):
+        self.ops = ops
+
+    def knn(self, xyz_dev, k):
+        ops = self.ops
+        base = ops.knn(xyz_dev, k)
+        C, N, _ = xyz_dev.shape
+        from ogmm_amd import _lib
+        if _lib.load().ogmm_knn_packed_supported(N, k) == 1:
+            chw = xyz_dev.transpose(1, 2).contiguous()                     # [C,3,N]: the model's input layout
+            xyz2, packed = ops.pack_clouds(chw, chw)                        # 2C clouds: the set twice
+            assert torch.equal(xyz2[:C], xyz_dev) and torch.equal(xyz2[C:], xyz_dev)
+            got = ops.knn(xyz2, k, packed=packed)
+            assert torch.equal(got[:C], base) and torch.equal(got[C:], base), "the packed kNN kernel differs from the LDS one in %d rows" % int((got[:C] != base).any(-1).sum())
+        return base
+
+
+@pytest.fixture(scope="module")
+def ops(raw_ops):          # every test sees the operator module; its knn() checks both kernels
+    class W:
+        def __getattr__(self, name):
+            return getattr(raw_ops, name)
+    w = W()
+    w.knn = _KnnBoth(raw_ops).knn
+    return w
+
+
+@pytest.mark.parametrize("C,N,k", [(4, 1024, 20), (3, 200, 12), (2, 2048, 5), (2, 717, 20), (1, 64, 32), (2, 33, 1), (2, 2048, 20), (3, 1000, 8)])
 def test_knn_identical_indices(ops, C, N, k):
     """Distance rows are bit-identical to the reference's, and the kept neighbour SET equals torch.topk's even when
     rank k is an exact tie (the expanded formula quantises distances to ~3e-8, so ties are not rare).  Only the order
