@@ -325,27 +325,29 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz
         for (int p = KL - 1; p > 0; --p) dk[p] = __builtin_amdgcn_fmed3f(dk[p - 1], d, dk[p]);
         dk[0] = fminf(dk[0], d);
     };
+    // A quarter chunk (8 candidates = two entries) lives in 32 SGPRs while the next quarter's two s_load_dwordx16 are in flight: 64 SGPRs in all (a whole
+    // half chunk per buffer was 128 and spilled to VGPR lanes: a v_readlane per use).
     {
-        f32x16k c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];          // half a chunk (16 candidates) in 64 SGPRs, the other half requested behind it
+        f32x16k a0 = cp[0], a1 = cp[1], b0, b1;
+        auto quarter = [&](const f32x16k v0, const f32x16k v1, unsigned& mask, float worst) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v0, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v1, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
+        };
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int j = ch * 32;
             const float worst = dk[KL - 1];
             unsigned mask = 0u;
-            const f32x16k d0 = cp[ch * 8 + 4], d1 = cp[ch * 8 + 5], d2 = cp[ch * 8 + 6], d3 = cp[ch * 8 + 7];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x16k v = e == 0 ? c0 : (e == 1 ? c1 : (e == 2 ? c2 : c3));
-#pragma unroll
-                for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
-            }
             const int nx = ch + 1 < n_chunks ? ch + 1 : ch;          // (the last chunk re-requests itself: no branch around the loads)
-            c0 = cp[nx * 8]; c1 = cp[nx * 8 + 1]; c2 = cp[nx * 8 + 2]; c3 = cp[nx * 8 + 3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x16k v = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
-#pragma unroll
-                for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
-            }
+            b0 = cp[ch * 8 + 2]; b1 = cp[ch * 8 + 3];
+            quarter(a0, a1, mask, worst);
+            a0 = cp[ch * 8 + 4]; a1 = cp[ch * 8 + 5];
+            quarter(b0, b1, mask, worst);
+            b0 = cp[ch * 8 + 6]; b1 = cp[ch * 8 + 7];
+            quarter(a0, a1, mask, worst);
+            a0 = cp[nx * 8]; a1 = cp[nx * 8 + 1];
+            quarter(b0, b1, mask, worst);
             while (__any(mask != 0u)) {
                 const bool mine = mask != 0u;
                 const int t = mine ? __clz(mask) : 0;
@@ -371,35 +373,30 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz
         }
     };
     {
-        f32x16k c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+        f32x16k a0 = cp[0], a1 = cp[1], b0, b1;
+        auto quarter = [&](const f32x16k v0, const f32x16k v1, unsigned& lt, unsigned& le) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f32x2k d = dist2(e ? v1 : v0, p);
+                    const float da = fmaxf(d[0], 1e-12f), db = fmaxf(d[1], 1e-12f);
+                    mark_lt(lt, da, tau); mark_le(le, da, tau);
+                    mark_lt(lt, db, tau); mark_le(le, db, tau);
+                }
+        };
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int j = ch * 32;
             unsigned lt = 0u, le = 0u;
-            const f32x16k d0 = cp[ch * 8 + 4], d1 = cp[ch * 8 + 5], d2 = cp[ch * 8 + 6], d3 = cp[ch * 8 + 7];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x16k v = e == 0 ? c0 : (e == 1 ? c1 : (e == 2 ? c2 : c3));
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const f32x2k d = dist2(v, p);
-                    const float da = fmaxf(d[0], 1e-12f), db = fmaxf(d[1], 1e-12f);
-                    mark_lt(lt, da, tau); mark_le(le, da, tau);
-                    mark_lt(lt, db, tau); mark_le(le, db, tau);
-                }
-            }
             const int nx = ch + 1 < n_chunks ? ch + 1 : ch;
-            c0 = cp[nx * 8]; c1 = cp[nx * 8 + 1]; c2 = cp[nx * 8 + 2]; c3 = cp[nx * 8 + 3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x16k v = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const f32x2k d = dist2(v, p);
-                    const float da = fmaxf(d[0], 1e-12f), db = fmaxf(d[1], 1e-12f);
-                    mark_lt(lt, da, tau); mark_le(le, da, tau);
-                    mark_lt(lt, db, tau); mark_le(le, db, tau);
-                }
-            }
+            b0 = cp[ch * 8 + 2]; b1 = cp[ch * 8 + 3];
+            quarter(a0, a1, lt, le);
+            a0 = cp[ch * 8 + 4]; a1 = cp[ch * 8 + 5];
+            quarter(b0, b1, lt, le);
+            b0 = cp[ch * 8 + 6]; b1 = cp[ch * 8 + 7];
+            quarter(a0, a1, lt, le);
+            a0 = cp[nx * 8]; a1 = cp[nx * 8 + 1];
+            quarter(b0, b1, lt, le);
             while (le != 0u) {
                 const int t = __clz(le);
                 const unsigned bit = 0x80000000u >> t;
