@@ -252,6 +252,7 @@ class GMMReg(nn.Module):
         self._side = None
         self._side2 = None
         self._ws = None             # persistent zero-initialised buffers of the eval forward (_workspace)
+        self._swap = None           # cloud map of the cross-attention (src <-> tgt), per batch size
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved.  (data_ptr, _version) catches optimizer steps,
@@ -401,11 +402,20 @@ class GMMReg(nn.Module):
 
         if fps_starts is None:
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
-        fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()   # [stage][src clouds | tgt clouds]
+        # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
+        # tensor makes the host wait for the copy -- which is queued behind everything this stream still has to run, i.e. for the end of the PREVIOUS
+        # forward.  Every forward then started on an idle GPU with its first ~10 launches bound by the host's launch latency (round 5 trace: 240 us
+        # from the step's first kernel to its kNN kernel).  (The caching host allocator keeps the pinned block alive until the copy has run.)
+        if fps_starts.device.type == "cpu" and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            fps_starts = fps_starts.reshape(3, 2 * B).to(torch.int32).pin_memory().to(dev, non_blocking=True)
+        else:
+            fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
 
         # [C,N,3] (src clouds, then tgt clouds) and the pair-major candidate copy the kNN kernels read through the scalar cache: one launch
         xyz, xyz4p = ops.pack_clouds(src, tgt)
-        swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
+        if self._swap is None or self._swap.device != dev or self._swap.numel() != C:          # (cached per batch size: four tiny launches per forward otherwise)
+            self._swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
+        swap = self._swap
         # Latency-bound selection kernels (one workgroup per cloud: FPS chains, the k=5 graph, later the E/M loop) run on a
         # side stream next to the GEMM-bound main stream: they occupy <= C of the 256 CUs.  Every tensor they touch stays
         # referenced until the streams are joined again.
