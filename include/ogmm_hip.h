@@ -41,14 +41,18 @@ const char* ogmm_last_error(void);
  * heap-select / introselect is re-stated for such rows); the set is written in (distance, index) order
  * (torch's order among equal distances is unspecified and no caller depends on it).  1 <= k <= 32, k <= N. */
 int ogmm_knn(const float* xyz /*[C][N][3]*/, int C, int N, int k, int32_t* idx /*[C][N][k]*/, void* stream);
-/* (ABI 25) The forward's input stage, models/gmmreg.py:50 -> lib/utils.py:37-44: src, tgt [B][3][N] -> xyz [2B][N][3] (src clouds, then tgt clouds) and the
- * pair-major candidate copy xyz4p [2B][NP/2][8] = (x_j, x_j+1, y_j, y_j+1, z_j, z_j+1, |p_j|^2, |p_j+1|^2), NP = N rounded up to 32 (padding |p|^2 = +inf),
- * which ogmm_knn_packed reads through the scalar cache: the same distance values and neighbour sets as ogmm_knn (same operation sequence per candidate, two
- * candidates per packed-fp32 instruction), without the broadcast LDS read per candidate.  ogmm_knn_packed_supported: 1 while cloud + candidate lists fit
- * 64 KiB of LDS (N <= 2816 at k = 20), else use ogmm_knn. */
-int ogmm_pack_clouds(const float* src, const float* tgt, int B, int N, float* xyz, float* xyz4p, void* stream);
-int ogmm_knn_packed_supported(int N, int k);
-int ogmm_knn_packed(const float* xyz, const float* xyz4p, int C, int N, int k, int32_t* idx, void* stream);
+/* (ABI 25) The forward's input stage, models/gmmreg.py:50: src, tgt [B][3][N] -> xyz [2B][N][3] (src clouds, then tgt clouds; torch.cat + transpose + contiguous). */
+int ogmm_pack_clouds(const float* src, const float* tgt, int B, int N, float* xyz, void* stream);
+/* (ABI 25) The head of the forward in one launch: the k-NN graph of the EdgeConv layers (lib/utils.py:37-44, as ogmm_knn: identical neighbour sets, rank-k
+ * ties resolved with torch.topk's selection) and -- when idx5 != NULL -- the 5-NN graph of the positional encoding (lib/utils.py:52 <- models/attn.py:69: its
+ * own topk call, own rank-5 ties) + the encoding's hidden maps (models/attn.py:65-73, as ogmm_pos_hidden: bit-identical), all from the one copy of the cloud the
+ * workgroup holds in LDS.  workspace: ogmm_knn_pos_head_workspace_bytes(C, N) bytes of scratch (scan A's mark words: scan B visits only marked candidates).
+ * ogmm_knn_pos_head_supported(N, k): 1 for 9 <= k <= 32 while cloud + candidate lists + the tie scratch fit 64 KiB of LDS (N <= 2816 at k = 20). */
+int ogmm_knn_pos_head_supported(int N, int k);
+int64_t ogmm_knn_pos_head_workspace_bytes(int C, int N);
+int ogmm_knn_pos_head(const float* xyz, int C, int N, int k, int32_t* idx /*[C][N][k]*/, int32_t* idx5 /*[C][N][5] or NULL*/, const float* w_dis, const float* s_dis,
+                      const float* t_dis, const float* w_ang, const float* s_ang, const float* t_ang, float* hid_dis /*[C*N][64]*/, float* hid_ang, void* workspace,
+                      void* stream);
 /* torch.topk(v, k, dim = -1, largest)[1] of a row-major [rows][n] map (row stride ldv) with the reference CPU kernel's choice among TIED values (the same
  * re-statement of ATen's selection as ogmm_knn's tie resolution): the Welsch term of the training loss (lib/loss.py:92, :95) takes the top_k points of the 0 / 1
  * ground-truth overlap labels, so with more than top_k ones the kept set -- and the loss -- depends on it.  idx [rows][k] in (value, index) order. */

@@ -49,9 +49,10 @@ PROTOTYPES = {
     "ogmm_last_error": [],
     "ogmm_topk_rows": [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_knn": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
-    "ogmm_pack_clouds": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "ogmm_knn_packed_supported": [c_int, c_int],
-    "ogmm_knn_packed": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ogmm_pack_clouds": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "ogmm_knn_pos_head_supported": [c_int, c_int],
+    "ogmm_knn_pos_head_workspace_bytes": [c_int, c_int],
+    "ogmm_knn_pos_head": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_fps": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_gather_rows": [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_gemm_nt": [POINTER(GemmDesc), c_void_p],

@@ -278,45 +278,47 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ xyz
 }
 
 // ------------------------------------------------------------------------------------------------
-// Round 5: the same two scans with the candidates in SCALAR registers and the distances in packed fp32.
-// knn2_kernel reads every candidate with one broadcast ds_read_b128 per wave: 2 scans x N reads of 8 LDS cycles each are 262 k LDS cycles per CU at
-// N = 1024 (4 workgroups of 4 waves) -- more than the kernel's vector instructions need, and the reason it sat at 221 us.  A candidate is the same for
-// every lane, i.e. wave-uniform data: here it arrives by s_load_dwordx16 from a PAIR-MAJOR copy of the cloud (ogmm_pack_clouds: entry j / 2 holds
-// x_j, x_j+1, y_j, y_j+1, z_j, z_j+1, |p_j|^2, |p_j+1|^2), and an SGPR pair is directly the second operand of v_pk_mul_f32 / v_pk_fma_f32 /
-// v_pk_add_f32 -- two candidates per instruction, each half an ordinary IEEE fp32 mul / fma / add, so the distance VALUES are the same bits as
-// knn_dist_raw's (same operation sequence per candidate; -ffp-contract=off).  The list is padded to a multiple of 32 candidates with |p|^2 = +inf
-// entries (distance +inf: never below any threshold), which removes the scalar tail loops.  The LDS copy of the cloud stays for what needs random
-// access: the insertions (a handful per chunk), the short-list ladder and the folded tie resolution.
-typedef float f32x2k __attribute__((ext_vector_type(2)));
-typedef float f32x16k __attribute__((ext_vector_type(16)));
+// Round 5: the head of the forward as ONE kernel (knn4_kernel).
+//  (1) Scan B without a second pass over the cloud.  knn2_kernel's scan B recomputes all N distances to find the <= 2k - 1 candidates with d <= tau:
+//      36 % of the kernel's vector instructions.  Scan A already knows which candidates can matter: a candidate of the final set has d <= tau <= the
+//      list's worst entry at the time its chunk was scanned, i.e. it was MARKED (raw d < worst; the one exception -- d == worst == tau -- has k + 1
+//      earlier candidates at d <= tau in front of it and is never among the first k by (distance, index)).  So scan A keeps its 32-bit mark word per
+//      chunk (a coalesced store to a global bitmap, [chunk][thread]: 4 N bytes per query, L2-resident) and scan B walks the ~120 marked candidates
+//      of its query in index order instead of all N.  Same lists, same ladder, same flags: the neighbour sets are identical.
+//  (2) HEAD: the 5-NN graph of the positional encoding (lib/utils.py:52 <- models/attn.py:69: its own topk call in the reference) is the first five
+//      entries of the sorted 20-NN list -- with its OWN rank-5 tie flag (d[4] == d[5]) resolved by torch.topk(k = 5)'s selection, as knn_kernel<9> +
+//      the tie pass did -- and the positional front end (models/attn.py:65-73, pos_hidden_kernel) needs nothing but the cloud, its centroid and that
+//      graph: both are computed here, from the cloud this workgroup already holds in LDS.  pos_hidden_kernel evaluated a point's geometry (three
+//      divisions and a square root per neighbour) once per CHANNEL, 64-fold; here once per point, then the 64 channels expand the six scalars.  The
+//      centroid is summed in pos_hidden_kernel's order (thread t: points t, t + 256, ...; wave sums; four partials) and every expression is the same,
+//      so hid_dis / hid_ang are bit-identical.  Two kernels (85-165 us and 190 us alone) leave the forward's head, where they competed with this one
+//      for the chip in front of the persistent EdgeConv kernel.
+struct knn_pos_args {          // HEAD outputs / constants (nullptr idx5 = plain kNN)
+    int32_t* idx5;             // [C][N][5]
+    const float *w_dis, *s_dis, *t_dis, *w_ang, *s_ang, *t_ang;      // [64] each (models/attn.py:34-57 hidden layers, BatchNorm folded)
+    float *hid_dis, *hid_ang;  // [C*N][64]
+};
 
-template <int KL>
-__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz4p, int N, int NP, int k, int32_t* __restrict__ idx, int fold_ties) {
+template <int KL, bool HEAD>
+__global__ __launch_bounds__(256) void knn4_kernel(const float* __restrict__ xyz, int N, int k, int32_t* __restrict__ idx, unsigned* __restrict__ bitmap,
+                                                   int fold_ties, const knn_pos_args pa) {
     extern __shared__ __attribute__((aligned(16))) float4 pts[];   // [N], then the candidate lists [2 (KL-1)][256] int16
     short* __restrict__ buf = reinterpret_cast<short*>(pts + N) + threadIdx.x;          // entry i of this thread at buf[i * 256]
     const int c = blockIdx.y;
-    const float* __restrict__ cloud = xyz4p + (int64_t)c * NP * 4;
+    const float* __restrict__ cloud = xyz + (int64_t)c * N * 3;
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
-        const float* __restrict__ e = cloud + (j >> 1) * 8 + (j & 1);
-        pts[j] = make_float4(e[0], e[2], e[4], e[6]);
+        const float x = cloud[3 * j], y = cloud[3 * j + 1], z = cloud[3 * j + 2];
+        pts[j] = make_float4(x, y, z, sqnorm3(x, y, z));
     }
     __syncthreads();
     const int q_raw = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q_raw >= N && !fold_ties) return;
-    const bool live = q_raw < N;
+    const bool live = q_raw < N;          // (every thread stays for the workgroup barriers behind the scans)
     const int q = live ? q_raw : N - 1;
     const float4 pq = pts[q];
-    const f32x2k qx = {pq.x, pq.x}, qy = {pq.y, pq.y}, qz = {pq.z, pq.z}, qw = {pq.w, pq.w}, m2 = {-2.0f, -2.0f};
-    const f32x16k* __restrict__ cp = reinterpret_cast<const f32x16k*>(cloud);          // one entry = 2 pairs = 4 candidates
-    auto dist2 = [&](const f32x16k v, int p) -> f32x2k {          // raw distances of candidates 2p, 2p + 1 of the entry (knn_dist_raw, two at a time)
-        const f32x2k xj = {v[8 * p + 0], v[8 * p + 1]}, yj = {v[8 * p + 2], v[8 * p + 3]}, zj = {v[8 * p + 4], v[8 * p + 5]}, wj = {v[8 * p + 6], v[8 * p + 7]};
-        f32x2k dot = qx * xj;
-        dot = __builtin_elementwise_fma(qy, yj, dot);
-        dot = __builtin_elementwise_fma(qz, zj, dot);
-        return __builtin_elementwise_fma(m2, dot, qw) + wj;
-    };
-    const int n_chunks = NP / 32;
-    // ---- scan A: the k+1 smallest distances
+    constexpr int CHK = 32;
+    const int n_chunks = N / CHK;
+    unsigned* __restrict__ bm = bitmap + ((int64_t)c * gridDim.x + blockIdx.x) * (int64_t)n_chunks * 256 + threadIdx.x;          // word ch of this thread at bm[ch * 256]
+    // ---- scan A: the k+1 smallest distances; every chunk's mark word is kept
     float dk[KL];
 #pragma unroll
     for (int p = 0; p < KL; ++p) dk[p] = __builtin_inff();
@@ -325,37 +327,31 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz
         for (int p = KL - 1; p > 0; --p) dk[p] = __builtin_amdgcn_fmed3f(dk[p - 1], d, dk[p]);
         dk[0] = fminf(dk[0], d);
     };
-    // A quarter chunk (8 candidates = two entries) lives in 32 SGPRs while the next quarter's two s_load_dwordx16 are in flight: 64 SGPRs in all (a whole
-    // half chunk per buffer was 128 and spilled to VGPR lanes: a v_readlane per use).
-    {
-        f32x16k a0 = cp[0], a1 = cp[1], b0, b1;
-        auto quarter = [&](const f32x16k v0, const f32x16k v1, unsigned& mask, float worst) {
+    float4 ca[16], cb[16];          // the two halves of a chunk, each requested while the other one is processed (knn2_kernel)
+    auto fetch = [&](float4 (&dst)[16], int j0) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v0, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
+        for (int t = 0; t < 16; ++t) dst[t] = pts[j0 + t];          // (past the cloud: the candidate lists' bytes, never used as candidates)
+    };
+    int j = 0;
+    fetch(ca, 0);
+    for (int ch = 0; ch < n_chunks; ++ch, j += CHK) {
+        const float worst = dk[KL - 1];
+        unsigned mask = 0u;
+        fetch(cb, j + 16);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) { const f32x2k d = dist2(v1, p); mark_lt(mask, d[0], worst); mark_lt(mask, d[1], worst); }
-        };
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const int j = ch * 32;
-            const float worst = dk[KL - 1];
-            unsigned mask = 0u;
-            const int nx = ch + 1 < n_chunks ? ch + 1 : ch;          // (the last chunk re-requests itself: no branch around the loads)
-            b0 = cp[ch * 8 + 2]; b1 = cp[ch * 8 + 3];
-            quarter(a0, a1, mask, worst);
-            a0 = cp[ch * 8 + 4]; a1 = cp[ch * 8 + 5];
-            quarter(b0, b1, mask, worst);
-            b0 = cp[ch * 8 + 6]; b1 = cp[ch * 8 + 7];
-            quarter(a0, a1, mask, worst);
-            a0 = cp[nx * 8]; a1 = cp[nx * 8 + 1];
-            quarter(b0, b1, mask, worst);
-            while (__any(mask != 0u)) {
-                const bool mine = mask != 0u;
-                const int t = mine ? __clz(mask) : 0;
-                insert_d(mine ? knn_dist(pq, pts[j + t]) : __builtin_inff());
-                mask &= ~(0x80000000u >> t);
-            }
+        for (int t = 0; t < 16; ++t) mark_lt(mask, knn_dist_raw(pq, ca[t]), worst);
+        fetch(ca, j + CHK);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mark_lt(mask, knn_dist_raw(pq, cb[t]), worst);
+        bm[ch * 256] = mask;
+        while (__any(mask != 0u)) {
+            const bool mine = mask != 0u;
+            const int t = mine ? __clz(mask) : 0;
+            insert_d(mine ? knn_dist(pq, pts[j + t]) : __builtin_inff());
+            mask &= ~(0x80000000u >> t);
         }
     }
+    for (; j < N; ++j) insert_d(knn_dist(pq, pts[j]));
     float tau = 0.0f, d_next = -1.0f;
 #pragma unroll
     for (int p = 0; p < KL; ++p) {
@@ -363,7 +359,7 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz
         if (p == k) d_next = dk[p];
     }
     const bool boundary_tie = k < N && tau == d_next;
-    // ---- scan B: the candidates that can be among the first k, in index order (clamped distances, as knn2_kernel)
+    // ---- scan B over the marked candidates only, in index order
     int cnt = 0, ties = 0;
     auto append = [&](int jj, bool less) {
         if (less || ties < k) {
@@ -373,36 +369,21 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz
         }
     };
     {
-        f32x16k a0 = cp[0], a1 = cp[1], b0, b1;
-        auto quarter = [&](const f32x16k v0, const f32x16k v1, unsigned& lt, unsigned& le) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const f32x2k d = dist2(e ? v1 : v0, p);
-                    const float da = fmaxf(d[0], 1e-12f), db = fmaxf(d[1], 1e-12f);
-                    mark_lt(lt, da, tau); mark_le(le, da, tau);
-                    mark_lt(lt, db, tau); mark_le(le, db, tau);
-                }
-        };
+        unsigned word = n_chunks > 0 ? bm[0] : 0u;          // (this thread's own stores: program order makes them visible to it)
         for (int ch = 0; ch < n_chunks; ++ch) {
-            const int j = ch * 32;
-            unsigned lt = 0u, le = 0u;
-            const int nx = ch + 1 < n_chunks ? ch + 1 : ch;
-            b0 = cp[ch * 8 + 2]; b1 = cp[ch * 8 + 3];
-            quarter(a0, a1, lt, le);
-            a0 = cp[ch * 8 + 4]; a1 = cp[ch * 8 + 5];
-            quarter(b0, b1, lt, le);
-            b0 = cp[ch * 8 + 6]; b1 = cp[ch * 8 + 7];
-            quarter(a0, a1, lt, le);
-            a0 = cp[nx * 8]; a1 = cp[nx * 8 + 1];
-            quarter(b0, b1, lt, le);
-            while (le != 0u) {
-                const int t = __clz(le);
-                const unsigned bit = 0x80000000u >> t;
-                append(j + t, (lt & bit) != 0u);
-                le &= ~bit;
+            const unsigned next = ch + 1 < n_chunks ? bm[(ch + 1) * 256] : 0u;
+            while (word != 0u) {          // (per-lane loop over this lane's marks)
+                const int t = __clz(word);
+                const int jj = ch * CHK + t;
+                const float d = knn_dist(pq, pts[jj]);
+                if (d <= tau) append(jj, d < tau);
+                word &= ~(0x80000000u >> t);
             }
+            word = next;
+        }
+        for (j = n_chunks * CHK; j < N; ++j) {
+            const float d = knn_dist(pq, pts[j]);
+            if (d <= tau) append(j, d < tau);
         }
     }
     // ---- the full ladder over the short list (strict '<': equal distances keep their index order)
@@ -433,41 +414,93 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xyz
         for (int p = 0; p < KL - 1; ++p)
             if (p < k) out[p] = (p == 0 && boundary_tie) ? ~ik[0] : ik[p];
     }
-    if (!fold_ties) return;
-    if (!__syncthreads_or(live && boundary_tie)) return;
+    bool tie5 = false;
+    if constexpr (HEAD) {
+        tie5 = 5 < N && dl[4] == dl[5];          // torch.topk(k = 5)'s own boundary
+        if (live) {
+            int32_t* o5 = pa.idx5 + ((int64_t)c * N + q) * 5;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) o5[p] = ik[p];
+        }
+    }
+    // ---- rows with an exact tie at rank k (and, HEAD, at rank 5): torch.topk's own selection, by this workgroup, in the LDS the lists no longer need
     __shared__ int tie_rows[256];
     __shared__ int n_tie;
-    if (threadIdx.x == 0) n_tie = 0;
-    __syncthreads();
-    if (live && boundary_tie) tie_rows[atomicAdd(&n_tie, 1)] = q;
-    __syncthreads();
-    const int nt = n_tie;
-    int prev = -1;
-    for (int f = 0; f < nt; ++f) {
-        int row = 0x7fffffff;
-        for (int g = 0; g < nt; ++g) { const int r = tie_rows[g]; if (r > prev && r < row) row = r; }
-        prev = row;
-        resolve_ties_in_block(pts, N, k, row, idx + (int64_t)c * N * k, reinterpret_cast<void*>(pts + N), fold_ties == 2);
+    auto resolve = [&](bool flagged, int kk, int32_t* base, bool lists) {
+        if (!__syncthreads_or(live && flagged)) return;
+        if (threadIdx.x == 0) n_tie = 0;
+        __syncthreads();
+        if (live && flagged) tie_rows[atomicAdd(&n_tie, 1)] = q;
+        __syncthreads();
+        const int nt = n_tie;
+        int prev = -1;
+        for (int f = 0; f < nt; ++f) {          // ascending row order (rows are independent; deterministic all the same)
+            int row = 0x7fffffff;
+            for (int g = 0; g < nt; ++g) { const int r = tie_rows[g]; if (r > prev && r < row) row = r; }
+            prev = row;
+            resolve_ties_in_block(pts, N, kk, row, base, reinterpret_cast<void*>(pts + N), lists);
+        }
+        __syncthreads();
+    };
+    if (fold_ties) resolve(boundary_tie, k, idx + (int64_t)c * N * k, fold_ties == 2);
+    if constexpr (HEAD) {
+        resolve(tie5, 5, pa.idx5 + (int64_t)c * N * 5, false);
+        // ---- positional front end (pos_hidden_kernel's arithmetic, once per point)
+        __shared__ double part[4][3];
+        __shared__ float geo[256][6];          // d2, alpha[0..4] of this workgroup's points
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        double sx = 0, sy = 0, sz = 0;
+        for (int jj = tid; jj < N; jj += 256) { const float4 p = pts[jj]; sx += p.x; sy += p.y; sz += p.z; }
+        sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
+        if (lane == 0) { part[wave][0] = sx; part[wave][1] = sy; part[wave][2] = sz; }
+        __syncthreads();
+        const float fn = (float)N;
+        const float cx = (float)(part[0][0] + part[1][0] + part[2][0] + part[3][0]) / fn;
+        const float cy = (float)(part[0][1] + part[1][1] + part[2][1] + part[3][1]) / fn;
+        const float cz = (float)(part[0][2] + part[1][2] + part[2][2] + part[3][2]) / fn;
+        if (live) {
+            const float xi = pq.x, yi = pq.y, zi = pq.z;
+            const float gx = xi - cx, gy = yi - cy, gz = zi - cz;
+            const float d2 = (gx * gx + gy * gy) + gz * gz;
+            const float gn = fmaxf(sqrtf(d2), 1e-12f);
+            const float ux = gx / gn, uy = gy / gn, uz = gz / gn;
+            geo[tid][0] = d2;
+            const int32_t* nb = pa.idx5 + ((int64_t)c * N + q) * 5;          // (a resolved row differs from the registers: read what the graph says)
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                const float4 pj = pts[tie5 ? nb[e] : ik[e]];
+                const float lx = pj.x - xi, ly = pj.y - yi, lz = pj.z - zi;
+                const float ln = fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-12f);
+                geo[tid][1 + e] = ((lx / ln) * ux + (ly / ln) * uy) + (lz / ln) * uz;
+            }
+        }
+        __syncthreads();
+        const int ch = lane;
+        const float wd = pa.w_dis[ch], sd = pa.s_dis[ch], td = pa.t_dis[ch];
+        const float wa = pa.w_ang[ch], sa = pa.s_ang[ch], ta = pa.t_ang[ch];
+        auto leaky = [](float v) { return v > 0.0f ? v : 0.2f * v; };
+        for (int r = 0; r < 64; ++r) {
+            const int pl = r * 4 + wave, i = blockIdx.x * 256 + pl;
+            if (i >= N) break;
+            const int64_t row = (int64_t)c * N + i;
+            pa.hid_dis[row * 64 + ch] = leaky(fmaf(wd * geo[pl][0], sd, td));
+            float best = -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 5; ++e) best = fmaxf(best, leaky(fmaf(wa * geo[pl][1 + e], sa, ta)));
+            pa.hid_ang[row * 64 + ch] = best;
+        }
     }
 }
 
-// src, tgt [B][3][N] (the model's input layout, models/gmmreg.py:50) -> xyz [2B][N][3] (src clouds, then tgt clouds: what torch.cat + transpose + contiguous
-// made in two launches) and the pair-major candidate copy xyz4p [2B][NP / 2][8] of knn3_kernel (NP = N rounded up to 32; padding: 0, 0, 0, |p|^2 = +inf).
-__global__ __launch_bounds__(256) void pack_clouds_kernel(const float* __restrict__ src, const float* __restrict__ tgt, int B, int N, int NP,
-                                                          float* __restrict__ xyz, float* __restrict__ xyz4p) {
+// src, tgt [B][3][N] (the model's input layout, models/gmmreg.py:50) -> xyz [2B][N][3] (src clouds, then tgt clouds): what torch.cat + transpose +
+// contiguous made in two launches
+__global__ __launch_bounds__(256) void pack_clouds_kernel(const float* __restrict__ src, const float* __restrict__ tgt, int B, int N, float* __restrict__ xyz) {
     const int c = blockIdx.y;
     const float* __restrict__ in = (c < B ? src + (int64_t)c * 3 * N : tgt + (int64_t)(c - B) * 3 * N);
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= NP) return;
-    float x = 0.0f, y = 0.0f, z = 0.0f, w = __builtin_inff();
-    if (j < N) {
-        x = in[j]; y = in[N + j]; z = in[2 * N + j];
-        w = sqnorm3(x, y, z);
-        float* __restrict__ o = xyz + ((int64_t)c * N + j) * 3;
-        o[0] = x; o[1] = y; o[2] = z;
-    }
-    float* __restrict__ e = xyz4p + (int64_t)c * NP * 4 + (j >> 1) * 8 + (j & 1);
-    e[0] = x; e[2] = y; e[4] = z; e[6] = w;
+    if (j >= N) return;
+    float* __restrict__ o = xyz + ((int64_t)c * N + j) * 3;
+    o[0] = in[j]; o[1] = in[N + j]; o[2] = in[2 * N + j];
 }
 
 // ---- std::nth_element's partition, by the whole workgroup, with the element moves of the sequential loop
@@ -843,48 +876,55 @@ extern "C" int ogmm_knn(const float* xyz, int C, int N, int k, int32_t* idx, voi
     return ogmm::check_launch("ogmm_knn(resolve ties)");
 }
 
-extern "C" int ogmm_pack_clouds(const float* src, const float* tgt, int B, int N, float* xyz, float* xyz4p, void* stream) {
-    OGMM_REQUIRE(src && tgt && xyz && xyz4p && B > 0 && N > 0 && ogmm::aligned16(xyz4p), "ogmm_pack_clouds: null / unaligned pointer or empty input");
-    const int NP = (N + 31) / 32 * 32;
-    hipLaunchKernelGGL(pack_clouds_kernel, dim3((unsigned)((NP + 255) / 256), (unsigned)(2 * B)), dim3(256), 0, ogmm::as_stream(stream), src, tgt, B, N, NP, xyz, xyz4p);
+extern "C" int ogmm_pack_clouds(const float* src, const float* tgt, int B, int N, float* xyz, void* stream) {
+    OGMM_REQUIRE(src && tgt && xyz && B > 0 && N > 0, "ogmm_pack_clouds: null pointer or empty input");
+    hipLaunchKernelGGL(pack_clouds_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)(2 * B)), dim3(256), 0, ogmm::as_stream(stream), src, tgt, B, N, xyz);
     return ogmm::check_launch("ogmm_pack_clouds");
 }
 
-extern "C" int ogmm_knn_packed_supported(int N, int k) {
-    if (N <= 0 || k < 1 || k > 32 || k > N) return 0;
-    const int KLsel = k <= 8 ? 9 : (k <= 20 ? 21 : 33);
-    return (size_t)N * sizeof(float4) + (size_t)2 * (KLsel - 1) * 256 * sizeof(short) <= 64 * 1024 ? 1 : 0;
+static bool knn_head_fits(int N, int k, int* fold_out) {
+    if (N <= 0 || k <= 8 || k > 32 || k > N || N < 6) return false;
+    const int KLsel = k <= 20 ? 21 : 33;
+    const size_t lds = (size_t)N * sizeof(float4), lds2 = lds + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
+    if (lds2 > 64 * 1024) return false;
+    // both tie resolutions (rank k, rank 5) run in the LDS of the candidate lists: the scratch of ogmm_knn's folded form
+    const size_t lists_bytes = lds2 - lds;
+    const bool heap = (long long)k * 64 <= N;
+    int fold = 0;
+    if (!heap && (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)) <= lists_bytes) fold = 2;
+    else if (heap && (size_t)N * sizeof(ogmm_select::Cand) <= lists_bytes) fold = 1;
+    else if (!heap && (size_t)N * sizeof(ogmm_select::Cand) <= lists_bytes) fold = 1;          // (introselect by one thread: correct, slower on a flagged row)
+    if (fold_out) *fold_out = fold;
+    return fold != 0 && (size_t)N * sizeof(ogmm_select::Cand) <= lists_bytes;          // rank 5 takes the heap branch whenever 5 * 64 <= N, else one thread's introselect
 }
 
-extern "C" int ogmm_knn_packed(const float* xyz, const float* xyz4p, int C, int N, int k, int32_t* idx, void* stream) {
-    OGMM_REQUIRE(xyz && xyz4p && idx && C > 0 && N > 0 && ogmm::aligned16(xyz4p), "ogmm_knn_packed: null / unaligned pointer or empty input");
-    OGMM_REQUIRE(k >= 1 && k <= 32 && k <= N, "ogmm_knn_packed: need 1 <= k <= min(32, N), got k=%d N=%d", k, N);
-    OGMM_REQUIRE(ogmm_knn_packed_supported(N, k), "ogmm_knn_packed: N=%d with k=%d does not fit 64 KiB of LDS (cloud + candidate lists); use ogmm_knn", N, k);
-    const int NP = (N + 31) / 32 * 32;
-    const int KLsel = k <= 8 ? 9 : (k <= 20 ? 21 : 33);
-    const size_t lds = (size_t)N * sizeof(float4), lds2 = lds + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
-    static const int fold_env = [] { const char* e = getenv("OGMM_KNN_FOLD_TIES"); return e ? atoi(e) : 1; }();
+extern "C" int ogmm_knn_pos_head_supported(int N, int k) { return knn_head_fits(N, k, nullptr) ? 1 : 0; }
+
+extern "C" int64_t ogmm_knn_pos_head_workspace_bytes(int C, int N) {
+    return (int64_t)C * ((N + 255) / 256) * (N / 32) * 256 * (int64_t)sizeof(unsigned) + 256;
+}
+
+extern "C" int ogmm_knn_pos_head(const float* xyz, int C, int N, int k, int32_t* idx, int32_t* idx5, const float* w_dis, const float* s_dis, const float* t_dis,
+                                 const float* w_ang, const float* s_ang, const float* t_ang, float* hid_dis, float* hid_ang, void* workspace, void* stream) {
+    OGMM_REQUIRE(xyz && idx && workspace && C > 0 && N > 0, "ogmm_knn_pos_head: null pointer or empty input");
     int fold = 0;
-    if (fold_env) {          // (as ogmm_knn: the tie scratch in the LDS of the candidate lists, which are dead by then)
-        const size_t lists_bytes = lds2 - lds;
-        const bool heap = (long long)k * 64 <= N;
-        if (!heap && (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)) <= lists_bytes) fold = 2;
-        else if (heap && (size_t)N * sizeof(ogmm_select::Cand) <= lists_bytes) fold = 1;
-    }
+    OGMM_REQUIRE(knn_head_fits(N, k, &fold), "ogmm_knn_pos_head: N=%d, k=%d is outside this kernel's range (ogmm_knn_pos_head_supported); use ogmm_knn + ogmm_pos_hidden", N, k);
+    const bool head = idx5 != nullptr;
+    OGMM_REQUIRE(!head || (w_dis && s_dis && t_dis && w_ang && s_ang && t_ang && hid_dis && hid_ang), "ogmm_knn_pos_head: the positional front end needs all six constants and both outputs");
+    const int KLsel = k <= 20 ? 21 : 33;
+    const size_t lds2 = (size_t)N * sizeof(float4) + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
+    knn_pos_args pa = {idx5, w_dis, s_dis, t_dis, w_ang, s_ang, t_ang, hid_dis, hid_ang};
     hipStream_t s = ogmm::as_stream(stream);
     dim3 grid((N + 255) / 256, C);
-    if (k <= 8) hipLaunchKernelGGL(knn3_kernel<9>, grid, dim3(256), lds2, s, xyz4p, N, NP, k, idx, fold);
-    else if (k <= 20) hipLaunchKernelGGL(knn3_kernel<21>, grid, dim3(256), lds2, s, xyz4p, N, NP, k, idx, fold);
-    else hipLaunchKernelGGL(knn3_kernel<33>, grid, dim3(256), lds2, s, xyz4p, N, NP, k, idx, fold);
-    if (int rc = ogmm::check_launch("ogmm_knn_packed")) return rc;
-    if (fold) return 0;
-    static ogmm::PerDeviceOnce attr_once;
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_resolve_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    const int64_t rows = (int64_t)C * N;
-    const bool lists = (long long)k * 64 > N && (size_t)N * (sizeof(ogmm_select::Cand) + 2 * sizeof(int)) <= 156 * 1024;
-    const size_t ties_lds = (size_t)N * (sizeof(ogmm_select::Cand) + (lists ? 2 * sizeof(int) : 0));
-    hipLaunchKernelGGL(knn_resolve_ties_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), ties_lds, s, xyz, N, k, rows, idx, lists ? 1 : 0);
-    return ogmm::check_launch("ogmm_knn_packed(resolve ties)");
+    unsigned* bm = reinterpret_cast<unsigned*>(workspace);
+    if (KLsel == 21) {
+        if (head) hipLaunchKernelGGL((knn4_kernel<21, true>), grid, dim3(256), lds2, s, xyz, N, k, idx, bm, fold, pa);
+        else hipLaunchKernelGGL((knn4_kernel<21, false>), grid, dim3(256), lds2, s, xyz, N, k, idx, bm, fold, pa);
+    } else {
+        if (head) hipLaunchKernelGGL((knn4_kernel<33, true>), grid, dim3(256), lds2, s, xyz, N, k, idx, bm, fold, pa);
+        else hipLaunchKernelGGL((knn4_kernel<33, false>), grid, dim3(256), lds2, s, xyz, N, k, idx, bm, fold, pa);
+    }
+    return ogmm::check_launch("ogmm_knn_pos_head");
 }
 
 extern "C" int ogmm_fps(const float* xyz, int C, int N, int npoint, int n_sets, const int32_t* start, int32_t* ids, void* stream) {

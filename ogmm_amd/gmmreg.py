@@ -411,8 +411,7 @@ class GMMReg(nn.Module):
         else:
             fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
 
-        # [C,N,3] (src clouds, then tgt clouds) and the pair-major candidate copy the kNN kernels read through the scalar cache: one launch
-        xyz, xyz4p = ops.pack_clouds(src, tgt)
+        xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
         if self._swap is None or self._swap.device != dev or self._swap.numel() != C:          # (cached per batch size: four tiny launches per forward otherwise)
             self._swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
         swap = self._swap
@@ -440,21 +439,29 @@ class GMMReg(nn.Module):
         # statistics behind its read.
         ws = self._workspace(dev, main, C, N, D, XW)
         stats3, extra = ws["stats3"], ws["extra"]
-        with torch.cuda.stream(side):
-            idx5 = ops.knn(xyz, 5, packed=xyz4p)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
-            hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
+        # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch on the main stream
+        # (ops.knn_pos_head: the 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud
+        # the kernel already holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay
+        # on a side stream.
+        fused_head = ops.knn_pos_head_supported(N, k)
+        if fused_head:
+            idx, idx5, hd, ha = ops.knn_pos_head(xyz, k, L["pos"])
         with torch.cuda.stream(side2):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
             ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
+        if not fused_head:
+            with torch.cuda.stream(side):
+                idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
+                hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
         side.wait_stream(side2)
         sel_done = torch.cuda.Event()
         sel_done.record(side)
         xyz.record_stream(side2)
         xyz.record_stream(side)
-        xyz4p.record_stream(side)
-        for t_ in (ids_a, ids_j, idx5, hd, ha):
+        if not fused_head:
+            idx = ops.knn(xyz, k)
+        for t_ in (ids_a, ids_j) + (() if fused_head else (idx5, hd, ha)):
             t_.record_stream(main)
-        idx = ops.knn(xyz, k, packed=xyz4p)
 
         # ---- DGCNN (models/dgcnn.py:133-154)
         R = C * N

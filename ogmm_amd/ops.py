@@ -88,34 +88,51 @@ def _p(t):
 
 
 # ---------------------------------------------------------------------------------------------- selection
-KNN_PACKED = os.environ.get("OGMM_KNN_PACKED", "1") != "0"          # A/B switch: 0 = the LDS-broadcast kernels (ogmm_knn) everywhere
+KNN_HEAD = os.environ.get("OGMM_KNN_HEAD", "1") != "0"          # A/B switch: 0 = ogmm_knn (k = 20), ogmm_knn (k = 5) and ogmm_pos_hidden as three launches
 
 
 def pack_clouds(src, tgt):
-    """src, tgt [B,3,N] (models/gmmreg.py:50) -> xyz [2B,N,3] (src clouds, then tgt clouds) and the pair-major candidate copy [2B, NP/2, 8] that knn(...,
-    packed=) reads through the scalar cache (include/ogmm_hip.h: ogmm_pack_clouds): one launch instead of torch's cat + transpose copy."""
+    """src, tgt [B,3,N] (models/gmmreg.py:50) -> xyz [2B,N,3] (src clouds, then tgt clouds): one launch instead of torch's cat + transpose copy."""
     B, _, N = src.shape
     src, tgt = _f32(src, "src").contiguous(), _f32(tgt, "tgt").contiguous()
-    NP = (N + 31) // 32 * 32
     xyz = torch.empty((2 * B, N, 3), dtype=torch.float32, device=src.device)
-    xyz4p = torch.empty((2 * B, NP // 2, 8), dtype=torch.float32, device=src.device)
-    _lib.call("ogmm_pack_clouds", _p(src), _p(tgt), B, N, _p(xyz), _p(xyz4p), _stream())
-    return xyz, xyz4p
+    _lib.call("ogmm_pack_clouds", _p(src), _p(tgt), B, N, _p(xyz), _stream())
+    return xyz
 
 
-def knn(xyz, k, packed=None):
-    """xyz [C,N,3] -> idx [C,N,k] int32   (lib/utils.py:37-44).  packed: pack_clouds' second output for the same clouds -- the scalar-load kernel takes it
-    where it applies (same neighbour sets; tests/test_hip_ops.py compares the two kernels' outputs for identity)."""
+def knn(xyz, k):
+    """xyz [C,N,3] -> idx [C,N,k] int32   (lib/utils.py:37-44)."""
     xyz = _f32(xyz, "xyz")
     assert xyz.is_contiguous() and xyz.dim() == 3 and xyz.shape[2] == 3
     C, N, _ = xyz.shape
     idx = torch.empty((C, N, k), dtype=torch.int32, device=xyz.device)
-    if packed is not None and KNN_PACKED and _lib.load().ogmm_knn_packed_supported(N, k) == 1:
-        assert packed.is_contiguous() and packed.shape == (C, (N + 31) // 32 * 16, 8)
-        _lib.call("ogmm_knn_packed", _p(xyz), _p(packed), C, N, k, _p(idx), _stream())
-        return idx
     _lib.call("ogmm_knn", _p(xyz), C, N, k, _p(idx), _stream())
     return idx
+
+
+def knn_pos_head_supported(N, k):
+    return KNN_HEAD and _lib.load().ogmm_knn_pos_head_supported(N, k) == 1
+
+
+def knn_pos_head(xyz, k, pos=None):
+    """The forward's head in one launch (include/ogmm_hip.h: ogmm_knn_pos_head): idx [C,N,k] as knn(xyz, k) and -- with pos = the packed "pos" layer
+    (w_dis, s_dis, t_dis, w_ang, s_ang, t_ang) -- idx5 [C,N,5] as knn(xyz, 5) and (hid_dis, hid_ang) [C*N,64] as pos_hidden(xyz, idx5, 5, pos).
+    Returns idx or (idx, idx5, hid_dis, hid_ang)."""
+    xyz = _f32(xyz, "xyz")
+    assert xyz.is_contiguous() and xyz.dim() == 3 and xyz.shape[2] == 3
+    C, N, _ = xyz.shape
+    dev = xyz.device
+    idx = torch.empty((C, N, k), dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.load().ogmm_knn_pos_head_workspace_bytes(C, N), dtype=torch.uint8, device=dev)
+    if pos is None:
+        _lib.call("ogmm_knn_pos_head", _p(xyz), C, N, k, _p(idx), None, None, None, None, None, None, None, None, None, _p(ws), _stream())
+        return idx
+    idx5 = torch.empty((C, N, 5), dtype=torch.int32, device=dev)
+    hd = torch.empty((C * N, 64), dtype=torch.float32, device=dev)
+    ha = torch.empty_like(hd)
+    _lib.call("ogmm_knn_pos_head", _p(xyz), C, N, k, _p(idx), _p(idx5), _p(pos["w_dis"]), _p(pos["s_dis"]), _p(pos["t_dis"]), _p(pos["w_ang"]), _p(pos["s_ang"]),
+              _p(pos["t_ang"]), _p(hd), _p(ha), _p(ws), _stream())
+    return idx, idx5, hd, ha
 
 
 def fps(xyz, npoint, start=None):

@@ -31,9 +31,9 @@ def clouds(C, N, seed=0, kind="partial"):
 
 # ------------------------------------------------------------------------------------------------ K1
 class _KnnBoth:
-    """ops.knn through BOTH kernels: the LDS-broadcast one (ogmm_knn) and, where it applies, the scalar-load / packed-fp32 one (ogmm_knn_packed, round 5) on
-    ogmm_pack_clouds' pair-major copy.  The two index tensors must be IDENTICAL (same distance bits, same insertion order, same tie resolution), so every
-    kNN test below pins both; pack_clouds' point-major output must be the clouds themselves."""
+    """ops.knn through BOTH forms: the plain kernels (ogmm_knn) and, where it applies, the fused head kernel (ogmm_knn_pos_head, round 5: scan B over scan A's
+    marks; the 5-NN graph and the positional front end folded in).  Index tensors must be IDENTICAL (same distance bits, same insertion order, same tie
+    resolution), the 5-NN graph must be knn(xyz, 5)'s and the hidden maps pos_hidden's, bit for bit -- so every kNN test below pins both forms."""
 
     def __init__(self, ops):
         self.ops = ops
@@ -42,13 +42,19 @@ class _KnnBoth:
         ops = self.ops
         base = ops.knn(xyz_dev, k)
         C, N, _ = xyz_dev.shape
-        from ogmm_amd import _lib
-        if _lib.load().ogmm_knn_packed_supported(N, k) == 1:
+        if ops.knn_pos_head_supported(N, k):
+            got = ops.knn_pos_head(xyz_dev, k)
+            assert torch.equal(got, base), "the fused head kernel's %d-NN graph differs from ogmm_knn's in %d rows" % (k, int((got != base).any(-1).sum()))
+            g = torch.Generator().manual_seed(N * 31 + k)
+            pos = {key: (torch.rand(64, generator=g) * 2 - 0.5).cuda() for key in ("w_dis", "s_dis", "t_dis", "w_ang", "s_ang", "t_ang")}
+            got, idx5, hd, ha = ops.knn_pos_head(xyz_dev, k, pos)
+            ref5 = ops.knn(xyz_dev, 5)
+            assert torch.equal(got, base) and torch.equal(idx5, ref5), "5-NN graph differs in %d rows" % int((idx5 != ref5).any(-1).sum())
+            hd_r, ha_r = ops.pos_hidden(xyz_dev, ref5, 5, pos)
+            assert torch.equal(hd, hd_r) and torch.equal(ha, ha_r), "positional hidden maps differ: %.3e / %.3e" % ((hd - hd_r).abs().max().item(), (ha - ha_r).abs().max().item())
             chw = xyz_dev.transpose(1, 2).contiguous()                     # [C,3,N]: the model's input layout
-            xyz2, packed = ops.pack_clouds(chw, chw)                        # 2C clouds: the set twice
+            xyz2 = ops.pack_clouds(chw, chw)
             assert torch.equal(xyz2[:C], xyz_dev) and torch.equal(xyz2[C:], xyz_dev)
-            got = ops.knn(xyz2, k, packed=packed)
-            assert torch.equal(got[:C], base) and torch.equal(got[C:], base), "the packed kNN kernel differs from the LDS one in %d rows" % int((got[:C] != base).any(-1).sum())
         return base
 
 
