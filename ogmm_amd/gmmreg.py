@@ -253,6 +253,12 @@ class GMMReg(nn.Module):
         self._side2 = None
         self._ws = None             # persistent zero-initialised buffers of the eval forward (_workspace)
         self._swap = None           # cloud map of the cross-attention (src <-> tgt), per batch size
+        self._head = None
+        # Opt-in for serving loops: the head of a forward (cloud stacking, kNN graph + positional front end, FPS chains: everything that depends on the
+        # inputs alone) is queued on its own stream WITHOUT waiting for what the current stream still has to run, so that it overlaps the latency-bound tail
+        # of the previous forward.  Contract when True: `src` / `tgt` (and `fps_starts`) must be COMPLETE when forward() is called -- not pending on the
+        # current stream -- e.g. inputs resident from an earlier synchronisation, or produced on another stream the caller has waited on.
+        self.pipeline_head = False
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved.  (data_ptr, _version) catches optimizer steps,
@@ -402,35 +408,47 @@ class GMMReg(nn.Module):
 
         if fps_starts is None:
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
-        # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
-        # tensor makes the host wait for the copy -- which is queued behind everything this stream still has to run, i.e. for the end of the PREVIOUS
-        # forward.  Every forward then started on an idle GPU with its first ~10 launches bound by the host's launch latency (round 5 trace: 240 us
-        # from the step's first kernel to its kNN kernel).  (The caching host allocator keeps the pinned block alive until the copy has run.)
-        if fps_starts.device.type == "cpu" and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-            fps_starts = fps_starts.reshape(3, 2 * B).to(torch.int32).pin_memory().to(dev, non_blocking=True)
+        main = torch.cuda.current_stream()
+        fused_head = ops.knn_pos_head_supported(N, k)
+        # `pipeline_head` (opt-in, see __init__): the head of THIS forward -- anchor draws, cloud stacking, kNN + positional front end, FPS chains; all of it
+        # depends on nothing but the inputs -- goes to its own stream WITHOUT waiting for the work the current stream still holds, so in a loop of forwards
+        # it runs under the latency-bound tail of the previous one (cluster means, matching, loss: ~0.2 ms on a mostly idle chip).
+        pipelined = bool(self.pipeline_head) and fused_head and not torch.cuda.is_current_stream_capturing()
+        if pipelined:
+            if self._head is None or self._head.device != dev:
+                self._head = torch.cuda.Stream(device=dev)
+            hs = self._head
         else:
-            fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
-
-        xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
+            hs = main
+        with torch.cuda.stream(hs):
+            # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
+            # tensor makes the host wait for the copy, which is queued behind everything the stream still has to run (the caching host allocator keeps the
+            # pinned block alive until the copy has run).
+            if fps_starts.device.type == "cpu" and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                fps_starts = fps_starts.reshape(3, 2 * B).to(torch.int32).pin_memory().to(dev, non_blocking=True)
+            else:
+                fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
+            xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
+            # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch (ops.knn_pos_head: the
+            # 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud the kernel already
+            # holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay on a side stream.
+            if fused_head:
+                idx, idx5, hd, ha = ops.knn_pos_head(xyz, k, L["pos"])
         if self._swap is None or self._swap.device != dev or self._swap.numel() != C:          # (cached per batch size: four tiny launches per forward otherwise)
             self._swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
         swap = self._swap
-        # Latency-bound selection kernels (one workgroup per cloud: FPS chains, the k=5 graph, later the E/M loop) run on a
-        # side stream next to the GEMM-bound main stream: they occupy <= C of the 256 CUs.  Every tensor they touch stays
-        # referenced until the streams are joined again.
-        main = torch.cuda.current_stream()
+        # Latency-bound selection kernels (one workgroup per cloud: FPS chains, later the E/M loop) run on a side stream next to the GEMM-bound main
+        # stream: they occupy <= C of the 256 CUs.  Every tensor they touch stays referenced until the streams are joined again.  Everything queued here
+        # has to be ON the chip before the persistent EdgeConv kernel starts (~0.25 ms into the forward): that kernel holds every CU's registers and LDS
+        # for ~0.7 ms, and a selection kernel that is still queued then runs after it, next to -- and slowing -- the first GEMM.
         if self._side is None or self._side.device != dev:
             self._side = torch.cuda.Stream(device=dev)
         side = self._side
-        side.wait_stream(main)
+        side.wait_stream(hs)
         if self._side2 is None or self._side2.device != dev:
             self._side2 = torch.cuda.Stream(device=dev)
         side2 = self._side2
-        side2.wait_stream(main)
-        # Two side streams, because everything queued here has to be ON the chip before the persistent EdgeConv kernel starts (~0.25 ms
-        # into the forward): that kernel holds every CU's registers and LDS for ~0.8 ms, and a selection kernel that is still queued then
-        # runs after it, next to -- and slowing -- the first GEMM.  In one queue the 5-NN chain (knn, tie resolution, positional front
-        # end) and the FPS chains take ~0.4 ms; side by side they are through in time.
+        side2.wait_stream(hs)
         R = C * N
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
         # the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0: persistent per (stream, shape), zeroed when created.
@@ -439,13 +457,6 @@ class GMMReg(nn.Module):
         # statistics behind its read.
         ws = self._workspace(dev, main, C, N, D, XW)
         stats3, extra = ws["stats3"], ws["extra"]
-        # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch on the main stream
-        # (ops.knn_pos_head: the 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud
-        # the kernel already holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay
-        # on a side stream.
-        fused_head = ops.knn_pos_head_supported(N, k)
-        if fused_head:
-            idx, idx5, hd, ha = ops.knn_pos_head(xyz, k, L["pos"])
         with torch.cuda.stream(side2):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
             ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
@@ -458,6 +469,13 @@ class GMMReg(nn.Module):
         sel_done.record(side)
         xyz.record_stream(side2)
         xyz.record_stream(side)
+        fps_starts.record_stream(side2)
+        if pipelined:
+            main.wait_stream(hs)
+            for t_ in (xyz, idx, idx5, hd, ha):
+                t_.record_stream(main)
+            src.record_stream(hs)
+            tgt.record_stream(hs)
         if not fused_head:
             idx = ops.knn(xyz, k)
         for t_ in (ids_a, ids_j) + (() if fused_head else (idx5, hd, ha)):
