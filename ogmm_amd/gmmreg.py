@@ -429,6 +429,8 @@ class GMMReg(nn.Module):
             else:
                 fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
             xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
+            inputs_ready = torch.cuda.Event()          # what the FPS chains wait for: the stacked clouds and the anchor draws, NOT the kNN kernel behind them
+            inputs_ready.record(hs)
             # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch (ops.knn_pos_head: the
             # 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud the kernel already
             # holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay on a side stream.
@@ -444,11 +446,11 @@ class GMMReg(nn.Module):
         if self._side is None or self._side.device != dev:
             self._side = torch.cuda.Stream(device=dev)
         side = self._side
-        side.wait_stream(hs)
+        side.wait_event(inputs_ready)
         if self._side2 is None or self._side2.device != dev:
             self._side2 = torch.cuda.Stream(device=dev)
         side2 = self._side2
-        side2.wait_stream(hs)
+        side2.wait_event(inputs_ready)
         R = C * N
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
         # the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0: persistent per (stream, shape), zeroed when created.
@@ -467,6 +469,10 @@ class GMMReg(nn.Module):
         side.wait_stream(side2)
         sel_done = torch.cuda.Event()
         sel_done.record(side)
+        # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU: queued behind the kNN kernel
+        # (round 5, first form of the fused head) they ran next to EdgeConv instead -- slower for both, and their chains came out different from run to
+        # run (tools/graph_dbg.py; the chains are identical whenever they do not share the chip with that kernel).  The wait costs nothing: they finish with the kNN kernel.
+        main.wait_event(sel_done)
         xyz.record_stream(side2)
         xyz.record_stream(side)
         fps_starts.record_stream(side2)
