@@ -451,6 +451,11 @@ class GMMReg(nn.Module):
             self._side2 = torch.cuda.Stream(device=dev)
         side2 = self._side2
         side2.wait_event(inputs_ready)
+        if pipelined:
+            # the FPS chains do NOT run ahead: beside the kernels of the previous forward (EdgeConv, the GEMM engine) their picks came out different from run to
+            # run (tools/graph_dbg.py) -- cause not established; beside the kNN kernel, or alone, they are reproducible.  They start when the previous
+            # forward has left the main stream; the kNN graph of this forward is finished by then.
+            side2.wait_stream(main)
         R = C * N
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
         # the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0: persistent per (stream, shape), zeroed when created.
