@@ -253,12 +253,6 @@ class GMMReg(nn.Module):
         self._side2 = None
         self._ws = None             # persistent zero-initialised buffers of the eval forward (_workspace)
         self._swap = None           # cloud map of the cross-attention (src <-> tgt), per batch size
-        self._head = None
-        # Opt-in for serving loops: the head of a forward (cloud stacking, kNN graph + positional front end, FPS chains: everything that depends on the
-        # inputs alone) is queued on its own stream WITHOUT waiting for what the current stream still has to run, so that it overlaps the latency-bound tail
-        # of the previous forward.  Contract when True: `src` / `tgt` (and `fps_starts`) must be COMPLETE when forward() is called -- not pending on the
-        # current stream -- e.g. inputs resident from an earlier synchronisation, or produced on another stream the caller has waited on.
-        self.pipeline_head = False
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved.  (data_ptr, _version) catches optimizer steps,
@@ -410,16 +404,7 @@ class GMMReg(nn.Module):
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
         main = torch.cuda.current_stream()
         fused_head = ops.knn_pos_head_supported(N, k)
-        # `pipeline_head` (opt-in, see __init__): the head of THIS forward -- anchor draws, cloud stacking, kNN + positional front end, FPS chains; all of it
-        # depends on nothing but the inputs -- goes to its own stream WITHOUT waiting for the work the current stream still holds, so in a loop of forwards
-        # it runs under the latency-bound tail of the previous one (cluster means, matching, loss: ~0.2 ms on a mostly idle chip).
-        pipelined = bool(self.pipeline_head) and fused_head and not torch.cuda.is_current_stream_capturing()
-        if pipelined:
-            if self._head is None or self._head.device != dev:
-                self._head = torch.cuda.Stream(device=dev)
-            hs = self._head
-        else:
-            hs = main
+        hs = main
         with torch.cuda.stream(hs):
             # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
             # tensor makes the host wait for the copy, which is queued behind everything the stream still has to run (the caching host allocator keeps the
@@ -451,11 +436,6 @@ class GMMReg(nn.Module):
             self._side2 = torch.cuda.Stream(device=dev)
         side2 = self._side2
         side2.wait_event(inputs_ready)
-        if pipelined:
-            # the FPS chains do NOT run ahead: beside the kernels of the previous forward (EdgeConv, the GEMM engine) their picks came out different from run to
-            # run (tools/graph_dbg.py) -- cause not established; beside the kNN kernel, or alone, they are reproducible.  They start when the previous
-            # forward has left the main stream; the kNN graph of this forward is finished by then.
-            side2.wait_stream(main)
         R = C * N
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
         # the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0: persistent per (stream, shape), zeroed when created.
@@ -474,19 +454,14 @@ class GMMReg(nn.Module):
         side.wait_stream(side2)
         sel_done = torch.cuda.Event()
         sel_done.record(side)
-        # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU: queued behind the kNN kernel
-        # (round 5, first form of the fused head) they ran next to EdgeConv instead -- slower for both, and their chains came out different from run to
-        # run (tools/graph_dbg.py; the chains are identical whenever they do not share the chip with that kernel).  The wait costs nothing: they finish with the kNN kernel.
+        # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU.  Queued behind the kNN kernel
+        # (round 5, first form of the fused head) they ran next to EdgeConv instead: slower for both, and inside the forward their picks then came out
+        # different from run to run (tools/determinism_check.py; alone beside any kernel family they are reproducible -- tools/fps_corun.py -- so the cause is
+        # not established; with this order every mode of that tool is bit-reproducible).  The wait costs nothing: they finish with the kNN kernel.
         main.wait_event(sel_done)
         xyz.record_stream(side2)
         xyz.record_stream(side)
         fps_starts.record_stream(side2)
-        if pipelined:
-            main.wait_stream(hs)
-            for t_ in (xyz, idx, idx5, hd, ha):
-                t_.record_stream(main)
-            src.record_stream(hs)
-            tgt.record_stream(hs)
         if not fused_head:
             idx = ops.knn(xyz, k)
         for t_ in (ids_a, ids_j) + (() if fused_head else (idx5, hd, ha)):

@@ -1,5 +1,5 @@
-"""Developer aid (GPU box): run-to-run determinism of consecutive eval forwards -- serial and with GMMReg.pipeline_head, with and without a synchronisation
-between the forwards -- compared output by output and, for one batch, stage by stage (which intermediate is the first to differ)."""
+"""Developer aid (GPU box): run-to-run determinism of consecutive eval forwards, with and without a synchronisation between them, compared output by output
+and stage by stage (which intermediate is the first to differ)."""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from argparse import Namespace
@@ -14,7 +14,6 @@ for i, (B, N) in enumerate(((6, 1024), (4, 717), (6, 1024), (4, 717), (64, 1024)
 torch.cuda.synchronize()
 keys = ("knn_idx", "fps_anchor", "fps_J", "emb", "x0", "ft", "f", "o", "f2", "gamma", "mu", "muf", "near")
 def run(flag, sync, capture=False):
-    model.pipeline_head = flag
     res = []
     with torch.no_grad():
         for s, t, st in batches:
@@ -26,7 +25,7 @@ def run(flag, sync, capture=False):
 ref = run(False, True, True)
 bad = 0
 for rep in range(3):
-    for tag, flag, sync, capt in (("serial sync capture", False, True, True), ("serial nosync", False, False, False), ("pipe sync", True, True, False), ("pipe nosync", True, False, False), ("pipe nosync capture", True, False, True)):
+    for tag, flag, sync, capt in (("sync capture", False, True, True), ("nosync", False, False, False), ("nosync capture", False, False, True)):
         got = run(flag, sync, capt)
         same = [all(torch.equal(x, y) for x, y in zip(a, b)) for a, b in zip(ref, got)]
         bad += sum(not v for v in same)
