@@ -21,7 +21,7 @@ OGMM_TRAIN_GRAPH=0 timeout 500 python3 bench.py --workload train --steps 5 --war
 rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format rocpd -- $BENCH > $out/trace.log 2>&1
 db=$(find $out/trace -name "*.db" | head -1)
 { echo "# commit $commit"; echo "# rocprofv3 --kernel-trace --stats -- $BENCH   (9 forwards: 2 warm-up + 1 counting + 5 timed + ...; the first one also packs the weights)"; python3 tools/rocpd_stats.py $db; } > $out/${tag}_kernel_stats.txt
-{ echo "# one eval step (B=64, N=1024, J=16) as dispatched: start, gap to the previous kernel's end (negative: overlapped with a side stream), duration, grid"; python3 tools/rocpd_timeline.py $db "knn2_kernel<21>" | head -70; } > $out/${tag}_step_timeline.txt
+{ echo "# one eval step (B=64, N=1024, J=16) as dispatched: start, gap to the previous kernel's end (negative: overlapped with a side stream), duration, grid"; python3 tools/rocpd_timeline.py $db "pack_clouds_kernel" | head -70; } > $out/${tag}_step_timeline.txt
 
 # 3. PMC passes (separate runs)
 {
@@ -64,10 +64,20 @@ rm -rf $out/trace_train
 { echo "# commit $commit"; timeout 1800 python3 tools/parity_distribution.py --workloads cfg1,cfg2,cfg3,n717 --pairs 256,64,32,128 2>&1 | grep -v amdgpu.ids;
   echo; echo "# PARITY lines of pytest -m gpu (tests/test_hip_forward.py, test_hip_parity_tail.py, test_hip_deepgmr.py, test_hip_icp.py)";
   timeout 1500 python3 -m pytest tests/test_hip_forward.py tests/test_hip_parity_tail.py tests/test_hip_deepgmr.py tests/test_hip_icp.py -m gpu -q -s 2>&1 | grep -E "PARITY|TRAINED|passed|failed"; } > $out/${tag}_parity.txt
-{ echo "# commit $commit"; echo "# weight family sharp (synth.fill_state_dict(profile='sharp')): the shipped budget, three terms everywhere, round 3's budget (for the record: NOT parity-safe), the exact-fp32 engine";
+{ echo "# commit $commit"; echo "# weight family sharp (synth.fill_state_dict(profile='sharp')): the shipped budget on the full windows, then three terms everywhere and the exact-fp32 engine on the SAME windows (round 5: configs[1] pairs 0..127 incl. 75 / 84 / 112, N = 717 pairs 300..427), round 3's budget for the record (NOT parity-safe)";
   timeout 900 python3 tools/parity_distribution.py --profile sharp --workloads cfg1,cfg2,n717 --pairs 128,32,128 2>&1 | grep -v amdgpu.ids;
-  timeout 600 python3 tools/parity_distribution.py --profile sharp --budget none --workloads cfg1,n717 --pairs 64,64 2>&1 | grep -v amdgpu.ids;
-  timeout 600 python3 tools/parity_distribution.py --profile sharp --budget r3 --workloads cfg1,n717 --pairs 64,64 2>&1 | grep -v amdgpu.ids;
-  timeout 600 python3 tools/parity_distribution.py --profile sharp --precision f32 --workloads cfg1,n717 --pairs 64,64 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_parity_sharp.txt
+  timeout 900 python3 tools/parity_distribution.py --profile sharp --budget none --workloads cfg1,n717 --pairs 128,128 2>&1 | grep -v amdgpu.ids;
+  timeout 900 python3 tools/parity_distribution.py --profile sharp --precision f32 --workloads cfg1,n717 --pairs 128,128 2>&1 | grep -v amdgpu.ids;
+  timeout 600 python3 tools/parity_distribution.py --profile sharp --budget r3 --workloads cfg1 --pairs 64 2>&1 | grep -v amdgpu.ids;
+  echo; echo "# tools/parity_probe.py: pairs 64..127 in one batch, four arithmetics, the reference's own probes, stage by stage";
+  timeout 900 python3 tools/parity_probe.py --first 64 --pairs 64 --ids 75,84,112,99,124 2>&1 | grep -v amdgpu.ids;
+  echo; echo "# room clouds (configs[3] shape), both weight families, 32 pairs each";
+  timeout 900 python3 tools/parity_distribution.py --workloads cfg3 --pairs 32 2>&1 | grep -v amdgpu.ids;
+  timeout 900 python3 tools/parity_distribution.py --profile sharp --workloads cfg3 --pairs 32 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_parity_sharp.txt
+# 6. a weight family that has left the initial regime: 5000 training steps, regime report, every-pair parity (tools/parity_trained.py)
+{ echo "# commit $commit"; timeout 1500 python3 tools/parity_trained.py --steps 5000 --pairs 128 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_parity_trained.txt
+# 7. run-to-run reproducibility of consecutive forwards; the kNN head and the cluster-mean kernel alone
+{ echo "# commit $commit"; timeout 300 python3 tools/determinism_check.py 2>&1 | grep -v amdgpu.ids; timeout 300 python3 tools/fps_corun.py 2>&1 | grep -v amdgpu.ids;
+  timeout 200 python3 tools/knn_time.py 2>&1 | grep -v amdgpu.ids; timeout 100 python3 tools/featmean_time.py 2>&1 | grep -v amdgpu.ids; timeout 100 python3 tools/host_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_head_and_determinism.txt
 rm -rf $out/trace $out/pmc_*          # the rocpd databases exceed what gpurun copies back; the summaries above are what gets committed
 ls -la $out | head -40
