@@ -446,6 +446,7 @@ class GMMReg(nn.Module):
         stats3, extra = ws["stats3"], ws["extra"]
         with torch.cuda.stream(side2):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
+        with torch.cuda.stream(side if fused_head else side2):                  # (beside the anchor chains, not behind them: the EdgeConv kernel waits for both)
             ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
         if not fused_head:
             with torch.cuda.stream(side):
