@@ -46,13 +46,21 @@ def overlap_mse(src_o, tgt_o, src_overlap, tgt_overlap):
 
 def welsch_loss(src, tgt, R, t, src_overlap, tgt_overlap, alpha=10.0, top_k=512):
     """`WelschLoss.forward` (lib/loss.py:83-106) with the predicted motion given as (R, t) instead of the 4x4 the
-    reference packs first (lib/se3.py:29-52).  src, tgt [B,N,3]."""
+    reference packs first (lib/se3.py:29-52).  src, tgt [B,N,3].
+
+    Tie semantics of the label top-k (lib/loss.py:92, :95).  The labels are 0 / 1, so with more than top_k ones (or fewer: then zeros are drawn too) WHICH points
+    `torch.topk` keeps is decided by its kernel's selection moves, not by the values.  Parity is defined against the reference's CPU evaluation -- the only one that
+    can be pinned here: the goldens of tests/golden/make_golden_train.py come from it -- and on the device `ops.topk_rows` replays ATen's CPU selection move for move.
+    The reference's own GPU runs use torch's CUDA top-k, whose choice among ties is unspecified and differs from both; the loss is a mean over whichever tied points
+    are drawn (5e-4 apart in the Welsch term at N = 1024, top_k = 512).  Rows beyond `ops.TOPK_ROWS_MAX_N` points fall back to the device library's top-k."""
     moved = torch.bmm(src, R.transpose(1, 2)) + t.reshape(-1, 1, 3)
     if moved.is_cuda:
-        # the labels are 0 / 1: with more than top_k ones WHICH of them torch.topk keeps is decided by the CPU kernel's selection moves (the reference's loss is
-        # computed from them); the device library's own top-k breaks those ties differently -- 5e-4 in the Welsch term at N = 1024, top_k = 512
         from . import ops
-        s_ids, t_ids = ops.topk_rows(src_overlap.float().contiguous(), top_k), ops.topk_rows(tgt_overlap.float().contiguous(), top_k)
+        if src_overlap.shape[-1] <= ops.TOPK_ROWS_MAX_N:
+            s_ids, t_ids = ops.topk_rows(src_overlap.float().contiguous(), top_k), ops.topk_rows(tgt_overlap.float().contiguous(), top_k)
+        else:          # (the LDS-resident candidate list of ogmm_topk_rows ends there: the device library's own tie choice from here on)
+            s_ids = torch.topk(src_overlap, k=top_k, dim=-1)[1]
+            t_ids = torch.topk(tgt_overlap, k=top_k, dim=-1)[1]
     else:
         s_ids = torch.topk(src_overlap, k=top_k, dim=-1)[1]
         t_ids = torch.topk(tgt_overlap, k=top_k, dim=-1)[1]

@@ -1017,6 +1017,9 @@ def kabsch_bwd(src, corr, w, gR, gt):
     return g_src, g_corr, g_w
 
 
+TOPK_ROWS_MAX_N = 20224          # ogmm_topk_rows: the row's candidates live in LDS (158 KiB / 8 B)
+
+
 def topk_rows(v, k, largest=True):
     """torch.topk(v, k, dim=-1, largest)[1] for v [rows, n] with the reference CPU kernel's choice among tied values (ogmm_topk_rows) -> int64 [rows, k]"""
     assert v.dim() == 2 and v.stride(1) == 1

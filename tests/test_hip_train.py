@@ -202,6 +202,32 @@ def test_topk_rows_keeps_what_the_reference_cpu_topk_keeps(rows, n, k):
     assert torch.equal(ops.topk_rows(x.to(DEV), k, largest=False).cpu(), torch.topk(x, k, dim=-1, largest=False)[1])
 
 
+@pytest.mark.parametrize("frac", [0.1, 1.0, 0.0, 0.6])
+def test_welsch_loss_on_the_device_draws_the_reference_cpu_ties(frac):
+    """the Welsch term with FEWER ones than top_k (zeros are drawn too), with ALL ones, with none, and with more ones than top_k -- the device
+    evaluation (ogmm_topk_rows + nearest-point kernel) against the CPU evaluation of the same function (torch.topk's CPU kernel + cdist: the reference's arithmetic)."""
+    B, N, top_k = 3, 1024, 512
+    g = torch.Generator().manual_seed(int(frac * 100) + 7)
+    src, tgt = torch.rand(B, N, 3, generator=g) - 0.5, torch.rand(B, N, 3, generator=g) - 0.5
+    Rq = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+    R, t = Rq * torch.sign(torch.det(Rq))[:, None, None], torch.randn(B, 3, generator=g) * 0.2
+    so, to = (torch.rand(B, N, generator=g) < frac).float(), (torch.rand(B, N, generator=g) < frac).float()
+    want = losses.welsch_loss(src, tgt, R, t, so, to, 10.0, top_k)
+    got = losses.welsch_loss(src.to(DEV), tgt.to(DEV), R.to(DEV), t.to(DEV), so.to(DEV), to.to(DEV), 10.0, top_k)
+    assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item())), (frac, got.item(), want.item())
+
+
+def test_welsch_loss_beyond_the_topk_kernels_row_limit_falls_back():
+    ops = __import__("ogmm_amd.ops", fromlist=["x"])
+    B, N = 1, ops.TOPK_ROWS_MAX_N + 256
+    g = torch.Generator().manual_seed(3)
+    src, tgt = (torch.rand(B, N, 3, generator=g) - 0.5).to(DEV), (torch.rand(B, N, 3, generator=g) - 0.5).to(DEV)
+    lab = torch.rand(B, N, generator=g).to(DEV)          # distinct values: no ties, the same points whatever kernel selects them
+    got = losses.welsch_loss(src, tgt, torch.eye(3, device=DEV)[None], torch.zeros(1, 3, device=DEV), lab, lab, 10.0, 512)
+    want = losses.welsch_loss(src.cpu(), tgt.cpu(), torch.eye(3)[None], torch.zeros(1, 3), lab.cpu(), lab.cpu(), 10.0, 512)
+    assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item()))
+
+
 @pytest.mark.parametrize("cout,k,k1", [(512, 512, None), (1024, 516, 512), (256, 1024, None), (64, 6, None), (128, 64, None), (516, 1024, None), (1, 256, None)])
 def test_per_step_weight_split_in_two_launches_equals_the_tensor_expressions(cout, k, k1, monkeypatch):
     """ogmm_split_weight (round 4): scale + fragment image of W, and of W^T straight from W, against rounds 1-3's path (ogmm_pow2_scale + tensor expressions /
