@@ -28,7 +28,6 @@ from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
 _EM_SCHED = int(os.environ.get("OGMM_EM_SCHED", "0"))
-_EM_PRIME = os.environ.get("OGMM_EM_PRIME", "1") != "0"          # A/B switch: 0 = the E/M call fills its exit workspace itself, in front of its kernel
 # Measured budget (DESIGN.md section 4 "Per-layer term budget").  Round 4: an entry stays only if the layer's rounding holds the 1e-5 bar on BOTH weight
 # families of the parity suite -- the closed-form default fill AND synth.fill_state_dict(profile="sharp") (peaked attention, saturated overlap scores).
 # Round 3's entries for conv2.0 / conv2.3 (weight rounded), the three Q projections and the attention's score product (both rounded) were measured on
@@ -457,7 +456,7 @@ class GMMReg(nn.Module):
         sel_done = torch.cuda.Event()
         sel_done.record(side)
         em_xws = None
-        if _EM_PRIME and self.sinkhorn_thresh and self.sinkhorn_thresh > 0 and _EM_SCHED in (0, 1, 3) and not capture:
+        if self.sinkhorn_thresh and self.sinkhorn_thresh > 0 and _EM_SCHED in (0, 1, 3) and not capture:
             with torch.cuda.stream(side):          # the E/M's exit workspace, filled now (behind the selections) on the stream the E/M will run on: not between the overlap scores and the E/M kernel
                 em_xws = ops.gmm_em_prime(C, N, 10, 10, B, dev)
         # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU.  Queued behind the kNN kernel
