@@ -312,11 +312,7 @@ int ogmm_gmm_em_chip_cached(int N, int J);
 int ogmm_gmm_em(const float* xyz, const float* o /*[C][N]*/, const int32_t* ids0 /*[C][J]*/, int C, int N, int J,
                 int iters, int sk_iters, float epsilon, float tau, double thresh, int group_size,
                 float* gamma /*[C][N][J]*/, float* pi /*[C][J]*/, float* mu /*[C][J][3]*/, float* resid, int32_t* sweeps,
-                void* exit_ws, int exit_ws_primed, void* stream);
-/* (ABI 25) the two fills the call needs in exit_ws (counters to zero, residual slots to "not yet published"), alone: a caller that runs them EARLY -- the forward
- * does, on its side stream at its start -- passes exit_ws_primed = 1 and the E/M kernel starts the moment its inputs are ready (as two tiny launches in front of it,
- * queued behind a GEMM, they delayed it by ~120 us).  exit_ws_primed = 0: the call fills the workspace itself. */
-int ogmm_gmm_em_exit_prime(void* exit_ws, int C, int N, int iters, int sk_iters, int group_size, void* stream);
+                void* exit_ws, void* stream);
 
 /* K15 for shapes whose N x J cost matrix exceeds one CU's LDS: the same loop as a fixed sequence of grid-wide kernels over a cost
  * matrix kept in `workspace` (ogmm_gmm_em_workspace_bytes, 256-byte aligned) -- or, for grids that fit one resident round, one launch whose
@@ -325,7 +321,7 @@ int ogmm_gmm_em_exit_prime(void* exit_ws, int C, int N, int iters, int sk_iters,
 int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J);
 int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
                       float epsilon, float tau, double thresh, int group_size, float* gamma, float* pi, float* mu, float* resid,
-                      int32_t* sweeps, void* exit_ws, int exit_ws_primed, void* workspace, void* stream);
+                      int32_t* sweeps, void* exit_ws, void* workspace, void* stream);
 
 /* ---- K16: mu_feat = gamma^T feats / (N pi + 1e-5).  lib/utils.py:289 / :130-140. */
 int ogmm_gmm_feat_mean(const float* gamma, const float* pi, const float* feats, int64_t ld, int C, int N, int J, int D,

@@ -91,11 +91,10 @@ PROTOTYPES = {
     "ogmm_gmm_em_chip_max_group": [c_int, c_int],
     "ogmm_gmm_em_chip_cached": [c_int, c_int],
     "ogmm_gmm_em": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_double, c_int,
-                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    "ogmm_gmm_em_exit_prime": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_gmm_em_workspace_bytes": [c_int, c_int, c_int],
     "ogmm_gmm_em_multi": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_double, c_int,
-                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_gmm_feat_mean": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "ogmm_match_kabsch": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_kabsch": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],

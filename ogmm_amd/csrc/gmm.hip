@@ -1066,10 +1066,6 @@ extern "C" int64_t ogmm_gmm_em_exit_workspace_bytes(int C, int N, int iters, int
     return (int64_t)ogmm::em_exit_bytes(C, N, iters, sk_iters, group_size);
 }
 
-extern "C" int ogmm_gmm_em_exit_prime(void* exit_ws, int C, int N, int iters, int sk_iters, int group_size, void* stream) {
-    return ogmm::em_exit_prime(exit_ws, C, N, iters, sk_iters, group_size, ogmm::as_stream(stream));
-}
-
 // Largest call group the on-chip kernels take with the early exit on: the clouds of a group wait for each other, so one resident round of
 // workgroups must hold a whole group (one 1024-thread workgroup per CU at these LDS sizes).  0: the shape does not run on chip.
 extern "C" int ogmm_gmm_em_chip_cached(int N, int J) { return N > 0 && J > 0 && em_chip_lds(N, J, true) <= 128 * 1024 ? 1 : 0; }
@@ -1090,13 +1086,13 @@ extern "C" int ogmm_gmm_em_chip_max_group(int N, int J) {
 // sweeps that did not run; sweeps [C / group_size][iters] (may be NULL) the number of sweeps each E-step ran for each call group.
 extern "C" int ogmm_gmm_em(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
                            float epsilon, float tau, double thresh, int group_size, float* gamma, float* pi, float* mu, float* resid,
-                           int32_t* sweeps, void* exit_ws, int exit_ws_primed, void* stream) {
+                           int32_t* sweeps, void* exit_ws, void* stream) {
     OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu, "ogmm_gmm_em: null pointer");
     OGMM_REQUIRE(C > 0 && N > 0 && J > 0 && J <= N && iters > 0 && sk_iters >= 0 && epsilon > 0 && tau > 0, "ogmm_gmm_em: bad sizes C=%d N=%d J=%d", C, N, J);
     const size_t lds = em_chip_lds(N, J, false);
     OGMM_REQUIRE(lds <= 160 * 1024, "ogmm_gmm_em: N=%d, J=%d needs %zu B of LDS (> 160 KiB)", N, J, lds);
     ogmm::EmExit x;
-    if (int rc = ogmm::em_exit_setup(x, thresh, group_size, C, N, iters, sk_iters, resid, sweeps, exit_ws, ogmm::as_stream(stream), exit_ws_primed != 0)) return rc;
+    if (int rc = ogmm::em_exit_setup(x, thresh, group_size, C, N, iters, sk_iters, resid, sweeps, exit_ws, ogmm::as_stream(stream))) return rc;
     if (x.on) {
         const int cap = ogmm_gmm_em_chip_max_group(N, J);
         OGMM_REQUIRE(x.G <= cap, "ogmm_gmm_em: a call group of %d clouds does not fit one resident round (%d) with the early exit on: use ogmm_gmm_em_multi", x.G, cap);

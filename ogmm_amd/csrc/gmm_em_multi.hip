@@ -731,7 +731,7 @@ extern "C" int64_t ogmm_gmm_em_workspace_bytes(int C, int N, int J) {
 
 extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t* ids0, int C, int N, int J, int iters, int sk_iters,
                                  float epsilon, float tau, double thresh, int group_size, float* gamma, float* pi, float* mu, float* resid,
-                                 int32_t* sweeps, void* exit_ws, int exit_ws_primed, void* workspace, void* stream) {
+                                 int32_t* sweeps, void* exit_ws, void* workspace, void* stream) {
     using namespace ogmm;
     OGMM_REQUIRE(xyz && o && ids0 && gamma && pi && mu && workspace, "ogmm_gmm_em_multi: null pointer");
     OGMM_REQUIRE(J <= 128, "ogmm_gmm_em_multi: at most 128 clusters (a row of exponents lives in registers), got %d", J);
@@ -740,7 +740,7 @@ extern "C" int ogmm_gmm_em_multi(const float* xyz, const float* o, const int32_t
     OGMM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "ogmm_gmm_em_multi: workspace must be 256-byte aligned");
     hipStream_t s = as_stream(stream);
     EmExit x;
-    if (int rc = em_exit_setup(x, thresh, group_size, C, N, iters, sk_iters, resid, sweeps, exit_ws, s, exit_ws_primed != 0)) return rc;
+    if (int rc = em_exit_setup(x, thresh, group_size, C, N, iters, sk_iters, resid, sweeps, exit_ws, s)) return rc;
     char* p = static_cast<char*>(workspace);
     EmWs w;
     w.cost = reinterpret_cast<float*>(p);  p += align256((size_t)C * J * N * 4);

@@ -157,10 +157,8 @@ static inline size_t em_exit_bytes(int C, int N, int iters, int sk, int group_si
 }
 
 // Carves `ws` (em_exit_bytes, 256-byte aligned; may be NULL when thresh <= 0), zeroes the counters, pre-fills the two optional outputs.  0 / error code.
-// primed: the caller has already run em_exit_prime on this workspace (ogmm_gmm_em_exit_prime: the forward does it at its start, on the side stream, so that the
-// two fills do not sit between the overlap scores and the E/M kernel -- as tiny launches behind a GEMM they delayed it by ~120 us)
 static inline int em_exit_setup(EmExit& x, double thresh, int group_size, int C, int N, int iters, int sk, float* resid, int32_t* sweeps, void* ws,
-                                hipStream_t s, bool primed = false) {
+                                hipStream_t s) {
     x = EmExit{};
     x.thresh = thresh;
     x.on = thresh > 0.0 && sk > 1 ? 1 : 0;          // with one sweep there is nothing to leave early
@@ -187,24 +185,13 @@ static inline int em_exit_setup(EmExit& x, double thresh, int group_size, int C,
     x.decision = x.gcount + ng * iters * sk;
     x.kstop = x.decision + ng * iters * sk;
     x.ccount = x.kstop + ng * iters;
-    if (!primed) (void)hipMemsetAsync(ip, 0, ints * 4, s);
+    (void)hipMemsetAsync(ip, 0, ints * 4, s);
     p += em_exit_align(ints * 4);
     x.rc = reinterpret_cast<float*>(p);
-    if (!primed) (void)hipMemsetAsync(x.rc, 0xFF, (size_t)iters * sk * C * 4, s);          // "not yet published" (em_exit_decide_wave)
+    (void)hipMemsetAsync(x.rc, 0xFF, (size_t)iters * sk * C * 4, s);          // "not yet published" (em_exit_decide_wave)
     p += em_exit_align((size_t)iters * sk * C * 4);
     x.dupart = reinterpret_cast<float*>(p); p += em_exit_align(2 * (size_t)C * chunks * 4);
     x.u2 = reinterpret_cast<float*>(p);
-    return 0;
-}
-
-// the two fills of em_exit_setup alone, for a workspace of em_exit_bytes(C, N, iters, sk, group_size)
-static inline int em_exit_prime(void* ws, int C, int N, int iters, int sk, int group_size, hipStream_t s) {
-    OGMM_REQUIRE(ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "ogmm_gmm_em_exit_prime: the workspace must be non-null and 256-byte aligned");
-    const size_t G = group_size > 0 ? (size_t)group_size : (size_t)C, ng = ((size_t)C + G - 1) / G;
-    const size_t ints = 64 + 2 * ng * (size_t)iters * (size_t)sk + ng * (size_t)iters + (size_t)iters * (size_t)sk * (size_t)C;
-    char* p = static_cast<char*>(ws);
-    (void)hipMemsetAsync(p, 0, ints * 4, s);
-    (void)hipMemsetAsync(p + em_exit_align(ints * 4), 0xFF, (size_t)iters * sk * C * 4, s);
     return 0;
 }
 

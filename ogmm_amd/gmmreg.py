@@ -455,10 +455,6 @@ class GMMReg(nn.Module):
         side.wait_stream(side2)
         sel_done = torch.cuda.Event()
         sel_done.record(side)
-        em_xws = None
-        if self.sinkhorn_thresh and self.sinkhorn_thresh > 0 and _EM_SCHED in (0, 1, 3) and not capture:
-            with torch.cuda.stream(side):          # the E/M's exit workspace, filled now (behind the selections) on the stream the E/M will run on: not between the overlap scores and the E/M kernel
-                em_xws = ops.gmm_em_prime(C, N, 10, 10, B, dev)
         # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU.  Queued behind the kNN kernel
         # (round 5, first form of the fused head) they ran next to EdgeConv instead: slower for both, and inside the forward their picks then came out
         # different from run to run (tools/determinism_check.py; alone beside any kernel family they are reproducible -- tools/fps_corun.py -- so the cause is
@@ -535,7 +531,7 @@ class GMMReg(nn.Module):
             # clouds are separate wkeans_plus calls (models/gmmreg.py:100-101).  capture=True also records every sweep's residual and the
             # number of sweeps every E-step ran: see sinkhorn_exit_margin()
             return ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=self.sinkhorn_thresh, group_size=B,
-                              return_resid=capture, return_sweeps=capture, status=self._status, xws=em_xws if em_sched != 1 else None)
+                              return_resid=capture, return_sweeps=capture, status=self._status)
         em_sched = _EM_SCHED          # experiment switch (OGMM_EM_SCHED): 0 = beside the whole last transformer (default), 1 = serial behind it, 2 = high-priority stream, 3 = queued behind its attention kernel
         em_stream = side
         if em_sched == 2:

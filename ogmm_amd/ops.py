@@ -667,17 +667,8 @@ def overlap_cross(S, o_src, o_tgt, ldo_in, wo_src, wo_tgt, ldo, two_pass=False):
 
 
 # ---------------------------------------------------------------------------------------------- GMM head
-def gmm_em_prime(C, N, iters, sk_iters, group_size, device):
-    """The exit workspace of gmm_em(...), filled ahead of time on the CURRENT stream (ogmm_gmm_em_exit_prime): hand it to gmm_em(xws=...) on the same stream
-    (or behind an event) and the E/M kernel starts without two fills in front of it."""
-    lib = _lib.load()
-    xws = torch.empty(lib.ogmm_gmm_em_exit_workspace_bytes(C, N, iters, sk_iters, group_size), dtype=torch.uint8, device=device)
-    _lib.call("ogmm_gmm_em_exit_prime", _p(xws), C, N, iters, sk_iters, group_size, _stream())
-    return xws
-
-
 def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=1e-2, group_size=None, engine=None, return_resid=False,
-           return_sweeps=False, status=None, xws=None):
+           return_sweeps=False, status=None):
     """-> gamma [C,N,J], pi [C,J], mu [C,J,3] (, resid [C,iters,sk_iters]) (, sweeps int32 [C/group_size, iters])   (lib/utils.py:269-288).
     thresh / group_size: the reference's Sinkhorn early exit (lib/utils.py:99-102): an E-step's sweeps end after the first sweep whose residual,
     averaged over the `group_size` clouds of one reference call (None: all C clouds are one call), is below thresh; thresh <= 0 runs every sweep.
@@ -702,16 +693,12 @@ def gmm_em(xyz, o, ids0, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=1e
             engine = "multi"          # the clouds of a call group wait for each other on chip: a group beyond one resident round takes the launch sequence
     resid = torch.empty((C, iters, sk_iters), dtype=torch.float32, device=dev) if return_resid else None
     sweeps = torch.empty((C // G, iters), dtype=torch.int32, device=dev) if return_sweeps else None
-    primed = 0
-    if xws is not None:          # gmm_em_prime(C, N, iters, sk_iters, G, device) ran earlier on this stream
-        assert xws.numel() == lib.ogmm_gmm_em_exit_workspace_bytes(C, N, iters, sk_iters, G) and xws.device == dev
-        primed = 1
-    elif exit_on or return_resid:
+    xws = None
+    if exit_on or return_resid:
         xws = torch.empty(lib.ogmm_gmm_em_exit_workspace_bytes(C, N, iters, sk_iters, G), dtype=torch.uint8, device=dev)
-    if xws is not None:
         xws.record_stream(torch.cuda.current_stream())
     head = (_p(_f32(xyz, "xyz")), _p(_f32(o, "o")), _p(_i32(ids0, "ids0")), C, N, J, iters, sk_iters, epsilon, tau, float(thresh or 0.0), G,
-            _p(gamma), _p(pi), _p(mu), _p(resid), _p(sweeps), _p(xws), primed)
+            _p(gamma), _p(pi), _p(mu), _p(resid), _p(sweeps), _p(xws))
     if engine == "multi":
         ws = torch.empty(lib.ogmm_gmm_em_workspace_bytes(C, N, J), dtype=torch.uint8, device=dev)
         _lib.call("ogmm_gmm_em_multi", *head, _p(ws), _stream())
