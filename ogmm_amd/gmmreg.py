@@ -452,19 +452,20 @@ class GMMReg(nn.Module):
             with torch.cuda.stream(side):
                 idx5 = ops.knn(xyz, 5)        # its own top-k call in the reference (lib/utils.py:52): ties at rank 5 resolve independently
                 hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
-        side.wait_stream(side2)
-        sel_done = torch.cuda.Event()
-        sel_done.record(side)
+        fps_done, side_done = torch.cuda.Event(), torch.cuda.Event()
+        fps_done.record(side2)
+        side_done.record(side)
+        if not fused_head:
+            idx = ops.knn(xyz, k)
         # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU.  Queued behind the kNN kernel
         # (round 5, first form of the fused head) they ran next to EdgeConv instead: slower for both, and inside the forward their picks then came out
         # different from run to run (tools/determinism_check.py; alone beside any kernel family they are reproducible -- tools/fps_corun.py -- so the cause is
         # not established; with this order every mode of that tool is bit-reproducible).  The wait costs nothing: they finish with the kNN kernel.
-        main.wait_event(sel_done)
+        main.wait_event(fps_done)          # (each side stream directly: a hand-over through a second stream costs another ~15 us)
+        main.wait_event(side_done)
         xyz.record_stream(side2)
         xyz.record_stream(side)
         fps_starts.record_stream(side2)
-        if not fused_head:
-            idx = ops.knn(xyz, k)
         for t_ in (ids_a, ids_j) + (() if fused_head else (idx5, hd, ha)):
             t_.record_stream(main)
 
@@ -483,7 +484,6 @@ class GMMReg(nn.Module):
         emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU, eng=eng)
 
         # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)
-        main.wait_event(sel_done)
         x0 = torch.empty((R, D), dtype=torch.float32, device=dev)
         ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2], eng=eng)
         ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:], eng=eng)
