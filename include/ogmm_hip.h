@@ -177,12 +177,6 @@ typedef struct ogmm_gemm {
 } ogmm_gemm;
 
 int ogmm_gemm_nt(const ogmm_gemm* desc /*HOST pointer*/, void* stream);
-/* (ABI 25) A chain of 2 or 3 plain layers -- descs[l + 1].A is descs[l].C (same leading dimension, K1 = descs[l].N, one piece), whole 256-row / 256-column tiles,
- * N >= 512, nothing fused but scale / shift / activation / residual: the CONV stacks of models/dgcnn.py:19-28 -- as ONE launch of the LDS-DMA engine: a workgroup
- * walks its 256-row panel through every layer (1 x 1 convolutions are row-wise), per tile the arithmetic of ogmm_gemm_nt (bit-identical outputs, intermediates
- * included: they are still written).  ogmm_gemm_chain_supported: 1 / 0 for a HOST array of descriptors. */
-int ogmm_gemm_chain_supported(const ogmm_gemm* descs /*HOST array*/, int n);
-int ogmm_gemm_chain(const ogmm_gemm* descs /*HOST array*/, int n, void* stream);
 /* 1 if ogmm_gemm_nt takes the fused overlap block (ovl_rowpart) for B pairs of N points with D channels, else 0 (the caller then runs the
  * similarity GEMM into S and ogmm_overlap_cross_ws). */
 int ogmm_gemm_overlap_fusable(int B, int N, int D);

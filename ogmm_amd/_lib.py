@@ -56,8 +56,6 @@ PROTOTYPES = {
     "ogmm_fps": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_gather_rows": [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_gemm_nt": [POINTER(GemmDesc), c_void_p],
-    "ogmm_gemm_chain_supported": [c_void_p, c_int],
-    "ogmm_gemm_chain": [c_void_p, c_int, c_void_p],
     "ogmm_gemm_overlap_fusable": [c_int, c_int, c_int],
     "ogmm_gemm_rowdot_fusable": [c_int, c_int, c_int, c_int],
     "ogmm_gemm_normbwd_fusable": [c_int, c_int, c_int, c_int],

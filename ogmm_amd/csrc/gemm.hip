@@ -150,15 +150,6 @@ int gemm_nt_f16x3(const ogmm_gemm& g, hipStream_t s);
 int gemm_nt_f16x3_frag(const ogmm_gemm& g, hipStream_t s);
 bool gemm_f16x3_v10_applicable(const ogmm_gemm& g);
 bool gemm_f16x3_v8_applicable(const ogmm_gemm& g);
-bool gemm_v10_chain_supported(const ogmm_gemm* d, int n);
-int gemm_v10_chain(const ogmm_gemm* d, int n, hipStream_t s);
-}
-
-// 2 or 3 plain layers, each reading its predecessor's output, as ONE launch (gemm_f16x3_v10_chain_kernel): per tile the same arithmetic as ogmm_gemm_nt.
-extern "C" int ogmm_gemm_chain_supported(const ogmm_gemm* descs, int n) { return ogmm::gemm_v10_chain_supported(descs, n) ? 1 : 0; }
-extern "C" int ogmm_gemm_chain(const ogmm_gemm* descs, int n, void* stream) {
-    OGMM_REQUIRE(descs != nullptr && n >= 2 && n <= 3, "ogmm_gemm_chain: 2 or 3 descriptors");
-    return ogmm::gemm_v10_chain(descs, n, ogmm::as_stream(stream));
 }
 
 extern "C" int ogmm_gemm_nt(const ogmm_gemm* d, void* stream) {

@@ -48,18 +48,30 @@ __device__ unsigned long long g_v10_probe[4];
 //   puts the two lane halves on disjoint banks.  Same k order, same split, same products: bit-identical to the plain form on a transposed copy.
 //   TA = 2: the same, and the column sums of A_mem (sum over k of A[m][k] = the bias gradient dy.sum(0)) ride along: every lane adds the eight raw values of
 //   each fragment it reads (fp32 tree of 8, then fp64) in gaps the split leaves free; the n-tile-0 workgroups add them to a_colsum[m] (fp64 atomics).
-// One 256 x 256 tile of the product (the whole body of the engine: prologue, K loop, epilogue), as a function so that one workgroup can run several tiles in
-// sequence (gemm_f16x3_v10_chain_kernel below); the one-tile kernel is this function behind the tile map.
 template <int ABL, bool AFF, bool OVL, int TERMS = 3, bool NBS = false, int TA = 0>
-__device__ __forceinline__ void v10_tile(const ogmm_gemm& g, const int tile_m, const int tile_n, const int n_tiles, const int zb, unsigned char* const smem10, const int tid) {
+__global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
     static_assert(TERMS == 3 || ((TERMS == 2 || TERMS == 1) && !AFF), "TERMS < 3 has no InstanceNorm-on-A form (its transform pieces need the gaps of 12 MFMAs)");
     static_assert(!TA || (!AFF && !OVL && !NBS && TERMS >= 2), "the transposed-A form exists for the plain product with three or two terms");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
+
+    const int bid = blockIdx.x;
     long long probe_c0 = 0, probe_w0 = 0;
     if (ABL & 2048) { probe_c0 = clock64(); probe_w0 = wall_clock64(); }
+    int tile_m, tile_n;
+    if (m_tiles_signed < 0) {
+        tile_m = bid / n_tiles;
+        tile_n = bid % n_tiles;
+    } else {            // XCD-aware map (block b runs on XCD b % 8): all N tiles of an M panel on one XCD
+        const int xcd = bid & 7, local = bid >> 3;
+        tile_m = (local / n_tiles) * 8 + xcd;
+        tile_n = local % n_tiles;
+        if (tile_m >= m_tiles_signed) return;
+    }
 
-    const int lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
+    const int zb = blockIdx.z;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int m_end = min(g.M, m0 + BM);
     const int nk1 = g.K1 / BK8, nk2 = g.K2 / BK8, nk = nk1 + nk2;
@@ -468,48 +480,6 @@ __device__ __forceinline__ void v10_tile(const ogmm_gemm& g, const int tile_m, c
     }
 }
 
-template <int ABL, bool AFF, bool OVL, int TERMS = 3, bool NBS = false, int TA = 0>
-__global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, const int m_tiles_signed, const int n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
-    const int bid = blockIdx.x;
-    int tile_m, tile_n;
-    if (m_tiles_signed < 0) {
-        tile_m = bid / n_tiles;
-        tile_n = bid % n_tiles;
-    } else {            // XCD-aware map (block b runs on XCD b % 8): all N tiles of an M panel on one XCD
-        const int xcd = bid & 7, local = bid >> 3;
-        tile_m = (local / n_tiles) * 8 + xcd;
-        tile_n = local % n_tiles;
-        if (tile_m >= m_tiles_signed) return;
-    }
-    v10_tile<ABL, AFF, OVL, TERMS, NBS, TA>(g, tile_m, tile_n, n_tiles, blockIdx.z, smem10, threadIdx.x);
-}
-
-// A CHAIN of plain layers in one launch (round 5): layer l + 1 reads layer l's output as its A operand, and a 1 x 1 convolution is row-wise, so the 256-row
-// panel a workgroup owns depends on no other panel through the whole chain (CONV of models/dgcnn.py:19-28: conv1 = 512 -> 1024 -> 1024 -> 512).  One workgroup
-// walks its panel through every N tile of every layer; wave w stages exactly the 64 rows it stored itself in the previous layer (s_waitcnt vmcnt(0) on its own
-// stores is all the ordering there is), the rows come back from the XCD's L2 instead of HBM, two launch boundaries per chain disappear and the workgroups drift
-// apart, so their output bursts no longer hit HBM at the same instant.  Per tile the arithmetic is v10_tile's: bit-identical to the separate launches.
-struct ogmm_gemm_chain_args { int n; ogmm_gemm g[3]; };
-__global__ __launch_bounds__(T) void gemm_f16x3_v10_chain_kernel(const ogmm_gemm_chain_args ch, const int m_tiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem10[];
-    const int bid = blockIdx.x;
-    const int panel = bid;          // (consecutive blocks land on consecutive XCDs; a panel never leaves its workgroup, so no map is needed)
-    if (panel >= m_tiles) return;
-    for (int l = 0; l < ch.n; ++l) {
-        const ogmm_gemm& g = ch.g[l];
-        const int n_tiles = g.N / BN;
-        for (int tn = 0; tn < n_tiles; ++tn) {
-            // opaque per tile: everything v10_tile derives from the lane (DMA offsets, fragment addresses) is recomputed per tile instead of being hoisted
-            // out of the loops and kept alive through a body that owns the whole register file (70 spilled registers otherwise)
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            v10_tile<0, false, false, 3, false, 0>(g, panel, tn, n_tiles, 0, smem10, tid);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores of layer l have left: they are its own A rows of layer l + 1
-    }
-}
-
 }  // namespace
 
 namespace ogmm {
@@ -558,38 +528,6 @@ extern "C" int ogmm_debug_v10_probe(unsigned long long* host3) {
 #endif
 
 namespace ogmm {
-
-// a layer the chain kernel takes: the plain three-term product on whole tiles, nothing fused but scale / shift / activation / residual
-static bool v10_chain_layer_ok(const ogmm_gemm& g) {
-    return gemm_f16x3_v10_applicable(g) && g.precision == OGMM_PREC_F16X3_FRAG && g.batch_outer * g.batch_inner == 1 && g.M % BM == 0 && g.N % BN == 0 && g.N >= 512 &&
-           !g.col_stats && !g.a_scale && !g.ovl_rowpart && !g.rd_out && !g.a_gather_ids && !g.nb_mean && !g.a_trans && g.pool_k == 0 && !g.row_affine &&
-           (g.terms == 0 || g.terms == 3) && g.C != nullptr;
-}
-
-bool gemm_v10_chain_supported(const ogmm_gemm* d, int n) {
-    static const int enabled = [] { const char* e = getenv("OGMM_GEMM_CHAIN"); return e ? atoi(e) : 1; }();
-    if (!enabled || !d || n < 2 || n > 3) return false;
-    for (int l = 0; l < n; ++l) {
-        if (!v10_chain_layer_ok(d[l]) || d[l].M != d[0].M) return false;
-        // layer l + 1 reads exactly what layer l stores: same rows, one piece, its K = the stored columns
-        if (l > 0 && !(d[l].A == d[l - 1].C && d[l].lda == d[l - 1].ldc && d[l].K1 == d[l - 1].N && d[l].K2 == 0)) return false;
-        // nobody in the chain may overwrite what a later tile of the same panel still reads (outputs distinct from every input of the chain)
-        for (int k = 0; k <= l; ++k) if (d[l].C == d[k].A || (d[k].A2 && d[l].C == d[k].A2) || (d[k].Res && d[l].C == d[k].Res && k != l)) return false;
-    }
-    return true;
-}
-
-int gemm_v10_chain(const ogmm_gemm* d, int n, hipStream_t s) {
-    OGMM_REQUIRE(gemm_v10_chain_supported(d, n), "ogmm_gemm_chain: the layers do not form a chain the LDS-DMA engine takes (ogmm_gemm_chain_supported)");
-    ogmm_gemm_chain_args ch;
-    ch.n = n;
-    for (int l = 0; l < n; ++l) ch.g[l] = d[l];
-    const int m_tiles = d[0].M / BM;
-    static ogmm::PerDeviceOnce attr_once;
-    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_v10_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipLaunchKernelGGL(gemm_f16x3_v10_chain_kernel, dim3((unsigned)m_tiles), dim3(T), LDS_BYTES, s, ch, m_tiles);
-    return check_launch("ogmm_gemm_chain(f16x3 v10)");
-}
 
 int gemm_nt_f16x3_v10(const ogmm_gemm& g, hipStream_t s) {
     switch (g.precision) {

@@ -362,10 +362,9 @@ class GMMReg(nn.Module):
     @staticmethod
     def _stack3(eng, S, x, x2=None):
         """models/dgcnn.py:19-28 (`CONV`, used='proj') with a Cout > 1 last layer."""
-        with ops.gemm_chain():          # three plain layers, each reading its predecessor: one launch where the engine takes the chain (ops.gemm_chain)
-            h = ops.conv1x1(x, S["0"], ACT_RELU, x2=x2, eng=eng)
-            h = ops.conv1x1(h, S["3"], ACT_RELU, eng=eng)
-            return ops.conv1x1(h, S["6"], eng=eng)
+        h = ops.conv1x1(x, S["0"], ACT_RELU, x2=x2, eng=eng)
+        h = ops.conv1x1(h, S["3"], ACT_RELU, eng=eng)
+        return ops.conv1x1(h, S["6"], eng=eng)
 
     def forward(self, src, tgt, is_test=False, fps_starts=None, capture=False):
         """models/gmmreg.py:50-119.  `fps_starts` (int64/int32 [6,B], optional) pins the six `torch.randint` draws of

@@ -340,11 +340,6 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
         d.rd_out, d.rd_ld = head[3].data_ptr(), head[4]
         if C is None:
             store_c = False
-    if _CHAIN is not None:          # inside `with gemm_chain():` -- the launch is deferred: the layers may run as one chain kernel (ogmm_gemm_chain)
-        nb_ = batch[0] * batch[1]
-        _CHAIN.append((d, 2.0 * M * N * (K1 + K2) * nb_, 4.0 * (M * (K1 + K2) + M * N + (M * N if res is not None else 0)) + 4.0 * N * (K1 + K2),
-                       "f16x3" if split is not None else "f32"))
-        return
     variant = None
     if GEMM_TIMELINE is not None:
         variant = ("f16x3" if split is not None else "f32") + ("_pool" if pool_k else "") + ("_n64" if N <= 64 else "")
@@ -364,52 +359,6 @@ def gemm_nt(A, lda, K1, B, ldb, M, N, C=None, ldc=0, A2=None, lda2=0, K2=0, scal
     issued = 1 if split is None or (single_term and d.precision == PREC_F16_FRAG) else (
         terms if terms in (1, 2) and split.get("variant") == PREC_F16X3_FRAG and a_affine is None and pool_k == 0 and N >= (512 if terms == 1 else 256) else 3)
     GEMM_TIMELINE.append((e0, e1, 2.0 * M * N * (K1 + K2) * nb, variant, abytes, issued))
-
-
-_CHAIN = None
-GEMM_CHAIN = os.environ.get("OGMM_GEMM_CHAIN", "1") != "0"          # A/B switch: 0 = every layer its own launch
-
-
-class gemm_chain:
-    """`with ops.gemm_chain(): h = conv1x1(x, L0, ...); h = conv1x1(h, L1, ...); y = conv1x1(h, L2, ...)` -- the launches inside are collected and, where
-    ogmm_gemm_chain_supported says so (2-3 plain layers of the LDS-DMA engine, each reading its predecessor's output), run as ONE launch in which a workgroup
-    walks its 256-row panel through all layers (include/ogmm_hip.h: ogmm_gemm_chain; per tile the same arithmetic: bit-identical outputs).  Otherwise the
-    layers are launched one by one, as without the context.  Tensors used inside must stay alive until the context exits (they do: the caller holds them)."""
-
-    def __enter__(self):
-        global _CHAIN
-        assert _CHAIN is None, "gemm_chain contexts do not nest"
-        _CHAIN = []
-        return self
-
-    def __exit__(self, exc_type, exc, tb):
-        global _CHAIN
-        items, _CHAIN = _CHAIN, None
-        if exc_type is not None or not items:
-            return False
-        n = len(items)
-        arr = (GemmDesc * n)(*[it[0] for it in items])
-        lib = _lib.load()
-        fused = GEMM_CHAIN and 2 <= n <= 3 and lib.ogmm_gemm_chain_supported(ctypes.byref(arr), n) == 1
-        timed = GEMM_TIMELINE is not None and (GEMM_TIMELINE_ONLY is None or "f16x3" in GEMM_TIMELINE_ONLY)
-        if fused:
-            if timed:
-                e0, e1 = _timing_event(), _timing_event()
-                e0.record()
-            _lib.call("ogmm_gemm_chain", ctypes.byref(arr), n, _stream())
-            if timed:
-                e1.record()
-                GEMM_TIMELINE.append((e0, e1, sum(it[1] for it in items), "f16x3", sum(it[2] for it in items), 3))
-            return False
-        for d, flop, nbytes, tag in items:
-            if timed:
-                e0, e1 = _timing_event(), _timing_event()
-                e0.record()
-            _lib.call("ogmm_gemm_nt", ctypes.byref(d), _stream())
-            if timed:
-                e1.record()
-                GEMM_TIMELINE.append((e0, e1, flop, tag, nbytes, 3 if tag == "f16x3" else 1))
-        return False
 
 
 def instnorm_fusable(layer_split, N):
