@@ -475,19 +475,26 @@ __global__ __launch_bounds__(256) void knn4_kernel(const float* __restrict__ xyz
             }
         }
         __syncthreads();
-        const int ch = lane;
-        const float wd = pa.w_dis[ch], sd = pa.s_dis[ch], td = pa.t_dis[ch];
-        const float wa = pa.w_ang[ch], sa = pa.s_ang[ch], ta = pa.t_ang[ch];
+        // a lane takes four channels of one point, a wave four points per trip: 1 KiB per store instruction instead of 256 B (the two maps are 67 MB)
+        const int ch = (lane & 15) * 4, sub = lane >> 4;
+        const float4 wd = *reinterpret_cast<const float4*>(pa.w_dis + ch), sd = *reinterpret_cast<const float4*>(pa.s_dis + ch), td = *reinterpret_cast<const float4*>(pa.t_dis + ch);
+        const float4 wa = *reinterpret_cast<const float4*>(pa.w_ang + ch), sa = *reinterpret_cast<const float4*>(pa.s_ang + ch), ta = *reinterpret_cast<const float4*>(pa.t_ang + ch);
         auto leaky = [](float v) { return v > 0.0f ? v : 0.2f * v; };
-        for (int r = 0; r < 64; ++r) {
-            const int pl = r * 4 + wave, i = blockIdx.x * 256 + pl;
-            if (i >= N) break;
+        for (int r = 0; r < 16; ++r) {
+            const int pl = wave * 64 + r * 4 + sub, i = blockIdx.x * 256 + pl;
+            if (i >= N) continue;
             const int64_t row = (int64_t)c * N + i;
-            pa.hid_dis[row * 64 + ch] = leaky(fmaf(wd * geo[pl][0], sd, td));
-            float best = -__builtin_inff();
+            const float d2 = geo[pl][0];
+            *reinterpret_cast<float4*>(pa.hid_dis + row * 64 + ch) =
+                make_float4(leaky(fmaf(wd.x * d2, sd.x, td.x)), leaky(fmaf(wd.y * d2, sd.y, td.y)), leaky(fmaf(wd.z * d2, sd.z, td.z)), leaky(fmaf(wd.w * d2, sd.w, td.w)));
+            float4 best = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
 #pragma unroll
-            for (int e = 0; e < 5; ++e) best = fmaxf(best, leaky(fmaf(wa * geo[pl][1 + e], sa, ta)));
-            pa.hid_ang[row * 64 + ch] = best;
+            for (int e = 0; e < 5; ++e) {
+                const float al = geo[pl][1 + e];
+                best.x = fmaxf(best.x, leaky(fmaf(wa.x * al, sa.x, ta.x))); best.y = fmaxf(best.y, leaky(fmaf(wa.y * al, sa.y, ta.y)));
+                best.z = fmaxf(best.z, leaky(fmaf(wa.z * al, sa.z, ta.z))); best.w = fmaxf(best.w, leaky(fmaf(wa.w * al, sa.w, ta.w)));
+            }
+            *reinterpret_cast<float4*>(pa.hid_ang + row * 64 + ch) = best;
         }
     }
 }
@@ -911,6 +918,8 @@ extern "C" int ogmm_knn_pos_head(const float* xyz, int C, int N, int k, int32_t*
     OGMM_REQUIRE(knn_head_fits(N, k, &fold), "ogmm_knn_pos_head: N=%d, k=%d is outside this kernel's range (ogmm_knn_pos_head_supported); use ogmm_knn + ogmm_pos_hidden", N, k);
     const bool head = idx5 != nullptr;
     OGMM_REQUIRE(!head || (w_dis && s_dis && t_dis && w_ang && s_ang && t_ang && hid_dis && hid_ang), "ogmm_knn_pos_head: the positional front end needs all six constants and both outputs");
+    OGMM_REQUIRE(!head || (ogmm::aligned16(w_dis) && ogmm::aligned16(s_dis) && ogmm::aligned16(t_dis) && ogmm::aligned16(w_ang) && ogmm::aligned16(s_ang) && ogmm::aligned16(t_ang) &&
+                           ogmm::aligned16(hid_dis) && ogmm::aligned16(hid_ang)), "ogmm_knn_pos_head: constants and hidden maps must be 16-byte aligned");
     const int KLsel = k <= 20 ? 21 : 33;
     const size_t lds2 = (size_t)N * sizeof(float4) + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
     knn_pos_args pa = {idx5, w_dis, s_dis, t_dis, w_ang, s_ang, t_ang, hid_dis, hid_ang};
