@@ -404,23 +404,21 @@ class GMMReg(nn.Module):
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
         main = torch.cuda.current_stream()
         fused_head = ops.knn_pos_head_supported(N, k)
-        hs = main
-        with torch.cuda.stream(hs):
-            # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
-            # tensor makes the host wait for the copy, which is queued behind everything the stream still has to run (the caching host allocator keeps the
-            # pinned block alive until the copy has run).
-            if fps_starts.device.type == "cpu" and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-                fps_starts = fps_starts.reshape(3, 2 * B).to(torch.int32).pin_memory().to(dev, non_blocking=True)
-            else:
-                fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
-            xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
-            inputs_ready = torch.cuda.Event()          # what the FPS chains wait for: the stacked clouds and the anchor draws, NOT the kNN kernel behind them
-            inputs_ready.record(hs)
-            # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch (ops.knn_pos_head: the
-            # 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud the kernel already
-            # holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay on a side stream.
-            if fused_head:
-                idx, idx5, hd, ha = ops.knn_pos_head(xyz, k, L["pos"])
+        # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
+        # tensor makes the host wait for the copy, which is queued behind everything the stream still has to run (the caching host allocator keeps the
+        # pinned block alive until the copy has run).
+        if fps_starts.device.type == "cpu" and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            fps_starts = fps_starts.reshape(3, 2 * B).to(torch.int32).pin_memory().to(dev, non_blocking=True)
+        else:
+            fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
+        xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
+        inputs_ready = torch.cuda.Event()          # what the FPS chains wait for: the stacked clouds and the anchor draws, NOT the kNN kernel behind them
+        inputs_ready.record(main)
+        # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch (ops.knn_pos_head: the
+        # 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud the kernel already
+        # holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay on a side stream.
+        if fused_head:
+            idx, idx5, hd, ha = ops.knn_pos_head(xyz, k, L["pos"])
         if self._swap is None or self._swap.device != dev or self._swap.numel() != C:          # (cached per batch size: four tiny launches per forward otherwise)
             self._swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
         swap = self._swap
@@ -582,7 +580,8 @@ class GMMReg(nn.Module):
         main.wait_event(clu_done)
 
         if capture:
-            cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0], o_logit=extra[:, 1],
+            cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, wo=extra[:, 0].clone(), o_logit=extra[:, 1].clone(),          # (clones: `extra` is the persistent workspace, the next forward overwrites it)
+                      
                        o=o, gamma=gamma, pi=pi, mu=mu, muf=muf, near=near, row_loss=row_loss, sinkhorn_resid=em[3], sinkhorn_sweeps=em[4])
             self.last_intermediates = cap
         ws["clean"] = True
