@@ -89,3 +89,34 @@ def test_knn_distance_is_fma_chain():
     acc = f32(a[:, :, None, 1] * a[:, None, :, 1] + acc)
     acc = f32(a[:, :, None, 2] * a[:, None, :, 2] + acc)
     assert (acc != mm).mean() < 1e-3   # identical here; tolerate a different BLAS on another host
+
+
+def test_one_ulp_jitter_probe_is_deterministic_small_and_separates_conditioning():
+    """oracle/split_emulation.py "ulp:<seed>" (round 5; the host-independent part of tests/parity_util.reference_spread): every GEMM input moved by one unit in
+    the last place with a random sign.  The probe must be (i) a pure function of its seed, (ii) different between seeds, (iii) a last-place perturbation -- a
+    convolution's output moves by ~1e-7 relative, not more -- and (iv) on a well-conditioned pair of the default weight family it moves R by ~1e-6 rad: the scale
+    against which 5e-6 counts as "ill-conditioned"."""
+    from argparse import Namespace
+    import torch.nn.functional as F
+    from oracle import split_emulation as E
+    from ogmm_amd import synth
+    from ogmm_amd.gmmreg import GMMReg
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(2, 64, 300, generator=g), torch.randn(32, 64, 1, generator=g)
+    exact = F.conv1d(x, w)
+    a, a2, b = E.conv(x, w, None, "ulp:1"), E.conv(x, w, None, "ulp:1"), E.conv(x, w, None, "ulp:2")
+    assert torch.equal(a, a2) and not torch.equal(a, b) and not torch.equal(a, exact)
+    rel = ((a - exact).abs().max() / exact.abs().max()).item()
+    assert 0 < rel < 1e-6, rel
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    m = GMMReg(512, 16, cfg)
+    synth.fill_state_dict(m.state_dict())
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    src, tgt, _, _ = synth.make_batch(0, 1, 512, "partial")
+    st = synth.fps_starts_for(0, 1, 512)
+    with torch.no_grad():
+        ref = O.forward(P, cfg, src, tgt, st)[0]
+        with E.policy(lambda name: "ulp:1"):
+            jit = O.forward(P, cfg, src, tgt, st)[0]
+    moved = O.rotation_error_rad(jit.double(), ref.double()).max().item()
+    assert 0 < moved < 5e-6, moved
