@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 25
+#define OGMM_ABI_VERSION 26
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -455,6 +455,11 @@ int ogmm_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk,
  * Rows of dy / x must be aligned to the kernel's vector loads (4 floats for n > 64, 2 for n > 32; 2 floats for k > 32). */
 int64_t ogmm_weight_grad_thin_streams(int n, int k);
 int ogmm_weight_grad_thin(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t R, int n, int k, float* part, void* stream);
+/* the same reduction on the engines' fp16x3 arithmetic (round 5: the fp32 form is matrix-bound on the 256 x 128 per-edge layer): every value is split
+ * into two binary16 in registers, three v_mfma_f32_32x32x16_f16 per product block, fp32 accumulation; `overflow` (device int32 or NULL) gets bit 0 when
+ * an operand exceeds binary16's range.  Same partial layout, same alignment rules. */
+int ogmm_weight_grad_thin_f16x3(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t R, int n, int k, float* part, int* overflow,
+                                void* stream);
 
 /* ---- T8: the overlap block (models/gmmreg.py:75-80) in training: ogmm_overlap_cross that also saves the row / column softmax
  * statistics (stats [B][4][N] = row max, row sum, column max, column sum), and its backward: given a = dL/dwo_src, b = dL/dwo_tgt

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -125,6 +125,7 @@ PROTOTYPES = {
                                c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "ogmm_weight_grad_thin_streams": [c_int, c_int],
     "ogmm_weight_grad_thin": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p],
+    "ogmm_weight_grad_thin_f16x3": [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ogmm_kabsch_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogmm_pow2_scale": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ogmm_nearest_point": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

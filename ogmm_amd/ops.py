@@ -1103,13 +1103,20 @@ def weight_grad_thin_supported(dy, x):
             and x.stride(0) % kv == 0 and dy.data_ptr() % (4 * nv) == 0 and x.data_ptr() % (4 * kv) == 0)
 
 
-def weight_grad_thin(dy, x):
-    """dW = dY^T X for thin layers in exact fp32 (kernel T9): dy [R, n], x [R, k] -> [n, k]"""
+DW_THIN_F16X3 = os.environ.get("OGMM_DW_THIN_F16X3", "1") != "0"      # 0: the exact-fp32 thin reduction in the fp16x3 training step too (A/B)
+
+
+def weight_grad_thin(dy, x, split=False, overflow=None):
+    """dW = dY^T X for thin layers (kernel T9): dy [R, n], x [R, k] -> [n, k].  split=False: exact fp32; split=True: the engines' fp16x3 arithmetic
+    (the fp16x3 training step: dy carries the trainer's power-of-two loss scale, `overflow` reports operands beyond binary16's range)."""
     R, n = dy.shape
     k = x.shape[1]
     if n > 256 and k <= 64 and n % 256 == 0:          # a wide layer's few-channel input piece (conv2.net.0's two overlap channels): 256 outputs at a time
-        return torch.cat([weight_grad_thin(dy[:, c0:c0 + 256], x) for c0 in range(0, n, 256)], dim=0)
+        return torch.cat([weight_grad_thin(dy[:, c0:c0 + 256], x, split, overflow) for c0 in range(0, n, 256)], dim=0)
     streams = _lib.load().ogmm_weight_grad_thin_streams(n, k)
     part = torch.empty((streams, n, k), dtype=torch.float32, device=dy.device)
-    _lib.call("ogmm_weight_grad_thin", _p(_f32(dy, "dy")), dy.stride(0), _p(_f32(x, "x")), x.stride(0), R, n, k, _p(part), _stream())
+    if split and DW_THIN_F16X3:
+        _lib.call("ogmm_weight_grad_thin_f16x3", _p(_f32(dy, "dy")), dy.stride(0), _p(_f32(x, "x")), x.stride(0), R, n, k, _p(part), _p(overflow), _stream())
+    else:
+        _lib.call("ogmm_weight_grad_thin", _p(_f32(dy, "dy")), dy.stride(0), _p(_f32(x, "x")), x.stride(0), R, n, k, _p(part), _stream())
     return part.sum(dim=0)

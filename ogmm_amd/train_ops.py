@@ -232,7 +232,9 @@ class _Linear(torch.autograd.Function):
                 dyc = dy.contiguous()
                 for i_, (p_, w_) in enumerate(zip(pieces, wide)):
                     if not w_:
-                        parts[i_] = ops.weight_grad_thin(dyc, p_) if ops.weight_grad_thin_supported(dyc, p_) else dyc.t() @ p_
+                        # (round 5: on the engines' fp16x3 arithmetic in the fp16x3 step -- the exact-fp32 reduction is matrix-bound on the 256 x 128 per-edge layer)
+                        parts[i_] = (ops.weight_grad_thin(dyc, p_, split=ctx.precision == "f16x3", overflow=ctx.overflow)
+                                     if ops.weight_grad_thin_supported(dyc, p_) else dyc.t() @ p_)
             dW = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         if ctx.has_bias and ctx.needs_input_grad[3] and db is None:
             db = torch.zeros(dy.shape[1], dtype=dy.dtype, device=dy.device) if ctx.bias_grad_is_zero else dy.sum(dim=0)

@@ -80,9 +80,12 @@ def test_norm_act_pool_forward_backward(points, k, cols, want_h, act):
     assert _rel(out["hip"][5], out["ref"][5]) < 1e-5 and _rel(out["hip"][6], out["ref"][6]) < 1e-5
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("R,n,k", [(200000, 256, 128), (123457, 128, 64), (65536, 64, 64), (300001, 64, 6), (50000, 64, 1), (70000, 256, 64),
                                    (999, 96, 40), (4096, 1, 256)])
-def test_weight_grad_thin(R, n, k):
+def test_weight_grad_thin(R, n, k, split):
+    """split=False: exact fp32 (v_mfma_f32_32x32x2_f32); split=True (round 5): the engines' fp16x3 arithmetic, every operand split in registers --
+    both against the fp64 product at fp32-class distance; the split form also on gradient-like operands (a few large entries over many tiny ones)."""
     from ogmm_amd import ops
     g = torch.Generator().manual_seed(R)
     dy = torch.randn(R, n, generator=g).to(DEV)
@@ -90,9 +93,20 @@ def test_weight_grad_thin(R, n, k):
     if not ops.weight_grad_thin_supported(dy, x):
         assert n == 1 or (96 * 0 + n) % 2                      # only the unaligned single-column case may be unsupported here
         return
-    got = ops.weight_grad_thin(dy, x)
+    ovf = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got = ops.weight_grad_thin(dy, x, split=split, overflow=ovf)
     want = dy.double().t() @ x.double()
     assert _rel(got, want) < 2e-6, _rel(got, want)
+    assert int(ovf.item()) == 0
+    if split:
+        dy2 = dy * torch.exp2(torch.randint(-24, 8, (R, 1), generator=g).float()).to(DEV)          # rows spanning 2^-24 ... 2^7, as loss-scaled gradients do
+        got = ops.weight_grad_thin(dy2, x, split=True, overflow=ovf)
+        want = dy2.double().t() @ x.double()
+        assert _rel(got, want) < 2e-6, _rel(got, want)
+        assert int(ovf.item()) == 0
+        dy2[R // 2, 0] = 1.0e5                                 # beyond binary16: the overflow word must say so
+        ops.weight_grad_thin(dy2, x, split=True, overflow=ovf)
+        assert int(ovf.item()) & 1
 
 
 @pytest.mark.parametrize("points,k,cols", [(1000, 20, 64), (333, 5, 64), (4096, 12, 256)])
