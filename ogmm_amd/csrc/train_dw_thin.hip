@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void dw_thin_kernel(const float* __restrict__ 
 using h8t = __attribute__((ext_vector_type(8))) _Float16;
 
 // (a paired form -- one v_cvt_pk_f16_f32 per two values, the residuals from the packed register through v_cvt_f32_f16_sdwa -- has 40 % fewer vector
-//  instructions and runs 4.7x SLOWER on the part: 8998 against 1885 us on the 256 x 128 layer, same box, same launch; kept per element)
+//  instructions and ran 4.7x SLOWER in this kernel: 8998 against 1885 us on the 256 x 128 layer, same box, same launch.  The instructions themselves are not
+//  slow -- tools/sdwa_rate.hip measures all three sequences within 8 % of each other, subnormal results included -- so it is the schedule the compiler
+//  made of it at 254 registers; kept per element)
 template <int V>
 __device__ __forceinline__ void split_rows(const float (&v)[8][V], h8t (&hi)[V], h8t (&lo)[V], float& amax) {
 #pragma unroll
