@@ -125,6 +125,49 @@ __global__ __launch_bounds__(256) void victim_dense_kernel(Rec* __restrict__ rec
     }
 }
 
+// The same question for v_fma_mix_f32 (the engines' in-register binary16 split uses it with op_sel:[1,0,0] op_sel_hi:[1,0,0]: the HIGH half of a packed
+// register as the binary16 multiplicand), which shares the VOP3P encoding and its operand-select bits with the packed-fp32 instructions.
+__global__ __launch_bounds__(256) void victim_mix_kernel(Rec* __restrict__ rec, uint32_t* __restrict__ count, int iters, int max_rec) {
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x;
+    uint32_t pk[8];
+    float acc[16], ref[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 lo = (_Float16)(0.5f + 0.01f * (float)((tid + j) & 31)), hi = (_Float16)(-0.25f - 0.02f * (float)((tid * 3 + j) & 31));
+        pk[j] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = ref[j] = 0.0f;
+    float c = 1.0f + 1e-3f * (float)(wg & 7);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * j]) : "v"(pk[j]), "v"(c));                       // low half
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * j + 1]) : "v"(pk[j]), "v"(c));    // high half
+            float lo, hi; uint32_t sh;
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(lo) : "v"(pk[j]));
+            asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(sh) : "v"(pk[j]));
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hi) : "v"(sh));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ref[2 * j]) : "v"(lo), "v"(c));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ref[2 * j + 1]) : "v"(hi), "v"(c));
+        }
+        if ((it & 63) == 63) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (__float_as_uint(acc[j]) != __float_as_uint(ref[j])) {
+                    const uint32_t slot = atomicAdd(count, 1u);
+                    if ((int)slot < max_rec) {
+                        Rec r; r.wg = wg; r.lane = tid; r.it = (uint32_t)it; r.half = (j & 1) ? 2u : 1u; r.got = __float_as_uint(acc[j]); r.want = __float_as_uint(ref[j]);
+                        r.form = 5; r.pad = (uint32_t)j;
+                        rec[slot] = r;
+                    }
+                }
+                acc[j] = ref[j] = 0.0f;
+            }
+        }
+    }
+}
+
 // KIND 3: v_pk_fma_f32 (plain)  KIND 4: v_pk_mul_f32 / v_pk_add_f32  KIND 5: LDS traffic (ds_write_b64 / ds_read_b128)  KIND 6: global loads
 // KIND 7: matrix + packed + LDS together   KIND 8: v_pk_fma_f32 with crossed op_sel (as the victim)
 // KIND 9: matrix (f16) + scalar VALU   KIND 10: matrix (fp32 32x32x2) + packed + LDS   KIND 11: matrix (f16 16x16x32) + scalar VALU
@@ -260,6 +303,16 @@ int main(int argc, char** argv) {
             printf("    lanes 0-15 / 16-31 / 32-47 / 48-63: %u %u %u %u    low only / high only / both: %u %u %u    accumulator even / odd: %u %u\n",
                    q[0], q[1], q[2], q[3], h[1], h[2], h[3], par[0], par[1]);
         }
+    }
+    for (int kind = 0; kind < 3; ++kind) {          // v_fma_mix_f32 with a high-half select beside the neighbours that break the packed-fp32 forms
+        CHECK(hipMemset(count, 0, 4));
+        if (kind == 0) hipLaunchKernelGGL(neighbour2_kernel<9>, dim3(wgs), dim3(256), 0, s1, sink, src, n_iters / 2);
+        if (kind == 1) hipLaunchKernelGGL(neighbour2_kernel<7>, dim3(wgs), dim3(256), 0, s1, sink, src, n_iters / 2);
+        if (kind == 2) hipLaunchKernelGGL(neighbour2_kernel<11>, dim3(wgs), dim3(256), 0, s1, sink, src, n_iters / 2);
+        hipLaunchKernelGGL(victim_mix_kernel, dim3(wgs), dim3(256), 0, s0, rec, count, v_iters / 4, max_rec);
+        CHECK(hipDeviceSynchronize());
+        uint32_t n = 0; CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
+        printf("neighbour %-30s victim v_fma_mix_f32 with low- and high-half selects        : %8u mismatches\n", kind == 0 ? "matrix f16 + scalar VALU" : kind == 1 ? "matrix + packed + LDS" : "matrix f16 16x16x32 + scalar", n);
     }
     {   // what does a wrong result hold?  Checked after every row (one product per accumulator), beside the f16 matrix + scalar neighbour
         uint32_t* alt; CHECK(hipMalloc(&alt, 4)); CHECK(hipMemset(alt, 0, 4)); CHECK(hipMemset(count, 0, 4));
