@@ -79,5 +79,14 @@ rm -rf $out/trace_train
 # 7. run-to-run reproducibility of consecutive forwards; the kNN head and the cluster-mean kernel alone
 { echo "# commit $commit"; timeout 300 python3 tools/determinism_check.py 2>&1 | grep -v amdgpu.ids; timeout 300 python3 tools/fps_corun.py 2>&1 | grep -v amdgpu.ids;
   timeout 200 python3 tools/knn_time.py 2>&1 | grep -v amdgpu.ids; timeout 100 python3 tools/featmean_time.py 2>&1 | grep -v amdgpu.ids; timeout 100 python3 tools/host_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_head_and_determinism.txt
+# 8. (round 5) the packed-fp32 / f16-matrix co-run hazard: the standalone reproducer, the guard kernels beside the product GEMMs, the product kernels beside them,
+#    the thin weight gradient and the normalisation backward per shape
+{ echo "# commit $commit"; echo "== tools/pk_mfma_hazard.hip (no product code)";
+  hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -fno-slp-vectorize tools/pk_mfma_hazard.hip -o /tmp/pk_mfma_hazard 2>/dev/null && timeout 300 /tmp/pk_mfma_hazard;
+  echo; echo "== tools/corun_guard.py (tools/lds_guard.hip beside the product GEMMs)"; timeout 300 python3 tools/corun_guard.py 2>&1 | grep -v amdgpu.ids | head -24;
+  echo; echo "== tools/corun_debug.py (library as built)"; timeout 300 python3 tools/corun_debug.py 2>&1 | grep -v amdgpu.ids;
+  echo; echo "== tools/corun_victims.py (library as built)"; timeout 300 python3 tools/corun_victims.py 2>&1 | grep -v amdgpu.ids | tail -20; } > $out/${tag}_pk_mfma_hazard_rerun.txt
+{ echo "# commit $commit"; timeout 300 python3 tools/dw_thin_time.py 2>&1 | grep -v amdgpu.ids; timeout 300 python3 tools/norm_bwd_time.py 2>&1 | grep -v amdgpu.ids;
+  timeout 300 python3 tools/train_call_census.py 128 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_train_kernels.txt
 rm -rf $out/trace $out/pmc_*          # the rocpd databases exceed what gpurun copies back; the summaries above are what gets committed
 ls -la $out | head -40

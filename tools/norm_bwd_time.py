@@ -29,10 +29,10 @@ for rows, cols, group, k in ((262144, 512, 1024, 0), (262144, 512, 131072, 0), (
         gb_in = rows * cols * 8 / 1e9
     t = timed(lambda: ops.norm_bwd(x, dy, group, scale, shift, mean, rstd, ops.ACT_RELU, dpool=dpool, arg=arg, k=k))
     gb = 2 * gb_in + rows * cols * 4 / 1e9
-    print("%-34s %10.1f %10.2f %10.2f   (reduce + apply)" % ("%d x %d g=%d k=%d" % (rows, cols, group, k), t, gb, gb / t * 1e-3 * 1e3))
+    print("%-34s %10.1f %10.2f %10.2f   (reduce + apply)" % ("%d x %d g=%d k=%d" % (rows, cols, group, k), t, gb, gb / t * 1e3))
     if not k:
         sums = torch.zeros(G, cols, 2, dtype=torch.float64, device=dev)
         t = timed(lambda: ops.norm_bwd_apply(x, dy, group, scale, shift, mean, rstd, sums))
         gb = rows * cols * 12 / 1e9
-        print("%-34s %10.1f %10.2f %10.2f   (apply alone)" % ("", t, gb, gb / t * 1e-3 * 1e3))
+        print("%-34s %10.1f %10.2f %10.2f   (apply alone)" % ("", t, gb, gb / t * 1e3))
     del x, dy, dpool, arg

@@ -168,6 +168,53 @@ __global__ __launch_bounds__(256) void victim_mix_kernel(Rec* __restrict__ rec, 
     }
 }
 
+// ... and for the pair the engines actually use for the split residuals: v_fma_mixlo_f16 d, h, -1.0, t op_sel_hi:[1,0,0] (low half of h) and
+// v_fma_mixhi_f16 d, h, -1.0, t op_sel:[1,0,0] op_sel_hi:[1,0,0] (HIGH half of h: a non-default select), 2252 of each in the library.
+__global__ __launch_bounds__(256) void victim_mixhalf_kernel(Rec* __restrict__ rec, uint32_t* __restrict__ count, int iters, int max_rec) {
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x;
+    float t0[8], t1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { t0[j] = 0.37f + 0.013f * (float)((tid + 5 * j) & 63) + 1e-4f * (float)(wg & 15); t1[j] = -1.91f + 0.021f * (float)((tid * 3 + j) & 63); }
+    for (int it = 0; it < iters; ++it) {
+        uint32_t pk[8], d[8], ref[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[j]) : "v"(t0[j]), "v"(t1[j]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            d[j] = 0;
+            asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(d[j]) : "v"(pk[j]), "v"(t0[j]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d[j]) : "v"(pk[j]), "v"(t1[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {          // the same residuals through scalar instructions
+            float h0, h1; uint32_t sh, r0, r1;
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(h0) : "v"(pk[j]));
+            asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(sh) : "v"(pk[j]));
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(h1) : "v"(sh));
+            float e0 = t0[j] - h0, e1 = t1[j] - h1;
+            asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(r0) : "v"(e0));
+            asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(r1) : "v"(e1));
+            ref[j] = (r0 & 0xffffu) | (r1 << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (d[j] != ref[j]) {
+                const uint32_t slot = atomicAdd(count, 1u);
+                if ((int)slot < max_rec) {
+                    Rec r; r.wg = wg; r.lane = tid; r.it = (uint32_t)it; r.half = ((d[j] ^ ref[j]) & 0xffffu ? 1u : 0u) | ((d[j] ^ ref[j]) >> 16 ? 2u : 0u); r.got = d[j]; r.want = ref[j];
+                    r.form = 6; r.pad = (uint32_t)j;
+                    rec[slot] = r;
+                }
+            }
+            t0[j] += 1e-3f; t1[j] -= 7e-4f;
+        }
+        if ((it & 1023) == 1023) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { t0[j] = 0.37f + 0.013f * (float)((tid + 5 * j) & 63); t1[j] = -1.91f + 0.021f * (float)((tid * 3 + j) & 63); }
+        }
+    }
+}
+
 // KIND 3: v_pk_fma_f32 (plain)  KIND 4: v_pk_mul_f32 / v_pk_add_f32  KIND 5: LDS traffic (ds_write_b64 / ds_read_b128)  KIND 6: global loads
 // KIND 7: matrix + packed + LDS together   KIND 8: v_pk_fma_f32 with crossed op_sel (as the victim)
 // KIND 9: matrix (f16) + scalar VALU   KIND 10: matrix (fp32 32x32x2) + packed + LDS   KIND 11: matrix (f16 16x16x32) + scalar VALU
@@ -313,6 +360,16 @@ int main(int argc, char** argv) {
         CHECK(hipDeviceSynchronize());
         uint32_t n = 0; CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
         printf("neighbour %-30s victim v_fma_mix_f32 with low- and high-half selects        : %8u mismatches\n", kind == 0 ? "matrix f16 + scalar VALU" : kind == 1 ? "matrix + packed + LDS" : "matrix f16 16x16x32 + scalar", n);
+    }
+    for (int kind = 0; kind < 3; ++kind) {          // the split residuals' v_fma_mixlo_f16 / v_fma_mixhi_f16 pair
+        CHECK(hipMemset(count, 0, 4));
+        if (kind == 0) hipLaunchKernelGGL(neighbour2_kernel<9>, dim3(wgs), dim3(256), 0, s1, sink, src, n_iters / 2);
+        if (kind == 1) hipLaunchKernelGGL(neighbour2_kernel<7>, dim3(wgs), dim3(256), 0, s1, sink, src, n_iters / 2);
+        if (kind == 2) hipLaunchKernelGGL(neighbour2_kernel<11>, dim3(wgs), dim3(256), 0, s1, sink, src, n_iters / 2);
+        hipLaunchKernelGGL(victim_mixhalf_kernel, dim3(wgs), dim3(256), 0, s0, rec, count, v_iters / 4, max_rec);
+        CHECK(hipDeviceSynchronize());
+        uint32_t n = 0; CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
+        printf("neighbour %-30s victim v_fma_mixlo_f16 + v_fma_mixhi_f16 (high-half select)         : %8u mismatches\n", kind == 0 ? "matrix f16 + scalar VALU" : kind == 1 ? "matrix + packed + LDS" : "matrix f16 16x16x32 + scalar", n);
     }
     {   // what does a wrong result hold?  Checked after every row (one product per accumulator), beside the f16 matrix + scalar neighbour
         uint32_t* alt; CHECK(hipMalloc(&alt, 4)); CHECK(hipMemset(alt, 0, 4)); CHECK(hipMemset(count, 0, 4));
