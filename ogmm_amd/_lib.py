@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libogmm_hip.so")
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_F16X3, PREC_F16X3_FRAG, PREC_F16_FRAG = 0, 1, 2, 3
@@ -76,6 +76,8 @@ PROTOTYPES = {
     "ogmm_attention_bwd_supported": [c_int, c_int],
     "ogmm_attention_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
                            c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
+    "ogmm_attention_bwd_f16x3": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
+                           c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],
     "ogmm_instnorm_relu": [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p],
     "ogmm_instnorm_finalize": [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p],

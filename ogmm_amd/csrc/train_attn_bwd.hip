@@ -31,6 +31,18 @@ constexpr int TQ = 32;                   // queries per tile
 constexpr int PT = 130;                  // floats per row of the Q / dO tiles     (8-byte aligned rows, conflict-free b64 column reads)
 constexpr int PX = 132;                  // floats per row of the dS exchange tile (16-byte aligned rows)
 constexpr int PP = 34;                   // floats per row of a wave's transposition patch
+constexpr int PH = 136;                  // binary16 per row of the split Q / dO tiles (SPLIT form): 16-byte aligned rows, conflict-free b128 reads
+
+using h8b = __attribute__((ext_vector_type(8))) _Float16;
+using h4b = __attribute__((ext_vector_type(4))) _Float16;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// hi = rn(v), lo = rn(v - hi) in binary16; amax collects |v| for the range check
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo, float& amax) {
+    amax = fmaxf(amax, fabsf(v));
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -38,16 +50,29 @@ constexpr int PP = 34;                   // floats per row of a wave's transposi
 // indices, so one 8-byte read feeds both
 __device__ __forceinline__ constexpr int sel(int s, int lh) { return 4 * (s >> 1) + 2 * lh + (s & 1); }
 
+// SPLIT (round 5, the fp16x3 training step): the two products that contract over the head dimension -- S^T = K Q^T and dP^T = V dO^T, 128 of the 320
+// fp32 matrix instructions of a tile -- run on the engines' arithmetic instead: K and V rows of the wave are held as binary16 hi / lo planes (same
+// register count), the staged Q / dO tile is ALSO written as split planes [query][d], and a 16-deep v_mfma_f32_32x32x16_f16 step (lane = key / query,
+// 8 consecutive d per lane half) replaces eight 2-deep fp32 steps: 48 matrix instructions of 32 cycles for 128 of 64.  The accumulator layout is the
+// same, so everything behind the two blocks is untouched; the three products that contract over queries / keys (P, dS as operands) stay exact fp32:
+// dS has no fixed scale, and binary16's range would need a per-tile one.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
                                                             const float* __restrict__ v, int64_t ldv, const float* __restrict__ dout,
                                                             int64_t lddo, int N, int H, float scale, float* __restrict__ dq, int64_t lddq,
-                                                            float* __restrict__ dk, int64_t lddk, float* __restrict__ dv, int64_t lddv) {
+                                                            float* __restrict__ dk, int64_t lddk, float* __restrict__ dv, int64_t lddv,
+                                                            int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) float smem_ab[];
     float* Qs = smem_ab;                               // [TQ][PT]
     float* dOs = Qs + TQ * PT;                         // [TQ][PT]
     float* dSx = dOs + TQ * PT;                        // [TQ][PX]   dS of the tile, all keys
     float* Xs = dSx + TQ * PX;                         // [4 waves][3][32]  (max, sum, sum e*dP) per query
     float* patch = Xs + 4 * 3 * 32;                    // [4 waves][2][32][PP]
+    _Float16* Qh = reinterpret_cast<_Float16*>(patch + 4 * 2 * 32 * PP);          // SPLIT: [TQ][PH] x {Q hi, Q lo, dO hi, dO lo}
+    _Float16* Ql = Qh + TQ * PH;
+    _Float16* Gh = Ql + TQ * PH;
+    _Float16* Gl = Gh + TQ * PH;
+    float amax = 0.0f;
 
     const int h = blockIdx.x % H, c = blockIdx.x / H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,16 +85,34 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     float* Sp = Pp + 32 * PP;
 
     // ---- the wave's constant slices of K and V
-    float krow[64], vrow[64], kcol[64];
+    float krow[SPLIT ? 1 : 64], vrow[SPLIT ? 1 : 64], kcol[64];
+    h8b kh[SPLIT ? 8 : 1], kl[SPLIT ? 8 : 1], vh[SPLIT ? 8 : 1], vl[SPLIT ? 8 : 1];          // SPLIT: step u holds d = 16 u + 8 lh ... + 7 of the lane's key
     {
-        const float* __restrict__ kr = kc + (int64_t)(32 * wave + lr) * ldk + 2 * lh;
-        const float* __restrict__ vr = vc + (int64_t)(32 * wave + lr) * ldv + 2 * lh;
+        if constexpr (SPLIT) {
+            const float* __restrict__ kr = kc + (int64_t)(32 * wave + lr) * ldk + 8 * lh;
+            const float* __restrict__ vr = vc + (int64_t)(32 * wave + lr) * ldv + 8 * lh;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const f32x2b a = *reinterpret_cast<const f32x2b*>(kr + 4 * j);
-            const f32x2b b = *reinterpret_cast<const f32x2b*>(vr + 4 * j);
-            krow[2 * j] = a[0]; krow[2 * j + 1] = a[1];
-            vrow[2 * j] = b[0]; vrow[2 * j + 1] = b[1];
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const f32x2b a = *reinterpret_cast<const f32x2b*>(kr + 16 * u + i);
+                    const f32x2b b = *reinterpret_cast<const f32x2b*>(vr + 16 * u + i);
+                    _Float16 h, l;
+                    split1(a[0], h, l, amax); kh[u][i] = h; kl[u][i] = l;
+                    split1(a[1], h, l, amax); kh[u][i + 1] = h; kl[u][i + 1] = l;
+                    split1(b[0], h, l, amax); vh[u][i] = h; vl[u][i] = l;
+                    split1(b[1], h, l, amax); vh[u][i + 1] = h; vl[u][i + 1] = l;
+                }
+        } else {
+            const float* __restrict__ kr = kc + (int64_t)(32 * wave + lr) * ldk + 2 * lh;
+            const float* __restrict__ vr = vc + (int64_t)(32 * wave + lr) * ldv + 2 * lh;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const f32x2b a = *reinterpret_cast<const f32x2b*>(kr + 4 * j);
+                const f32x2b b = *reinterpret_cast<const f32x2b*>(vr + 4 * j);
+                krow[2 * j] = a[0]; krow[2 * j + 1] = a[1];
+                vrow[2 * j] = b[0]; vrow[2 * j + 1] = b[1];
+            }
         }
 #pragma unroll
         for (int s = 0; s < 64; ++s) kcol[s] = kc[(int64_t)sel(s, lh) * ldk + 32 * wave + lr];
@@ -103,6 +146,17 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
             f32x2b* gd = reinterpret_cast<f32x2b*>(dOs + row * PT + c4);
             qd[0] = f32x2b{qst[u][0], qst[u][1]}; qd[1] = f32x2b{qst[u][2], qst[u][3]};
             gd[0] = f32x2b{gst[u][0], gst[u][1]}; gd[1] = f32x2b{gst[u][2], gst[u][3]};
+            if constexpr (SPLIT) {
+                h4b qh, ql, gh, gl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 h, l;
+                    split1(qst[u][e], h, l, amax); qh[e] = h; ql[e] = l;
+                    split1(gst[u][e], h, l, amax); gh[e] = h; gl[e] = l;
+                }
+                *reinterpret_cast<h4b*>(Qh + row * PH + c4) = qh; *reinterpret_cast<h4b*>(Ql + row * PH + c4) = ql;
+                *reinterpret_cast<h4b*>(Gh + row * PH + c4) = gh; *reinterpret_cast<h4b*>(Gl + row * PH + c4) = gl;
+            }
         }
     };
 
@@ -121,7 +175,27 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         f32x16b sacc, pacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
-        {
+        if constexpr (SPLIT) {
+            const int off = lr_t * PH + 8 * lh_t;
+            // the planes of step u + 1 are requested before the matrix instructions of step u are issued (one wave per SIMD: nobody else hides the LDS latency)
+            h8b bqh[2], bql[2], bgh[2], bgl[2];
+            bqh[0] = *reinterpret_cast<const h8b*>(Qh + off); bql[0] = *reinterpret_cast<const h8b*>(Ql + off);
+            bgh[0] = *reinterpret_cast<const h8b*>(Gh + off); bgl[0] = *reinterpret_cast<const h8b*>(Gl + off);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u + 1 < 8) {
+                    bqh[(u + 1) & 1] = *reinterpret_cast<const h8b*>(Qh + off + 16 * (u + 1)); bql[(u + 1) & 1] = *reinterpret_cast<const h8b*>(Ql + off + 16 * (u + 1));
+                    bgh[(u + 1) & 1] = *reinterpret_cast<const h8b*>(Gh + off + 16 * (u + 1)); bgl[(u + 1) & 1] = *reinterpret_cast<const h8b*>(Gl + off + 16 * (u + 1));
+                }
+                sacc = MFMA16(kh[u], bql[u & 1], sacc);
+                pacc = MFMA16(vh[u], bgl[u & 1], pacc);
+                sacc = MFMA16(kl[u], bqh[u & 1], sacc);
+                pacc = MFMA16(vl[u], bgh[u & 1], pacc);
+                sacc = MFMA16(kh[u], bqh[u & 1], sacc);
+                pacc = MFMA16(vh[u], bgh[u & 1], pacc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
             const float* __restrict__ qb = Qs + lr_t * PT + 2 * lh_t;
             const float* __restrict__ gb = dOs + lr_t * PT + 2 * lh_t;
             // operands of step j + 2 are requested before the MFMAs of step j are issued (a read right in front of its use leaves
@@ -255,6 +329,9 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         }
     }
 
+    if constexpr (SPLIT) {
+        if (overflow && !(amax <= 65504.0f)) atomicOr(overflow, 1);          // an operand beyond binary16's range (or NaN / Inf): the trainer lowers its loss scale
+    }
     // ---- dK, dV blocks of the wave: lane = column d, registers = keys
     {
         float* __restrict__ dkc = dk + ((int64_t)c * BM + 32 * wave) * lddk + h * BDH + lr;
@@ -273,24 +350,45 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
 }
 
 constexpr int BWD_LDS_BYTES = (2 * TQ * PT + TQ * PX + 4 * 3 * 32 + 4 * 2 * 32 * PP) * 4;
-PerDeviceOnce g_bwd_once;
+constexpr int BWD_LDS_BYTES_SPLIT = BWD_LDS_BYTES + 4 * TQ * PH * 2;
+PerDeviceOnce g_bwd_once, g_bwd_once_split;
 
 }  // namespace
 
 extern "C" int ogmm_attention_bwd_supported(int M, int dh) { return (M == BM && dh == BDH) ? 1 : 0; }
 
-extern "C" int ogmm_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
-                                  int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk,
-                                  int64_t lddk, float* dv, int64_t lddv, void* stream) {
+static int attention_bwd_impl(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
+                              int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk,
+                              int64_t lddk, float* dv, int64_t lddv, bool split, int* overflow, void* stream) {
     OGMM_REQUIRE(q && k && v && dout && dq && dk && dv, "ogmm_attention_bwd: null pointer");
     OGMM_REQUIRE(C > 0 && N > 0 && H > 0, "ogmm_attention_bwd: empty problem (C=%d N=%d H=%d)", C, N, H);
     OGMM_REQUIRE(M == BM && dh == BDH, "ogmm_attention_bwd: built for M = %d anchors and dh = %d (got M=%d dh=%d)", BM, BDH, M, dh);
     OGMM_REQUIRE(ldq % 4 == 0 && lddo % 4 == 0 && ldk % 2 == 0 && ldv % 2 == 0 && aligned16(q) && aligned16(dout) && aligned16(k) && aligned16(v),
                  "ogmm_attention_bwd: q / dout rows must be 16-byte aligned, k / v rows 8-byte aligned");
     OGMM_REQUIRE((int64_t)C * H < (int64_t)1 << 31, "ogmm_attention_bwd: C * H exceeds the grid limit");
+    if (split) {
+        OGMM_REQUIRE(ldk % 2 == 0 && ldv % 2 == 0, "ogmm_attention_bwd_f16x3: k / v rows must be 8-byte aligned");
+        if (g_bwd_once_split.first())
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES_SPLIT);
+        hipLaunchKernelGGL(attention_bwd_kernel<true>, dim3(C * H), dim3(256), BWD_LDS_BYTES_SPLIT, as_stream(stream), q, ldq, k, ldk, v, ldv, dout, lddo, N, H,
+                           scale, dq, lddq, dk, lddk, dv, lddv, overflow);
+        return check_launch("ogmm_attention_bwd_f16x3");
+    }
     if (g_bwd_once.first())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES);
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(C * H), dim3(256), BWD_LDS_BYTES, as_stream(stream), q, ldq, k, ldk, v, ldv, dout, lddo, N, H,
-                       scale, dq, lddq, dk, lddk, dv, lddv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES);
+    hipLaunchKernelGGL(attention_bwd_kernel<false>, dim3(C * H), dim3(256), BWD_LDS_BYTES, as_stream(stream), q, ldq, k, ldk, v, ldv, dout, lddo, N, H,
+                       scale, dq, lddq, dk, lddk, dv, lddv, (int*)nullptr);
     return check_launch("ogmm_attention_bwd");
+}
+
+extern "C" int ogmm_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
+                                  int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk,
+                                  int64_t lddk, float* dv, int64_t lddv, void* stream) {
+    return attention_bwd_impl(q, ldq, k, ldk, v, ldv, dout, lddo, C, N, M, H, dh, scale, dq, lddq, dk, lddk, dv, lddv, false, nullptr, stream);
+}
+
+extern "C" int ogmm_attention_bwd_f16x3(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
+                                        int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk,
+                                        int64_t lddk, float* dv, int64_t lddv, int* overflow, void* stream) {
+    return attention_bwd_impl(q, ldq, k, ldk, v, ldv, dout, lddo, C, N, M, H, dh, scale, dq, lddq, dk, lddk, dv, lddv, true, overflow, stream);
 }

@@ -397,10 +397,11 @@ class _Attention(torch.autograd.Function):
     kernel is not built for (M != 128) re-form the scores with batched library GEMMs + softmax and differentiate those."""
 
     @staticmethod
-    def forward(ctx, q, k, v, C, N, M, H):
+    def forward(ctx, q, k, v, C, N, M, H, precision="f32", overflow=None):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         ctx.save_for_backward(q, k, v)
         ctx.dims = (C, N, M, H)
+        ctx.split, ctx.overflow = precision == "f16x3", overflow
         return ops.attention(q, k, v, C, N, M, H)
 
     @staticmethod
@@ -408,12 +409,13 @@ class _Attention(torch.autograd.Function):
         C, N, M, H = ctx.dims
         if FUSED_ATTENTION_BWD and ops.attention_bwd_supported(M, ctx.saved_tensors[0].shape[1] // H):
             q, k, v = ctx.saved_tensors
-            return ops.attention_bwd(q, k, v, _rm(g), C, N, M, H) + (None, None, None, None)
+            # (round 5: in the fp16x3 step the two products over the head dimension run on the engines' arithmetic, ogmm_attention_bwd_f16x3)
+            return ops.attention_bwd(q, k, v, _rm(g), C, N, M, H, split=ctx.split, overflow=ctx.overflow) + (None,) * 6
         q, k, v = (t_.detach().requires_grad_(True) for t_ in ctx.saved_tensors)
         with torch.enable_grad():
             o = _attention_torch(q, k, v, *ctx.dims)
         gq, gk, gv = torch.autograd.grad(o, (q, k, v), g)
-        return gq, gk, gv, None, None, None, None
+        return gq, gk, gv, None, None, None, None, None, None
 
 
 class _OverlapCross(torch.autograd.Function):
@@ -626,7 +628,7 @@ class TrainOps:
     def attention(self, q, k, v, C, N, M, H):
         """softmax(q k^T / sqrt(dh)) v per cloud and head; head-major channels.  q [C*N,D], k, v [C*M,D] -> [C*N,D]"""
         if ops.attention_supported(M, q.shape[1] // H):
-            return _Attention.apply(q, k, v, C, N, M, H)
+            return _Attention.apply(q, k, v, C, N, M, H, self.precision, self.overflow)
         return _attention_torch(q, k, v, C, N, M, H)
 
     def l2norm_rows(self, f):

@@ -510,10 +510,12 @@ def test_fused_attention(ops, C, N, M):
     assert (got3 - ref).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("C,N", [(2, 1024), (3, 300), (1, 717), (2, 20)])
-def test_attention_backward_kernel(ops, C, N):
+def test_attention_backward_kernel(ops, C, N, split):
     """Kernel T11 against fp64 autograd of models/attn.py:78-82: dq, dk, dv for whole and ragged query tiles, a large-scale dO (the
-    trainer's 2^16 loss scale), strided q / k / v / dO views; every output element is written (the buffers start as NaN)."""
+    trainer's 2^16 loss scale), strided q / k / v / dO views; every output element is written (the buffers start as NaN).
+    split=True (round 5): the two products over the head dimension on the engines' fp16x3 arithmetic -- same bar; an operand beyond binary16 sets the overflow word."""
     torch.manual_seed(C * 1000 + N)
     H, dh, M = 4, 128, 128
     D = H * dh
@@ -524,7 +526,9 @@ def test_attention_backward_kernel(ops, C, N):
     prob = torch.softmax(torch.einsum("cnhd,cmhd->chnm", qd.view(C, N, H, dh), kd.view(C, M, H, dh)) / dh ** .5, dim=-1)
     out = torch.einsum("chnm,cmhd->cnhd", prob, vd.view(C, M, H, dh)).reshape(C * N, D)
     rq, rk, rv = torch.autograd.grad(out, (qd, kd, vd), g.double())
-    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), dev(g), C, N, M, H)
+    ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), dev(g), C, N, M, H, split=split, overflow=ovf)
+    assert int(ovf.item()) == 0
     for name, got, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
         got = got.cpu().double()
         assert torch.isfinite(got).all(), name
@@ -533,8 +537,13 @@ def test_attention_backward_kernel(ops, C, N):
     # strided operands: q | k-padding in one buffer, keys | values produced by one GEMM, dO a column slice
     kv = dev(torch.cat([k, v], 1))
     qg = dev(torch.cat([q, g], 1))
-    dq2, dk2, dv2 = ops.attention_bwd(qg[:, :D], kv[:, :D], kv[:, D:], qg[:, D:], C, N, M, H)
+    dq2, dk2, dv2 = ops.attention_bwd(qg[:, :D], kv[:, :D], kv[:, D:], qg[:, D:], C, N, M, H, split=split, overflow=ovf)
     assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
+    if split:
+        g2 = g.clone()
+        g2[N // 2, 7] = 1.0e5                                  # beyond binary16
+        ops.attention_bwd(dev(q), dev(k), dev(v), dev(g2), C, N, M, H, split=True, overflow=ovf)
+        assert int(ovf.item()) & 1
 
 
 def test_attention_backward_in_autograd(ops, monkeypatch):
