@@ -448,12 +448,14 @@ int ogmm_attention_bwd_supported(int M, int dh);
 int ogmm_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
                        int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk,
                        float* dv, int64_t lddv, void* stream);
-/* the same backward with the two products that contract over the head dimension (S = Q K^T, dP = dO V^T) on the engines' fp16x3 arithmetic
- * (round 5; the fp16x3 training step): K / V rows and the staged Q / dO tile are split into two binary16 in the kernel; the three products
- * with P / dS as operands stay exact fp32.  `overflow` (device int32 or NULL) gets bit 0 when q, k, v or dout exceed binary16's range. */
+/* the same backward on the engines' fp16x3 arithmetic (round 5; the fp16x3 training step), every operand split into two binary16 in the kernel.
+ * all_products = 0: only the two products that contract over the head dimension (S = Q K^T, dP = dO V^T); the three with P / dS as operands stay
+ * exact fp32.  all_products = 1 (csrc/train_attn_bwd16.hip): all five -- P as P * 2^10, dS with a per-tile power of two taken from the tile's largest
+ * |dS| (dQ un-scaled per tile, the running dK re-scaled exactly when the exponent changes).  `overflow` (device int32 or NULL) gets bit 0 when
+ * q, k, v or dout exceed binary16's range. */
 int ogmm_attention_bwd_f16x3(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
                              int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk,
-                             float* dv, int64_t lddv, int* overflow, void* stream);
+                             float* dv, int64_t lddv, int all_products, int* overflow, void* stream);
 
 /* ---- T9: weight gradient of the thin layers (per-edge EdgeConv maps, the 6 -> 64 edge layer, the 1 -> 64 positional layers):
  * part[s][n][k] = sum over the rows of stream s of dY[r][n] X[r][k], exact fp32 on v_mfma_f32_32x32x2_f32 (HBM-bound);

@@ -77,7 +77,7 @@ PROTOTYPES = {
     "ogmm_attention_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
                            c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
     "ogmm_attention_bwd_f16x3": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
-                           c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
+                                 c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     "ogmm_softmax_rows": [c_void_p, c_int64, c_int, c_int64, c_void_p],
     "ogmm_instnorm_relu": [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p],
     "ogmm_instnorm_finalize": [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p],

@@ -387,8 +387,20 @@ extern "C" int ogmm_attention_bwd(const float* q, int64_t ldq, const float* k, i
     return attention_bwd_impl(q, ldq, k, ldk, v, ldv, dout, lddo, C, N, M, H, dh, scale, dq, lddq, dk, lddk, dv, lddv, false, nullptr, stream);
 }
 
+int ogmm_attention_bwd16_launch(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout, int64_t lddo,
+                                int C, int N, int H, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                                int* overflow, void* stream);          // train_attn_bwd16.hip
+
 extern "C" int ogmm_attention_bwd_f16x3(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* dout,
                                         int64_t lddo, int C, int N, int M, int H, int dh, float scale, float* dq, int64_t lddq, float* dk,
-                                        int64_t lddk, float* dv, int64_t lddv, int* overflow, void* stream) {
-    return attention_bwd_impl(q, ldq, k, ldk, v, ldv, dout, lddo, C, N, M, H, dh, scale, dq, lddq, dk, lddk, dv, lddv, true, overflow, stream);
+                                        int64_t lddk, float* dv, int64_t lddv, int all_products, int* overflow, void* stream) {
+    if (!all_products)
+        return attention_bwd_impl(q, ldq, k, ldk, v, ldv, dout, lddo, C, N, M, H, dh, scale, dq, lddq, dk, lddk, dv, lddv, true, overflow, stream);
+    OGMM_REQUIRE(q && k && v && dout && dq && dk && dv, "ogmm_attention_bwd_f16x3: null pointer");
+    OGMM_REQUIRE(C > 0 && N > 0 && H > 0, "ogmm_attention_bwd_f16x3: empty problem (C=%d N=%d H=%d)", C, N, H);
+    OGMM_REQUIRE(M == BM && dh == BDH, "ogmm_attention_bwd_f16x3: built for M = %d anchors and dh = %d (got M=%d dh=%d)", BM, BDH, M, dh);
+    OGMM_REQUIRE(ldq % 4 == 0 && lddo % 4 == 0 && ldk % 2 == 0 && ldv % 2 == 0 && aligned16(q) && aligned16(dout) && aligned16(k) && aligned16(v),
+                 "ogmm_attention_bwd_f16x3: q / dout rows must be 16-byte aligned, k / v rows 8-byte aligned");
+    OGMM_REQUIRE((int64_t)C * H < (int64_t)1 << 31, "ogmm_attention_bwd_f16x3: C * H exceeds the grid limit");
+    return ogmm_attention_bwd16_launch(q, ldq, k, ldk, v, ldv, dout, lddo, C, N, H, scale, dq, lddq, dk, lddk, dv, lddv, overflow, stream);
 }

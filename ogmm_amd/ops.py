@@ -543,12 +543,13 @@ def attention_bwd_supported(M, dh):
     return bool(_lib.load().ogmm_attention_bwd_supported(M, dh))
 
 
-ATTN_BWD_F16X3 = os.environ.get("OGMM_ATTN_BWD_F16X3", "1") != "0"      # 0: the exact-fp32 attention backward in the fp16x3 training step too (A/B)
+ATTN_BWD_F16X3 = int(os.environ.get("OGMM_ATTN_BWD_F16X3", "2"))      # fp16x3 step: 0 = exact-fp32 attention backward, 1 = S and dP on the fp16x3 arithmetic, 2 = all five products (A/B)
 
 
 def attention_bwd(q, k, v, dout, C, N, M, H, split=False, overflow=None):
     """Backward of attention(): (dq [C*N, D], dk [C*M, D], dv [C*M, D]) from dout = dL/dO; scores re-formed on chip (kernel T11).
-    split=True (the fp16x3 training step): S = Q K^T and dP = dO V^T on the engines' fp16x3 arithmetic, `overflow` reports operands beyond binary16."""
+    split: False = exact fp32; True = the fp16x3 training step's form (OGMM_ATTN_BWD_F16X3, default 2); 1 = S = Q K^T and dP = dO V^T on the engines'
+    fp16x3 arithmetic; 2 = all five products (csrc/train_attn_bwd16.hip).  `overflow` reports operands beyond binary16."""
     D = q.shape[1]
     dh = D // H
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and dout.stride(1) == 1
@@ -556,10 +557,11 @@ def attention_bwd(q, k, v, dout, C, N, M, H, split=False, overflow=None):
     dq = torch.empty((C * N, D), dtype=torch.float32, device=q.device)
     dk = torch.empty((C * M, D), dtype=torch.float32, device=q.device)
     dv = torch.empty((C * M, D), dtype=torch.float32, device=q.device)
-    if split and ATTN_BWD_F16X3:
+    level = ATTN_BWD_F16X3 if split is True else int(split)
+    if level:
         _lib.call("ogmm_attention_bwd_f16x3", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0),
                   _p(_f32(dout, "dout")), dout.stride(0), C, N, M, H, dh, 1.0 / dh ** .5, _p(dq), dq.stride(0), _p(dk), dk.stride(0),
-                  _p(dv), dv.stride(0), _p(overflow), _stream())
+                  _p(dv), dv.stride(0), 1 if level >= 2 else 0, _p(overflow), _stream())
         return dq, dk, dv
     _lib.call("ogmm_attention_bwd", _p(_f32(q, "q")), q.stride(0), _p(_f32(k, "k")), k.stride(0), _p(_f32(v, "v")), v.stride(0),
               _p(_f32(dout, "dout")), dout.stride(0), C, N, M, H, dh, 1.0 / dh ** .5, _p(dq), dq.stride(0), _p(dk), dk.stride(0),

@@ -510,12 +510,14 @@ def test_fused_attention(ops, C, N, M):
     assert (got3 - ref).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, 1, 2])
 @pytest.mark.parametrize("C,N", [(2, 1024), (3, 300), (1, 717), (2, 20)])
 def test_attention_backward_kernel(ops, C, N, split):
     """Kernel T11 against fp64 autograd of models/attn.py:78-82: dq, dk, dv for whole and ragged query tiles, a large-scale dO (the
     trainer's 2^16 loss scale), strided q / k / v / dO views; every output element is written (the buffers start as NaN).
-    split=True (round 5): the two products over the head dimension on the engines' fp16x3 arithmetic -- same bar; an operand beyond binary16 sets the overflow word."""
+    split = 1 (round 5): the two products over the head dimension on the engines' fp16x3 arithmetic; split = 2: all five (P as P * 2^10, dS with a per-tile
+    power of two) -- same bar, also with dO tiles spanning 2^-10 ... 2^4 (tiles whose dS differ by many binades: the running dK is re-scaled between them);
+    an operand beyond binary16 sets the overflow word."""
     torch.manual_seed(C * 1000 + N)
     H, dh, M = 4, 128, 128
     D = H * dh
@@ -525,7 +527,7 @@ def test_attention_backward_kernel(ops, C, N, split):
     qd, kd, vd = (t_.double().requires_grad_(True) for t_ in (q, k, v))
     prob = torch.softmax(torch.einsum("cnhd,cmhd->chnm", qd.view(C, N, H, dh), kd.view(C, M, H, dh)) / dh ** .5, dim=-1)
     out = torch.einsum("chnm,cmhd->cnhd", prob, vd.view(C, M, H, dh)).reshape(C * N, D)
-    rq, rk, rv = torch.autograd.grad(out, (qd, kd, vd), g.double())
+    rq, rk, rv = torch.autograd.grad(out, (qd, kd, vd), g.double(), retain_graph=True)
     ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
     dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), dev(g), C, N, M, H, split=split, overflow=ovf)
     assert int(ovf.item()) == 0
@@ -540,9 +542,23 @@ def test_attention_backward_kernel(ops, C, N, split):
     dq2, dk2, dv2 = ops.attention_bwd(qg[:, :D], kv[:, :D], kv[:, D:], qg[:, D:], C, N, M, H, split=split, overflow=ovf)
     assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
     if split:
+        # gradient TILES (32 queries) of very different magnitude, 2^-10 ... 2^4, so that consecutive tiles take different powers of two for dS.  (Within a
+        # tile the rows share a scale: the binary16 split of dO has an absolute floor of 2^-25 per element, as for every operand of the engines, so rows far
+        # below their map's maximum are not resolved relative to themselves by any of the forms -- the bar is relative to the tile.)
+        ex = torch.randint(-10, 5, ((N + 31) // 32,)).float().repeat_interleave(32)[:N].repeat(C)
+        gw = g * torch.exp2(ex)[:, None]
+        rq, rk, rv = torch.autograd.grad(out, (qd, kd, vd), gw.double())
+        dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), dev(gw), C, N, M, H, split=split, overflow=ovf)
+        assert int(ovf.item()) == 0
+        for name, got, ref in (("dk", dk, rk), ("dv", dv, rv)):
+            err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 2e-6, (name, err)
+        rowmax = rq.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)          # dq rows inherit their query's scale: compare row by row
+        err = ((dq.cpu().double() - rq).abs() / rowmax).max().item()
+        assert err < 2e-5, ("dq rows", err)
         g2 = g.clone()
         g2[N // 2, 7] = 1.0e5                                  # beyond binary16
-        ops.attention_bwd(dev(q), dev(k), dev(v), dev(g2), C, N, M, H, split=True, overflow=ovf)
+        ops.attention_bwd(dev(q), dev(k), dev(v), dev(g2), C, N, M, H, split=split, overflow=ovf)
         assert int(ovf.item()) & 1
 
 

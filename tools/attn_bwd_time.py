@@ -21,7 +21,8 @@ def timed(fn, n=5):
 
 t_k = timed(lambda: ops.attention_bwd(q, k, v, g, C, N, M, H))
 ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-t_s = timed(lambda: ops.attention_bwd(q, k, v, g, C, N, M, H, split=True, overflow=ovf))
+t_s = timed(lambda: ops.attention_bwd(q, k, v, g, C, N, M, H, split=1, overflow=ovf))
+t_a = timed(lambda: ops.attention_bwd(q, k, v, g, C, N, M, H, split=2, overflow=ovf))
 def lib():
     a, b, c_ = (t_.detach().requires_grad_(True) for t_ in (q, k, v))
     o = train_ops._attention_torch(a, b, c_, C, N, M, H)
@@ -30,3 +31,4 @@ t_l = timed(lib)
 flops = 5 * 2.0 * C * N * M * D
 print("attention backward C=%d: kernel %.3f ms (%.1f TFLOP/s fp32 MFMA), library path %.3f ms" % (C, t_k, flops / t_k / 1e9, t_l))
 print("attention backward C=%d, S and dP on the fp16x3 arithmetic (round 5): %.3f ms (%.1f TFLOP/s algorithmic)" % (C, t_s, flops / t_s / 1e9))
+print("attention backward C=%d, all five products on the fp16x3 arithmetic (round 5): %.3f ms (%.1f TFLOP/s algorithmic)" % (C, t_a, flops / t_a / 1e9))
