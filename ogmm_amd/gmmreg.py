@@ -256,6 +256,14 @@ class GMMReg(nn.Module):
         self._side2 = None
         self._ws = None             # persistent zero-initialised buffers of the eval forward (_workspace)
         self._swap = None           # cloud map of the cross-attention (src <-> tgt), per batch size
+        self._head = None
+        # Opt-in for serving loops: the head of a forward (cloud stacking, kNN graph + positional front end, FPS chains: everything that depends on the
+        # inputs alone) is queued on its own streams WITHOUT waiting for what the current stream still has to run, so that it overlaps the latency-bound tail
+        # of the previous forward.  Contract when True: `src` / `tgt` (and `fps_starts`) must be COMPLETE when forward() is called -- not pending on the
+        # current stream -- e.g. inputs resident from an earlier synchronisation, or produced on another stream the caller has waited on.
+        # (First built and withdrawn in the first half of round 5: the FPS chains were not reproducible beside the previous forward's GEMMs.  That was the
+        # packed-fp32 hazard -- DESIGN.md section 4 -- and is gone with it: tests/test_hip_forward.py::test_pipelined_head_...)
+        self.pipeline_head = False
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 
     # -- packed-weight cache: rebuilt when any parameter/buffer was modified or moved.  (data_ptr, _version) catches optimizer steps,
@@ -407,21 +415,32 @@ class GMMReg(nn.Module):
             fps_starts = torch.stack([torch.randint(0, N, (B,), dtype=torch.long) for _ in range(6)])
         main = torch.cuda.current_stream()
         fused_head = ops.knn_pos_head_supported(N, k)
-        # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
-        # tensor makes the host wait for the copy, which is queued behind everything the stream still has to run (the caching host allocator keeps the
-        # pinned block alive until the copy has run).
-        if fps_starts.device.type == "cpu" and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-            fps_starts = fps_starts.reshape(3, 2 * B).to(torch.int32).pin_memory().to(dev, non_blocking=True)
+        # `pipeline_head` (opt-in, see __init__): the head of THIS forward -- anchor draws, cloud stacking, kNN + positional front end, FPS chains; all of it
+        # depends on nothing but the inputs -- goes to its own streams WITHOUT waiting for the work the current stream still holds, so in a loop of forwards
+        # it runs under the tail of the previous one (cluster means, matching, loss: ~0.2 ms on a mostly idle chip) and beside its last GEMMs.
+        pipelined = bool(self.pipeline_head) and fused_head and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+        if pipelined:
+            if self._head is None or self._head[0].device != dev:
+                self._head = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            hs, hs_fps = self._head
         else:
-            fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
-        xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
-        inputs_ready = torch.cuda.Event()          # what the FPS chains wait for: the stacked clouds and the anchor draws, NOT the kNN kernel behind them
-        inputs_ready.record(main)
-        # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch (ops.knn_pos_head: the
-        # 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud the kernel already
-        # holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay on a side stream.
-        if fused_head:
-            idx, idx5, hd, ha = ops.knn_pos_head(xyz, k, L["pos"])
+            hs = hs_fps = main
+        with torch.cuda.stream(hs):
+            # [stage][src clouds | tgt clouds] on the device.  Host draws travel through PINNED memory with a non-blocking copy: `.to(device)` of a pageable
+            # tensor makes the host wait for the copy, which is queued behind everything the stream still has to run (the caching host allocator keeps the
+            # pinned block alive until the copy has run).
+            if fps_starts.device.type == "cpu" and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                fps_starts = fps_starts.reshape(3, 2 * B).to(torch.int32).pin_memory().to(dev, non_blocking=True)
+            else:
+                fps_starts = fps_starts.reshape(3, 2 * B).to(device=dev, dtype=torch.int32).contiguous()
+            xyz = ops.pack_clouds(src, tgt)          # [C,N,3] (src clouds, then tgt clouds): one launch
+            inputs_ready = torch.cuda.Event()          # what the FPS chains wait for: the stacked clouds and the anchor draws, NOT the kNN kernel behind them
+            inputs_ready.record(hs)
+            # The head (round 5): the 20-NN graph, the positional encoding's 5-NN graph and its hidden maps come out of ONE launch (ops.knn_pos_head: the
+            # 5-NN set is the head of the sorted 20-NN list, with its own rank-5 tie resolution, and the front end needs only the cloud the kernel already
+            # holds) -- two kernels less that had to be on the chip before the persistent EdgeConv kernel starts.  Only the FPS chains stay on a side stream.
+            if fused_head:
+                idx, idx5, hd, ha = ops.knn_pos_head(xyz, k, L["pos"])
         if self._swap is None or self._swap.device != dev or self._swap.numel() != C:          # (cached per batch size: four tiny launches per forward otherwise)
             self._swap = torch.cat([torch.arange(B, C, device=dev), torch.arange(0, B, device=dev)]).to(torch.int32)      # built on the device: capturable
         swap = self._swap
@@ -450,7 +469,11 @@ class GMMReg(nn.Module):
         stats3, extra = ws["stats3"], ws["extra"]
         with torch.cuda.stream(side2):
             ids_a = ops.fps(xyz, M, fps_starts)                                   # [3,C,M]: all three random-start samplings at once
-        with torch.cuda.stream(side if fused_head else side2):                  # (beside the anchor chains, not behind them: the EdgeConv kernel waits for both)
+        # (beside the anchor chains, not behind them: the EdgeConv kernel waits for both.  Pipelined: on a stream of its own -- `side` still holds the previous
+        #  forward's E/M and clustering loss, behind which the sampling would not run ahead)
+        if pipelined:
+            hs_fps.wait_event(inputs_ready)
+        with torch.cuda.stream(hs_fps if pipelined else (side if fused_head else side2)):
             ids_j = ops.fps(xyz, J, None)                                         # centre-start sampling for the GMM init
         if not fused_head:
             with torch.cuda.stream(side):
@@ -458,7 +481,7 @@ class GMMReg(nn.Module):
                 hd, ha = ops.pos_hidden(xyz, idx5, 5, L["pos"])      # positional front end (models/attn.py:65-73): needs only xyz and the 5-NN graph
         fps_done, side_done = torch.cuda.Event(), torch.cuda.Event()
         fps_done.record(side2)
-        side_done.record(side)
+        side_done.record(hs_fps if pipelined else side)
         if not fused_head:
             idx = ops.knn(xyz, k)
         # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU.  Queued behind the kNN kernel
@@ -473,6 +496,13 @@ class GMMReg(nn.Module):
         fps_starts.record_stream(side2)
         for t_ in (ids_a, ids_j) + (() if fused_head else (idx5, hd, ha)):
             t_.record_stream(main)
+        if pipelined:
+            main.wait_stream(hs)
+            xyz.record_stream(hs_fps)
+            for t_ in (xyz, idx, idx5, hd, ha):
+                t_.record_stream(main)
+            src.record_stream(hs)
+            tgt.record_stream(hs)
 
         # ---- DGCNN (models/dgcnn.py:133-154)
         R = C * N

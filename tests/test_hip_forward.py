@@ -411,3 +411,31 @@ def test_consecutive_forwards_are_bit_reproducible_without_a_synchronisation():
                 for x, y in zip(a, b):
                     assert torch.equal(x, y)
     assert not model.fp16_overflowed()
+
+
+def test_pipelined_head_gives_the_same_outputs_over_consecutive_forwards():
+    """GMMReg.pipeline_head (round 5): the head of a forward -- kNN graph, positional front end, all FPS chains -- on its own streams, not waiting for the previous
+    forward's tail.  Consecutive forwards on different resident batches, enqueued without a synchronisation in between, must give exactly the outputs of the
+    serial order (same kernels, same inputs: bit-identical), also when the batches alternate between shapes (the workspace is keyed per shape), three times over:
+    the FPS chains now run beside the previous forward's GEMMs, the schedule in which they were NOT reproducible before the library lost its packed-fp32
+    instructions."""
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    model, _ = build(cfg, 16)
+    batches = []
+    for i, (B, N) in enumerate(((6, 1024), (4, 717), (6, 1024), (4, 717), (32, 1024), (32, 1024))):
+        src, tgt, _, _ = synth.make_batch(40 + 10 * i, B, N, "partial")
+        batches.append((src.cuda(), tgt.cuda(), synth.fps_starts_for(40 + 10 * i, B, N)))
+    torch.cuda.synchronize()
+    ref = None
+    for flag in (False, True, True, True):
+        model.pipeline_head = flag
+        with torch.no_grad():
+            res = [[x.clone() for x in model(s, t, fps_starts=st)] for s, t, st in batches]          # no synchronisation between the forwards
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = res
+            continue
+        for a, b in zip(ref, res):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+    assert not model.fp16_overflowed()
