@@ -27,5 +27,16 @@ done
 } > $out/${tag}_pmc_counters.txt
 { echo "# commit $commit"; timeout 300 python3 tools/determinism_check.py 2>&1 | grep -v amdgpu.ids; timeout 300 python3 tools/fps_corun.py 2>&1 | grep -v amdgpu.ids;
   timeout 200 python3 tools/knn_time.py 2>&1 | grep -v amdgpu.ids; timeout 100 python3 tools/featmean_time.py 2>&1 | grep -v amdgpu.ids; timeout 100 python3 tools/host_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_head_and_determinism.txt
-rm -rf $out/trace $out/pmc_*
+# the other workloads and the training step (kernel statistics, per-operation breakdown, the training kernels alone)
+for w in cfg2 cfg3; do timeout 400 python3 bench.py --workload $w --steps 5 --warmup 2 --cpu-sample 0 --secondary 0 2>/dev/null | tail -1 > $out/${tag}_bench_$w.json; done
+timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_train_bench_b128.json
+OGMM_TRAIN_GRAPH=0 timeout 500 python3 bench.py --workload train --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $out/${tag}_train_bench_b128_eager.json
+rocprofv3 --kernel-trace --stats -d $out/trace_train -o r --output-format rocpd -- python3 bench.py --workload train --steps 3 --warmup 2 --cpu-sample 0 > $out/trace_train.log 2>&1
+dbt=$(find $out/trace_train -name "*.db" | head -1)
+{ echo "# commit $commit"; echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload train --steps 3 --warmup 2 --cpu-sample 0   (training steps of 128 pairs: 2 eager + the recording one + 1 warm-up replay + 3 timed replays + 1 eager bracketed step)"; python3 tools/rocpd_stats.py $dbt; } > $out/${tag}_train_kernel_stats.txt
+{ echo "# commit $commit"; echo "# tools/train_breakdown.py 128: forward / backward of the autograd functions of one training step (events)"; timeout 300 python3 tools/train_breakdown.py 128 2>&1 | grep -v amdgpu.ids;
+  echo "# tools/attn_bwd_time.py"; timeout 200 python3 tools/attn_bwd_time.py 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_train_breakdown.txt
+{ echo "# commit $commit"; timeout 300 python3 tools/dw_thin_time.py 2>&1 | grep -v amdgpu.ids; timeout 300 python3 tools/norm_bwd_time.py 2>&1 | grep -v amdgpu.ids;
+  timeout 300 python3 tools/train_call_census.py 128 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_train_kernels.txt
+rm -rf $out/trace $out/pmc_* $out/trace_train
 ls -la $out | grep $tag
