@@ -324,26 +324,55 @@ class _NormLinear(torch.autograd.Function):
         return dy, None, dg, dbeta, None, dW, db, None, None, (dout if ctx.has_res else None)
 
 
+GATHER_SPARSE = os.environ.get("OGMM_GATHER_SPARSE", "1") != "0"      # 0: the anchor gathers' gradients as dense zero-filled maps through ogmm_add_n (A/B)
+
+
 class _Fanout(torch.autograd.Function):
     """n handles of one feature map for its n consumers; the backward adds their gradients in ONE pass (ogmm_add_n) instead of autograd's
-    n - 1 pairwise accumulations (each 2 reads + 1 write of the map)."""
+    n - 1 pairwise accumulations (each 2 reads + 1 write of the map).  `stash` (round 5): a consumer that only GATHERS rows of its handle
+    (_GatherRows: the anchors, 128 of a cloud's 1024 rows) does not return a dense gradient map -- zero-filled, scattered into and read again by
+    the sum, 1.1 GB of traffic per gather at 128 pairs -- but leaves (rows, gradient rows) here, and the sum gets them by one index_add_ on 1 / 8 of its rows."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, stash=None):
+        ctx.stash, ctx.x_shape = stash, tuple(x.shape)
+        ctx.set_materialize_grads(False)          # a handle whose consumer left its gradient in the stash arrives as None, not as a zero map
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
         gs = [g_ for g_ in grads if g_ is not None]
+        sparse = list(ctx.stash) if ctx.stash else []
+        if ctx.stash:
+            ctx.stash.clear()
+        if not gs and not sparse:
+            return None, None, None
         if not gs:
-            return None, None
-        if len(gs) == 1:
-            return gs[0], None
-        gs = [_rm(g_) for g_ in gs]
-        out = ops.add_n(gs[:8])
-        for i in range(8, len(gs), 7):
-            out = ops.add_n([out] + gs[i:i + 7])
-        return out, None
+            out = torch.zeros(ctx.x_shape, dtype=sparse[0][1].dtype, device=sparse[0][1].device)
+        elif len(gs) == 1:
+            out = gs[0].clone() if sparse else gs[0]          # (never scatter into a tensor another node may hold)
+        elif gs:
+            gs = [_rm(g_) for g_ in gs]
+            out = ops.add_n(gs[:8])
+            for i in range(8, len(gs), 7):
+                out = ops.add_n([out] + gs[i:i + 7])
+        for rows, g in sparse:
+            out.index_add_(0, rows, g)
+        return out, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """feats.index_select(0, rows) for a handle of a _Fanout: the backward hands (rows, gradient rows) to the fan-out's sum instead of a dense map."""
+
+    @staticmethod
+    def forward(ctx, feats, rows, stash):
+        ctx.rows, ctx.stash = rows, stash
+        return feats.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.stash.append((ctx.rows, g.contiguous()))
+        return None, None, None
 
 
 class _L2Norm(torch.autograd.Function):
@@ -608,7 +637,14 @@ class TrainOps:
 
     def fanout(self, x, n):
         """n handles of x, one per consumer (see _Fanout)"""
-        return _Fanout.apply(x, n) if x.requires_grad else (x,) * n
+        if not x.requires_grad:
+            return (x,) * n
+        stash = [] if GATHER_SPARSE else None
+        outs = _Fanout.apply(x, n, stash)
+        if stash is not None:
+            for o in outs:
+                o._ogmm_stash = stash          # gather_points() on a handle leaves its gradient rows here
+        return outs
 
     def instnorm_relu(self, z, C, N, stats=None):
         """InstanceNorm1d (no affine, biased variance, eps 1e-5) over the N points of each cloud, then ReLU"""
@@ -623,6 +659,9 @@ class TrainOps:
         S = ids.shape[1]
         clouds = torch.arange(C, device=feats.device) if cloud_map is None else cloud_map
         rows = (clouds[:, None] * N + ids[clouds]).reshape(C * S)
+        stash = getattr(feats, "_ogmm_stash", None)
+        if stash is not None and feats.requires_grad:
+            return _GatherRows.apply(feats, rows, stash)
         return feats.index_select(0, rows)
 
     def attention(self, q, k, v, C, N, M, H):

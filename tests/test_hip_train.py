@@ -396,6 +396,34 @@ def test_fanout_adds_gradients_in_one_pass(rows, cols, n):
     assert TrainOps().fanout(x.detach(), 3)[2] is not None
 
 
+@pytest.mark.parametrize("n_dense", [0, 1, 3])
+def test_fanout_takes_a_gathers_gradient_as_rows(n_dense):
+    """Round 5: a handle of a fan-out that is only GATHERED from (gather_points: the anchors) leaves (rows, gradient rows) with the fan-out instead of a dense
+    zero-filled map; the sum then gets them by one index_add_.  Same gradient as the dense path (the gathered rows are distinct), with 0, 1 and 3 dense consumers
+    beside TWO gathers of the same map, and an unused handle in between."""
+    C, N, D, S = 3, 200, 64, 16
+    g = torch.Generator().manual_seed(7 + n_dense)
+    x0 = torch.randn(C * N, D, generator=g).to(DEV)
+    ids = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(C)]).to(DEV)
+    ids2 = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(C)]).to(DEV)
+    gd = [torch.randn(C * N, D, generator=g).to(DEV) for _ in range(n_dense)]
+    gg, gg2 = torch.randn(C * S, D, generator=g).to(DEV), torch.randn(C * S, D, generator=g).to(DEV)
+    o = TrainOps()
+    x = x0.clone().requires_grad_(True)
+    hs = o.fanout(x, n_dense + 3)
+    a = o.gather_points(hs[0], C, N, ids)
+    a2 = o.gather_points(hs[-1], C, N, ids2)
+    assert type(a.grad_fn).__name__.startswith("_GatherRows")
+    loss = (a * gg).sum() + (a2 * gg2).sum() + sum((h_ * g_).sum() for h_, g_ in zip(hs[1:1 + n_dense], gd))          # hs[n_dense + 1] stays unused
+    loss.backward()
+    xr = x0.clone().requires_grad_(True)
+    r = RefTrainOps()
+    loss_r = (r.gather_points(xr, C, N, ids) * gg).sum() + (r.gather_points(xr, C, N, ids2) * gg2).sum() + sum((xr * g_).sum() for g_ in gd)
+    loss_r.backward()
+    assert torch.allclose(x.grad, xr.grad, rtol=0, atol=1e-5 * float(xr.grad.abs().max()))
+    assert torch.equal(a.detach(), r.gather_points(x0, C, N, ids))
+
+
 @pytest.mark.parametrize("B,J,reflect", [(5, 16, False), (3, 8, True), (4, 128, False)])
 def test_kabsch_forward_backward(B, J, reflect):
     g = torch.Generator().manual_seed(B * J)
