@@ -132,10 +132,11 @@ def forward_train(ops, P, cfg, n_clusters, src, tgt, fps_starts, cap=None):
     f2 = transformer(ops, P, "sattn2", (f_q, f_m), a2, C, N, M, H, res=f_r)       # gmmreg.py:92-97
 
     gamma, pi, mu = ops.gmm_em(xyz, o.detach(), ids_j)                            # no gradient (lib/utils.py:275-288)
-    muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)                                  # [C,J,D], gradient to f2 only
+    f2_m, f2_g = ops.fanout(f2, 2)                                                # (round 5: the nearest-point gather below hands its 16 gradient rows per cloud to this sum)
+    muf = ops.gmm_feat_mean(gamma, pi, f2_m, C, N)                                # [C,J,D], gradient to f2 only
     R, t = ops.match_kabsch(mu[:B], mu[B:], muf[:B], muf[B:], 0.05)               # gmmreg.py:102-103
     near = ops.nearest_point(xyz, mu)                                             # [C,J] (lib/utils.py:244-254)
-    anchors_f = ops.gather_points(f2, C, N, near).view(C, J, D)
+    anchors_f = ops.gather_points(f2_g, C, N, near).view(C, J, D)
     clu = 0.5 * (losses.info_nce(anchors_f[:B], muf[:B], 0.1) + losses.info_nce(anchors_f[B:], muf[B:], 0.1))
     if cap is not None:
         cap.update(knn_idx=idx, fps_anchor=ids_a, fps_J=ids_j, emb=emb, x0=x0, ft=ft, f=f, f2=f2, o=o, gamma=gamma, pi=pi, mu=mu,
