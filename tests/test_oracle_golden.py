@@ -120,3 +120,37 @@ def test_one_ulp_jitter_probe_is_deterministic_small_and_separates_conditioning(
             jit = O.forward(P, cfg, src, tgt, st)[0]
     moved = O.rotation_error_rad(jit.double(), ref.double()).max().item()
     assert 0 < moved < 5e-6, moved
+
+
+def test_summation_order_probe_is_exact_products_in_another_order():
+    """oracle/split_emulation.py "sum:<seed>" (round 5, late; the second host-independent part of reference_spread): every contraction as four interleaved partial
+    contractions added in a seeded order.  It must (i) be a pure function of its seed and differ between seeds, (ii) stay a rounding-level change -- as close to
+    the fp64 product as the plain fp32 call is -- for convolutions and for the weight-free contractions (attention scores, similarity), and (iii) leave a
+    well-conditioned pair of the default family within ~1e-6 rad: it must not make ordinary pairs look ill-conditioned."""
+    from argparse import Namespace
+    import torch.nn.functional as F
+    from oracle import split_emulation as E
+    from ogmm_amd import synth
+    from ogmm_amd.gmmreg import GMMReg
+    g = torch.Generator().manual_seed(1)
+    x, w = torch.randn(2, 256, 300, generator=g), torch.randn(32, 256, 1, generator=g)
+    exact, truth = F.conv1d(x, w), F.conv1d(x.double(), w.double())
+    a, a2, b = E.conv(x, w, None, "sum:1"), E.conv(x, w, None, "sum:1"), E.conv(x, w, None, "sum:2")
+    assert torch.equal(a, a2) and not torch.equal(a, b) and not torch.equal(a, exact)
+    assert (a.double() - truth).abs().max() < 2 * (exact.double() - truth).abs().max() + 1e-6
+    q, k = torch.randn(3, 4, 50, 32, generator=g), torch.randn(3, 4, 20, 32, generator=g)
+    s_ = E.einsum("bhnd,bhmd->bhnm", q, k, "sum:3")
+    t_ = torch.einsum("bhnd,bhmd->bhnm", q.double(), k.double())
+    assert not torch.equal(s_, torch.einsum("bhnd,bhmd->bhnm", q, k)) and (s_.double() - t_).abs().max() < 1e-5
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    m = GMMReg(512, 16, cfg)
+    synth.fill_state_dict(m.state_dict())
+    P = {k_: v.clone() for k_, v in m.state_dict().items()}
+    src, tgt, _, _ = synth.make_batch(0, 1, 512, "partial")
+    st = synth.fps_starts_for(0, 1, 512)
+    with torch.no_grad():
+        ref = O.forward(P, cfg, src, tgt, st)[0]
+        with E.policy(lambda name: "sum:2"):
+            other = O.forward(P, cfg, src, tgt, st)[0]
+    moved = O.rotation_error_rad(other.double(), ref.double()).max().item()
+    assert 0 < moved < 5e-6, moved
