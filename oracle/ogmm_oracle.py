@@ -121,7 +121,7 @@ def sinkhorn_log(cost, p, q=None, epsilon=1e-2, thresh=1e-2, max_iter=100, resid
         if diff.mean().item() < thresh:
             break
     K = (-cost + u[:, :, None] + v[:, None, :]) / epsilon
-    return torch.exp(K), iters
+    return _emu.ew(torch.exp(K), 'em.gamma'), iters
 
 
 def gmm_moments(gamma, pts):
@@ -273,7 +273,7 @@ def transformer(P, name, src, anchors, heads, cap=None):
     q = _conv(P, name + '.attn.proj.0', src).view(B, dh, heads, -1)
     kk = _conv(P, name + '.attn.proj.1', anchors).view(B, dh, heads, -1)
     vv = _conv(P, name + '.attn.proj.2', anchors).view(B, dh, heads, -1)
-    prob = torch.softmax(_einsum(name + '.attn.qk', 'bdhn,bdhm->bhnm', q, kk) / dh ** .5, dim=-1)
+    prob = _emu.ew(torch.softmax(_einsum(name + '.attn.qk', 'bdhn,bdhm->bhnm', q, kk) / dh ** .5, dim=-1), name + '.attn.softmax')
     if cap is not None:                                       # diagnostic only: how peaked the attention is (mean over queries of the largest probability; 1/M = uniform)
         cap.setdefault('attn_maxprob_list_' + name, []).append(prob.max(dim=-1)[0].mean().item())
         cap['attn_maxprob_' + name] = sum(cap['attn_maxprob_list_' + name]) / len(cap['attn_maxprob_list_' + name])
@@ -297,7 +297,7 @@ def match_and_solve(mu_s, mu_t, f_s, f_t):
     """models/dgcnn.py:96-115 (`GMMSVD.forward`, is_sk=False) + lib/utils.py:222-226.
     mu_* [B,J,3], f_* [B,J,D] -> R [B,3,3], t [B,3]."""
     sim = torch.einsum('bnd,bmd->bnm', F.normalize(f_s, dim=-1, p=2), F.normalize(f_t, dim=-1, p=2))
-    sc = torch.softmax(sim / 0.05, dim=2)
+    sc = _emu.ew(torch.softmax(sim / 0.05, dim=2), 'match.softmax')
     corr = torch.einsum('bmd,bnm->bdn', mu_t, sc)
     w = sc.sum(dim=-1).unsqueeze(1)
     R, t = kabsch(mu_s.transpose(1, 2), corr, w)
@@ -368,8 +368,8 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
     sim = _einsum('similarity', 'bdm,bdn->bmn', fn['src'], fn['tgt'])
     for s in pts:
         o_logit[s] = conv_stack(P, 'proj', f[s], False)
-    wo = {'src': torch.einsum('bmn,bdn->bdm', torch.softmax(sim, dim=-1), o_logit['src']),
-          'tgt': torch.einsum('bmn,bdm->bdn', torch.softmax(sim, dim=1), o_logit['tgt'])}
+    wo = {'src': torch.einsum('bmn,bdn->bdm', _emu.ew(torch.softmax(sim, dim=-1), 'overlap.softmax.rows'), o_logit['src']),
+          'tgt': torch.einsum('bmn,bdm->bdn', _emu.ew(torch.softmax(sim, dim=1), 'overlap.softmax.cols'), o_logit['tgt'])}
     o = {}
     for s in pts:                                           # gmmreg.py:82-89
         fo = conv_stack(P, 'conv2', torch.cat([f[s], wo[s], o_logit[s]], dim=1), True)

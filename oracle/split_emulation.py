@@ -16,6 +16,10 @@ The HIP path's GEMM engine multiplies fp32 operands as sums of binary16 terms on
                   in a seeded order: what any tiled or multi-threaded fp32 GEMM does differently from the next one.  One-ulp input jitter perturbs what goes
                   INTO the sums; this perturbs HOW they are summed, which is the difference between two fp32 implementations that the jitter can miss
                   (sharp configs[1] pair 298: jitter 2e-6, two summation orders of the same engine 2e-5 apart; profiles/round5_parity_extended.txt).
+    "ew:<seed>"   NOT an engine mode -- the third conditioning probe (round 5, late): exact fp32 GEMMs, but the results of the reference's TRANSCENDENTAL steps -- the
+                  attention softmax, the overlap block's two softmaxes, the matching softmax, the E/M's final exp -- moved by one unit in the last place (ew()
+                  below, called by the oracle at those sites; the identity without a policy).  A second implementation differs from the reference there too (v_exp_f32,
+                  another order in the softmax sums), which the two GEMM probes do not model.
 This module restates those roundings on the CPU so that the oracle can answer, per layer, "what does rounding THIS layer's operands do to
 (R, t)?" -- the measurement behind the engine's per-layer term budget (tools/term_budget.py) and behind the stated tolerance of the reduced
 precision mode (tests/test_hip_forward.py::test_reduced_precision_mode_against_the_emulating_oracle).  It emulates the operand roundings, not
@@ -53,6 +57,8 @@ def mode_of(name):
     m = _POLICY(name)
     if m is not None and (m.startswith("ulp:") or m.startswith("sum:")):
         return m
+    if m is not None and m.startswith("ew:"):
+        return None          # (the GEMMs of an "ew" evaluation are exact)
     if m is not None and m not in MODES:
         raise ValueError("unknown emulation mode %r for %s" % (m, name))
     return None if m == "f32" else m
@@ -82,6 +88,18 @@ def _jitter(a, mode, salt):
     g = torch.Generator().manual_seed((int(mode[4:]) * 1000003 + salt) % (2 ** 31))
     sign = torch.randint(0, 2, a.shape, generator=g, dtype=torch.int8).to(a.dtype) * 2 - 1
     return a * (1.0 + sign * 2.0 ** -24) if a.dtype == torch.float32 else a
+
+
+def ew(x, site):
+    """the oracle's hook at its softmax / exp sites: x unchanged unless an "ew:<seed>" policy is installed, then x (1 +- 2^-24) with a random sign per element"""
+    if _POLICY is None or x.dtype != torch.float32:
+        return x
+    m = _POLICY(site)
+    if m is None or not m.startswith("ew:"):
+        return x
+    g = torch.Generator().manual_seed((int(m[3:]) * 1000003 + sum(ord(c) for c in site) * 7919 + x.numel()) % (2 ** 31))
+    sign = torch.randint(0, 2, x.shape, generator=g, dtype=torch.int8).to(x.dtype) * 2 - 1
+    return x * (1.0 + sign * 2.0 ** -24)
 
 
 def _resummed(parts, mode):

@@ -154,3 +154,35 @@ def test_summation_order_probe_is_exact_products_in_another_order():
             other = O.forward(P, cfg, src, tgt, st)[0]
     moved = O.rotation_error_rad(other.double(), ref.double()).max().item()
     assert 0 < moved < 5e-6, moved
+
+
+def test_transcendental_step_probe_is_the_identity_without_a_policy_and_a_last_place_change_with_one():
+    """oracle/split_emulation.py ew() / "ew:<seed>" (round 5, late; the third host-independent part of reference_spread): the oracle's softmax / exp results moved
+    by one unit in the last place.  Without a policy the hook returns its argument (the oracle stays bit-identical to the reference: the golden tests above); with
+    one it is deterministic per (seed, site), differs between seeds and sites, changes nothing by more than 2^-23 relative, leaves the GEMMs exact, and moves a
+    well-conditioned pair by ~1e-6 rad."""
+    from argparse import Namespace
+    from oracle import split_emulation as E
+    from ogmm_amd import synth
+    from ogmm_amd.gmmreg import GMMReg
+    x = torch.softmax(torch.randn(4, 7, 33, generator=torch.Generator().manual_seed(3)), -1)
+    assert E.ew(x, "a.softmax") is x
+    with E.policy(lambda name: "ew:1"):
+        a, a2, b = E.ew(x, "a.softmax"), E.ew(x, "a.softmax"), E.ew(x, "b.softmax")
+        assert E.mode_of("emd.conv1") is None          # GEMMs exact under an "ew" policy
+    with E.policy(lambda name: "ew:2"):
+        c = E.ew(x, "a.softmax")
+    assert torch.equal(a, a2) and not torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, x)
+    assert ((a - x).abs() <= x.abs() * 2.0 ** -23).all()
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
+    m = GMMReg(512, 16, cfg)
+    synth.fill_state_dict(m.state_dict())
+    P = {k_: v.clone() for k_, v in m.state_dict().items()}
+    src, tgt, _, _ = synth.make_batch(0, 1, 512, "partial")
+    st = synth.fps_starts_for(0, 1, 512)
+    with torch.no_grad():
+        ref = O.forward(P, cfg, src, tgt, st)[0]
+        with E.policy(lambda name: "ew:1"):
+            other = O.forward(P, cfg, src, tgt, st)[0]
+    moved = O.rotation_error_rad(other.double(), ref.double()).max().item()
+    assert 0 < moved < 5e-6, moved
