@@ -169,7 +169,11 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
     float* __restrict__ Cm = g.C;
     const float* __restrict__ Rm = g.Res;
     const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 tot1 = zero4, tot2 = zero4;        // column statistics of this wave's MT*32 rows (InstanceNorm fusion)
+    // column statistics of this wave's MT*32 rows (InstanceNorm / BatchNorm fusion), accumulated in fp64 from the first value on (round 6): the consumer forms
+    // var = E[y^2] - mean^2, and with fp32 partial sums of y^2 that difference loses |mean|^2 / var units of 2^-24 -- a channel whose mean is 30 ... 100 standard
+    // deviations (the sharp weight family has them: mean^2 / var up to 9500) got its normalised values 1e-5 off, which the parity tail's ill-conditioned pairs
+    // amplify (tools/tail_bisect.py; DESIGN.md section 2 "Round 6").  The squares of fp32 values are exact in fp64.
+    double tot1[4] = {0.0, 0.0, 0.0, 0.0}, tot2[4] = {0.0, 0.0, 0.0, 0.0};
     // Fast path: the workgroup's whole tile is inside the matrix and scale / shift are per column.  A lane's four columns are the same
     // in every pass (idx % F4_PER_ROW == lane % F4_PER_ROW), so scale / shift are fetched once, and every load and store below is
     // unconditional.  That matters beyond the instruction count: with loads or stores under per-lane conditions the compiler cannot
@@ -227,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
                 *reinterpret_cast<f32x4*>(Cm + (int64_t)(row0 + q * RSTEP) * g.ldc + col) = v;
                 if (stats) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { tot1[e] += v[e]; tot2[e] = fmaf(v[e], v[e], tot2[e]); }
+                    for (int e = 0; e < 4; ++e) { const double vd = (double)v[e]; tot1[e] += vd; tot2[e] = fma(vd, vd, tot2[e]); }
                 }
             }
         };
@@ -308,7 +312,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
                 *reinterpret_cast<f32x4*>(Cm + (int64_t)row * g.ldc + col) = v;
                 if (g.col_stats) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { tot1[e] += v[e]; tot2[e] = fmaf(v[e], v[e], tot2[e]); }
+                    for (int e = 0; e < 4; ++e) { const double vd = (double)v[e]; tot1[e] += vd; tot2[e] = fma(vd, vd, tot2[e]); }
                 }
             }
         }
@@ -326,8 +330,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
             double* st = g.col_stats + (int64_t)((first_row >> 8) & g.col_stats_slot_mask) * g.col_stats_slot_stride + ((int64_t)(first_row / g.group_rows) * g.N + col) * 2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                atomicAdd(st + 2 * e, (double)tot1[e]);
-                atomicAdd(st + 2 * e + 1, (double)tot2[e]);
+                atomicAdd(st + 2 * e, tot1[e]);
+                atomicAdd(st + 2 * e + 1, tot2[e]);
             }
         }
     }
@@ -337,7 +341,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
 // from the accumulator layout (lane = column, register = row: the 32 lanes of a half wave write one 128-byte row segment -- a full line --
 // per store), no LDS for the values.  Requires the slab to be inside the matrix, per-column scale / shift, no pooling.  Column statistics
 // (InstanceNorm fusion): a lane sums its 16 rows, the two half waves are folded with one cross-lane move, and the wave's NB * 32 partial sums go
-// to `stat_lds` ([row block = stat_slot, by default the wave][NB * 32][2] floats, the caller's K loop is over): the caller adds the eight waves up and issues ONE fp64 atomic per
+// to `stat_lds` ([row block = stat_slot, by default the wave][NB * 32][2] DOUBLES -- 32 KiB for eight row blocks of 256 columns; floats in the NBS form --, the caller's K loop is over): the caller adds the eight waves up and issues ONE fp64 atomic per
 // column and statistic per tile (per wave it would be 4096 atomics per tile: measured +10 % on the 1024-wide layers that feed a normalisation).
 // RES_AHEAD (a caller with ~128 registers to spare: the 512-register engine): all NB * 16 residual values of the slab are requested before the first
 // one is used, so that their latency is exposed once per slab instead of once per column block.
@@ -412,7 +416,7 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
                     for (int r = 0; r < 16; ++r) rr[r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
                 }
             }
-            float sum1 = 0.0f, sum2 = 0.0f;
+            double sum1 = 0.0, sum2 = 0.0;          // fp64 from the first value on: see gemm_epilogue_wide
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float y = fmaf(acc[j][r], s1, t1);
@@ -421,14 +425,15 @@ __device__ __forceinline__ void gemm_epilogue_rowblock(const ogmm_gemm& g, f32x1
                 else if (KIND == OGMM_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
                 if (Rm) y += rr[r];
                 cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = y;
-                if (stats) { sum1 += y; sum2 = fmaf(y, y, sum2); }
+                if (stats) { const double yd = (double)y; sum1 += yd; sum2 = fma(yd, yd, sum2); }
             }
             if (stats) {
                 sum1 += __shfl_xor(sum1, 32, 64);
                 sum2 += __shfl_xor(sum2, 32, 64);
                 if (lh == 0) {
-                    stat_lds[(wave * NB * 32 + j * 32 + lr) * 2] = sum1;
-                    stat_lds[(wave * NB * 32 + j * 32 + lr) * 2 + 1] = sum2;
+                    double* sd = reinterpret_cast<double*>(stat_lds);
+                    sd[(wave * NB * 32 + j * 32 + lr) * 2] = sum1;
+                    sd[(wave * NB * 32 + j * 32 + lr) * 2 + 1] = sum2;
                 }
             }
         }

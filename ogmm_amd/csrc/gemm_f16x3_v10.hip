@@ -463,7 +463,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v10_kernel(const ogmm_gemm g, co
             for (int which = 0; which < 2; ++which) {
                 double tot = 0.0;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) tot += (double)stat_lds[(w * 256 + c) * 2 + which];
+                for (int w = 0; w < 8; ++w) tot += NBS ? (double)stat_lds[(w * 256 + c) * 2 + which] : reinterpret_cast<const double*>(stat_lds)[(w * 256 + c) * 2 + which];
                 atomicAdd(g.col_stats + (int64_t)((m0 >> 8) & g.col_stats_slot_mask) * g.col_stats_slot_stride + ((int64_t)(m0 / g.group_rows) * g.N + n0 + c) * 2 + which, tot);
             }
         }

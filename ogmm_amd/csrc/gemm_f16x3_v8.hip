@@ -268,7 +268,7 @@ __global__ __launch_bounds__(T) void gemm_f16x3_v8_kernel(const ogmm_gemm g, con
             const int c = tid & 255, which = tid >> 8;
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) tot += (double)stat_lds[(w * 256 + c) * 2 + which];
+            for (int w = 0; w < 8; ++w) tot += reinterpret_cast<const double*>(stat_lds)[(w * 256 + c) * 2 + which];
             atomicAdd(g.col_stats + (int64_t)((m0 >> 8) & g.col_stats_slot_mask) * g.col_stats_slot_stride + ((int64_t)(m0 / g.group_rows) * g.N + n0 + c) * 2 + which, tot);
         }
     } else {

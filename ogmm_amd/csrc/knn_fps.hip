@@ -889,11 +889,15 @@ extern "C" int ogmm_pack_clouds(const float* src, const float* tgt, int B, int N
     return ogmm::check_launch("ogmm_pack_clouds");
 }
 
+constexpr size_t KNN_HEAD_STATIC_LDS = 8 * 1024;          // >= knn4_kernel's group_segment_fixed_size (tests/test_abi_and_host.py reads it off the code object)
 static bool knn_head_fits(int N, int k, int* fold_out) {
     if (N <= 0 || k <= 8 || k > 32 || k > N || N < 6) return false;
     const int KLsel = k <= 20 ? 21 : 33;
     const size_t lds = (size_t)N * sizeof(float4), lds2 = lds + (size_t)2 * (KLsel - 1) * 256 * sizeof(short);
-    if (lds2 > 64 * 1024) return false;
+    // the workgroup's budget is 64 KiB INCLUDING knn4_kernel's static arrays (tie_rows, geo, the tie resolution's scratch: ~8.3 KiB; ADVICE.md round 5 -- the
+    // check used to bound the dynamic part alone, so N = 2369 ... 2816 answered "supported" for a 72 KiB workgroup nothing had ever launched).  Beyond it the
+    // forward takes the three-kernel head (ogmm_knn + ogmm_knn(5) + ogmm_pos_hidden).
+    if (lds2 + KNN_HEAD_STATIC_LDS > 64 * 1024) return false;
     // both tie resolutions (rank k, rank 5) run in the LDS of the candidate lists: the scratch of ogmm_knn's folded form
     const size_t lists_bytes = lds2 - lds;
     const bool heap = (long long)k * 64 <= N;

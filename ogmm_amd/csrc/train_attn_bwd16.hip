@@ -328,7 +328,16 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float* __res
                 }
         }
     }
-    if (overflow && !(amax <= 65504.0f)) atomicOr(overflow, 1);          // an operand beyond binary16's range (or NaN / Inf): the trainer lowers its loss scale
+    {
+        // v_max_f32 returns its non-NaN operand, so a NaN in q / k / v / dO never shows in amax; it does reach dV (through P or dO) or dK
+        // (through dP), so the two accumulator sets tell
+        float chk = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { chk = fmaf(dvacc[t][r], 0.0f, chk); chk = fmaf(dkacc[t][r], 0.0f, chk); }
+        if (overflow && (!(amax <= 65504.0f) || chk != chk)) atomicOr(overflow, 1);          // an operand beyond binary16's range, Inf or NaN: the trainer lowers its loss scale
+    }
 
     // ---- dK, dV blocks of the wave: lane = column d, registers = keys
     {

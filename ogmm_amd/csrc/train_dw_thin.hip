@@ -167,7 +167,16 @@ __global__ __launch_bounds__(256, 2) void dw_thin16_kernel(const float* __restri
                 acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[e], bh[f], acc[e][f], 0, 0, 0);
             }
     }
-    if (overflow && !(amax <= 65504.0f)) atomicOr(overflow, 1);          // (NaN / Inf inputs land here too)
+    // v_max_f32 returns its non-NaN operand, so a NaN operand never shows in amax: NaN (and an Inf whose binary16 hi part met a zero)
+    // is read off the accumulators instead -- every input element of the workgroup's slab multiplies into one of them
+    float chk = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = 0; f < KV; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk = fmaf(acc[e][f][r], 0.0f, chk);
+    if (overflow && (!(amax <= 65504.0f) || chk != chk)) atomicOr(overflow, 1);          // an operand beyond binary16's range, Inf or NaN
     float* __restrict__ out = part + stream * (int64_t)n * k;
 #pragma unroll
     for (int e = 0; e < NV; ++e)

@@ -255,6 +255,7 @@ class GMMReg(nn.Module):
         self._side = None
         self._side2 = None
         self._ws = None             # persistent zero-initialised buffers of the eval forward (_workspace)
+        self._capture_ws = None     # ... and the set capture_graph() prepares for the forward it records
         self._swap = None           # cloud map of the cross-attention (src <-> tgt), per batch size
         self._head = None
         # Opt-in for serving loops: the head of a forward (cloud stacking, kNN graph + positional front end, FPS chains: everything that depends on the
@@ -312,6 +313,14 @@ class GMMReg(nn.Module):
         """Persistent zero-initialised buffers of the eval forward, one set per (stream, shape) -- a model that is driven from two streams at once gets
         two sets -- at most four sets are kept.  `clean` is False while a forward is between its first accumulation and its last finalize: a forward that
         raised in between leaves statistics behind, and the next one re-zeroes them."""
+        if torch.cuda.is_current_stream_capturing():
+            # Under stream capture nothing may be created or trusted here: a torch.zeros would be RECORDED (and its 16.8 MB fill replayed with every graph
+            # launch), and a `clean` flag set by an earlier capture on the same capture stream says nothing about memory the graph has not run on yet.
+            # capture_graph() hands in a set it created and zeroed eagerly, owns for the graph's lifetime and never shares (ADVICE.md round 5).
+            ws = self._capture_ws
+            if ws is None or ws["key"] != (str(dev), C, N, D, XW):
+                raise OgmmError("eval forward under stream capture without a prepared workspace: use GMMReg.capture_graph()")
+            return ws
         key = (str(dev), stream.cuda_stream, C, N, D, XW)
         if self._ws is None:
             self._ws = {}
@@ -732,9 +741,20 @@ class GMMReg(nn.Module):
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
         self._raise_pending_overflow(wait=True)          # the warm-up forwards' range check, before anything is recorded
+        # the recorded forward's persistent buffers: created and zeroed HERE (eagerly, before anything is recorded), owned by the returned closure -- not an entry of
+        # the per-stream cache, so no other forward, capture or eviction ever touches memory a live graph addresses
+        D, C = self.emb_dims, 2 * batch
+        XW = self._layers()["conv2"]["0"]["W"].shape[1] - D
+        ws = {"stats3": torch.zeros((3, C, 2 * D, 2), dtype=torch.float64, device=dev),
+              "extra": torch.zeros((C * n_points, XW), dtype=torch.float32, device=dev), "clean": True, "key": (str(dev), C, n_points, D, XW)}
+        torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph), torch.no_grad():
-            outs = self.forward(s_src, s_tgt, fps_starts=s_starts)
+        self._capture_ws = ws
+        try:
+            with torch.cuda.graph(graph), torch.no_grad():
+                outs = self.forward(s_src, s_tgt, fps_starts=s_starts)
+        finally:
+            self._capture_ws = None
 
         def run(src, tgt, fps_starts=None):
             if tuple(src.shape) != (batch, 3, n_points) or tuple(tgt.shape) != (batch, 3, n_points):
@@ -747,6 +767,7 @@ class GMMReg(nn.Module):
             graph.replay()
             return outs
         run.graph = graph
+        run.workspace = ws          # (keeps the graph's statistics / conv2 side-input buffers alive as long as the closure)
         return run
 
     def overflow_flag(self, device=None):

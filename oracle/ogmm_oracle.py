@@ -319,7 +319,10 @@ def forward(P, cfg, src, tgt, fps_starts=None, cap=None, inject=None, train=Fals
     P: the reference state_dict (153 keys); cfg: gnn_k, num_heads, km_clusters (+ n_clusters);
     src, tgt [B,3,N].  fps_starts [6,B] pins the random FPS starts (drawn like the reference
     when None).  `cap` (dict) receives intermediates; `inject` may carry 'knn_idx_src/tgt' to
-    pin the kNN graph.  Returns (R [B,3,3], t [B,3], src_o [B,N], tgt_o [B,N], loss [])."""
+    pin the kNN graph, and -- for stage-by-stage bisection of a second implementation (tools/tail_bisect.py) -- any of
+    'emb_<s>', 'ft_<s>', 'f_<s>', 'f2_<s>' [B,D,N], 'o_<s>' [B,N], 'em_<s>' = (gamma [B,N,J], pi [B,J], mu [B,J,3]) and
+    'muf_<s>' [B,J,D] (s = src / tgt): the stage's own result is replaced by the injected one and everything downstream
+    is evaluated in this file's arithmetic.  Returns (R [B,3,3], t [B,3], src_o [B,N], tgt_o [B,N], loss [])."""
     global _BN_TRAINING
     _BN_TRAINING = bool(train)
     try:
@@ -349,6 +352,7 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
     for s in pts:                                           # gmmreg.py:52-57
         c = {}
         emb[s] = dgcnn_embed(P, pts[s], k, inject.get('knn_idx_' + s), c)
+        emb[s] = inject.get('emb_' + s, emb[s])
         cap['knn_idx_' + s] = c['knn_idx']
         cap['emb_' + s] = emb[s]
     for s in pts:
@@ -357,12 +361,12 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
         pos = pos_encoding(P, pts[s], 5, cap['knn_idx_' + s][:, :, :5] if k >= 5 and 'knn_idx_' + s in inject else None)
         cap['pos_' + s] = pos
         x = emb[s] + pos
-        ft[s] = conv_stack(P, 'conv1', transformer(P, 'sattn1', x, a0[s], H, cap) + x, True)
+        ft[s] = inject['ft_' + s] if 'ft_' + s in inject else conv_stack(P, 'conv1', transformer(P, 'sattn1', x, a0[s], H, cap) + x, True)
         cap['ft_' + s] = ft[s]
     for s in pts:                                           # gmmreg.py:67-70
         a1[s] = anchors(s, ft[s], 1)
     for s in pts:                                           # gmmreg.py:71-72
-        f[s] = transformer(P, 'cattn', ft[s], a1[other[s]], H, cap) + ft[s]
+        f[s] = inject['f_' + s] if 'f_' + s in inject else transformer(P, 'cattn', ft[s], a1[other[s]], H, cap) + ft[s]
         cap['f_' + s] = f[s]
     fn = {s: F.normalize(f[s]) for s in pts}                # gmmreg.py:74-80
     sim = _einsum('similarity', 'bdm,bdn->bmn', fn['src'], fn['tgt'])
@@ -373,19 +377,24 @@ def _forward(P, cfg, src, tgt, fps_starts, cap, inject):
     o = {}
     for s in pts:                                           # gmmreg.py:82-89
         fo = conv_stack(P, 'conv2', torch.cat([f[s], wo[s], o_logit[s]], dim=1), True)
-        o[s] = torch.sigmoid(conv_stack(P, 'overlap', fo, True)).view(B, -1)
+        o[s] = inject['o_' + s] if 'o_' + s in inject else torch.sigmoid(conv_stack(P, 'overlap', fo, True)).view(B, -1)
         cap['wo_' + s] = wo[s]
         cap['o_' + s] = o[s]
     a2, f2 = {}, {}
     for s in pts:                                           # gmmreg.py:92-95
         a2[s] = anchors(s, f[s], 2)
     for s in pts:                                           # gmmreg.py:96-97
-        f2[s] = transformer(P, 'sattn2', f[s], a2[s], H, cap) + f[s]
+        f2[s] = inject['f2_' + s] if 'f2_' + s in inject else transformer(P, 'sattn2', f[s], a2[s], H, cap) + f[s]
         cap['f2_' + s] = f2[s]
     clu = {}
     for s in pts:                                           # gmmreg.py:100-101, :24-29
         st, rs = [], []
         clu[s] = weighted_em(xyz[s], f2[s].transpose(1, 2), o[s], J, iters=10, tau=1.0, stats=st, resid=rs)
+        if 'em_' + s in inject:                                 # (gamma, pi, mu) of another implementation; the feature means follow from ITS gamma, in this arithmetic
+            g_, pi_, mu_ = inject['em_' + s]
+            clu[s] = (g_, pi_, mu_, gmm_moments(g_, f2[s].transpose(1, 2))[1], clu[s][4])
+        if 'muf_' + s in inject:
+            clu[s] = clu[s][:3] + (inject['muf_' + s], clu[s][4])
         cap['gamma_' + s], cap['pi_' + s], cap['mu_' + s], cap['muf_' + s], cap['fpsJ_' + s] = clu[s]
         cap['sk_iters_' + s] = st                               # sweeps every E-step ran (lib/utils.py:99-102: the batch-mean early exit)
         cap['sk_resid_' + s] = rs                               # every sweep's per-cloud residual [B], in execution order

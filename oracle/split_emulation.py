@@ -9,7 +9,7 @@ The HIP path's GEMM engine multiplies fp32 operands as sums of binary16 terms on
     "bf16" both operands rounded to bfloat16    what BASELINE configs[2] literally names; shown for comparison
     "f32" / None  exact fp32 (the reference's arithmetic)
     "ulp:<seed>"  NOT an engine mode -- a conditioning probe (round 5): exact fp32 arithmetic on operands whose activation side was moved by ONE UNIT IN THE
-                  LAST PLACE with a random sign per element (x (1 +- 2^-24), seeded per layer): the classical stochastic-arithmetic estimate (CESTAC / CADNA)
+                  LAST PLACE with a random sign per element (each element to its upper or lower fp32 neighbour, seeded per layer): the classical stochastic-arithmetic estimate (CESTAC / CADNA)
                   of how far a result is defined.  A pair whose (R, t) moves by >= 5e-6 under it is ill-conditioned whatever host evaluates the reference.
     "sum:<seed>"  NOT an engine mode -- the second conditioning probe (round 5, late): exact fp32 products, ANOTHER ORDER OF ADDITIONS.  Every contraction is
                   evaluated as four partial contractions over an interleaved split of its index (k = seed-shifted residues mod 4) whose fp32 results are added
@@ -83,15 +83,22 @@ def split16(x, scale_pow2=False):
     return hi, rn16(x - hi), inv
 
 
+def one_ulp(a, sign):
+    """every element of `a` moved to its NEIGHBOURING fp32 value, away from zero where sign = +1, towards zero where sign = -1 (zeros stay).
+    (Round 5 built this as a * (1 + sign * 2^-24) with the factor held in fp32: 1 + 2^-24 rounds to 1, so only the sign = -1 half ever moved --
+    ADVICE.md round 5; tests/test_oracle_golden.py::test_one_ulp_probe_moves_both_ways keeps it two-sided.)"""
+    return torch.nextafter(a, a + sign * a)
+
+
 def _jitter(a, mode, salt):
     """a moved by one unit in the last place, random sign per element; deterministic in (seed of the mode, salt = the operand's shape)"""
     g = torch.Generator().manual_seed((int(mode[4:]) * 1000003 + salt) % (2 ** 31))
     sign = torch.randint(0, 2, a.shape, generator=g, dtype=torch.int8).to(a.dtype) * 2 - 1
-    return a * (1.0 + sign * 2.0 ** -24) if a.dtype == torch.float32 else a
+    return one_ulp(a, sign) if a.dtype == torch.float32 else a
 
 
 def ew(x, site):
-    """the oracle's hook at its softmax / exp sites: x unchanged unless an "ew:<seed>" policy is installed, then x (1 +- 2^-24) with a random sign per element"""
+    """the oracle's hook at its softmax / exp sites: x unchanged unless an "ew:<seed>" policy is installed, then every element moved to a neighbouring fp32 value, random direction per element"""
     if _POLICY is None or x.dtype != torch.float32:
         return x
     m = _POLICY(site)
@@ -99,7 +106,7 @@ def ew(x, site):
         return x
     g = torch.Generator().manual_seed((int(m[3:]) * 1000003 + sum(ord(c) for c in site) * 7919 + x.numel()) % (2 ** 31))
     sign = torch.randint(0, 2, x.shape, generator=g, dtype=torch.int8).to(x.dtype) * 2 - 1
-    return x * (1.0 + sign * 2.0 ** -24)
+    return one_ulp(x, sign)
 
 
 def _resummed(parts, mode):

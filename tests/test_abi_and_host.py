@@ -147,3 +147,17 @@ def test_hot_kernels_do_not_spill():
         assert found, "kernel %s not found in the build" % h
         for r in found:
             assert r[4] == 0 and r[5] == 0, "%s spills: %d registers, %d bytes of scratch" % (r[1], r[4], r[5])
+    # ogmm_knn_pos_head_supported bounds dynamic + STATIC LDS of the head kernel by 64 KiB; the constant it adds for the static part
+    # (KNN_HEAD_STATIC_LDS = 8 KiB, knn_fps.hip) must cover what the build really declares
+    head = [r for r in rows if "knn4_kernel<" in r[1]]
+    assert head and max(r[6] for r in head) <= 8 * 1024, [(r[1][:60], r[6]) for r in head]
+
+
+def test_knn_head_fit_counts_static_lds(lib):
+    """N * 16 B of points + the candidate lists (2 * 20 * 256 int16 at k <= 20, 2 * 32 * 256 beyond) + 8 KiB of static arrays <= 64 KiB: N = 2304 is the last
+    cloud size the fused head takes at k = 20 (it used to answer "supported" up to 2816 for a 72 KiB workgroup), 1536 at k = 32; the forward falls back to the
+    three-kernel head beyond (tests/test_hip_ops.py::test_knn_head_boundary runs both sides on the GPU)."""
+    assert lib.ogmm_knn_pos_head_supported(2304, 20) == 1 and lib.ogmm_knn_pos_head_supported(2305, 20) == 0
+    assert lib.ogmm_knn_pos_head_supported(2816, 20) == 0
+    assert lib.ogmm_knn_pos_head_supported(1536, 32) == 1 and lib.ogmm_knn_pos_head_supported(1537, 32) == 0
+    assert lib.ogmm_knn_pos_head_supported(1024, 20) == 1 and lib.ogmm_knn_pos_head_supported(2048, 20) == 1

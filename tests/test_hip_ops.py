@@ -68,6 +68,18 @@ def ops(raw_ops):          # every test sees the operator module; its knn() chec
     return w
 
 
+@pytest.mark.parametrize("N,fused", [(2304, True), (2305, False)])
+def test_knn_head_boundary(ops, raw_ops, N, fused):
+    """the largest cloud the fused head kernel takes (dynamic + static LDS = 64 KiB at N = 2304, k = 20) gives ogmm_knn's graph (the
+    wrapper's knn() compares both forms bit for bit), and one point more reports "unsupported", so that the forward takes the three-kernel head."""
+    assert bool(raw_ops.knn_pos_head_supported(N, 20)) == fused
+    xyz = clouds(2, N, seed=N).cuda()
+    idx = ops.knn(xyz, 20).cpu().long()
+    ref = torch.topk(O.sq_dist_expanded(xyz.cpu(), xyz.cpu()), 20, dim=-1, largest=False, sorted=True)
+    d = O.sq_dist_expanded(xyz.cpu(), xyz.cpu())
+    assert torch.equal(torch.gather(d, 2, idx), ref[0])          # the same distance multiset per row, ascending: ties may swap indices only
+
+
 @pytest.mark.parametrize("C,N,k", [(4, 1024, 20), (3, 200, 12), (2, 2048, 5), (2, 717, 20), (1, 64, 32), (2, 33, 1), (2, 2048, 20), (3, 1000, 8)])
 def test_knn_identical_indices(ops, C, N, k):
     """Distance rows are bit-identical to the reference's, and the kept neighbour SET equals torch.topk's even when
@@ -560,6 +572,14 @@ def test_attention_backward_kernel(ops, C, N, split):
         g2[N // 2, 7] = 1.0e5                                  # beyond binary16
         ops.attention_bwd(dev(q), dev(k), dev(v), dev(g2), C, N, M, H, split=split, overflow=ovf)
         assert int(ovf.item()) & 1
+        # a NaN operand (v_max_f32 drops it from the running maximum) must raise the word too -- in every one of the four operands
+        for which in range(4):
+            ovf.zero_()
+            t4 = [q.clone(), k.clone(), v.clone(), g.clone()]
+            t4[which][t4[which].shape[0] // 3, 5] = float("nan")
+            ops.attention_bwd(dev(t4[0]), dev(t4[1]), dev(t4[2]), dev(t4[3]), C, N, M, H, split=split, overflow=ovf)
+            assert int(ovf.item()) & 1, "NaN in operand %d not flagged" % which
+        ovf.zero_()
 
 
 def test_attention_backward_in_autograd(ops, monkeypatch):

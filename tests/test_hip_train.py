@@ -107,6 +107,12 @@ def test_weight_grad_thin(R, n, k, split):
         dy2[R // 2, 0] = 1.0e5                                 # beyond binary16: the overflow word must say so
         ops.weight_grad_thin(dy2, x, split=True, overflow=ovf)
         assert int(ovf.item()) & 1
+        for which in range(2):          # NaN operands (dropped by v_max_f32 from the running maximum) raise the word as well
+            ovf.zero_()
+            dy3, x3 = dy.clone(), x.clone()
+            (dy3 if which == 0 else x3)[R // 3, 0] = float("nan")
+            ops.weight_grad_thin(dy3, x3, split=True, overflow=ovf)
+            assert int(ovf.item()) & 1, "NaN in %s not flagged" % ("dy" if which == 0 else "x")
 
 
 @pytest.mark.parametrize("points,k,cols", [(1000, 20, 64), (333, 5, 64), (4096, 12, 256)])

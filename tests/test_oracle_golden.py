@@ -122,6 +122,32 @@ def test_one_ulp_jitter_probe_is_deterministic_small_and_separates_conditioning(
     assert 0 < moved < 5e-6, moved
 
 
+def test_one_ulp_probe_moves_both_ways():
+    """the round-5 probes multiplied by (1 + sign * 2^-24) with the factor held in fp32, where 1 + 2^-24 == 1 -- only the sign = -1 half of the
+    elements ever moved, all of them downwards.  one_ulp() goes to the neighbouring fp32 value: every non-zero element moves, by exactly one unit in the last
+    place, about half of them up and half of them down; zeros stay."""
+    from oracle import split_emulation as E
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(4096, generator=g)
+    a[::97] = 0.0
+    sign = torch.randint(0, 2, a.shape, generator=g, dtype=torch.int8).float() * 2 - 1
+    b = E.one_ulp(a, sign)
+    nz = a != 0
+    assert torch.equal(b[~nz], a[~nz]) and bool((b[nz] != a[nz]).all())
+    steps = (b.view(torch.int32) - a.view(torch.int32))[nz]
+    assert set(steps.tolist()) == {-1, 1}
+    grew = (b.abs() > a.abs())[nz]
+    assert torch.equal(grew, sign[nz] > 0) and 0.4 < grew.float().mean() < 0.6
+    for mode, fn in (("ulp:1", lambda: E._jitter(a, "ulp:1", 7)), ("ew:1", None)):
+        if fn is not None:
+            j = fn()
+        else:
+            with E.policy(lambda name: "ew:1"):
+                j = E.ew(a, "x.softmax")
+        up = (j.abs() > a.abs())[nz].float().mean().item()
+        assert bool((j[nz] != a[nz]).all()) and 0.4 < up < 0.6, (mode, up)
+
+
 def test_summation_order_probe_is_exact_products_in_another_order():
     """oracle/split_emulation.py "sum:<seed>" (round 5, late; the second host-independent part of reference_spread): every contraction as four interleaved partial
     contractions added in a seeded order.  It must (i) be a pure function of its seed and differ between seeds, (ii) stay a rounding-level change -- as close to
