@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float* __res
     _Float16* PTl = PTh + 32 * CPP;
     _Float16* STh = PTl + 32 * CPP;
     _Float16* STl = STh + 32 * CPP;
-    float amax = 0.0f;
+    float amax = 0.0f, nan_probe = 0.0f;          // nan_probe: x * 0 summed over every operand element -- NaN as soon as one of them is NaN (or Inf)
 
     // ---- the wave's constant slices: K and V rows (A operands over d), K columns (B operand over keys)
     h8c kh[8], kl[8], vh[8], vl[8], kch[8], kcl[8];
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float* __res
                 const f32x2c a = *reinterpret_cast<const f32x2c*>(kr + 16 * u + i);
                 const f32x2c b = *reinterpret_cast<const f32x2c*>(vr + 16 * u + i);
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(b[0]), fabsf(b[1]))));
+                nan_probe = fmaf(a[0], 0.0f, fmaf(a[1], 0.0f, fmaf(b[0], 0.0f, fmaf(b[1], 0.0f, nan_probe))));
                 _Float16 hh, ll;
                 split1c(a[0], hh, ll); kh[u][i] = hh; kl[u][i] = ll;
                 split1c(a[1], hh, ll); kh[u][i + 1] = hh; kl[u][i + 1] = ll;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 amax = fmaxf(amax, fmaxf(fabsf(qst[u][e]), fabsf(gst[u][e])));
+                nan_probe = fmaf(qst[u][e], 0.0f, fmaf(gst[u][e], 0.0f, nan_probe));
                 split1c(qst[u][e], qh_[u][e], ql_[u][e]);
                 split1c(gst[u][e], gh_[u][e], gl_[u][e]);
             }
@@ -328,16 +330,9 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float* __res
                 }
         }
     }
-    {
-        // v_max_f32 returns its non-NaN operand, so a NaN in q / k / v / dO never shows in amax; it does reach dV (through P or dO) or dK
-        // (through dP), so the two accumulator sets tell
-        float chk = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { chk = fmaf(dvacc[t][r], 0.0f, chk); chk = fmaf(dkacc[t][r], 0.0f, chk); }
-        if (overflow && (!(amax <= 65504.0f) || chk != chk)) atomicOr(overflow, 1);          // an operand beyond binary16's range, Inf or NaN: the trainer lowers its loss scale
-    }
+    // v_max_f32 returns its non-NaN operand, so a NaN in q / k / v / dO never shows in amax, and the range clamps of the split launder it before the accumulators
+    // could tell: nan_probe says so
+    if (overflow && (!(amax <= 65504.0f) || nan_probe != nan_probe)) atomicOr(overflow, 1);          // an operand beyond binary16's range, Inf or NaN: the trainer lowers its loss scale
 
     // ---- dK, dV blocks of the wave: lane = column d, registers = keys
     {

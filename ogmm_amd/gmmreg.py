@@ -18,7 +18,6 @@ the reference are independent, models/gmmreg.py:52-53) and feature maps are poin
 """
 import math
 
-import os
 import torch
 from torch import nn
 
@@ -27,10 +26,6 @@ from ._lib import OgmmError
 from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
-_EM_SCHED = int(os.environ.get("OGMM_EM_SCHED", "0"))
-# Reproducer of the round-5 finding (DESIGN.md section 4 "FPS before EdgeConv, always"; tools/determinism_check.py): 1 = the FPS chains are queued BEHIND the kNN
-# kernel and the EdgeConv kernel does not wait for them -- the schedule in which their picks came out different from run to run.  Never set in production.
-_FPS_BEHIND_KNN = os.environ.get("OGMM_FPS_BEHIND_KNN", "0") == "1"
 # Measured budget (DESIGN.md section 4 "Per-layer term budget").  Round 4: an entry stays only if the layer's rounding holds the 1e-5 bar on BOTH weight
 # families of the parity suite -- the closed-form default fill AND synth.fill_state_dict(profile="sharp") (peaked attention, saturated overlap scores).
 # Round 3's entries for conv2.0 / conv2.3 (weight rounded), the three Q projections and the attention's score product (both rounded) were measured on
@@ -246,7 +241,7 @@ class GMMReg(nn.Module):
         self.sinkhorn_thresh = 1e-2      # lib/utils.py:73 (`thresh` default, which wkeans_plus :281 does not override); <= 0 runs every sweep
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
         self.fold_conv2_overlap = True      # conv2.net.6 and overlap.net.0 (two linear maps in a row) as one 1024 -> 256 layer
-        self.fuse_overlap = os.environ.get("OGMM_FUSE_OVERLAP", "1") != "0"            # overlap block's softmax-dots in the similarity GEMM's epilogue where the engine takes it (ops.overlap_fusable)
+        self.fuse_overlap = True            # overlap block's softmax-dots in the similarity GEMM's epilogue where the engine takes it (ops.overlap_fusable)
         self._overflow = None          # device int32[1]: the engines' fp16 range flag ...
         self._status = None            # ... and its neighbour word: protocol errors of kernels with bounded on-chip / cross-workgroup waits (_lib.STATUS_*)
         self._overflow_host = self._overflow_event = None
@@ -336,7 +331,7 @@ class GMMReg(nn.Module):
         ws["clean"] = False
         return ws
 
-    def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0, kv_terms=0, qk_terms=0, after_attention=None):
+    def _transformer(self, eng, L, x, anchor_feats, anchor_ids, C, N, res, cloud_map=None, stats=None, q_terms=0, kv_terms=0, qk_terms=0):
         """models/attn.py:78-111: mlp(cat[x, merge(softmax(q k^T / sqrt(dh)) v)]) (+ res).  x [C*N, D]; the anchors [C, M, D] are rows
         anchor_ids [C, M] of anchor_feats [C*N, D] (of the cloud cloud_map[c], if given): lib/utils.py:111-127."""
         D, H = self.emb_dims, self.config.num_heads
@@ -346,8 +341,6 @@ class GMMReg(nn.Module):
         if ops.attention_supported(M, dh):
             kv = ops.conv1x1_gathered(anchor_feats, C, N, anchor_ids, L["kv"], cloud_map=cloud_map, eng=eng, terms=kv_terms)      # keys | values in one GEMM, rows gathered by its DMA
             o = ops.attention(q, kv[:, :D], kv[:, D:], C, N, M, H, qk_terms=qk_terms if eng.split else 0)
-            if after_attention is not None:
-                after_attention()          # (scheduling experiment OGMM_EM_SCHED=3: side-stream work queued behind the attention kernel instead of beside it)
             if self.fold_merge:
                 mlp0, msg = L["mlp0_folded"], o                       # merge conv folded into mlp0's weights
             else:
@@ -465,9 +458,6 @@ class GMMReg(nn.Module):
             self._side2 = torch.cuda.Stream(device=dev)
         side2 = self._side2
         side2.wait_event(inputs_ready)
-        if _FPS_BEHIND_KNN:
-            side2.wait_stream(main)
-            side.wait_stream(main)
         R = C * N
         XW = L["conv2"]["0"]["W"].shape[1] - D                                   # conv2 input channels 512 (wo), 513 (o), zero pad to the packed width
         # the three transformers' InstanceNorm statistics and the [wo | o | pad] piece of conv2.net.0: persistent per (stream, shape), zeroed when created.
@@ -493,13 +483,10 @@ class GMMReg(nn.Module):
         side_done.record(hs_fps if pipelined else side)
         if not fused_head:
             idx = ops.knn(xyz, k)
-        # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU.  Queued behind the kNN kernel
-        # (round 5, first form of the fused head) they ran next to EdgeConv instead: slower for both, and inside the forward their picks then came out
-        # different from run to run (tools/determinism_check.py; alone beside any kernel family they are reproducible -- tools/fps_corun.py -- so the cause is
-        # not established; with this order every mode of that tool is bit-reproducible).  The wait costs nothing: they finish with the kNN kernel.
-        if not _FPS_BEHIND_KNN:
-            main.wait_event(fps_done)          # (each side stream directly: a hand-over through a second stream costs another ~15 us)
-            main.wait_event(side_done)
+        # The FPS chains run BESIDE the kNN kernel and must be through before the persistent EdgeConv kernel takes every CU (queued behind the kNN kernel they ran
+        # next to EdgeConv instead: slower for both).  The wait costs nothing: they finish with the kNN kernel.
+        main.wait_event(fps_done)          # (each side stream directly: a hand-over through a second stream costs another ~15 us)
+        main.wait_event(side_done)
         xyz.record_stream(side2)
         xyz.record_stream(side)
         fps_starts.record_stream(side2)
@@ -528,9 +515,6 @@ class GMMReg(nn.Module):
         emb = ops.conv1x1(xcat, L["emd5"], ACT_RELU, eng=eng)
 
         # ---- positional encoding added to the embedding (models/attn.py:59-75, gmmreg.py:58-61)
-        if _FPS_BEHIND_KNN:
-            main.wait_event(fps_done)
-            main.wait_event(side_done)
         x0 = torch.empty((R, D), dtype=torch.float32, device=dev)
         ops.conv1x1(hd, L["pos_dis2"], ACT_LEAKY02, out=x0[:, :D // 2], res=emb[:, :D // 2], eng=eng)
         ops.conv1x1(ha, L["pos_ang2"], ACT_LEAKY02, out=x0[:, D // 2:], res=emb[:, D // 2:], eng=eng)
@@ -579,37 +563,19 @@ class GMMReg(nn.Module):
             # number of sweeps every E-step ran: see sinkhorn_exit_margin()
             return ops.gmm_em(xyz, o, ids_j, iters=10, sk_iters=10, epsilon=1e-2, tau=1.0, thresh=self.sinkhorn_thresh, group_size=B,
                               return_resid=capture, return_sweeps=capture, status=self._status)
-        em_sched = _EM_SCHED          # experiment switch (OGMM_EM_SCHED): 0 = beside the whole last transformer (default), 1 = serial behind it, 2 = high-priority stream, 3 = queued behind its attention kernel
-        em_stream = side
-        if em_sched == 2:
-            if getattr(self, "_em_hi", None) is None or self._em_hi.device != dev:
-                self._em_hi = torch.cuda.Stream(device=dev, priority=-1)
-            em_stream = self._em_hi
-        em_box = {}
-
-        def launch_em():
-            em_stream.wait_stream(main)
-            with torch.cuda.stream(em_stream):
-                em_box["em"] = run_em()
-                em_box["done"] = torch.cuda.Event()
-                em_box["done"].record(em_stream)
-            o.record_stream(em_stream)
-            for t_ in em_box["em"][:3]:
-                t_.record_stream(main)
-        if em_sched in (0, 2):
-            launch_em()
-        f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0), kv_terms=tb.get("sattn2.kv", 0), qk_terms=tb.get("sattn2.qk", 0),
-                               after_attention=launch_em if em_sched == 3 else None)
-        if em_sched != 1:
-            if "em" not in em_box:          # (the transformer took a path without the fused attention: nothing called back)
-                launch_em()
-            em, em_done = em_box["em"], em_box["done"]
-            gamma, pi, mu = em[:3]
-        if em_sched == 1:
+        # beside the whole last transformer (measured alternatives -- serial behind it, a high-priority stream, queued behind the attention kernel -- were all slower
+        # or equal: HISTORY.md "Where the E/M runs")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             em = run_em()
-            gamma, pi, mu = em[:3]
-        else:
-            main.wait_event(em_done)
+            em_done = torch.cuda.Event()
+            em_done.record(side)
+        o.record_stream(side)
+        for t_ in em[:3]:
+            t_.record_stream(main)
+        gamma, pi, mu = em[:3]
+        f2 = self._transformer(eng, L["sattn2"], f, f, ids_a[2], C, N, res=f, stats=stats3[2], q_terms=tb.get("sattn2.q", 0), kv_terms=tb.get("sattn2.kv", 0), qk_terms=tb.get("sattn2.qk", 0))
+        main.wait_event(em_done)
 
         # ---- cluster features, matching, rigid solve, clustering loss (gmmreg.py:100-114)
         muf = ops.gmm_feat_mean(gamma, pi, f2, C, N)

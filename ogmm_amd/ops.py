@@ -3,7 +3,6 @@ device memory and the stream; every function enqueues HIP kernels of libogmm_hip
 stream and returns without synchronising.  All tensors must be CUDA (ROCm) tensors -- there is no CPU path.
 """
 import ctypes
-import os
 
 import torch
 
@@ -14,10 +13,12 @@ from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F16_FRAG, P
 # bench.py sets this to a list to time the GEMM-engine launches with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_flops)
 GEMM_TIMELINE = None
-NORM_BWD_FUSED = os.environ.get("OGMM_NORM_BWD_FUSED", "1") != "0"          # training: the normalisation backward's reduction in the dh GEMM's epilogue (A/B switch)
-FUSE_GATHER = os.environ.get("OGMM_FUSE_GATHER", "1") != "0"      # anchor rows gathered by the consuming GEMM's operand DMA (conv1x1_gathered)
-EDGECONV_PC = os.environ.get("OGMM_EDGECONV_PC", "1") != "0"      # the EdgeConv chain as a producer / consumer pipeline (k = 20)
-FUSE_HEAD = os.environ.get("OGMM_FUSE_HEAD", "1") != "0"      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
+# Alternatives kept for A/B measurements (tools/*.py and the tests assign these module attributes; nothing reads the environment): every default below is the
+# product path, every other value the form it replaced -- bit-identical where the comment says so.
+NORM_BWD_FUSED = True          # training: the normalisation backward's reduction in the dh GEMM's epilogue (A/B switch)
+FUSE_GATHER = True      # anchor rows gathered by the consuming GEMM's operand DMA (conv1x1_gathered)
+EDGECONV_PC = True      # the EdgeConv chain as a producer / consumer pipeline (k = 20)
+FUSE_HEAD = True      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
 GEMM_TIMELINE_ONLY = None      # optional set of variant tags: only those launches are bracketed by events (bench.py: the dominant engine only)
 KERNEL_TIMELINE = None         # bench.py: a list -> the EdgeConv and attention launches are bracketed too: (start_event, end_event, name, algorithmic flops, algorithmic bytes)
 _EVENT_POOL = []               # timing events are recycled: creating two torch events per launch costs more host time than the launch itself
@@ -88,7 +89,7 @@ def _p(t):
 
 
 # ---------------------------------------------------------------------------------------------- selection
-KNN_HEAD = os.environ.get("OGMM_KNN_HEAD", "1") != "0"          # A/B switch: 0 = ogmm_knn (k = 20), ogmm_knn (k = 5) and ogmm_pos_hidden as three launches
+KNN_HEAD = True          # A/B switch: 0 = ogmm_knn (k = 20), ogmm_knn (k = 5) and ogmm_pos_hidden as three launches
 
 
 def pack_clouds(src, tgt):
@@ -222,7 +223,7 @@ def split_f16(W, pad_to=8, frag=False, k1=None, exp=None, scale_t=None):
 
 
 _SPLIT_SLOTS = {}          # device -> [pool float32 [4096, 4] (zero), next slot]: the scale kernel's scratch, left zero by every call (ogmm_split_weight)
-SPLIT_WEIGHT_FUSED = os.environ.get("OGMM_SPLIT_WEIGHT_FUSED", "1") != "0"      # 0: rounds 1-3's path (tensor expressions + ogmm_pack_frag), for A/B timing
+SPLIT_WEIGHT_FUSED = True      # 0: rounds 1-3's path (tensor expressions + ogmm_pack_frag), for A/B timing
 
 
 def _split_slot(device):
@@ -433,7 +434,7 @@ def edgeconv_fused(xyz, idx, layers, xcat, status=None):
         args += [_p(sp["W_hi"]), _p(sp["W_lo"]), _p(l["scale"]), _p(l["shift"]), sp["inv_scale"]]
     # algorithmic work: the four 1x1 convolutions over C*N*k edges (models/dgcnn.py:121-124); bytes: xyz + idx in, xcat out
     E = float(C) * N * k
-    # k = 20 (the reference's gnn_k): the producer / consumer pipeline (edgeconv_pc.hip, bit-identical); OGMM_EDGECONV_PC=0: the barrier-phased kernel
+    # k = 20 (the reference's gnn_k): the producer / consumer pipeline (edgeconv_pc.hip, bit-identical); ops.EDGECONV_PC = False: the barrier-phased kernel
     fn = "ogmm_edgeconv_pc" if k == 20 and EDGECONV_PC else "ogmm_edgeconv_fused"
     tail = (_p(status),) if fn == "ogmm_edgeconv_pc" else ()
     _timed_call("edgeconv_fused_kernel", 2.0 * E * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 256), 4.0 * (3 * C * N + E + 512.0 * C * N),
@@ -543,7 +544,7 @@ def attention_bwd_supported(M, dh):
     return bool(_lib.load().ogmm_attention_bwd_supported(M, dh))
 
 
-ATTN_BWD_F16X3 = int(os.environ.get("OGMM_ATTN_BWD_F16X3", "2"))      # fp16x3 step: 0 = exact-fp32 attention backward, 1 = S and dP on the fp16x3 arithmetic, 2 = all five products (A/B)
+ATTN_BWD_F16X3 = 2      # fp16x3 step: 0 = exact-fp32 attention backward, 1 = S and dP on the fp16x3 arithmetic, 2 = all five products (A/B)
 
 
 def attention_bwd(q, k, v, dout, C, N, M, H, split=False, overflow=None):
@@ -931,8 +932,8 @@ def maxpool_k_bwd(dout, arg, k):
     return dh
 
 
-DW_MIN_TILES = int(os.environ.get("OGMM_DW_MIN_TILES", "0"))          # 0: 256 / 512 by shape (weight_grad); a number: that many tiles at least (A/B timing)
-DW_TRANSPOSED_A = os.environ.get("OGMM_DW_TRANSPOSED_A", "1") != "0"      # 0: materialise dY^T (ogmm_transpose_pad) as rounds 1-3 did (A/B timing, bit-identical)
+DW_MIN_TILES = 0          # 0: 256 / 512 by shape (weight_grad); a number: that many tiles at least (A/B timing)
+DW_TRANSPOSED_A = True      # 0: materialise dY^T (ogmm_transpose_pad) as rounds 1-3 did (A/B timing, bit-identical)
 
 
 def weight_grad(dy, xs, overflow=None, x_affine=None, colsum=False, chunk_rows=None, keep_parts=False, out_scale=None, parts_out=None, terms=0):
@@ -1114,7 +1115,7 @@ def weight_grad_thin_supported(dy, x):
             and x.stride(0) % kv == 0 and dy.data_ptr() % (4 * nv) == 0 and x.data_ptr() % (4 * kv) == 0)
 
 
-DW_THIN_F16X3 = os.environ.get("OGMM_DW_THIN_F16X3", "1") != "0"      # 0: the exact-fp32 thin reduction in the fp16x3 training step too (A/B)
+DW_THIN_F16X3 = True      # 0: the exact-fp32 thin reduction in the fp16x3 training step too (A/B)
 
 
 def weight_grad_thin(dy, x, split=False, overflow=None):

@@ -9,7 +9,6 @@ forwards (batched / plain hipBLASLt GEMMs through torch.matmul).  CPU tensors ar
 no CPU path here.  The plain-PyTorch statement of the same
 operations that the tests use as the numerical reference lives in tests/train_ref.py.
 """
-import os
 
 import torch
 import torch.nn.functional as F
@@ -244,19 +243,18 @@ class _Linear(torch.autograd.Function):
 # Term budget of the BACKWARD GEMMs (struct ogmm_gemm.terms; 0 / 3 = three binary16 products per fp32 product, 2 = the B operand rounded to binary16).  Default:
 # THREE terms everywhere.  Both reduced forms were built and measured this round (tools/bwd_terms_check.py at 32 pairs of 1024 points, both weight families;
 # DESIGN.md section 7) and are opt-in switches, not defaults:
-#   OGMM_BWD_TERMS_DW=2   dW = dY^T X with the fragment image of X^T (activations) rounded: -3.5 ms per 128-pair step (115.3 -> 111.6).  The weight gradients of the
+#   BWD_TERMS_DW = 2     dW = dY^T X with the fragment image of X^T (activations) rounded: -3.5 ms per 128-pair step (115.3 -> 111.6).  The weight gradients of the
 #     wide layers move by up to 1.0e-4 relative (median over all parameters 1.6e-7, p90 5e-5) -- a third of the reference's own fp32-vs-fp64 distance (2.5e-4 ...
 #     3.2e-4 median) and a sixth of the distance between two fp32-class evaluations of the same step (split engine vs exact-fp32 engine: 5e-4 ... 6e-4); on the
 #     reference-generated fixtures of that size the distance to the fp64 truth is unchanged to two digits for most parameters and grows by < 1e-4 for all (one
 #     whose three-term gradient is unusually accurate goes 4.9e-5 -> 7.5e-5; test_two_term_weight_gradient_stays_at_the_three_term_distance_from_the_truth).  But a single layer's dW is then 1e-4 from its fp64 value where three terms
 #     give 2e-6 (the layer tests' 2e-5 bar): an fp32-class engine by default, a labelled option for who wants the 3 %.
-#   OGMM_BWD_TERMS_DX=2   dX = dY W with W^T rounded: a rounded WEIGHT is a fixed perturbation of every row's gradient -- 2.6e-4 relative on ALL parameters, the size
+#   BWD_TERMS_DX = 2     dX = dY W with W^T rounded: a rounded WEIGHT is a fixed perturbation of every row's gradient -- 2.6e-4 relative on ALL parameters, the size
 #     of the reference's own distance; -2.1 ms.  Not recommended.
-# OGMM_BWD_TERMS sets both.
-_bt = os.environ.get("OGMM_BWD_TERMS", "0")
-BWD_TERMS_DX = int(os.environ.get("OGMM_BWD_TERMS_DX", _bt))
-BWD_TERMS_DW = int(os.environ.get("OGMM_BWD_TERMS_DW", _bt))
-FUSE_NORM_LINEAR = os.environ.get("OGMM_FUSE_NORM_LINEAR", "1") != "0"      # 0: write the normalised maps (A/B timing)
+# (module attributes: tools/bwd_terms_check.py and the tests assign them; nothing reads the environment)
+BWD_TERMS_DX = 0
+BWD_TERMS_DW = 0
+FUSE_NORM_LINEAR = True      # 0: write the normalised maps (A/B timing)
 
 
 class _NormLinear(torch.autograd.Function):
@@ -324,7 +322,7 @@ class _NormLinear(torch.autograd.Function):
         return dy, None, dg, dbeta, None, dW, db, None, None, (dout if ctx.has_res else None)
 
 
-GATHER_SPARSE = os.environ.get("OGMM_GATHER_SPARSE", "1") != "0"      # 0: the anchor gathers' gradients as dense zero-filled maps through ogmm_add_n (A/B)
+GATHER_SPARSE = True      # 0: the anchor gathers' gradients as dense zero-filled maps through ogmm_add_n (A/B)
 
 
 class _Fanout(torch.autograd.Function):
@@ -417,7 +415,7 @@ def _attention_torch(q, k, v, C, N, M, H):
     return (p @ vh).transpose(1, 2).reshape(C * N, D)
 
 
-FUSED_ATTENTION_BWD = os.environ.get("OGMM_ATTN_BWD", "1") != "0"      # 0: the library path, for A/B timing
+FUSED_ATTENTION_BWD = True      # 0: the library path, for A/B timing
 
 
 class _Attention(torch.autograd.Function):
@@ -466,7 +464,7 @@ class _OverlapCross(torch.autograd.Function):
         S, fn, ol, wo, stats = ctx.saved_tensors
         B, N = ctx.B, ctx.N
         D = fn.shape[1]
-        if ctx.engine and N % 64 == 0 and D % 64 == 0 and os.environ.get("OGMM_OVERLAP_BWD_LIB", "0") != "1":
+        if ctx.engine and N % 64 == 0 and D % 64 == 0:
             # both products on the fp16x3 engine (round 4; two batched fp32 library GEMMs before: 2.2 ms of the 128-pair step): dS[b] fn_tgt[b] reads dS as
             # it lies against a per-batch image of fn_tgt^T; dS[b]^T fn_src[b] is the weight gradient's dY^T X form with one row chunk per pair, un-summed.
             # dS is the engine's fp32 operand here, split into binary16 terms on the fly, and its entries are softmax gradients of order |g| / N: far into

@@ -17,6 +17,8 @@ from oracle import split_emulation as E
 from ogmm_amd import synth
 
 SPREAD_THREADS = (1, 4, 16)          # MKL's 1-thread GEMM sums in another order than its threaded one; threaded runs differ among themselves by less
+# (Round 6: the one-ulp probes of round 5 were ONE-SIDED -- 1 + 2^-24 is 1 in fp32, so only half of the elements moved, all downwards;
+# oracle/split_emulation.one_ulp now goes to the neighbouring fp32 value in either direction.  The probe set itself is unchanged.)
 # Round 5: the thread probes are a property of the HOST (sharp configs[1] pair 75: 4e-6 between 1 / 4 / 16 threads on the GPU box's CPU, 1.6e-5 between 1 / 8
 # threads on the build container's), so a pair could pass or fail the "ill-conditioned" test by where it ran.  Added: three evaluations of the reference's
 # algorithm in its own fp32 arithmetic with every GEMM's activation operand moved by ONE UNIT IN THE LAST PLACE, random sign per element
@@ -30,7 +32,7 @@ JITTER_SEEDS = (1, 2, 3)
 SUM_SEEDS = (1, 2, 3)
 # ... and two with the reference's softmax / exp results moved by one ulp ("ew:<seed>"): what a second implementation's exponentials and softmax sums do.
 EW_SEEDS = (1, 2)
-TAIL_FACTOR = 3.0                    # a tail pair's HIP distance may be at most this multiple of the reference's own spread on that pair (round 4: 4, with fewer probes)
+TAIL_FACTOR = 2.0                    # a tail pair's HIP distance may be at most this multiple of the reference's own spread on that pair (round 4: 4, round 5: 3; largest measured in round 6: 1.50)
 ILL_CONDITIONED = 5e-6               # ... and the pair must be visibly ill-conditioned: ordinary pairs spread by 0.3e-6 ... 3e-6
 
 
@@ -102,13 +104,11 @@ def reference_spread(P, cfg, src1, tgt1, starts1, threads=SPREAD_THREADS):
     return max(dr.values()), max(dt.values()), {k[1]: v for k, v in dr.items() if k[0] == first}
 
 
-def check_tail(label, r, t, inputs, P, cfg, first, min_within, bar=1e-5, strict=True, cap=None):
+def check_tail(label, r, t, inputs, P, cfg, first, min_within, bar=1e-5):
     """The parity statement as an assertion.  (i) at least `min_within` of the pairs are within `bar` in R and t; (ii) EVERY pair beyond it is one on which
     the reference itself is ill-conditioned -- its own spread (reference_spread) is >= ILL_CONDITIONED -- and this path's distance is within TAIL_FACTOR of
-    that spread.  Returns the tail table for printing.
-    strict=False (round 5, late; ONE window, see tests/test_hip_parity_tail.py "cfg1b"): the table is printed and the floor asserted, but (ii) is replaced by an
-    absolute cap -- the window on which an unasserted sweep found the rule NOT to hold (one pair at 4.6 x its spread, two at 1.1-1.3e-5 on pairs whose twelve
-    probes spread by 4.1-4.6e-6).  It stays in the suite so that its numbers are in every GPU log instead of outside the suite's view."""
+    that spread.  Returns the tail table for printing.  (Round 5 had a strict=False escape for one window; round 6 removed it with the cause: module docstring of
+    tests/test_hip_parity_tail.py.)"""
     src, tgt, starts = inputs
     n = r.numel()
     bad = [int(i) for i in torch.nonzero((r >= bar) | (t >= bar)).flatten()]
@@ -119,14 +119,8 @@ def check_tail(label, r, t, inputs, P, cfg, first, min_within, bar=1e-5, strict=
         print("PARITY-TAIL %s pair %d: HIP R %.2e t %.2e | reference's own spread R %.2e t %.2e, HIP / spread %.2f (%s)" % (
             label, first + i, r[i].item(), t[i].item(), sr, st, r[i].item() / max(sr, 1e-12), " ".join("%s %.1e" % kv for kv in probes.items())))
     within = n - len(bad)
-    print("PARITY-TAIL %s: %d of %d pairs within %.0e; %d beyond%s" % (label, within, n, bar, len(bad), ", all characterised" if strict else " (listed above)"))
+    print("PARITY-TAIL %s: %d of %d pairs within %.0e; %d beyond, all characterised" % (label, within, n, bar, len(bad)))
     assert within >= min_within, "%s: only %d of %d pairs within %.0e (stated floor: %d)" % (label, within, n, bar, min_within)
-    if not strict:
-        for pid, ri, ti, sr, st, _ in rows:
-            assert ri <= cap and ti <= cap, "%s pair %d: %.2e / %.2e beyond the absolute cap %.0e" % (label, pid, ri, ti, cap)
-        print("PARITY-TAIL %s: rule (ii) NOT asserted on this window: %d of its %d tail pairs would fail it (spread < %.0e, or beyond %g x the spread)" % (
-            label, sum(1 for _, ri, ti, sr, st, _ in rows if sr < ILL_CONDITIONED or ri > TAIL_FACTOR * sr or ti > TAIL_FACTOR * max(st, sr)), len(rows), ILL_CONDITIONED, TAIL_FACTOR))
-        return rows
     for pid, ri, ti, sr, st, _ in rows:
         assert sr >= ILL_CONDITIONED, "%s pair %d is %.2e from the reference although the reference is well defined there (spread %.2e)" % (label, pid, ri, sr)
         assert ri <= TAIL_FACTOR * sr and ti <= TAIL_FACTOR * max(st, sr), "%s pair %d: %.2e / %.2e, beyond %g x the reference's own spread %.2e / %.2e" % (label, pid, ri, ti, TAIL_FACTOR, sr, st)

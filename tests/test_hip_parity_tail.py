@@ -28,25 +28,25 @@ def _model(J, profile):
     return m.cuda().eval(), P, cfg
 
 
-# (weight family, workload): (N, J, first pair, pairs, stated floor of pairs within 1e-5, cloud kind).  The floors are the measured counts
-# (profiles/round5_parity*.txt) less a margin of two or three pairs.  N = 717 / J = 128 (the reference repo's own defaults) has 5.6 points per mixture component:
-# the thinnest margin of all shapes.  Round 5: the sharp windows are the FULL ones the round-4 profile had run and which contain
-# that profile's misses (configs[1] pairs 75 / 84 / 112; N = 717 pairs 309 / 357 / 422 / 348 ...), and the configs[3] room clouds (planes: exact kNN
-# ties at rank k, the hardest discrete case) are run pair by pair on both weight families on the E/M launch sequence a 64-pair-per-GPU batch takes.
+# (weight family, workload): (N, J, first pair, pairs, stated floor of pairs within 1e-5, cloud kind).  The floors are the measured counts of round 6
+# (profiles/round6_parity*.txt) less three pairs at most.  N = 717 / J = 128 (the reference repo's own defaults) has 5.6 points per mixture component: the thinnest
+# margin of all shapes.  The sharp windows are the FULL ones earlier profiles had run, misses included (configs[1] pairs 75 / 84 / 112; N = 717 pairs 309 / 357 /
+# 422 / 348 ...), and the configs[3] room clouds (planes: exact kNN ties at rank k, the hardest discrete case) are run pair by pair on both weight families on the
+# E/M launch sequence a 64-pair-per-GPU batch takes.
+# Round 6: EVERY window is strict.  "cfg1b" (sharp pairs 128..319) was the window on which round 5 found the tail rule NOT to hold (pair 287 at 4.6 x the spread,
+# pairs 160 / 301 beyond 1e-5 on well-conditioned pairs) and ran with strict=False.  tools/tail_bisect.py (the HIP path's stage results injected into the oracle one
+# stage at a time) traced it to the fused InstanceNorm: its statistics were E[y^2] - mean^2 from fp32 partial sums, which loses |mean|^2 / var units in the last
+# place, and the sharp family has channels at mean^2 / var ~ 10^3 ... 10^4.  With the sums in fp64 from the first value on (gemm_common.h) the window reads
+# 187 of 192 within 1e-5, max 3.2e-5, and all five tail pairs within 1.5 x the reference's own spread; DESIGN.md section 2.
 CASES = {
-    ("default", "cfg1"): (1024, 16, 0, 256, 252, "partial"),          # includes pair 128, round 3's worst (2.8e-5)
-    ("default", "n717"): (717, 128, 300, 128, 122, "partial"),        # includes pairs 334 and 413
-    ("sharp", "cfg1"): (1024, 16, 0, 128, 122, "partial"),            # round 4 tested 0..63 only; 75, 84, 112 are in 64..127
-    # round 5, late: pairs 128..319, the window in which a sweep outside the suite found the tail rule NOT to hold (profiles/round5_parity_extended.txt): 183 of 192
-    # within 1e-5, and of the nine beyond, pair 287 sits at 4.6 x the spread of the reference's twelve probes (pair 266 at 2.9 x), pairs 160 / 301 at 1.1-1.3e-5 with
-    # a spread of 4.1-4.6e-6 (below the 5e-6 that counts as ill-conditioned).  The exact-fp32 engine scatters the same way on this window (58 of 64 on 256..319, max
-    # 7.7e-5), so it is not the binary16 split -- the probes vary the reference's GEMMs only, a second implementation also differs in its exponentials, softmax and
-    # E/M summation orders.  Asserted here: the floor and an absolute cap of 6e-5; the rule's verdict per pair is PRINTED (check_tail(strict=False)).
-    ("sharp", "cfg1b"): (1024, 16, 128, 192, 180, "partial"),
-    ("sharp", "n717"): (717, 128, 300, 128, 106, "partial"),          # round 4 tested 300..363 only
+    ("default", "cfg1"): (1024, 16, 0, 256, 252, "partial"),          # measured 255; includes pair 128, round 3's worst (2.8e-5)
+    ("default", "n717"): (717, 128, 300, 128, 125, "partial"),        # measured 128; includes pairs 334 and 413
+    ("sharp", "cfg1"): (1024, 16, 0, 128, 120, "partial"),            # measured 123; 75, 84, 112 are in 64..127
+    ("sharp", "cfg1b"): (1024, 16, 128, 192, 184, "partial"),         # measured 187
+    ("sharp", "n717"): (717, 128, 300, 128, 112, "partial"),          # measured 115: all 13 beyond are within 1.26 x the reference's own spread
     ("sharp", "cfg2"): (2048, 64, 2000, 16, 15, "partial"),
     ("default", "cfg3"): (2048, 64, 3000, 16, 15, "room"),
-    ("sharp", "cfg3"): (2048, 64, 3000, 16, 14, "room"),
+    ("sharp", "cfg3"): (2048, 64, 3000, 16, 15, "room"),
 }
 
 
@@ -60,7 +60,7 @@ def test_every_pair_within_1e5_or_the_reference_itself_is_undefined_there(profil
     label = "%s weights, %s (N=%d J=%d, %s pairs %d..%d)" % (profile, workload, N, J, kind, first, first + B - 1)
     r, t, o, inputs = distribution(model, P, cfg, first, B, N, kind, label=label)
     assert not model.fp16_overflowed()
-    check_tail(label, r, t, inputs, P, cfg, first, floor, strict=workload != "cfg1b", cap=6e-5)
+    check_tail(label, r, t, inputs, P, cfg, first, floor)
     # the overlap scores are not part of the north star's bar; they are held to what the reference's own scores move by between thread counts
     # (default family 1e-5; sharp family: 2e-5 measured by tests/golden/make_golden.py, so 6e-5)
     assert o.max().item() < (1e-5 if profile == "default" else 6e-5)
@@ -119,4 +119,4 @@ def test_trained_weights_every_pair_against_the_oracle():
     label = "trained weights (500 steps), N=717 J=16, pairs 300..331"
     r, t, o, inputs = distribution(model, P, cfg, 300, 32, 717, "partial", label=label)
     assert not model.fp16_overflowed()
-    check_tail(label, r, t, inputs, P, cfg, 300, 28)
+    check_tail(label, r, t, inputs, P, cfg, 300, 29)
