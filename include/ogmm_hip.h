@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OGMM_ABI_VERSION 27
+#define OGMM_ABI_VERSION 28
 
 int ogmm_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -217,7 +217,6 @@ int ogmm_edgeconv_pc(const float* xyz, const int32_t* idx, int C, int N, int k, 
                         const void* h2, const void* l2, const float* s2, const float* t2, float inv2, const void* h3, const void* l3,
                         const float* s3, const float* t3, float inv3, const void* h4, const void* l4, const float* s4, const float* t4,
                         float inv4, float* xcat, int64_t ldx, int32_t* status, void* stream);
-
 /* ---- K7 front half: PositionEncoding up to its two 64-channel hidden maps.  models/attn.py:65-73:
  * centroid, g=|p-c|^2 -> conv_dis.0 (1->64)+BN+LeakyReLU -> hid_dis; 5-NN offsets, cosine with the
  * global offset -> conv_ang1 (1->64)+BN+LeakyReLU -> max over k_pos -> hid_ang.  The two 64->D/2
@@ -468,6 +467,23 @@ int ogmm_weight_grad_thin(const float* dy, int64_t lddy, const float* x, int64_t
  * an operand exceeds binary16's range.  Same partial layout, same alignment rules. */
 int ogmm_weight_grad_thin_f16x3(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t R, int n, int k, float* part, int* overflow,
                                 void* stream);
+
+/* ---- T10 (ABI 28): the small batched products of the training step that have no matrix-core shape (train_small.hip) -- until round 6 these were torch.matmul /
+ * torch.bmm calls, i.e. hipBLASLt kernels; exact fp32 fmaf chains in ascending contraction order.
+ * ogmm_small_bmm_nn: out[b][i][d] = sum_{j<m} S[b][i][j] X[b][j][d] (+ bias[d]); S and X by element strides (a transposed view costs nothing), out rows contiguous
+ * (row pitch ldO); contraction m <= 1024, any rows / D.  Replaces: the forward y = x W^T of the thin layers emd.conv1 (6 -> 64, models/dgcnn.py:121,138),
+ * pos.conv_dis.0 and pos.conv_ang1.0 (1 -> 64, models/attn.py:37-47) and their dx = dy W; the feature mean's backward df = gamma (dmu / (pi N + 1e-5))
+ * (lib/utils.py:138-140); corr = softmax(...) mu_t (models/dgcnn.py:109); and the S^T dOut / dG X halves of the backward of both forms.
+ * ogmm_small_bmm_nt: out[b][i][j] = alpha * sum_d A[b][i][d] B[b][j][d], one workgroup per 64 x 64 output tile, any D.  Replaces: the cluster-feature similarity of the matching
+ * (lib/utils.py:222-226 <- models/dgcnn.py:107), the Gram matrix of the clustering loss (lib/loss.py:40-47) and d(scores) = dcorr mu_t^T. */
+int ogmm_small_bmm_nn(const float* S, int64_t sS_b, int64_t sS_i, int64_t sS_j, const float* X, int64_t sX_b, int64_t sX_j, int64_t sX_d, const float* bias,
+                      int batch, int64_t rows, int m, int D, float* out, int64_t sO_b, int64_t ldO, void* stream);
+int ogmm_small_bmm_nt(const float* A, int64_t sA_b, int64_t ldA, const float* Bm, int64_t sB_b, int64_t ldB, int batch, int n, int m, int D, float alpha,
+                      float* out, int64_t sO_b, int64_t ldO, void* stream);
+
+/* out[rows[i]][0..D) += g[i][0..D) for i < n (fp32 atomics): the backward of index_points (lib/utils.py:111-127) -- the gradient rows of the anchors /
+ * nearest points added into their feature map's gradient (torch's index_add_ until round 6).  rows: int64 row numbers < out_rows (not checked on the device). */
+int ogmm_scatter_add_rows(float* out, int64_t ldo, int64_t out_rows, const int64_t* rows, const float* g, int64_t ldg, int64_t n, int D, void* stream);
 
 /* ---- T8: the overlap block (models/gmmreg.py:75-80) in training: ogmm_overlap_cross that also saves the row / column softmax
  * statistics (stats [B][4][N] = row max, row sum, column max, column sum), and its backward: given a = dL/dwo_src, b = dL/dwo_tgt

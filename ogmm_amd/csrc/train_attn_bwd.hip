@@ -38,8 +38,10 @@ using h4b = __attribute__((ext_vector_type(4))) _Float16;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 // hi = rn(v), lo = rn(v - hi) in binary16; amax collects |v| for the range check
-__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo, float& amax) {
+// (v_max_f32 returns its non-NaN operand: a NaN never shows in amax, so `probe` sums v * 0 -- NaN as soon as one operand is NaN or Inf)
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo, float& amax, float& probe) {
     amax = fmaxf(amax, fabsf(v));
+    probe = fmaf(v, 0.0f, probe);
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     _Float16* Ql = Qh + TQ * PH;
     _Float16* Gh = Ql + TQ * PH;
     _Float16* Gl = Gh + TQ * PH;
-    float amax = 0.0f;
+    float amax = 0.0f, nan_probe = 0.0f;
 
     const int h = blockIdx.x % H, c = blockIdx.x / H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                     const f32x2b a = *reinterpret_cast<const f32x2b*>(kr + 16 * u + i);
                     const f32x2b b = *reinterpret_cast<const f32x2b*>(vr + 16 * u + i);
                     _Float16 h, l;
-                    split1(a[0], h, l, amax); kh[u][i] = h; kl[u][i] = l;
-                    split1(a[1], h, l, amax); kh[u][i + 1] = h; kl[u][i + 1] = l;
-                    split1(b[0], h, l, amax); vh[u][i] = h; vl[u][i] = l;
-                    split1(b[1], h, l, amax); vh[u][i + 1] = h; vl[u][i + 1] = l;
+                    split1(a[0], h, l, amax, nan_probe); kh[u][i] = h; kl[u][i] = l;
+                    split1(a[1], h, l, amax, nan_probe); kh[u][i + 1] = h; kl[u][i + 1] = l;
+                    split1(b[0], h, l, amax, nan_probe); vh[u][i] = h; vl[u][i] = l;
+                    split1(b[1], h, l, amax, nan_probe); vh[u][i + 1] = h; vl[u][i + 1] = l;
                 }
         } else {
             const float* __restrict__ kr = kc + (int64_t)(32 * wave + lr) * ldk + 2 * lh;
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     _Float16 h, l;
-                    split1(qst[u][e], h, l, amax); qh[e] = h; ql[e] = l;
-                    split1(gst[u][e], h, l, amax); gh[e] = h; gl[e] = l;
+                    split1(qst[u][e], h, l, amax, nan_probe); qh[e] = h; ql[e] = l;
+                    split1(gst[u][e], h, l, amax, nan_probe); gh[e] = h; gl[e] = l;
                 }
                 *reinterpret_cast<h4b*>(Qh + row * PH + c4) = qh; *reinterpret_cast<h4b*>(Ql + row * PH + c4) = ql;
                 *reinterpret_cast<h4b*>(Gh + row * PH + c4) = gh; *reinterpret_cast<h4b*>(Gl + row * PH + c4) = gl;
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     }
 
     if constexpr (SPLIT) {
-        if (overflow && !(amax <= 65504.0f)) atomicOr(overflow, 1);          // an operand beyond binary16's range (or NaN / Inf): the trainer lowers its loss scale
+        if (overflow && (!(amax <= 65504.0f) || nan_probe != nan_probe)) atomicOr(overflow, 1);          // an operand beyond binary16's range, NaN or Inf: the trainer lowers its loss scale
     }
     // ---- dK, dV blocks of the wave: lane = column d, registers = keys
     {

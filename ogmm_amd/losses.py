@@ -6,6 +6,23 @@ import torch
 import torch.nn.functional as F
 
 
+def _bmm(a, b):
+    """a [B,R,m] b [B,m,D]: on the device the small-product kernel T10 (ogmm_small_bmm_nn, with autograd: train_ops._SmallNN) -- torch.bmm, i.e. a hipBLASLt
+    kernel, until round 6; on the CPU (the gloo / wiring tests) plain torch"""
+    if a.is_cuda:
+        from .train_ops import small_bmm
+        return small_bmm(a, b)
+    return torch.bmm(a, b)
+
+
+def _bmm_nt(a, b):
+    """a [B,n,D] b [B,m,D]^T, as _bmm"""
+    if a.is_cuda:
+        from .train_ops import small_bmm_nt
+        return small_bmm_nt(a, b)
+    return torch.bmm(a, b.transpose(1, 2))
+
+
 def info_nce(anchor, positive, tau):
     """`ConLoss.forward` (lib/loss.py:22-57) for one cloud set.  anchor, positive [B,n,D] -> scalar.
     Each of the B*2n rows is a softmax classification whose class 0 is the matching pair (x_i, y_i) and whose other
@@ -14,9 +31,9 @@ def info_nce(anchor, positive, tau):
     x = F.normalize(anchor, p=2, dim=-1)
     y = F.normalize(positive, p=2, dim=-1)
     both = torch.cat([x, y], dim=1)                                   # [B,2n,D]
-    sim = torch.bmm(both, both.transpose(1, 2)) / tau                 # blocks [[xx, xy], [yx, yy]]
-    i = torch.arange(n, device=anchor.device)
-    pos = torch.cat([sim[:, i, n + i], sim[:, n + i, i]], dim=1)      # [B,2n]: xy_ii for the x rows, yx_ii for the y rows
+    sim = _bmm_nt(both, both) / tau                                   # blocks [[xx, xy], [yx, yy]]
+    # [B,2n]: xy_ii for the x rows, yx_ii for the y rows -- the two off-diagonals as views (advanced indexing here meant an index_put with a sort in the backward)
+    pos = torch.cat([torch.diagonal(sim, offset=n, dim1=1, dim2=2), torch.diagonal(sim, offset=-n, dim1=1, dim2=2)], dim=1)
     # the negatives are every entry of a row except the two "diagonals" (self-similarity and the positive): row r drops columns r and (r + n) mod 2n.
     # As a gather with computed column indices (ascending, as a boolean mask would select them): no index_put, no mask -> nonzero, i.e. no host
     # synchronisation -- the loss can sit inside a recorded (HIP graph) training step.
@@ -34,7 +51,7 @@ def dcp_loss(R, R_gt, t, t_gt):
     """lib/loss.py:121-126"""
     B = R.shape[0]
     eye = torch.eye(3, dtype=R.dtype, device=R.device).expand(B, 3, 3)
-    return F.mse_loss(torch.bmm(R.transpose(1, 2), R_gt), eye) + F.mse_loss(t.reshape(B, 3), t_gt.reshape(B, 3))
+    return F.mse_loss(_bmm(R.transpose(1, 2), R_gt), eye) + F.mse_loss(t.reshape(B, 3), t_gt.reshape(B, 3))
 
 
 def overlap_mse(src_o, tgt_o, src_overlap, tgt_overlap):
@@ -53,7 +70,7 @@ def welsch_loss(src, tgt, R, t, src_overlap, tgt_overlap, alpha=10.0, top_k=512)
     can be pinned here: the goldens of tests/golden/make_golden_train.py come from it -- and on the device `ops.topk_rows` replays ATen's CPU selection move for move.
     The reference's own GPU runs use torch's CUDA top-k, whose choice among ties is unspecified and differs from both; the loss is a mean over whichever tied points
     are drawn (5e-4 apart in the Welsch term at N = 1024, top_k = 512).  Rows beyond `ops.TOPK_ROWS_MAX_N` points fall back to the device library's top-k."""
-    moved = torch.bmm(src, R.transpose(1, 2)) + t.reshape(-1, 1, 3)
+    moved = _bmm(src, R.transpose(1, 2)) + t.reshape(-1, 1, 3)
     if moved.is_cuda:
         from . import ops
         if src_overlap.shape[-1] <= ops.TOPK_ROWS_MAX_N:

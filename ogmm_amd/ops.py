@@ -17,7 +17,7 @@ GEMM_TIMELINE = None
 # product path, every other value the form it replaced -- bit-identical where the comment says so.
 NORM_BWD_FUSED = True          # training: the normalisation backward's reduction in the dh GEMM's epilogue (A/B switch)
 FUSE_GATHER = True      # anchor rows gathered by the consuming GEMM's operand DMA (conv1x1_gathered)
-EDGECONV_PC = True      # the EdgeConv chain as a producer / consumer pipeline (k = 20)
+EDGECONV_PC = True      # the EdgeConv chain as a producer / consumer pipeline (k = 20); False: the barrier-phased kernel
 FUSE_HEAD = True      # Cout = 1 heads in the producing layer's epilogue (conv1x1_head)
 GEMM_TIMELINE_ONLY = None      # optional set of variant tags: only those launches are bracketed by events (bench.py: the dominant engine only)
 KERNEL_TIMELINE = None         # bench.py: a list -> the EdgeConv and attention launches are bracketed too: (start_event, end_event, name, algorithmic flops, algorithmic bytes)
@@ -1064,6 +1064,40 @@ def pos_features(xyz, idx, centroid):
     xyz, idx, centroid = _f32(xyz, "xyz"), _i32(idx, "idx"), _f32(centroid, "centroid").contiguous()
     _lib.call("ogmm_pos_features", _p(xyz), _p(idx), C, N, k, _p(centroid), _p(d2), _p(alpha), _stream())
     return d2, alpha
+
+
+def scatter_add_rows_(out, rows, g):
+    """out[rows[i]] += g[i] in place (kernel T10; rows int64 [n], g [n, D] rows contiguous, out [R, D])"""
+    assert out.stride(1) == 1 and g.stride(1) == 1 and rows.dtype == torch.int64 and rows.is_contiguous() and g.shape[0] == rows.shape[0]
+    _lib.call("ogmm_scatter_add_rows", _p(_f32(out, "out")), out.stride(0), out.shape[0], _p(rows), _p(_f32(g, "g")), g.stride(0), rows.shape[0], out.shape[1], _stream())
+    return out
+
+
+def small_bmm_nn(S, X, bias=None, out=None):
+    """out[b] = S[b] X[b] (+ bias): S [B, R, m] and X [B, m, D] as ANY strided views (a transposed view costs nothing), contraction m <= 1024  -> [B, R, D]
+    (kernel T10, exact fp32 fmaf chains; the thin / tiny products the training step used to hand to torch.matmul: include/ogmm_hip.h)."""
+    B, R, m = S.shape
+    D = X.shape[2]
+    assert X.shape[0] == B and X.shape[1] == m and _f32(S, "S") is S and _f32(X, "X") is X
+    if out is None:
+        out = torch.empty((B, R, D), dtype=torch.float32, device=S.device)
+    assert out.stride(2) == 1 and out.shape == (B, R, D)
+    if bias is not None:
+        bias = _f32(bias, "bias").contiguous()
+    _lib.call("ogmm_small_bmm_nn", _p(S), S.stride(0), S.stride(1), S.stride(2), _p(X), X.stride(0), X.stride(1), X.stride(2), _p(bias), B, R, m, D,
+              _p(out), out.stride(0), out.stride(1), _stream())
+    return out
+
+
+def small_bmm_nt(A, Bm, alpha=1.0):
+    """out[b] = alpha A[b] Bm[b]^T: A [B, n, D], Bm [B, m, D] (rows contiguous) -> [B, n, m]   (kernel T10)"""
+    B, n, D = A.shape
+    m = Bm.shape[1]
+    assert Bm.shape[0] == B and Bm.shape[2] == D and A.stride(2) == 1 and Bm.stride(2) == 1
+    out = torch.empty((B, n, m), dtype=torch.float32, device=A.device)
+    _lib.call("ogmm_small_bmm_nt", _p(_f32(A, "A")), A.stride(0), A.stride(1), _p(_f32(Bm, "B")), Bm.stride(0), Bm.stride(1), B, n, m, D, float(alpha),
+              _p(out), out.stride(0), out.stride(1), _stream())
+    return out
 
 
 def l2norm_rows_bwd(x, g):

@@ -74,13 +74,18 @@ def transformer(ops, P, name, x, anchors, C, N, M, H, res=None):
     xq, x = x if isinstance(x, tuple) else (x, x)
     D = x.shape[1]
     dh = D // H
-    cp = torch.arange(D, device=x.device)
-    perm = (cp % dh) * H + (cp // dh)
-    q = ops.linear(xq, _w(P, name + ".attn.proj.0")[perm], _b(P, name + ".attn.proj.0")[perm])
-    kk = ops.linear(anchors, _w(P, name + ".attn.proj.1")[perm], _b(P, name + ".attn.proj.1")[perm])
-    vv = ops.linear(anchors, _w(P, name + ".attn.proj.2")[perm], _b(P, name + ".attn.proj.2")[perm])
+    # head-major re-ordering c' = h dh + d <- c = d H + h as a transposed VIEW of the parameter (one strided copy forwards, one backwards).  Until round 6 this
+    # was advanced indexing with a permutation vector, whose backward is index_put_(accumulate=True): a radix sort per weight and step (25 of them in the profile).
+    def rows_hm(w):          # [D, ...] -> rows in head-major order
+        return w.view(dh, H, *w.shape[1:]).transpose(0, 1).reshape(w.shape)
+
+    def cols_hm(w):          # [Dout, D] -> input columns in head-major order
+        return w.view(w.shape[0], dh, H).transpose(1, 2).reshape(w.shape)
+    q = ops.linear(xq, rows_hm(_w(P, name + ".attn.proj.0")), rows_hm(_b(P, name + ".attn.proj.0")))
+    kk = ops.linear(anchors, rows_hm(_w(P, name + ".attn.proj.1")), rows_hm(_b(P, name + ".attn.proj.1")))
+    vv = ops.linear(anchors, rows_hm(_w(P, name + ".attn.proj.2")), rows_hm(_b(P, name + ".attn.proj.2")))
     o = ops.attention(q, kk, vv, C, N, M, H)
-    msg = ops.linear(o, _w(P, name + ".attn.merge")[:, perm], _b(P, name + ".attn.merge"))
+    msg = ops.linear(o, cols_hm(_w(P, name + ".attn.merge")), _b(P, name + ".attn.merge"))
     z, st = ops.linear_stats(x, _w(P, name + ".mlp.0"), _b(P, name + ".mlp.0"), x2=msg, groups=C)
     return ops.instnorm_relu_linear(z, C, N, st, _w(P, name + ".mlp.3"), _b(P, name + ".mlp.3"), res=res)          # res: the caller's "+ x"
 

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from ._lib import OgmmError
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -106,17 +107,76 @@ class _MaxPoolK(torch.autograd.Function):
         return ops.maxpool_k_bwd(dout.contiguous(), arg, ctx.k), None
 
 
+class _SmallNN(torch.autograd.Function):
+    """out[b] = S[b] X[b]: S [B, R, m], X [B, m, D], contraction m <= 1024 (ops.small_bmm_nn, kernel T10).  Backward on the same two kernels:
+    dS = dOut X^T (both tiny: the nt form; a thin D: the nn form over D), dX = S^T dOut (the nn form over R <= 128)."""
+
+    @staticmethod
+    def forward(ctx, S, X):
+        ctx.save_for_backward(S, X)
+        return ops.small_bmm_nn(S, X)
+
+    @staticmethod
+    def backward(ctx, g):
+        S, X = ctx.saved_tensors
+        g = g.contiguous()
+        dS = dX = None
+        R, m, D = S.shape[1], S.shape[2], X.shape[2]
+        if ctx.needs_input_grad[0]:
+            if R <= 256 and m <= 256:
+                dS = ops.small_bmm_nt(g, X.contiguous())
+            elif D <= 128:
+                dS = ops.small_bmm_nn(g, X.transpose(1, 2))
+            else:
+                raise OgmmError("_SmallNN: no kernel for dS at R=%d m=%d D=%d" % (R, m, D))
+        if ctx.needs_input_grad[1]:
+            # a contraction over the rows: the nn form up to 128 of them, the nt form (both operands as [., R] rows) beyond
+            dX = ops.small_bmm_nn(S.transpose(1, 2), g) if R <= 128 else ops.small_bmm_nt(S.transpose(1, 2).contiguous(), g.transpose(1, 2).contiguous())
+        return dS, dX
+
+
+class _SmallNT(torch.autograd.Function):
+    """out[b] = alpha A[b] B[b]^T: A [B, n, D], B [B, m, D] (ops.small_bmm_nt, kernel T10); dA = alpha dOut B, dB = alpha dOut^T A (nn form)."""
+
+    @staticmethod
+    def forward(ctx, A, Bm, alpha):
+        A, Bm = A.contiguous(), Bm.contiguous()
+        ctx.save_for_backward(A, Bm)
+        ctx.alpha = alpha
+        return ops.small_bmm_nt(A, Bm, alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, Bm = ctx.saved_tensors
+        g = g.contiguous() * ctx.alpha if ctx.alpha != 1.0 else g.contiguous()
+        dA = ops.small_bmm_nn(g, Bm) if ctx.needs_input_grad[0] else None
+        dB = ops.small_bmm_nn(g.transpose(1, 2), A) if ctx.needs_input_grad[1] else None
+        return dA, dB, None
+
+
+def small_bmm(a, b):
+    """torch.bmm(a, b) for the training step's small products: a [B, R, m] x b [B, m, D], m <= 128, on kernel T10 with autograd"""
+    return _SmallNN.apply(a, b)
+
+
+def small_bmm_nt(a, b, alpha=1.0):
+    """alpha * torch.bmm(a, b^T) for a [B, n, D], b [B, m, D]"""
+    return _SmallNT.apply(a, b, alpha)
+
+
 class _ThinLinear(torch.autograd.Function):
     """y = x W^T + b for layers too thin for a matrix-core tile in the forward direction (the 6 -> 64 edge layer, the 1 -> 64
-    positional layers): the forward is an HBM-bound outer product (library call), the weight gradient the exact-fp32 thin
-    reduction kernel T9, dX (only the positional hidden layers need it) a library call."""
+    positional layers): the forward is an HBM-bound outer product and dX = dY W a 64-term row reduction (kernel T10: ops.small_bmm_nn, exact fp32 --
+    library GEMMs until round 6), the weight gradient the thin reduction kernel T9."""
 
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        y = x @ W.t()
-        return y if b is None else y + b
+        if not x.is_cuda:          # (CPU tensors only reach this through the tests' wiring seam)
+            y = x @ W.t()
+            return y if b is None else y + b
+        return ops.small_bmm_nn(x[None], W.detach().t()[None], bias=None if b is None else b.detach())[0]
 
     @staticmethod
     def backward(ctx, dy):
@@ -124,7 +184,7 @@ class _ThinLinear(torch.autograd.Function):
         dx = dW = db = None
         dyc = dy.contiguous()
         if ctx.needs_input_grad[0]:
-            dx = dyc @ W
+            dx = ops.small_bmm_nn(dyc[None], W.detach()[None])[0] if dyc.is_cuda and W.shape[0] <= 1024 else dyc @ W
         if ctx.needs_input_grad[1]:
             xc = x.contiguous()
             dW = ops.weight_grad_thin(dyc, xc) if ops.weight_grad_thin_supported(dyc, xc) else dyc.t() @ xc
@@ -355,8 +415,36 @@ class _Fanout(torch.autograd.Function):
             for i in range(8, len(gs), 7):
                 out = ops.add_n([out] + gs[i:i + 7])
         for rows, g in sparse:
-            out.index_add_(0, rows, g)
+            if out.is_cuda:
+                ops.scatter_add_rows_(out, rows.contiguous(), g)          # (kernel T10; torch's index_add_ until round 6)
+            else:
+                out.index_add_(0, rows, g)
         return out, None, None
+
+
+def _select_rows(feats, rows):
+    """feats[rows] for int64 row numbers: the library's index_select on the CPU seam, on the device the row-gather kernel K6 (one cloud of R rows: ids = rows)"""
+    if not feats.is_cuda or feats.stride(1) != 1:
+        return feats.index_select(0, rows)
+    return ops.gather_rows(feats, feats.stride(0), 1, feats.shape[0], feats.shape[1], rows.to(torch.int32)[None].contiguous())[0]
+
+
+class _SelectRows(torch.autograd.Function):
+    """feats[rows] with a dense gradient map (a gather whose source is no fan-out handle): zero map + the row scatter-add kernel"""
+
+    @staticmethod
+    def forward(ctx, feats, rows):
+        ctx.rows, ctx.shape = rows, tuple(feats.shape)
+        return _select_rows(feats, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        if out.is_cuda:
+            ops.scatter_add_rows_(out, ctx.rows.contiguous(), g.contiguous())
+        else:
+            out.index_add_(0, ctx.rows, g)
+        return out, None
 
 
 class _GatherRows(torch.autograd.Function):
@@ -365,7 +453,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, rows, stash):
         ctx.rows, ctx.stash = rows, stash
-        return feats.index_select(0, rows)
+        return _select_rows(feats, rows)
 
     @staticmethod
     def backward(ctx, g):
@@ -390,7 +478,7 @@ class _L2Norm(torch.autograd.Function):
 
 class _FeatMean(torch.autograd.Function):
     """mu_f = gamma^T f / (pi N + 1e-5) (lib/utils.py:130-140): ogmm_gmm_feat_mean forward; the gradient reaches f only
-    (gamma, pi come out of the no-grad E/M loop): df = gamma (dmu / (pi N + 1e-5)), a small batched library GEMM."""
+    (gamma, pi come out of the no-grad E/M loop): df = gamma (dmu / (pi N + 1e-5)), J-term rows on kernel T10."""
 
     @staticmethod
     def forward(ctx, gamma, pi, f, C, N):
@@ -401,7 +489,7 @@ class _FeatMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmu):
         gamma, pi = ctx.saved_tensors
-        df = torch.bmm(gamma, dmu / (pi * ctx.N + 1e-5)[:, :, None])
+        df = ops.small_bmm_nn(gamma, (dmu / (pi * ctx.N + 1e-5)[:, :, None]).contiguous())          # (kernel T10: J-term rows; torch.bmm until round 6)
         return None, None, df.reshape(-1, dmu.shape[2]), None, None
 
 
@@ -660,7 +748,7 @@ class TrainOps:
         stash = getattr(feats, "_ogmm_stash", None)
         if stash is not None and feats.requires_grad:
             return _GatherRows.apply(feats, rows, stash)
-        return feats.index_select(0, rows)
+        return _SelectRows.apply(feats, rows) if feats.requires_grad else _select_rows(feats, rows)
 
     def attention(self, q, k, v, C, N, M, H):
         """softmax(q k^T / sqrt(dh)) v per cloud and head; head-major channels.  q [C*N,D], k, v [C*M,D] -> [C*N,D]"""
@@ -684,9 +772,14 @@ class TrainOps:
 
     def match_kabsch(self, mu_s, mu_t, f_s, f_t, temperature):
         """models/dgcnn.py:96-115 + lib/se3.py:256-289"""
-        sim = F.normalize(f_s, dim=-1) @ F.normalize(f_t, dim=-1).transpose(1, 2)
-        sc = torch.softmax(sim / temperature, dim=2)                    # [B,J,J]
-        corr = sc @ mu_t                                                # [B,J,3]
+        if f_s.is_cuda and f_s.shape[1] <= 128:          # kernel T10 (torch.matmul until round 6)
+            sim = small_bmm_nt(F.normalize(f_s, dim=-1), F.normalize(f_t, dim=-1))
+            sc = torch.softmax(sim / temperature, dim=2)                # [B,J,J]
+            corr = small_bmm(sc, mu_t.contiguous())                     # [B,J,3]
+        else:
+            sim = F.normalize(f_s, dim=-1) @ F.normalize(f_t, dim=-1).transpose(1, 2)
+            sc = torch.softmax(sim / temperature, dim=2)
+            corr = sc @ mu_t
         w = sc.sum(dim=2)                                               # == 1 up to rounding
         return self.kabsch(mu_s, corr, w)
 

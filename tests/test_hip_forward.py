@@ -293,6 +293,50 @@ def test_reduced_precision_mode_against_the_emulating_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("profile,sample", [("default", (0, 9, 18, 27, 36, 45, 54, 63)), ("sharp", (5, 23, 41, 59))])
+def test_configs3_at_its_full_per_gpu_size(profile, sample):
+    """BASELINE configs[3] at the size ONE GPU takes of its 512-pair batch: 64 room-cloud pairs x 2048 points, J = 64, in ONE forward (the
+    suite had 16 pairs on the forced launch sequence and a 3-pair sample in the bench).  Every pair: R orthonormal with det +1, finite t, scores in (0, 1), all E-steps
+    ran their ten sweeps (so the per-call batch-mean exit did not couple the clouds and a pair is the oracle's single-pair computation); a strided sample of the
+    pairs against the oracle by the tail rule of tests/parity_util.py."""
+    from parity_util import check_tail
+    B, N, J, first = 64, 2048, 64, 3000
+    cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=J)
+    model, P = build(cfg, J, profile=profile)
+    src, tgt, _, _ = synth.make_batch(first, B, N, "room")
+    starts = synth.fps_starts_for(first, B, N)
+    with torch.no_grad():
+        R, t, so, to_, loss = model(src.cuda(), tgt.cuda(), fps_starts=starts, capture=True)
+    assert not model.fp16_overflowed()
+    sweeps = model.last_intermediates["sinkhorn_sweeps"].cpu()
+    assert int(sweeps.min()) == 10 and int(sweeps.max()) == 10, sweeps
+    R, t, so, to_ = R.cpu(), t.cpu(), so.cpu(), to_.cpu()
+    eye = torch.eye(3)[None].expand(B, 3, 3)
+    assert torch.isfinite(R).all() and torch.isfinite(t).all() and torch.isfinite(loss).all()
+    assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-5 and (torch.linalg.det(R) - 1).abs().max() < 1e-5
+    assert float(so.min()) > 0 and float(so.max()) < 1 and float(to_.min()) > 0 and float(to_.max()) < 1
+    ids = list(sample)
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    try:
+        r, tt, oo = [], [], []
+        for i in ids:
+            with torch.no_grad():
+                ref = O.forward(P, cfg, src[i:i + 1], tgt[i:i + 1], starts[:, i:i + 1])
+            r.append(O.rotation_error_rad(R[i:i + 1], ref[0])); tt.append(O.translation_error(t[i:i + 1], ref[1]))
+            oo.append(max((so[i:i + 1] - ref[2]).abs().max().item(), (to_[i:i + 1] - ref[3]).abs().max().item()))
+    finally:
+        torch.set_num_threads(old)
+    r, tt = torch.cat(r), torch.cat(tt)
+    label = "%s weights, configs[3] per-GPU batch (64 room pairs x 2048, J=64), sampled pairs %s" % (profile, [first + i for i in ids])
+    print("PARITY-DISTRIBUTION %s: R max %.2e median %.2e  t max %.2e  overlap max %.2e" % (label, r.max(), r.median(), tt.max(), max(oo)))
+    sel = torch.tensor(ids)
+    # (check_tail numbers its pairs first + position: hand it the sampled pairs as a contiguous block of their own)
+    check_tail(label, r, tt, (src[sel], tgt[sel], starts[:, sel]), P, cfg, 0, len(ids) - 1)
+    assert max(oo) < (1e-5 if profile == "default" else 6e-5)
+
+
+@pytest.mark.gpu
 def test_largest_supported_cloud_and_input_validation():
     """N = 4096 (the FPS / kNN kernels keep a whole cloud on chip: their documented ceiling), J = 64, against the CPU oracle; and the
     argument checks of the forward: wrong dtype, N_src != N_tgt, more neighbours / anchors / clusters than points."""

@@ -471,6 +471,32 @@ def test_edgeconv_fused_matches_oracle_dgcnn_front(ops, C, N, k):
     assert err < 5e-6 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("C,N", [(128, 1024), (3, 717), (1, 41), (1, 24)])
+def test_edgeconv_two_kernels_are_bit_identical(raw_ops, monkeypatch, C, N):
+    """k = 20: the barrier-phased kernel (ops.EDGECONV_PC = False) and the producer / consumer pipeline (the default) write the same xcat, bit for bit -- whole
+    chip (more tiles than workgroups), ragged point counts, a few tiles only -- on the sharp weight family."""
+    from ogmm_amd.gmmreg import pack_weights, state_spec
+    ops = raw_ops
+    sd = {key: torch.zeros(shape, dtype=torch.int64 if key.endswith("num_batches_tracked") else torch.float32) for key, shape in state_spec(512)}
+    synth.fill_state_dict(sd, profile="sharp")
+    L = pack_weights({key: v.cuda() for key, v in sd.items()}, 512, 4)
+    xyz = dev(clouds(C, N, seed=7)) if N >= 33 else dev(torch.randn(C, N, 3, generator=torch.Generator().manual_seed(N)))
+    k = 20 if N >= 20 else N
+    if k != 20:
+        pytest.skip("k = 20 only")
+    idx = ops.knn(xyz, k)
+    emd = [L["emd1"], L["emd2"], L["emd3"], L["emd4"]]
+    outs = []
+    for mode in (False, True):
+        monkeypatch.setattr(ops, "EDGECONV_PC", mode)
+        xcat = torch.full((C * N, 512), float("nan"), device="cuda")
+        st = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.edgeconv_fused(xyz, idx, emd, xcat, status=st)
+        assert int(st.item()) == 0 and bool(torch.isfinite(xcat).all())
+        outs.append(xcat)
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
 @pytest.mark.parametrize("C,N,Cmid,Cout", [(2, 256, 256, 128), (64, 1024, 1024, 512)])
 def test_gemm_fused_instance_norm(ops, C, N, Cmid, Cout):
     """conv -> InstanceNorm1d -> ReLU -> conv (models/attn.py:17-27): statistics from the first GEMM's epilogue, the

@@ -9,7 +9,7 @@ from ogmm_amd import losses, metric, synth
 from ogmm_amd.gmmreg import GMMReg
 from ogmm_amd.train_ops import TrainOps
 from train_ref import RefTrainOps
-from train_util import TRAIN_CASES, TRAIN_CASES_ENGINE, check_grads, load_train_case, noise_tol, profile_of
+from train_util import TRAIN_CASES, TRAIN_CASES_ENGINE, check_grads, load_train_case, noise_tol, profile_of, rt_tail_tol
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -113,6 +113,77 @@ def test_weight_grad_thin(R, n, k, split):
             (dy3 if which == 0 else x3)[R // 3, 0] = float("nan")
             ops.weight_grad_thin(dy3, x3, split=True, overflow=ovf)
             assert int(ovf.item()) & 1, "NaN in %s not flagged" % ("dy" if which == 0 else "x")
+
+
+@pytest.mark.parametrize("B,R,m,D,bias,transposed", [(1, 100003, 6, 64, True, False), (1, 70001, 1, 64, False, False), (1, 5003, 64, 1, False, False),
+                                                     (1, 4099, 64, 6, False, False), (4, 1024, 16, 512, False, False), (3, 16, 16, 3, False, True),
+                                                     (2, 300, 128, 512, False, False), (2, 33, 32, 514, False, True), (5, 1024, 3, 3, False, True), (1, 40001, 256, 1, True, False)])
+def test_small_bmm_nn(B, R, m, D, bias, transposed):
+    """kernel T10 (round 6: the thin / tiny products the training step used to give to torch.matmul): out[b] = S[b] X[b] (+ bias) against the fp64 product --
+    the thin layers' forward (m = 6, 1) and dx (m = 64, D = 1 / 6), the feature mean's backward (m = J = 16, D = 512), transposed views of both operands,
+    a contraction of 128 with D in two staging passes, D not a multiple of four (the scalar form)."""
+    from ogmm_amd import ops
+    g = torch.Generator().manual_seed(R + m)
+    S = torch.randn(B, m, R, generator=g).to(DEV).transpose(1, 2) if transposed else torch.randn(B, R, m, generator=g).to(DEV)
+    X = torch.randn(B, D, m, generator=g).to(DEV).transpose(1, 2) if transposed else torch.randn(B, m, D, generator=g).to(DEV)
+    b = torch.randn(D, generator=g).to(DEV) if bias else None
+    got = ops.small_bmm_nn(S, X, bias=b)
+    want = torch.bmm(S.double(), X.double()) + (b.double() if bias else 0.0)
+    assert got.shape == (B, R, D) and _rel(got, want) < 1e-6, _rel(got, want)
+
+
+def test_row_gather_and_scatter_add_of_the_training_step():
+    """train_ops._select_rows / _SelectRows (kernel K6 forwards, ogmm_scatter_add_rows backwards: index_select / index_add_ of the library until round 6): values,
+    the dense gradient with repeated rows, and the fan-out's sparse path."""
+    from ogmm_amd import ops, train_ops
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(5000, 512, generator=g).to(DEV)
+    rows = torch.randint(0, 5000, (777,), generator=g).to(DEV)
+    rows[5] = rows[6] = rows[7]                                   # repeated rows: their gradients add up
+    assert torch.equal(train_ops._select_rows(feats, rows), feats.index_select(0, rows))
+    up = torch.randn(777, 512, generator=g).to(DEV)
+    a, b = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    train_ops._SelectRows.apply(a, rows).backward(up)
+    b.index_select(0, rows).backward(up)
+    assert _rel(a.grad, b.grad) < 1e-6
+    out = torch.zeros(5000, 512, device=DEV)
+    ops.scatter_add_rows_(out, rows, up)
+    assert _rel(out, torch.zeros(5000, 512, device=DEV).index_add_(0, rows, up)) < 1e-6
+
+
+@pytest.mark.parametrize("B,n,m,D", [(5, 32, 32, 512), (3, 16, 16, 3), (2, 100, 70, 50), (1, 3, 3, 1024), (4, 128, 128, 512)])
+def test_small_bmm_nt_and_autograd(B, n, m, D):
+    """kernel T10: out[b] = alpha A[b] B[b]^T against fp64, and the two autograd wrappers (train_ops.small_bmm / small_bmm_nt) against torch.bmm's gradients --
+    the matching's similarity / soft correspondences, the clustering loss's Gram matrix, the 3 x 3 products of the motion losses (rows >> 128: the nt form of dX)."""
+    from ogmm_amd import ops, train_ops
+    g = torch.Generator().manual_seed(n * 7 + D)
+    A, Bm = torch.randn(B, n, D, generator=g).to(DEV), torch.randn(B, m, D, generator=g).to(DEV)
+    got = ops.small_bmm_nt(A, Bm, 0.5)
+    assert _rel(got, 0.5 * torch.bmm(A.double(), Bm.double().transpose(1, 2))) < 2e-6          # (a sequential fp32 chain over D terms)
+    up = torch.randn(B, n, m, generator=g).to(DEV)
+    res = {}
+    for tag in ("hip", "ref"):
+        a, b = A.clone().requires_grad_(True), Bm.clone().requires_grad_(True)
+        if tag == "hip":
+            out = train_ops.small_bmm_nt(a, b, 2.0)
+        else:
+            out = 2.0 * torch.bmm(a.double(), b.double().transpose(1, 2))
+        out.backward(up.to(out.dtype))
+        res[tag] = (out.detach(), a.grad, b.grad)
+    for x, y in zip(res["hip"], res["ref"]):
+        assert _rel(x, y) < 1e-6, _rel(x, y)
+    # nn form with autograd: S [B, n, m] X [B, m, D'] for a thin D' (dS through the nn form over D') and for rows beyond 128 (dX through the nt form)
+    for rows, dd in ((n, 3), (1024, 3), (40, D)):
+        S0, X0 = torch.randn(B, rows, m, generator=g).to(DEV), torch.randn(B, m, dd, generator=g).to(DEV)
+        up = torch.randn(B, rows, dd, generator=g).to(DEV)
+        res = {}
+        for tag in ("hip", "ref"):
+            s_, x_ = S0.clone().requires_grad_(True), X0.clone().requires_grad_(True)
+            out = train_ops.small_bmm(s_, x_) if tag == "hip" else torch.bmm(s_.double(), x_.double())
+            out.backward(up.to(out.dtype))
+            res[tag] = (out.detach(), s_.grad, x_.grad)
+        for x, y in zip(res["hip"], res["ref"]):
+            assert _rel(x, y) < 1e-6, (rows, dd, _rel(x, y))
 
 
 @pytest.mark.parametrize("points,k,cols", [(1000, 20, 64), (333, 5, 64), (4096, 12, 256)])
@@ -553,7 +624,8 @@ def test_training_step_matches_reference(name, precision):
         # the Welsch term sums 2 - exp(-a) - exp(-b) with a, b ~ 1e-6: every summand carries the 6e-8 rounding of "1 - tiny",
         # so the fp32 value itself is only defined to ~1e-5 (it enters the loss with weight 0.01)
         assert rep[kpart] <= noise_tol(fx, "loss", (1e-4 if kpart == "welsch" else 1e-5) * max(1.0, abs(float(fx["loss_" + kpart])))), kpart
-    assert rep["R"] < noise_tol(fx, "R", 1e-5) and rep["t"] < noise_tol(fx, "t", 1e-5) and rep["o"] < noise_tol(fx, "o", 1e-5)
+    tol_r, tol_t = rt_tail_tol(fx)          # the eval suite's rule: 1e-5, or 2 x the reference's own recorded spread where that is >= 5e-6
+    assert rep["R"] < tol_r and rep["t"] < tol_t and rep["o"] < noise_tol(fx, "o", 1e-5), (rep["R"], tol_r, rep["t"], tol_t)
     sd = model.state_dict()
     for key in (f[len("stat/"):] for f in fx.files if f.startswith("stat/")):
         np.testing.assert_allclose(sd[key].cpu().numpy(), fx["stat/" + key], rtol=1e-5, atol=1e-6, err_msg=key)

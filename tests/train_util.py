@@ -52,6 +52,17 @@ def noise_tol(fx, what, bar):
     return max(bar, min(3.0 * n, TOL_CAP[what]))
 
 
+def rt_tail_tol(fx):
+    """(R, t) tolerances of a TRAIN-mode forward by the eval suite's rule (tests/parity_util.check_tail): within 1e-5 -- unless the
+    fixture records that the reference's own train-mode result spreads by >= 5e-6 there (ILL_CONDITIONED), in which case TAIL_FACTOR = 2 x that spread, under
+    the same absolute cap as every noise-derived tolerance."""
+    n_r, n_t = noise_of(fx, "R"), noise_of(fx, "t")
+    assert n_r <= NOISE_MAX["R"] and n_t <= NOISE_MAX["t"], "fixture noise beyond NOISE_MAX: regenerate"
+    if n_r < 5e-6:
+        return 1e-5, 1e-5
+    return min(max(1e-5, 2.0 * n_r), TOL_CAP["R"]), min(max(1e-5, 2.0 * max(n_t, n_r)), TOL_CAP["R"])
+
+
 def filled_state(module_or_spec):
     """closed-form weights of ogmm_amd/synth.py as a fresh dict of tensors"""
     return synth.fill_state_dict(module_or_spec)
