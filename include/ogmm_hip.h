@@ -89,7 +89,7 @@ int ogmm_gather_rows(const float* feats, int64_t ld, int C, int N, int D, const 
  *   (hi = rn16(x), lo = rn16(x - hi): 22 significand bits) and a*b is evaluated as hi*hi + hi*lo + lo*hi on
  *   v_mfma_f32_32x32x16_f16 with fp32 accumulation (3 of 2.5 PFLOP/s MFMAs instead of 16 fp32-rate ones).  The
  *   dropped lo*lo term is 2^-22 relative; measured end to end it is indistinguishable from the exact-fp32 path
- *   (DESIGN.md "precision").  A is split on the fly from fp32; B must be given pre-split as B_hi/B_lo
+ *   (DESIGN.md section 2).  A is split on the fly from fp32; B must be given pre-split as B_hi/B_lo
  *   (binary16 [N][ldb_h], ldb_h a multiple of 8, columns beyond K zero) possibly pre-scaled by a power of two
  *   that the caller folds into alpha.  |A| must stay below 65504: larger values are clamped and *overflow
  *   (device int, optional) is set non-zero. */
@@ -158,7 +158,7 @@ typedef struct ogmm_gemm {
      *   1:      a_hi w_hi -- both operands rounded to binary16 (the 4-wave engine, N >= 512, only).
      * A permission, not an order: engines / shapes without the cheaper form run all three terms (results then differ from the two-term form
      * by the weight's rounding, 2^-12 relative per product).  Which layers of the path tolerate it -- R, t within 1e-5 of the reference over the
-     * parity distribution -- is measured, not assumed: tools/term_budget.py (CPU oracle with the same rounding) and DESIGN.md section 4. */
+     * parity distribution -- is measured, not assumed: tools/term_budget.py (CPU oracle with the same rounding) and HISTORY.md section 4. */
     int32_t terms;
     /* Normalisation-backward fusion (training; round 4): the GEMM computes dh = dY W (the gradient w.r.t. the ACTIVATION a = act(x * nb_scale + nb_shift) of a
      * normalised map x) and its epilogue turns it into dz = dh * act'(x * nb_scale + nb_shift), stores dz and accumulates the normalisation backward's two
@@ -237,7 +237,7 @@ int ogmm_pos_hidden(const float* xyz, const int32_t* idx, int idx_ld, int k_pos,
 int64_t ogmm_attention_workspace_bytes(int C, int M, int H, int dh);
 int ogmm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
                    int H, int dh, float scale, float* out, int64_t ldo, void* workspace, void* stream);
-/* The same with a term budget for the score product q k^T: qk_terms 0 / 3 = three binary16 terms (fp32-class), 1 = both operands
+/* The same with a term budget for the score product q k^T (HISTORY.md section 4): qk_terms 0 / 3 = three binary16 terms (fp32-class), 1 = both operands
  * rounded to binary16 -- one matrix instruction per block instead of three, no lo part of Q (a permission: kernels without that form run three). */
 int ogmm_attention_terms(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, int C, int N, int M,
                          int H, int dh, float scale, float* out, int64_t ldo, int qk_terms, void* workspace, void* stream);

@@ -501,7 +501,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
 // FUSED: no packed images -- the workgroup splits its (cloud, head)'s K and V rows itself while staging them (with one workgroup per (cloud, head),
 // as at B = 64, nothing is split twice, and the pack kernel with its workspace round trip disappears: -25 us per call).
 // QK1: the score product q k^T with BOTH operands rounded to binary16 (one matrix instruction per block instead of three, no lo part of Q): the
-// per-layer term budget's entry for the attention scores (measured insensitive like the Q projection itself).  P V keeps three.
+// per-layer term budget's entry for the attention scores (HISTORY.md section 4; measured insensitive like the Q projection itself).  P V keeps three.
 template <int MK, bool FUSED, bool QK1 = false>
 __global__ __launch_bounds__(512) void attention_t_kernel(const float* __restrict__ q, int64_t ldq, const f16x8* __restrict__ kimg,
                                                           const f16x8* __restrict__ vimg, const float* __restrict__ kraw, int64_t ldk,

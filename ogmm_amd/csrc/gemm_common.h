@@ -154,7 +154,7 @@ __device__ __forceinline__ void gemm_epilogue(const ogmm_gemm& g, f32x16 (&acc)[
 // that a lane owns 4 CONSECUTIVE columns of one row, then applies alpha*scale+shift / activation / residual on float4s
 // and stores with global_store_dwordx4 (16 lanes = one 256-byte row segment).  4x fewer store instructions than the
 // one-dword-per-lane MFMA layout: the output phase of these GEMMs is store-issue bound (measured: 36 % of a
-// 131072x512x512 launch), see DESIGN.md.  Needs N % 4 == 0, ldc % 4 == 0 (ldr % 4 == 0), 16-byte aligned C / Res.
+// 131072x512x512 launch), see HISTORY.md.  Needs N % 4 == 0, ldc % 4 == 0 (ldr % 4 == 0), 16-byte aligned C / Res.
 // `smem` must provide waves * 32 * (NT*32 + 4) floats and be free (the K loop has passed its last barrier).
 template <int MT, int NT, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0, int m_end,
@@ -179,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ogmm_gemm& g, f32x16 (&
     // unconditional.  That matters beyond the instruction count: with loads or stores under per-lane conditions the compiler cannot
     // count the operations in flight, so each pass's wait for its (optional) loads becomes s_waitcnt vmcnt(0) -- which also waits for
     // the PREVIOUS pass's store to be acknowledged.  The general form below therefore issues one store per HBM round trip per wave
-    // (the "store burst" of DESIGN.md: 14 % of a 131072x1024x1024 launch with the matrix cores idle).
+    // (the "store burst" of HISTORY.md: 14 % of a 131072x1024x1024 launch with the matrix cores idle).
     const bool tile_inside = m0 + WM * MT * 32 <= m_end && n0 + WN * NT * 32 <= g.N;
     if (tile_inside && !g.row_affine && 64 % F4_PER_ROW == 0 && g.act != OGMM_ACT_SIGMOID) {
         const int c4 = (lane % F4_PER_ROW) * 4, rl0 = lane / F4_PER_ROW;

@@ -32,7 +32,7 @@ __device__ unsigned long long g_v10_probe[4];
 // OVL: the GEMM is the batched similarity S = fn_src fn_tgt^T of the overlap block (models/gmmreg.py:75-80) and S is never stored: the epilogue
 // forms e = exp(S - 1) (|S| <= 1 for normalised rows, so no running maximum is needed: softmax(S) = e / sum e) and leaves, per tile, the partial
 // softmax-dots of its 256 rows against o_tgt and of its 256 columns against o_src as (1, sum e, sum e o) triples; ogmm_overlap_finalize merges them.
-// TERMS: matrix instructions per product block (struct ogmm_gemm.terms; the per-layer term budget of DESIGN.md section 4).
+// TERMS: matrix instructions per product block (struct ogmm_gemm.terms; the per-layer term budget of HISTORY.md section 4).
 //   3  lo*hi + hi*lo + hi*hi: fp32-class, the default
 //   2  lo*hi + hi*hi = (a_hi + a_lo) w_hi: the WEIGHT is rounded to binary16, the activation keeps both terms.  The lo plane of the weight image
 //      is not even fetched: 4 instead of 8 weight DMA instructions and 16 instead of 32 fragment reads per K step and wave.

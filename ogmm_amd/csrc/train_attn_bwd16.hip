@@ -15,7 +15,7 @@
 // tile); dQ of the tile is un-scaled when it is written, the running dK accumulator is kept in units of the current tile's 2^e (re-scaled by an exact
 // power of two whenever e changes), dV by 2^-10 at the end.
 // The transposed planes are written by 8-byte groups of four queries with the group index XOR-ed by the writer's (d / 32): rows of 72 bytes, writes
-// and reads both conflict-free (DESIGN.md section 7 has the bank arithmetic).
+// and reads both conflict-free (HISTORY.md section 7 has the bank arithmetic).
 #include "ogmm_common.h"
 
 namespace {

@@ -26,7 +26,7 @@ from ._lib import OgmmError
 from .ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 BN_EPS = 1e-5
-# Measured budget (DESIGN.md section 4 "Per-layer term budget").  Round 4: an entry stays only if the layer's rounding holds the 1e-5 bar on BOTH weight
+# Measured budget (HISTORY.md section 4 "Per-layer term budget").  Round 4: an entry stays only if the layer's rounding holds the 1e-5 bar on BOTH weight
 # families of the parity suite -- the closed-form default fill AND synth.fill_state_dict(profile="sharp") (peaked attention, saturated overlap scores).
 # Round 3's entries for conv2.0 / conv2.3 (weight rounded), the three Q projections and the attention's score product (both rounded) were measured on
 # the default fill only, where the attention is uniform to 1e-4 and every overlap score is 0.496 +- 0.003: on the sharp family each of them alone moves
@@ -236,7 +236,7 @@ class GMMReg(nn.Module):
         # binary16 ((a_hi + a_lo) w_hi: two matrix instructions per product block instead of three, x0.74-0.81 of the layer's time), 1 with both
         # operands rounded (a_hi w_hi: x0.5-0.63).  Only layers whose
         # rounding was measured to leave (R, t) within the parity bar are listed -- on the CPU oracle with the same rounding (tools/term_budget.py)
-        # and on the GPU's parity distribution (tools/parity_distribution.py); DESIGN.md section 4 has the table.  {} = three terms everywhere.
+        # and on the GPU's parity distribution (tools/parity_distribution.py); HISTORY.md section 4 has the table.  {} = three terms everywhere.
         self.term_budget = dict(TERM_BUDGET)
         self.sinkhorn_thresh = 1e-2      # lib/utils.py:73 (`thresh` default, which wkeans_plus :281 does not override); <= 0 runs every sweep
         self.fold_merge = True      # evaluate merge(attn) inside mlp.0 (one GEMM less per transformer)
@@ -258,7 +258,7 @@ class GMMReg(nn.Module):
         # of the previous forward.  Contract when True: `src` / `tgt` (and `fps_starts`) must be COMPLETE when forward() is called -- not pending on the
         # current stream -- e.g. inputs resident from an earlier synchronisation, or produced on another stream the caller has waited on.
         # (First built and withdrawn in the first half of round 5: the FPS chains were not reproducible beside the previous forward's GEMMs.  That was the
-        # packed-fp32 hazard -- DESIGN.md section 4 -- and is gone with it: tests/test_hip_forward.py::test_pipelined_head_...)
+        # packed-fp32 hazard -- HISTORY.md section 4 -- and is gone with it: tests/test_hip_forward.py::test_pipelined_head_...)
         self.pipeline_head = False
         self._train_ops = None      # tests inject the plain-PyTorch operation set (tests/train_ref.py) to check the graph wiring on CPU
 

@@ -302,7 +302,7 @@ class _Linear(torch.autograd.Function):
 
 # Term budget of the BACKWARD GEMMs (struct ogmm_gemm.terms; 0 / 3 = three binary16 products per fp32 product, 2 = the B operand rounded to binary16).  Default:
 # THREE terms everywhere.  Both reduced forms were built and measured this round (tools/bwd_terms_check.py at 32 pairs of 1024 points, both weight families;
-# DESIGN.md section 7) and are opt-in switches, not defaults:
+# HISTORY.md section 7) and are opt-in switches, not defaults:
 #   BWD_TERMS_DW = 2     dW = dY^T X with the fragment image of X^T (activations) rounded: -3.5 ms per 128-pair step (115.3 -> 111.6).  The weight gradients of the
 #     wide layers move by up to 1.0e-4 relative (median over all parameters 1.6e-7, p90 5e-5) -- a third of the reference's own fp32-vs-fp64 distance (2.5e-4 ...
 #     3.2e-4 median) and a sixth of the distance between two fp32-class evaluations of the same step (split engine vs exact-fp32 engine: 5e-4 ... 6e-4); on the

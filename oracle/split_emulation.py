@@ -1,7 +1,7 @@
 """Operand-rounding emulation for the CPU oracle -- TEST INFRASTRUCTURE ONLY (same rules as oracle/ogmm_oracle.py).
 
 The HIP path's GEMM engine multiplies fp32 operands as sums of binary16 terms on the f16 matrix cores with fp32 accumulation
-(DESIGN.md section 2):   x = hi + lo,  hi = rn16(x),  lo = rn16(x - hi)   (22 significand bits)
+(HISTORY.md section 2):   x = hi + lo,  hi = rn16(x),  lo = rn16(x - hi)   (22 significand bits)
     "x3"   a b ~ hi hi + hi lo + lo hi          the default engine (OGMM_PREC_F16X3*): fp32-class
     "x2a"  a b ~ hi (hi + lo)                   activation rounded to binary16, weight kept: 2 MFMAs per product block
     "x2w"  a b ~ (hi + lo) hi                   weight rounded to binary16, activation kept: 2 MFMAs

@@ -3,7 +3,7 @@
 Round 5 traced the run-to-run differences of FPS queued beside the GEMMs to the hardware, not to a race in any kernel: a packed-fp32
 instruction with non-default operand selects (the compiler's form of "pair (op) broadcast scalar") computes lanes 48-63 with the default selects
 when a wave of another kernel on the same SIMD issues an f16 matrix instruction beside it (tools/pk_mfma_hazard.hip: no product code;
-DESIGN.md section 4).  The library is built without packed-fp32 instructions (tests/test_isa_hazards.py); this is the behavioural check on the
+HISTORY.md section 4).  The library is built without packed-fp32 instructions (tests/test_isa_hazards.py); this is the behavioural check on the
 part itself: the kernels the forward runs on its side streams -- FPS, the cluster-feature means, the GMM E/M, the nearest-point search -- beside
 a stream that keeps launching the small-tile fp16x3 GEMM (the engine whose workgroups share compute units with them), 30 times each."""
 from argparse import Namespace

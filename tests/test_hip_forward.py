@@ -476,7 +476,7 @@ def test_pipelined_head_gives_the_same_outputs_over_consecutive_forwards():
     forward's tail.  Consecutive forwards on different resident batches, enqueued without a synchronisation in between, must give exactly the outputs of the
     serial order (same kernels, same inputs: bit-identical), also when the batches alternate between shapes (the workspace is keyed per shape), three times over:
     the FPS chains now run beside the previous forward's GEMMs, the schedule in which they were NOT reproducible before the library lost its packed-fp32
-    instructions."""
+    instructions (HISTORY.md section 4)."""
     cfg = Namespace(gnn_k=20, num_heads=4, km_clusters=128, overlap_radius=0.035, n_clusters=16)
     model, _ = build(cfg, 16)
     batches = []

@@ -1,4 +1,4 @@
-"""Co-run investigation, step 4: a guard kernel (tools/lds_guard.hip) that fills its LDS and registers with a pattern and
+"""Co-run investigation, step 4 (HISTORY.md section 4, round 5): a guard kernel (tools/lds_guard.hip) that fills its LDS and registers with a pattern and
 keeps re-reading them runs on one stream while the small-tile fp16x3 GEMM runs on another.  Says whether a neighbour's LDS words, registers or
 global loads are what changes, and to what.
 usage (GPU box): python3 tools/corun_guard.py        (tools/lds_guard.so is built first if it is missing: hipcc is on the box)"""

@@ -1,4 +1,4 @@
-"""The fused EdgeConv kernel alone at B=64 / N=1024 / k=20.  (The phase-by-phase ablation of DESIGN.md section 4 was done with temporary
+"""The fused EdgeConv kernel alone at B=64 / N=1024 / k=20.  (The phase-by-phase ablation of HISTORY.md section 4 was done with temporary
 switches in the kernel -- pooling / plane writes / MFMAs / layer 1 / flushes off one at a time -- read through OGMM_EDGE_ABL.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

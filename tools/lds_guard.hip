@@ -1,4 +1,4 @@
-// tools-only: a guard kernel for the co-run investigation.  Every workgroup fills its LDS allocation and a set of
+// tools-only: a guard kernel for the co-run investigation (HISTORY.md section 4, round 5).  Every workgroup fills its LDS allocation and a set of
 // registers with a pattern that encodes (workgroup, address), then spins: re-reading both, recording every word that is not what it wrote
 // (workgroup, address, value seen, iteration, hardware id) and restoring it.  Run on one stream beside a suspect kernel on another, it says
 // whether the suspect writes into a neighbour's LDS or registers, and what it wrote.

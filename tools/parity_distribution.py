@@ -1,5 +1,5 @@
 """Parity DISTRIBUTION of the HIP forward against the CPU oracle (GPU box): not four sampled pairs but every pair of a batch, per workload,
-with the tail stated -- the E/M + matching head is ill-conditioned, so the maximum over many pairs decides whether
+with the tail stated -- the E/M + matching head is ill-conditioned (HISTORY.md section 2), so the maximum over many pairs decides whether
 "R, t within 1e-5 of the reference" holds, not the median.
 
     python tools/parity_distribution.py [--workloads cfg1,cfg2,n717] [--pairs 64,32,32] [--budget default|none] [--precision f16x3|f32|f16]

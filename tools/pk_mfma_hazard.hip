@@ -1,4 +1,4 @@
-// tools-only: minimal reproducer for the co-run finding of round 5.  A "victim" kernel keeps computing the same fused
+// tools-only: minimal reproducer for the co-run finding of round 5 (HISTORY.md section 4).  A "victim" kernel keeps computing the same fused
 // multiply-add two ways -- one packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) and two scalar v_fma_f32 -- and records
 // every iteration where they disagree (iteration, lane, which half, both values).  A "neighbour" kernel streams matrix instructions
 // (v_mfma_f32_32x32x16_f16, v_mfma_f32_32x32x2_f32 or none: a VALU-only loop) on a second stream.  Both are sized so that their waves share SIMDs.

@@ -2,7 +2,7 @@
 // no split arithmetic before the barrier), through rings that keep the activations two K steps and the weights one K step
 // ahead of the matrix pipe; the fp32 -> (hi, lo) binary16 split of A happens in registers AFTER the fragment read.
 //
-// Why: in the register-staged engine (gemm_f16x3_v4.hip) the activation loads ride the waves' in-order
+// Why (HISTORY.md section 4): in the register-staged engine (gemm_f16x3_v4.hip) the activation loads ride the waves' in-order
 // vector-memory queue next to the weight-fragment loads, their split + ds_write pass sits in front of the tile's only
 // barrier, and the matrix pipe is ~50 % busy.  Here a wave's instruction stream between two barriers is 8 DMA issues,
 // 24 ds_read_b128, ~80 VALU and 48 MFMAs, and nothing in it waits for HBM except the counted `s_waitcnt vmcnt(4)` in front
