@@ -12,7 +12,11 @@ timeout 900 python3 bench.py --steps 20 --warmup 5 2> $out/bench_n1.err | tail -
 rocprofv3 --kernel-trace --stats -d $out/trace -o r --output-format rocpd -- $BENCH > $out/trace.log 2>&1
 db=$(find $out/trace -name "*.db" | head -1)
 { echo "# commit $commit"; echo "# rocprofv3 --kernel-trace --stats -- $BENCH   (9 forwards: 2 warm-up + 1 counting + 5 timed + ...; the first one also packs the weights)"; python3 tools/rocpd_stats.py $db; } > $out/${tag}_kernel_stats.txt
-{ echo "# commit $commit"; echo "# one eval step (B=64, N=1024, J=16) as dispatched: start, gap to the previous kernel's end (negative: overlapped with a side stream), duration, grid"; python3 tools/rocpd_timeline.py $db "pack_clouds_kernel" | head -70; } > $out/${tag}_step_timeline.txt
+# (the timeline from a SERIAL run: with the bench's pipelined head the kernels of consecutive forwards interleave)
+rocprofv3 --kernel-trace --stats -d $out/trace_s -o r --output-format rocpd -- $BENCH --pipeline-head 0 > $out/trace_s.log 2>&1
+dbs=$(find $out/trace_s -name "*.db" | head -1)
+{ echo "# commit $commit"; echo "# one SERIAL eval step (B=64, N=1024, J=16; $BENCH --pipeline-head 0) as dispatched: start, gap to the previous kernel's end (negative: overlapped with a side stream), duration, grid"; python3 tools/rocpd_timeline.py $dbs "pack_clouds_kernel" | head -52; } > $out/${tag}_step_timeline.txt
+rm -rf $out/trace_s
 {
 echo "# commit $commit"
 echo "# rocprofv3 --kernel-trace --pmc <counters> -- $BENCH   (separate passes per counter set; per-dispatch means, summed over the XCD instances rocprofv3 reports)"
