@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md chip table: fp32-matrix / dense f16 MFMA
 EVENT_EVERY = 4          # the dominant kernel's launches are bracketed by HIP events in every 4th timed step (see eval_leg)
-PMC_FILE = "profiles/round5_pmc_counters.txt"
+PMC_FILE = "profiles/round6_pmc_counters.txt"
 # workload -> (pairs per GPU and step, points, mixtures, algorithmic GFLOP per pair (FlopCounterMode on the reference), cloud kind, first pair id)
 WORKLOADS = {"cfg1": (64, 1024, 16, 52.82, "partial", 0), "cfg2": (256, 2048, 64, 107.50, "partial", 0), "cfg3": (64, 2048, 64, 107.50, "room", 0)}
 
