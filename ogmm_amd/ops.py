@@ -549,7 +549,7 @@ ATTN_BWD_F16X3 = 2      # fp16x3 step: 0 = exact-fp32 attention backward, 1 = S 
 
 def attention_bwd(q, k, v, dout, C, N, M, H, split=False, overflow=None):
     """Backward of attention(): (dq [C*N, D], dk [C*M, D], dv [C*M, D]) from dout = dL/dO; scores re-formed on chip (kernel T11).
-    split: False = exact fp32; True = the fp16x3 training step's form (OGMM_ATTN_BWD_F16X3, default 2); 1 = S = Q K^T and dP = dO V^T on the engines'
+    split: False = exact fp32; True = the fp16x3 training step's form (ops.ATTN_BWD_F16X3, default 2); 1 = S = Q K^T and dP = dO V^T on the engines'
     fp16x3 arithmetic; 2 = all five products (csrc/train_attn_bwd16.hip).  `overflow` reports operands beyond binary16."""
     D = q.shape[1]
     dh = D // H

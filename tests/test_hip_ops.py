@@ -609,7 +609,7 @@ def test_attention_backward_kernel(ops, C, N, split):
 
 
 def test_attention_backward_in_autograd(ops, monkeypatch):
-    """train_ops._Attention: the kernel path and the library path (OGMM_ATTN_BWD=0) give the same gradients"""
+    """train_ops._Attention: the kernel path and the library path (train_ops.FUSED_ATTENTION_BWD = False) give the same gradients"""
     from ogmm_amd import train_ops
     torch.manual_seed(5)
     C, N, M, H, D = 2, 256, 128, 4, 512
