@@ -43,6 +43,7 @@ CASES = {
     ("default", "n717"): (717, 128, 300, 128, 125, "partial"),        # measured 128; includes pairs 334 and 413
     ("sharp", "cfg1"): (1024, 16, 0, 128, 120, "partial"),            # measured 123; 75, 84, 112 are in 64..127
     ("sharp", "cfg1b"): (1024, 16, 128, 192, 184, "partial"),         # measured 187
+    ("sharp", "cfg1c"): (1024, 16, 320, 128, 121, "partial"),         # measured 124 (round 6's sweep beyond the asserted windows, profiles/round6_parity_sweep.txt: largest ratio 1.10)
     ("sharp", "n717"): (717, 128, 300, 128, 112, "partial"),          # measured 115: all 13 beyond are within 1.26 x the reference's own spread
     ("sharp", "cfg2"): (2048, 64, 2000, 16, 15, "partial"),
     ("default", "cfg3"): (2048, 64, 3000, 16, 15, "room"),
